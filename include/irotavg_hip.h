@@ -1,0 +1,172 @@
+/*
+ * irotavg_hip.h -- C ABI of libirotavg_hip.so, the MI355X (gfx950) rotation-averaging core that
+ * replaces the RAL library of ajparra/iRotAvg on the solve path.
+ *
+ * The reference has no FFI/plugin registry: its boundary is the C++ free-function API of
+ * `namespace irotavg` in ral/l1_irls.hpp:81-112, called from ral/test.cpp:285-302 and
+ * src/ViewGraph.cpp:1400-1417. Every entry point below names the reference interface it
+ * replaces. include/irotavg/l1_irls.hpp is a header-only C++ shim with the reference's names on
+ * top of this ABI; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Data layout (identical to the reference's Eigen types, ral/l1_irls.hpp:43-51):
+ *   Mat  : column-major fp64, leading dimension ld >= rows; quaternion columns [x, y, z, w];
+ *   I_t  : m pairs of int32 (first = i, second = j), 0-based; the first f rows of Q are fixed;
+ *   Vec  : contiguous fp64.
+ * All pointers in this header are HOST pointers unless a name ends in `_dev`.
+ *
+ * Error convention: the reference prints to stderr and calls exit(-1); this ABI returns one of
+ * the negative codes below and never throws or exits. There is NO CPU fallback: if no HIP
+ * device is usable every compute entry point returns IROTAVG_ERR_NO_DEVICE.
+ */
+#ifndef IROTAVG_HIP_H
+#define IROTAVG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IROTAVG_OK 0
+#define IROTAVG_ERR_BAD_ARG (-1)
+#define IROTAVG_ERR_NOT_SPANNING (-2) /* ral/l1_irls.cpp:970-977 */
+#define IROTAVG_ERR_SOLVER (-3)       /* ral/l1_irls.cpp:149-177 (UMFPACK failure) / PCG breakdown */
+#define IROTAVG_ERR_UNKNOWN_COST (-4) /* ral/l1_irls.cpp:723-726 */
+#define IROTAVG_ERR_NOMEM (-5)
+#define IROTAVG_ERR_HIP (-6)
+#define IROTAVG_ERR_NO_DEVICE (-7)
+#define IROTAVG_ERR_NOT_CONVERGED (-8) /* inner PCG hit its iteration cap */
+
+/* ral/l1_irls.hpp:56-57 -- the integer values are ABI */
+enum irotavg_cost {
+    IROTAVG_L2 = 0, IROTAVG_L1, IROTAVG_L15, IROTAVG_L05, IROTAVG_GEMAN_MCCLURE, IROTAVG_HUBER,
+    IROTAVG_PSEUDO_HUBER, IROTAVG_ANDREWS, IROTAVG_BISQUARE, IROTAVG_CAUCHY, IROTAVG_FAIR,
+    IROTAVG_LOGISTIC, IROTAVG_TALWAR, IROTAVG_WELSCH
+};
+
+/* Solver knobs that have no counterpart in the reference (it uses direct factorisations). */
+typedef struct irotavg_options {
+    double pcg_rtol;     /* stop when ||r||_2 <= pcg_rtol * ||b||_2 for every column; default 1e-10 */
+    int pcg_max_iters;   /* default 2000 */
+    int pcg_check_every; /* PCG iterations enqueued between host polls of the done flag; default 8 */
+    int mg_levels_max;   /* cap on multigrid levels (1 = plain Jacobi-PCG); default 16 */
+    int mg_agg0;         /* aggregate size of the finest level (0 = choose from the mean degree) */
+    int mg_agg;          /* aggregate size of the other levels; default 4 */
+    int mg_dense_max;    /* coarsest level is inverted densely once it has <= this many rows; default 64 */
+    double mg_omega;     /* damped-Jacobi factor; default 0.7 */
+    double mg_kc;        /* coarse-correction scale; default 1.0 */
+    int device;          /* HIP device ordinal; -1 = current device */
+    int reserved[7];
+} irotavg_options;
+
+void irotavg_default_options(irotavg_options *opt);
+
+/* Cumulative counters of a graph handle (since creation or the last reset). */
+typedef struct irotavg_stats {
+    int64_t pcg_solves;
+    int64_t pcg_iters;       /* total PCG iterations over all solves */
+    int64_t pcg_iters_last;  /* iterations of the most recent solve */
+    int64_t outer_iters;     /* IRLS + L1RA outer iterations */
+    int64_t edge_updates;    /* m * (IRLS outer iterations) */
+    double seconds_irls;     /* wall seconds inside irotavg_graph_irls */
+    double seconds_l1ra;
+    int levels;              /* multigrid levels in use */
+    int64_t level_rows[16];
+    int64_t level_nnz[16];
+    double last_relres[3];   /* ||r||/||b|| per column at the end of the last solve */
+} irotavg_stats;
+
+/* ---------------------------------------------------------------------------------------------
+ * One-shot drop-ins: same arguments as the reference functions, host pointers in, host
+ * pointers out. `A` of the reference signatures is derivable from (n, f, I) and is not passed.
+ * ------------------------------------------------------------------------------------------ */
+
+/* replaces irotavg::init_mst (ral/l1_irls.hpp:89, ral/l1_irls.cpp:915-979). Sequential sweep
+ * semantics (result depends on edge order) -- runs on the host by design. */
+int irotavg_init_mst(int64_t n, int64_t m, double *Q, int64_t ldq, const double *QQ,
+                     int64_t ldqq, const int32_t *I, int f);
+
+/* replaces irotavg::make_A (ral/l1_irls.hpp:91, ral/l1_irls.cpp:755-780): CSC arrays of the
+ * m x (n-f) incidence matrix incl. the edge-drop quirk of :770-771. colptr: n-f+1 entries,
+ * rowidx/vals: capacity 2m. Returns nnz or a negative error. */
+int64_t irotavg_make_A(int n, int f, int64_t m, const int32_t *I, int64_t *colptr,
+                       int64_t *rowidx, double *vals);
+
+/* replaces irotavg::l1ra (ral/l1_irls.hpp:100-102, ral/l1_irls.cpp:851-912) */
+int irotavg_l1ra(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                 int64_t ldqq, double *Q, int64_t ldq, int max_iters, double change_th, int *iter,
+                 double *runtime);
+
+/* replaces irotavg::irls (ral/l1_irls.hpp:104-107, ral/l1_irls.cpp:559-752). `weights` must
+ * hold m doubles. `runtime` is WALL seconds (the reference reports clock() CPU seconds). */
+int irotavg_irls(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                 int64_t ldqq, int cost, double sigma, double *Q, int64_t ldq, int max_iters,
+                 double change_th, double *weights, int *iters, double *runtime);
+
+/* replaces irotavg::quat_normalised (ral/l1_irls.hpp:112, ral/l1_irls.cpp:982-991) */
+int irotavg_quat_normalised(int64_t n, double *Q, int64_t ldq, int f);
+
+/* ---------------------------------------------------------------------------------------------
+ * Handle API: the graph (edges, relative rotations, adjacency, multigrid hierarchy, work
+ * vectors) stays resident in HBM across calls. One HIP stream per handle; a handle is not
+ * thread-safe, distinct handles are independent.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct irotavg_graph irotavg_graph;
+
+/* Uploads I and QQ, builds the adjacency and the hierarchy. opt may be NULL. */
+int irotavg_graph_create(irotavg_graph **g, int64_t m, int64_t n_total, int f, const int32_t *I,
+                         const double *QQ, int64_t ldqq, const irotavg_options *opt);
+void irotavg_graph_destroy(irotavg_graph *g);
+
+int irotavg_graph_set_rotations(irotavg_graph *g, const double *Q, int64_t ldq); /* H2D, all n_total rows */
+int irotavg_graph_get_rotations(irotavg_graph *g, double *Q, int64_t ldq);       /* D2H */
+int irotavg_graph_get_weights(irotavg_graph *g, double *weights);                /* D2H, m */
+int irotavg_graph_set_weights(irotavg_graph *g, const double *weights);          /* H2D, m */
+
+/* irls / l1ra / quat_normalised on the resident graph (same semantics as the one-shot calls) */
+int irotavg_graph_irls(irotavg_graph *g, int cost, double sigma, int max_iters, double change_th,
+                       int *iters, double *runtime, double *score_trace /* may be NULL */);
+int irotavg_graph_l1ra(irotavg_graph *g, int max_iters, double change_th, int *iter,
+                       double *runtime, double *score_trace /* may be NULL */);
+int irotavg_graph_quat_normalised(irotavg_graph *g);
+
+int irotavg_graph_get_stats(irotavg_graph *g, irotavg_stats *out);
+void irotavg_graph_reset_stats(irotavg_graph *g);
+int irotavg_graph_synchronize(irotavg_graph *g);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage-level entry points on the resident graph (used by the parity tests, which check every
+ * kernel against the oracle, and by bench.py's roofline leg).
+ * ------------------------------------------------------------------------------------------ */
+
+/* K1: r_k = log(Qinv_j (x) QQ_k (x) Q_i) for every edge (ral/l1_irls.cpp:109-127 + :498-532). */
+int irotavg_graph_edge_residual(irotavg_graph *g);
+/* D2H of the residual rows: out is m x 3 column-major, ld >= m */
+int irotavg_graph_get_residuals(irotavg_graph *g, double *out, int64_t ld);
+/* one weighted least-squares solve with the current weights and residuals
+ * (ral/l1_irls.cpp:596-612); X is n_u x 3 column-major (ld >= n_u), may be NULL. */
+int irotavg_graph_ls_solve(irotavg_graph *g, double *X, int64_t ldx);
+/* weight update from the current X and residuals (ral/l1_irls.cpp:614-727) */
+int irotavg_graph_update_weights(irotavg_graph *g, int cost, double sigma);
+/* score + exp map + Q update (ral/l1_irls.cpp:729-737); returns the score */
+int irotavg_graph_apply_step(irotavg_graph *g, double *score);
+/* one coordinate of the primal-dual LP (ral/l1_irls.cpp:228-468) on the resident graph:
+ * y is a host vector of m entries, x receives n_u entries. */
+int irotavg_graph_l1decode_pd(irotavg_graph *g, const double *y, int pdmaxiter, double *x,
+                              int *stuck);
+
+/* Times `reps` back-to-back launches of one kernel with HIP events on the handle's stream and
+ * returns the mean milliseconds per launch. which: 1 = K1 edge_residual, 2 = K2 weight update
+ * (Geman-McClure), 3 = level-0 assembly, 4 = level-0 SpMV (q = L p), 5 = one multigrid V-cycle,
+ * 6 = so(3) step kernel (non-destructive variant). */
+int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_per_launch);
+
+/* library / device info */
+const char *irotavg_version(void);
+int irotavg_device_count(void);
+const char *irotavg_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IROTAVG_HIP_H */

@@ -1,0 +1,52 @@
+"""Builds libirotavg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libirotavg_hip.so")
+SOURCES = ["build.cpp", "solver.hip", "l1pd.hip", "capi.cpp"]
+HEADERS = ["common.hpp", "graph.hpp", "kernels.hpp", "../../include/irotavg_hip.h"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS
+               if os.path.exists(os.path.join(CSRC, f)))
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src + ".o")
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
+               os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on %s" % src)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

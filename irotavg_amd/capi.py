@@ -1,0 +1,273 @@
+"""ctypes view of the C ABI in include/irotavg_hip.h (plumbing for tests, bench.py and the Python
+mirror of the RAL API in irotavg_amd/ral.py). All numerics live in libirotavg_hip.so; this module
+never computes rotations itself and raises if the library is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libirotavg_hip.so")
+
+OK = 0
+ERR_BAD_ARG, ERR_NOT_SPANNING, ERR_SOLVER, ERR_UNKNOWN_COST = -1, -2, -3, -4
+ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_CONVERGED = -5, -6, -7, -8
+
+# symbols declared in include/irotavg_hip.h (kept in sync by tests/test_abi.py)
+SYMBOLS = [
+    "irotavg_default_options", "irotavg_init_mst", "irotavg_make_A", "irotavg_l1ra", "irotavg_irls",
+    "irotavg_quat_normalised", "irotavg_graph_create", "irotavg_graph_destroy",
+    "irotavg_graph_set_rotations", "irotavg_graph_get_rotations", "irotavg_graph_get_weights",
+    "irotavg_graph_set_weights", "irotavg_graph_irls", "irotavg_graph_l1ra",
+    "irotavg_graph_quat_normalised", "irotavg_graph_get_stats", "irotavg_graph_reset_stats",
+    "irotavg_graph_synchronize", "irotavg_graph_edge_residual", "irotavg_graph_get_residuals",
+    "irotavg_graph_ls_solve", "irotavg_graph_update_weights", "irotavg_graph_apply_step",
+    "irotavg_graph_l1decode_pd", "irotavg_graph_time_kernel", "irotavg_version",
+    "irotavg_device_count", "irotavg_error_string",
+]
+
+
+class Options(C.Structure):
+    _fields_ = [("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int), ("pcg_check_every", C.c_int),
+                ("mg_levels_max", C.c_int), ("mg_agg0", C.c_int), ("mg_agg", C.c_int),
+                ("mg_dense_max", C.c_int), ("mg_omega", C.c_double), ("mg_kc", C.c_double),
+                ("device", C.c_int), ("reserved", C.c_int * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("pcg_solves", C.c_int64), ("pcg_iters", C.c_int64), ("pcg_iters_last", C.c_int64),
+                ("outer_iters", C.c_int64), ("edge_updates", C.c_int64),
+                ("seconds_irls", C.c_double), ("seconds_l1ra", C.c_double), ("levels", C.c_int),
+                ("level_rows", C.c_int64 * 16), ("level_nnz", C.c_int64 * 16),
+                ("last_relres", C.c_double * 3)]
+
+
+class IrotavgError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = lib().irotavg_error_string(code).decode()
+        super().__init__("%s: %s (code %d)" % (where, msg, code))
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_LIB = None
+
+
+def lib():
+    """Loads libirotavg_hip.so; fails loudly if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libirotavg_hip.so is missing: run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.irotavg_version.restype = C.c_char_p
+    L.irotavg_error_string.restype = C.c_char_p
+    L.irotavg_error_string.argtypes = [C.c_int]
+    L.irotavg_device_count.restype = C.c_int
+    L.irotavg_default_options.argtypes = [C.POINTER(Options)]
+    L.irotavg_default_options.restype = None
+    L.irotavg_init_mst.argtypes = [C.c_int64, C.c_int64, _dp, C.c_int64, _dp, C.c_int64, _ip, C.c_int]
+    L.irotavg_make_A.restype = C.c_int64
+    L.irotavg_make_A.argtypes = [C.c_int, C.c_int, C.c_int64, _ip, _i64p, _i64p, _dp]
+    L.irotavg_l1ra.argtypes = [C.c_int64, C.c_int64, C.c_int, _ip, _dp, C.c_int64, _dp, C.c_int64,
+                               C.c_int, C.c_double, C.POINTER(C.c_int), _dp]
+    L.irotavg_irls.argtypes = [C.c_int64, C.c_int64, C.c_int, _ip, _dp, C.c_int64, C.c_int,
+                               C.c_double, _dp, C.c_int64, C.c_int, C.c_double, _dp,
+                               C.POINTER(C.c_int), _dp]
+    L.irotavg_quat_normalised.argtypes = [C.c_int64, _dp, C.c_int64, C.c_int]
+    L.irotavg_graph_create.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int, _ip, _dp,
+                                       C.c_int64, C.POINTER(Options)]
+    L.irotavg_graph_destroy.argtypes = [vp]
+    L.irotavg_graph_destroy.restype = None
+    L.irotavg_graph_set_rotations.argtypes = [vp, _dp, C.c_int64]
+    L.irotavg_graph_get_rotations.argtypes = [vp, _dp, C.c_int64]
+    L.irotavg_graph_get_weights.argtypes = [vp, _dp]
+    L.irotavg_graph_set_weights.argtypes = [vp, _dp]
+    L.irotavg_graph_irls.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_double,
+                                     C.POINTER(C.c_int), _dp, _dp]
+    L.irotavg_graph_l1ra.argtypes = [vp, C.c_int, C.c_double, C.POINTER(C.c_int), _dp, _dp]
+    L.irotavg_graph_quat_normalised.argtypes = [vp]
+    L.irotavg_graph_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.irotavg_graph_reset_stats.argtypes = [vp]
+    L.irotavg_graph_reset_stats.restype = None
+    L.irotavg_graph_synchronize.argtypes = [vp]
+    L.irotavg_graph_edge_residual.argtypes = [vp]
+    L.irotavg_graph_get_residuals.argtypes = [vp, _dp, C.c_int64]
+    L.irotavg_graph_ls_solve.argtypes = [vp, _dp, C.c_int64]
+    L.irotavg_graph_update_weights.argtypes = [vp, C.c_int, C.c_double]
+    L.irotavg_graph_apply_step.argtypes = [vp, _dp]
+    L.irotavg_graph_l1decode_pd.argtypes = [vp, _dp, C.c_int, _dp, C.POINTER(C.c_int)]
+    L.irotavg_graph_time_kernel.argtypes = [vp, C.c_int, C.c_int, _dp]
+    _LIB = L
+    return L
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def fmat(a):
+    """float64 column-major copy: the reference's Eigen `Mat` layout."""
+    return np.array(a, dtype=np.float64, order="F", copy=True)
+
+
+def edges(I):
+    I = np.ascontiguousarray(I, dtype=np.int32)
+    if I.ndim != 2 or I.shape[1] != 2:
+        raise ValueError("I must be (m, 2)")
+    return I
+
+
+def default_options(**kw):
+    o = Options()
+    lib().irotavg_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def check(rc, where):
+    if rc != OK:
+        raise IrotavgError(rc, where)
+
+
+class Graph:
+    """Device-resident view-graph handle (irotavg_graph_* of include/irotavg_hip.h)."""
+
+    def __init__(self, I, QQ, n_total, f, **opts):
+        I = edges(I)
+        QQ = fmat(QQ)
+        self.m, self.n_total, self.f = len(I), int(n_total), int(f)
+        self.nu = self.n_total - self.f
+        self._h = C.c_void_p()
+        o = default_options(**opts)
+        rc = lib().irotavg_graph_create(C.byref(self._h), self.m, self.n_total, self.f, _i(I),
+                                        _d(QQ), QQ.shape[0], C.byref(o))
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise IrotavgError(rc, "irotavg_graph_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().irotavg_graph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_rotations(self, Q):
+        Q = fmat(Q)
+        assert Q.shape == (self.n_total, 4)
+        check(lib().irotavg_graph_set_rotations(self._h, _d(Q), Q.shape[0]), "set_rotations")
+
+    def get_rotations(self):
+        Q = np.zeros((self.n_total, 4), order="F")
+        check(lib().irotavg_graph_get_rotations(self._h, _d(Q), Q.shape[0]), "get_rotations")
+        return Q
+
+    def get_weights(self):
+        w = np.zeros(self.m)
+        check(lib().irotavg_graph_get_weights(self._h, _d(w)), "get_weights")
+        return w
+
+    def set_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        assert w.shape == (self.m,)
+        check(lib().irotavg_graph_set_weights(self._h, _d(w)), "set_weights")
+
+    def irls(self, cost=4, sigma=5 * np.pi / 180, max_iters=50, change_th=1e-3, allow_rc=()):
+        iters = C.c_int(0)
+        rt = C.c_double(0)
+        trace = np.full(max(max_iters, 1), np.nan)
+        rc = lib().irotavg_graph_irls(self._h, cost, sigma, max_iters, change_th, C.byref(iters),
+                                      C.byref(rt), _d(trace))
+        if rc != OK and rc not in allow_rc:
+            raise IrotavgError(rc, "irotavg_graph_irls")
+        return dict(rc=rc, iters=iters.value, runtime=rt.value, scores=trace[:iters.value].copy())
+
+    def l1ra(self, max_iters=5, change_th=1e-3, allow_rc=()):
+        iters = C.c_int(0)
+        rt = C.c_double(0)
+        trace = np.full(max(max_iters, 1), np.nan)
+        rc = lib().irotavg_graph_l1ra(self._h, max_iters, change_th, C.byref(iters), C.byref(rt),
+                                      _d(trace))
+        if rc != OK and rc not in allow_rc:
+            raise IrotavgError(rc, "irotavg_graph_l1ra")
+        return dict(rc=rc, iters=iters.value, runtime=rt.value, scores=trace[:iters.value].copy())
+
+    def quat_normalised(self):
+        check(lib().irotavg_graph_quat_normalised(self._h), "quat_normalised")
+
+    def stats(self):
+        s = Stats()
+        check(lib().irotavg_graph_get_stats(self._h, C.byref(s)), "get_stats")
+        d = {k: getattr(s, k) for k, _ in Stats._fields_
+             if k not in ("level_rows", "level_nnz", "last_relres")}
+        d["level_rows"] = list(s.level_rows)[:s.levels]
+        d["level_nnz"] = list(s.level_nnz)[:s.levels]
+        d["last_relres"] = list(s.last_relres)
+        return d
+
+    def reset_stats(self):
+        lib().irotavg_graph_reset_stats(self._h)
+
+    def synchronize(self):
+        check(lib().irotavg_graph_synchronize(self._h), "synchronize")
+
+    # stage-level entry points
+    def edge_residual(self):
+        check(lib().irotavg_graph_edge_residual(self._h), "edge_residual")
+
+    def get_residuals(self):
+        r = np.zeros((self.m, 3), order="F")
+        check(lib().irotavg_graph_get_residuals(self._h, _d(r), self.m), "get_residuals")
+        return r
+
+    def ls_solve(self, allow_rc=()):
+        X = np.zeros((self.nu, 3), order="F")
+        rc = lib().irotavg_graph_ls_solve(self._h, _d(X), self.nu)
+        if rc != OK and rc not in allow_rc:
+            raise IrotavgError(rc, "irotavg_graph_ls_solve")
+        return X
+
+    def update_weights(self, cost, sigma):
+        check(lib().irotavg_graph_update_weights(self._h, cost, sigma), "update_weights")
+
+    def apply_step(self):
+        s = C.c_double(0)
+        check(lib().irotavg_graph_apply_step(self._h, C.byref(s)), "apply_step")
+        return s.value
+
+    def l1decode_pd(self, y, pdmaxiter=2):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert y.shape == (self.m,)
+        x = np.zeros(self.nu)
+        stuck = C.c_int(0)
+        check(lib().irotavg_graph_l1decode_pd(self._h, _d(y), pdmaxiter, _d(x), C.byref(stuck)),
+              "l1decode_pd")
+        return x, stuck.value
+
+    def time_kernel(self, which, reps=20):
+        ms = C.c_double(0)
+        check(lib().irotavg_graph_time_kernel(self._h, which, reps, C.byref(ms)), "time_kernel")
+        return ms.value

@@ -1,0 +1,264 @@
+// build.cpp -- host-side construction of the device-resident graph: edge streams, the vertex
+// adjacency (CSR of the weighted Laplacian A'WA restricted to the free views) and the
+// aggregation hierarchy used by the multigrid preconditioner.
+//
+// Reference semantics encoded here:
+//  * make_A (ral/l1_irls.cpp:755-780): row k of A has +1 at column j-f and -1 at column i-f; if
+//    j < f the row is EMPTY even when i is free (:770-771); if only i < f the +1 stays.
+//  * make_AtA (ral/l1_irls.cpp:811-848): the Hessian pattern used by l1decode_pd skips fixed
+//    endpoints independently (:825-843), so an edge with i free, j fixed still adds to (i,i).
+// The CSR pattern is static for the life of the handle; only values are refreshed per solve.
+#include <algorithm>
+#include <numeric>
+
+#include "graph.hpp"
+
+namespace irh {
+
+static int pow2floor(int v) {
+    int p = 1;
+    while (2 * p <= v) p *= 2;
+    return p;
+}
+
+static int choose_lanes(int64_t nnz, int n) {
+    int avg = n > 0 ? (int)((nnz + n - 1) / n) : 1;
+    int l = pow2floor(std::max(avg / 2, 1));
+    return std::min(std::max(l, 2), 64);
+}
+
+int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
+    const int64_t m = g.m;
+    const int f = g.f;
+    const int nu = g.nu;
+    hipStream_t s = g.stream;
+
+    // ---- edge streams -------------------------------------------------------------------
+    g.mpad = (m + 63) / 64 * 64;  // streams are padded so kernels may read whole 16-B pairs
+    std::vector<int> ei((size_t)g.mpad, 0), ej((size_t)g.mpad, 0);
+    std::vector<uint8_t> eflag((size_t)g.mpad, 0);
+    for (int64_t k = 0; k < m; k++) {
+        const int i = I[2 * k], j = I[2 * k + 1];
+        if (i < 0 || j < 0 || i >= g.n_total || j >= g.n_total) return IROTAVG_ERR_BAD_ARG;
+        ei[k] = i;
+        ej[k] = j;
+        uint8_t fl = 0;
+        if (j >= f) {
+            if (i >= f && i == j) {
+                fl = EF_CI;  // self loop: the -1 overwrites the +1
+            } else {
+                fl |= EF_CJ;
+                if (i >= f) fl |= EF_CI;
+            }
+        }
+        eflag[k] = fl;
+    }
+    g.ei.upload(ei, s);
+    g.ej.upload(ej, s);
+    g.eflag.upload(eflag, s);
+    g.qq.alloc((size_t)4 * g.mpad);
+    g.qq.zero(s);
+    for (int c = 0; c < 4; c++)
+        IRH_CHECK(hipMemcpyAsync(g.qq.p + (size_t)c * g.mpad, QQ + (size_t)c * ldqq,
+                                 sizeof(double) * (size_t)m, hipMemcpyHostToDevice, s));
+    g.er.alloc((size_t)3 * g.mpad);
+    g.er.zero(s);
+    g.dw.alloc((size_t)g.mpad);
+    {
+        std::vector<double> ones((size_t)g.mpad, 1.0);
+        g.dw.upload(ones, s);
+        IRH_CHECK(hipStreamSynchronize(s));
+    }
+    g.Q.alloc((size_t)g.n_total);
+    g.Q.zero(s);
+
+    // ---- level-0 adjacency --------------------------------------------------------------
+    std::vector<int> rowptr((size_t)nu + 1, 0), bptr((size_t)nu + 1, 0);
+    for (int64_t k = 0; k < m; k++) {
+        const int i = ei[k] - f, j = ej[k] - f;
+        if (i >= 0 && j >= 0 && i != j) {
+            rowptr[i + 1]++;
+            rowptr[j + 1]++;
+        } else if (i >= 0 && j >= 0) {
+            bptr[i + 1]++;  // self loop
+        } else if (j >= 0) {
+            bptr[j + 1]++;  // i fixed
+        } else if (i >= 0) {
+            bptr[i + 1]++;  // j fixed (dropped by make_A, kept by make_AtA)
+        }
+    }
+    for (int v = 0; v < nu; v++) {
+        rowptr[v + 1] += rowptr[v];
+        bptr[v + 1] += bptr[v];
+    }
+    const int64_t nnz0 = rowptr[nu];
+    const int64_t nb = bptr[nu];
+    if (nnz0 > 0x7fffffffLL || m > 0x7fffffffLL) return IROTAVG_ERR_BAD_ARG;
+    struct Ent {
+        int col;
+        uint32_t eid;
+    };
+    std::vector<Ent> ents((size_t)nnz0);
+    std::vector<uint32_t> beid((size_t)nb);
+    std::vector<uint8_t> bflag((size_t)nb);
+    {
+        std::vector<int> pos(rowptr.begin(), rowptr.end() - 1), bpos(bptr.begin(), bptr.end() - 1);
+        for (int64_t k = 0; k < m; k++) {
+            const int i = ei[k] - f, j = ej[k] - f;
+            if (i >= 0 && j >= 0 && i != j) {
+                ents[pos[j]++] = Ent{i, (uint32_t)(k << 1) | 1u};  // row j: +1 coefficient
+                ents[pos[i]++] = Ent{j, (uint32_t)(k << 1)};       // row i: -1 coefficient
+            } else if (i >= 0 && j >= 0) {
+                beid[bpos[i]] = (uint32_t)(k << 1);
+                bflag[bpos[i]++] = BF_IRLS | BF_L1H | BF_NEG;
+            } else if (j >= 0) {
+                beid[bpos[j]] = (uint32_t)(k << 1) | 1u;
+                bflag[bpos[j]++] = BF_IRLS | BF_L1H;
+            } else if (i >= 0) {
+                beid[bpos[i]] = (uint32_t)(k << 1);
+                bflag[bpos[i]++] = BF_L1H;
+            }
+        }
+    }
+    // sort each row by column (edge order breaks ties): locality for the gathers and a
+    // canonical order for the coarse-level maps
+    for (int v = 0; v < nu; v++)
+        std::stable_sort(ents.begin() + rowptr[v], ents.begin() + rowptr[v + 1],
+                         [](const Ent &a, const Ent &b) { return a.col < b.col; });
+    std::vector<int> col((size_t)nnz0);
+    std::vector<uint32_t> slot_eid((size_t)nnz0);
+    for (int64_t t = 0; t < nnz0; t++) {
+        col[t] = ents[t].col;
+        slot_eid[t] = ents[t].eid;
+    }
+    ents.clear();
+    ents.shrink_to_fit();
+
+    g.slot_eid.upload(slot_eid, s);
+    g.bptr.upload(bptr, s);
+    g.beid.upload(beid, s);
+    g.bflag.upload(bflag, s);
+
+    // ---- hierarchy ----------------------------------------------------------------------
+    // Host patterns of every level first, uploads second.
+    struct HostLevel {
+        int n = 0, agg = 0;
+        std::vector<int> rowptr, col;  // off-diagonal pattern
+        std::vector<int> cptr, cidx;   // value refresh from the finer level (empty on level 0)
+    };
+    std::vector<HostLevel> H;
+    H.emplace_back();
+    H[0].n = nu;
+    H[0].rowptr = std::move(rowptr);
+    H[0].col = std::move(col);
+    const int max_levels = std::max(1, std::min(g.opt.mg_levels_max, (int)kMaxLevels));
+    while ((int)H.size() < max_levels && H.back().n > g.opt.mg_dense_max) {
+        HostLevel &F = H.back();
+        const int64_t fnnz = F.rowptr[F.n];
+        const int lanes = choose_lanes(fnnz, F.n);
+        // aggregate = `agg` contiguous rows; agg divides the rows-per-block of the row kernels
+        int agg = (H.size() == 1) ? g.opt.mg_agg0 : g.opt.mg_agg;
+        if (H.size() == 1 && agg <= 0) {
+            const int avg = F.n > 0 ? (int)(fnnz / F.n) : 0;
+            agg = avg >= 16 ? 8 : (avg >= 6 ? 4 : 2);
+        }
+        agg = pow2floor(std::max(agg, 2));
+        agg = std::min(agg, kBlock / lanes);
+        F.agg = agg;
+        HostLevel C;
+        C.n = (F.n + agg - 1) / agg;
+        C.rowptr.assign((size_t)C.n + 1, 0);
+        C.col.reserve((size_t)fnnz / 4 + 16);
+        C.cidx.reserve((size_t)fnnz);
+        C.cptr.push_back(0);
+        std::vector<std::pair<int, int>> tmp;  // (coarse col, fine slot)
+        for (int Ic = 0; Ic < C.n; Ic++) {
+            tmp.clear();
+            const int v0 = Ic * agg, v1 = std::min(F.n, v0 + agg);
+            for (int v = v0; v < v1; v++)
+                for (int t = F.rowptr[v]; t < F.rowptr[v + 1]; t++) {
+                    const int Jc = F.col[t] / agg;
+                    if (Jc != Ic) tmp.emplace_back(Jc, t);
+                }
+            std::sort(tmp.begin(), tmp.end());
+            for (size_t q = 0; q < tmp.size(); q++) {
+                if (q == 0 || tmp[q].first != tmp[q - 1].first) {
+                    if (q != 0) C.cptr.push_back((int)C.cidx.size());
+                    C.col.push_back(tmp[q].first);
+                }
+                C.cidx.push_back(tmp[q].second);
+            }
+            if (!tmp.empty()) C.cptr.push_back((int)C.cidx.size());
+            C.rowptr[Ic + 1] = (int)C.col.size();
+        }
+        H.push_back(std::move(C));
+    }
+
+    g.levels.clear();
+    g.levels.resize(H.size());
+    g.stats.levels = (int)H.size();
+    for (size_t lev = 0; lev < H.size(); lev++) {
+        Level &L = g.levels[lev];
+        HostLevel &h = H[lev];
+        L.n = h.n;
+        L.nnz = h.rowptr[h.n];
+        L.agg = h.agg;
+        L.lanes = choose_lanes(L.nnz, L.n);
+        L.rowptr.upload(h.rowptr, s);
+        L.col.upload(h.col, s);
+        L.val.alloc((size_t)L.nnz);
+        L.val.zero(s);
+        L.excess.alloc((size_t)L.n);
+        L.excess.zero(s);
+        L.diag.alloc((size_t)L.n);
+        L.idg.alloc((size_t)L.n);
+        L.diag.zero(s);
+        L.idg.zero(s);
+        if (lev > 0) {
+            L.cptr.upload(h.cptr, s);
+            L.cidx.upload(h.cidx, s);
+        }
+        L.b.alloc((size_t)L.n);
+        L.x.alloc((size_t)L.n);
+        L.y.alloc((size_t)L.n);
+        L.b.zero(s);
+        L.x.zero(s);
+        L.y.zero(s);
+        if (lev < (size_t)kMaxLevels) {
+            g.stats.level_rows[lev] = L.n;
+            g.stats.level_nnz[lev] = L.nnz;
+        }
+    }
+    // dense inverse of the coarsest level (only when it is small enough and there is a hierarchy)
+    g.ndense = 0;
+    if (g.levels.size() > 1 && g.levels.back().n <= std::min(g.opt.mg_dense_max, 88)) {
+        g.ndense = g.levels.back().n;
+        g.dense_inv.alloc((size_t)g.ndense * g.ndense);
+        g.dense_inv.zero(s);
+    }
+
+    // ---- PCG state ----------------------------------------------------------------------
+    g.X.alloc((size_t)nu);
+    g.P.alloc((size_t)nu);
+    g.AP.alloc((size_t)nu);
+    g.X.zero(s);
+    g.P.zero(s);
+    g.AP.zero(s);
+    g.part_pq.alloc((size_t)kMaxParts * 4);
+    g.part_rr.alloc((size_t)kMaxParts * 4);
+    g.part_rz.alloc((size_t)kMaxParts * 4);
+    g.part_score.alloc((size_t)kMaxParts * 4);
+    g.part_pq.zero(s);
+    g.part_rr.zero(s);
+    g.part_rz.zero(s);
+    g.part_score.zero(s);
+    g.scal.alloc(SC_COUNT);
+    g.scal.zero(s);
+    g.flags.alloc(FL_COUNT);
+    g.flags.zero(s);
+    g.h_part.assign((size_t)kMaxParts * 4, 0.0);
+    IRH_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
+    return IROTAVG_OK;
+}
+
+}  // namespace irh

@@ -1,0 +1,465 @@
+// capi.cpp -- extern "C" boundary of libirotavg_hip.so (see include/irotavg_hip.h).
+// No exception crosses this file; there is no CPU fallback for the compute entry points.
+#include <cmath>
+#include <new>
+
+#include "graph.hpp"
+
+using namespace irh;
+
+struct irotavg_graph {
+    Graph g;
+};
+
+#define API_TRY try {
+#define API_CATCH                          \
+    }                                      \
+    catch (const HipError &) {             \
+        return IROTAVG_ERR_HIP;            \
+    }                                      \
+    catch (const std::bad_alloc &) {       \
+        return IROTAVG_ERR_NOMEM;          \
+    }                                      \
+    catch (...) {                          \
+        return IROTAVG_ERR_HIP;            \
+    }
+
+extern "C" {
+
+const char *irotavg_version(void) { return "irotavg_hip 0.1 (gfx950)"; }
+
+int irotavg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *irotavg_error_string(int code) {
+    switch (code) {
+    case IROTAVG_OK: return "ok";
+    case IROTAVG_ERR_BAD_ARG: return "bad argument";
+    case IROTAVG_ERR_NOT_SPANNING: return "relative rotations do not span all the nodes in the view graph";
+    case IROTAVG_ERR_SOLVER: return "linear solver breakdown (non-finite values)";
+    case IROTAVG_ERR_UNKNOWN_COST: return "unknown cost";
+    case IROTAVG_ERR_NOMEM: return "out of memory";
+    case IROTAVG_ERR_HIP: return "HIP runtime error";
+    case IROTAVG_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case IROTAVG_ERR_NOT_CONVERGED: return "inner PCG did not converge within pcg_max_iters";
+    default: return "unknown error";
+    }
+}
+
+void irotavg_default_options(irotavg_options *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->pcg_rtol = 1e-10;
+    o->pcg_max_iters = 2000;
+    o->pcg_check_every = 8;
+    o->mg_levels_max = 16;
+    o->mg_agg0 = 0;
+    o->mg_agg = 4;
+    o->mg_dense_max = 64;
+    o->mg_omega = 0.7;
+    o->mg_kc = 1.0;
+    o->device = -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side pieces of the RAL API
+// ---------------------------------------------------------------------------------------------
+static inline void h_qmul(const double a[4], const double b[4], double o[4]) {
+    // [x y z w] Hamilton product (ral/l1_irls.cpp:99-105)
+    const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    const double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    const double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[0] = x;
+    o[1] = y;
+    o[2] = z;
+    o[3] = w;
+}
+
+// init_mst is a sequential, edge-order-dependent propagation (ral/l1_irls.cpp:915-979): each
+// sweep visits the edge list in order and a view takes its value from the first edge that
+// reaches it, so it is evaluated on the host exactly in that order. It is outside the
+// reference's timed region and O(sweeps * m).
+int irotavg_init_mst(int64_t n, int64_t m, double *Q, int64_t ldq, const double *QQ,
+                     int64_t ldqq, const int32_t *I, int f) {
+    if (!Q || !QQ || !I || n <= 0 || m < 0 || f <= 0 || ldq < n || ldqq < m)
+        return IROTAVG_ERR_BAD_ARG;  // assert(f>0) at :917
+    std::vector<char> seen((size_t)n, 0);
+    seen[0] = 1;
+    int64_t count = 1;
+    while (count < n) {
+        bool grew = false;
+        for (int64_t k = 0; k < m; k++) {
+            const int64_t a = I[2 * k], b = I[2 * k + 1];
+            if (a < 0 || b < 0 || a >= n || b >= n) return IROTAVG_ERR_BAD_ARG;
+            if (seen[a] && !seen[b]) {
+                if (b >= f) {  // forward: Q_b = QQ_k (x) Q_a (:941)
+                    const double qq[4] = {QQ[k], QQ[ldqq + k], QQ[2 * ldqq + k], QQ[3 * ldqq + k]};
+                    const double qa[4] = {Q[a], Q[ldq + a], Q[2 * ldq + a], Q[3 * ldq + a]};
+                    double r[4];
+                    h_qmul(qq, qa, r);
+                    for (int c = 0; c < 4; c++) Q[c * ldq + b] = r[c];
+                }
+                seen[b] = 1;
+                count++;
+                grew = true;
+            } else if (!seen[a] && seen[b]) {
+                if (a >= f) {  // backward: inverse formed by negating w only (:956-958)
+                    const double qq[4] = {QQ[k], QQ[ldqq + k], QQ[2 * ldqq + k], -QQ[3 * ldqq + k]};
+                    const double qb[4] = {Q[b], Q[ldq + b], Q[2 * ldq + b], Q[3 * ldq + b]};
+                    double r[4];
+                    h_qmul(qq, qb, r);
+                    for (int c = 0; c < 4; c++) Q[c * ldq + a] = r[c];
+                }
+                seen[a] = 1;
+                count++;
+                grew = true;
+            }
+        }
+        if (!grew && count < n) return IROTAVG_ERR_NOT_SPANNING;  // exit(-1) at :970-977
+    }
+    return IROTAVG_OK;
+}
+
+int64_t irotavg_make_A(int n, int f, int64_t m, const int32_t *I, int64_t *colptr,
+                       int64_t *rowidx, double *vals) {
+    if (n < 0 || f < 0 || n - f <= 1 || !I || !colptr || !rowidx || !vals)
+        return IROTAVG_ERR_BAD_ARG;  // asserts at ral/l1_irls.cpp:757-758
+    const int64_t nu = (int64_t)n - f;
+    std::vector<int64_t> cnt((size_t)nu + 1, 0);
+    auto row = [&](int64_t k, int64_t c[2], double v[2]) -> int {
+        const int64_t j = (int64_t)I[2 * k + 1] - f, i = (int64_t)I[2 * k] - f;
+        if (j < 0) return 0;  // :770-771 -- edge dropped even if i is free
+        if (i < 0) {
+            c[0] = j;
+            v[0] = 1.0;
+            return 1;
+        }
+        if (i == j) {  // the second coeffRef overwrites the first
+            c[0] = i;
+            v[0] = -1.0;
+            return 1;
+        }
+        c[0] = j;
+        v[0] = 1.0;
+        c[1] = i;
+        v[1] = -1.0;
+        return 2;
+    };
+    int64_t c[2];
+    double v[2];
+    for (int64_t k = 0; k < m; k++) {
+        const int ne = row(k, c, v);
+        for (int e = 0; e < ne; e++) {
+            if (c[e] >= nu) return IROTAVG_ERR_BAD_ARG;
+            cnt[c[e]]++;
+        }
+    }
+    colptr[0] = 0;
+    for (int64_t q = 0; q < nu; q++) colptr[q + 1] = colptr[q] + cnt[q];
+    for (int64_t q = 0; q < nu; q++) cnt[q] = colptr[q];
+    for (int64_t k = 0; k < m; k++) {
+        const int ne = row(k, c, v);
+        for (int e = 0; e < ne; e++) {
+            const int64_t p = cnt[c[e]]++;
+            rowidx[p] = k;
+            vals[p] = v[e];
+        }
+    }
+    return colptr[nu];
+}
+
+// ---------------------------------------------------------------------------------------------
+// handle API
+// ---------------------------------------------------------------------------------------------
+int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f, const int32_t *I,
+                         const double *QQ, int64_t ldqq, const irotavg_options *opt) {
+    if (!out || !I || !QQ || m <= 0 || n_total <= 0 || f < 0 || n_total - f < 1 || ldqq < m ||
+        n_total > 0x7fffffffLL)
+        return IROTAVG_ERR_BAD_ARG;
+    *out = nullptr;
+    if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
+    irotavg_graph *h = nullptr;
+    API_TRY
+    h = new irotavg_graph();
+    Graph &g = h->g;
+    if (opt)
+        g.opt = *opt;
+    else
+        irotavg_default_options(&g.opt);
+    if (g.opt.pcg_rtol <= 0) g.opt.pcg_rtol = 1e-10;
+    if (g.opt.mg_omega <= 0) g.opt.mg_omega = 0.7;
+    if (g.opt.mg_kc <= 0) g.opt.mg_kc = 1.0;
+    if (g.opt.mg_agg <= 0) g.opt.mg_agg = 4;
+    if (g.opt.mg_dense_max <= 0) g.opt.mg_dense_max = 64;
+    if (g.opt.mg_levels_max <= 0) g.opt.mg_levels_max = 16;
+    if (g.opt.pcg_max_iters <= 0) g.opt.pcg_max_iters = 2000;
+    if (g.opt.pcg_check_every <= 0) g.opt.pcg_check_every = 8;
+    if (g.opt.device >= 0) IRH_CHECK(hipSetDevice(g.opt.device));
+    IRH_CHECK(hipGetDevice(&g.device));
+    IRH_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.m = m;
+    g.n_total = n_total;
+    g.f = f;
+    g.nu = (int)(n_total - f);
+    const int rc = build_graph(g, I, QQ, ldqq);
+    if (rc != IROTAVG_OK) {
+        irotavg_graph_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return IROTAVG_OK;
+    }
+    catch (const HipError &) {
+        if (h) irotavg_graph_destroy(h);
+        return IROTAVG_ERR_HIP;
+    }
+    catch (const std::bad_alloc &) {
+        if (h) irotavg_graph_destroy(h);
+        return IROTAVG_ERR_NOMEM;
+    }
+    catch (...) {
+        if (h) irotavg_graph_destroy(h);
+        return IROTAVG_ERR_HIP;
+    }
+}
+
+void irotavg_graph_destroy(irotavg_graph *h) {
+    if (!h) return;
+    hipStream_t s = h->g.stream;
+    if (s) (void)hipStreamSynchronize(s);
+    h->g.stream = nullptr;
+    delete h;
+    if (s) (void)hipStreamDestroy(s);
+}
+
+int irotavg_graph_set_rotations(irotavg_graph *h, const double *Q, int64_t ldq) {
+    if (!h || !Q || ldq < h->g.n_total) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    std::vector<double4> aos((size_t)g.n_total);
+    for (int64_t i = 0; i < g.n_total; i++)
+        aos[i] = make_double4(Q[i], Q[ldq + i], Q[2 * ldq + i], Q[3 * ldq + i]);
+    g.Q.upload(aos.data(), aos.size(), g.stream);
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_get_rotations(irotavg_graph *h, double *Q, int64_t ldq) {
+    if (!h || !Q || ldq < h->g.n_total) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    std::vector<double4> aos((size_t)g.n_total);
+    IRH_CHECK(hipMemcpyAsync(aos.data(), g.Q.p, sizeof(double4) * aos.size(), hipMemcpyDeviceToHost,
+                             g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    for (int64_t i = 0; i < g.n_total; i++) {
+        Q[i] = aos[i].x;
+        Q[ldq + i] = aos[i].y;
+        Q[2 * ldq + i] = aos[i].z;
+        Q[3 * ldq + i] = aos[i].w;
+    }
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_get_weights(irotavg_graph *h, double *w) {
+    if (!h || !w) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    IRH_CHECK(hipMemcpyAsync(w, g.dw.p, sizeof(double) * (size_t)g.m, hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_set_weights(irotavg_graph *h, const double *w) {
+    if (!h || !w) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    IRH_CHECK(hipMemcpyAsync(g.dw.p, w, sizeof(double) * (size_t)g.m, hipMemcpyHostToDevice, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_irls(irotavg_graph *h, int cost, double sigma, int max_iters, double change_th,
+                       int *iters, double *runtime, double *trace) {
+    if (!h || !iters || !runtime) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    return run_irls(h->g, cost, sigma, max_iters, change_th, iters, runtime, trace);
+    API_CATCH
+}
+
+int irotavg_graph_l1ra(irotavg_graph *h, int max_iters, double change_th, int *iter, double *runtime,
+                       double *trace) {
+    if (!h || !iter || !runtime) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    return run_l1ra(h->g, max_iters, change_th, iter, runtime, trace);
+    API_CATCH
+}
+
+int irotavg_graph_quat_normalised(irotavg_graph *h) {
+    if (!h) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    normalise_rotations(h->g);
+    IRH_CHECK(hipStreamSynchronize(h->g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_get_stats(irotavg_graph *h, irotavg_stats *out) {
+    if (!h || !out) return IROTAVG_ERR_BAD_ARG;
+    *out = h->g.stats;
+    return IROTAVG_OK;
+}
+
+void irotavg_graph_reset_stats(irotavg_graph *h) {
+    if (!h) return;
+    irotavg_stats keep = h->g.stats;
+    std::memset(&h->g.stats, 0, sizeof(irotavg_stats));
+    h->g.stats.levels = keep.levels;
+    for (int i = 0; i < 16; i++) {
+        h->g.stats.level_rows[i] = keep.level_rows[i];
+        h->g.stats.level_nnz[i] = keep.level_nnz[i];
+    }
+}
+
+int irotavg_graph_synchronize(irotavg_graph *h) {
+    if (!h) return IROTAVG_ERR_BAD_ARG;
+    return hipStreamSynchronize(h->g.stream) == hipSuccess ? IROTAVG_OK : IROTAVG_ERR_HIP;
+}
+
+int irotavg_graph_edge_residual(irotavg_graph *h) {
+    if (!h) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    launch_edge_residual(h->g);
+    IRH_CHECK(hipStreamSynchronize(h->g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_get_residuals(irotavg_graph *h, double *out, int64_t ld) {
+    if (!h || !out || ld < h->g.m) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    for (int c = 0; c < 3; c++)
+        IRH_CHECK(hipMemcpyAsync(out + (size_t)c * ld, g.er.p + (size_t)c * g.mpad,
+                                 sizeof(double) * (size_t)g.m, hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_ls_solve(irotavg_graph *h, double *X, int64_t ldx) {
+    if (!h || (X && ldx < h->g.nu)) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    const int rc = ls_solve(g);
+    if (X) {
+        std::vector<double4> aos((size_t)g.nu);
+        IRH_CHECK(hipMemcpyAsync(aos.data(), g.X.p, sizeof(double4) * aos.size(),
+                                 hipMemcpyDeviceToHost, g.stream));
+        IRH_CHECK(hipStreamSynchronize(g.stream));
+        for (int i = 0; i < g.nu; i++) {
+            X[i] = aos[i].x;
+            X[ldx + i] = aos[i].y;
+            X[2 * ldx + i] = aos[i].z;
+        }
+    }
+    return rc;
+    API_CATCH
+}
+
+int irotavg_graph_update_weights(irotavg_graph *h, int cost, double sigma) {
+    if (!h) return IROTAVG_ERR_BAD_ARG;
+    if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
+    API_TRY
+    launch_update_weights(h->g, cost, sigma);
+    IRH_CHECK(hipStreamSynchronize(h->g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_apply_step(irotavg_graph *h, double *score) {
+    if (!h || !score) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    *score = apply_step(h->g);
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_l1decode_pd(irotavg_graph *h, const double *y, int pdmaxiter, double *x,
+                              int *stuck) {
+    if (!h || !y || !x) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    return l1decode_pd_dev(h->g, -1, y, pdmaxiter, x, stuck, 0);
+    API_CATCH
+}
+
+int irotavg_graph_time_kernel(irotavg_graph *h, int which, int reps, double *ms) {
+    if (!h || !ms || reps <= 0) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    return time_kernel(h->g, which, reps, ms);
+    API_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------
+// one-shot drop-ins
+// ---------------------------------------------------------------------------------------------
+int irotavg_irls(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                 int64_t ldqq, int cost, double sigma, double *Q, int64_t ldq, int max_iters,
+                 double change_th, double *weights, int *iters, double *runtime) {
+    if (!Q || !weights || !iters || !runtime) return IROTAVG_ERR_BAD_ARG;
+    if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
+    irotavg_graph *h = nullptr;
+    int rc = irotavg_graph_create(&h, m, n_total, f, I, QQ, ldqq, nullptr);
+    if (rc != IROTAVG_OK) return rc;
+    rc = irotavg_graph_set_rotations(h, Q, ldq);
+    if (rc == IROTAVG_OK)
+        rc = irotavg_graph_irls(h, cost, sigma, max_iters, change_th, iters, runtime, nullptr);
+    if (rc == IROTAVG_OK || rc == IROTAVG_ERR_NOT_CONVERGED) {
+        (void)irotavg_graph_get_rotations(h, Q, ldq);
+        (void)irotavg_graph_get_weights(h, weights);
+    }
+    irotavg_graph_destroy(h);
+    return rc;
+}
+
+int irotavg_l1ra(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                 int64_t ldqq, double *Q, int64_t ldq, int max_iters, double change_th, int *iter,
+                 double *runtime) {
+    if (!Q || !iter || !runtime) return IROTAVG_ERR_BAD_ARG;
+    irotavg_graph *h = nullptr;
+    int rc = irotavg_graph_create(&h, m, n_total, f, I, QQ, ldqq, nullptr);
+    if (rc != IROTAVG_OK) return rc;
+    rc = irotavg_graph_set_rotations(h, Q, ldq);
+    if (rc == IROTAVG_OK) rc = irotavg_graph_l1ra(h, max_iters, change_th, iter, runtime, nullptr);
+    if (rc == IROTAVG_OK) (void)irotavg_graph_get_rotations(h, Q, ldq);
+    irotavg_graph_destroy(h);
+    return rc;
+}
+
+// O(n) normalisation of host data: Eigen normalized() per row (ral/l1_irls.cpp:982-991). The
+// device-resident variant is irotavg_graph_quat_normalised.
+int irotavg_quat_normalised(int64_t n, double *Q, int64_t ldq, int f) {
+    if (!Q || n < 0 || ldq < n || f < 0) return IROTAVG_ERR_BAD_ARG;
+    for (int64_t i = f; i < n; i++) {
+        const double x = Q[i], y = Q[ldq + i], z = Q[2 * ldq + i], w = Q[3 * ldq + i];
+        const double n2 = x * x + y * y + z * z + w * w;
+        if (n2 > 0.0) {
+            const double nn = std::sqrt(n2);
+            Q[i] = x / nn;
+            Q[ldq + i] = y / nn;
+            Q[2 * ldq + i] = z / nn;
+            Q[3 * ldq + i] = w / nn;
+        }
+    }
+    return IROTAVG_OK;
+}
+
+}  // extern "C"
