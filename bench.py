@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+metric : IRLS edge-updates/s (= m * IRLS iterations / wall time of the `irls` call, inputs
+         resident in HBM) + iterations-to-converge, on the synthetic 100k-view / 2M-edge SO(3)
+         view-graph (SURVEY.md 8(d) generator, seed 0), Geman-McClure sigma = 5 deg,
+         change_th = 1e-3, max_iters = 100 -- the reference's defaults (src/ViewGraph.cpp:1402-1414).
+step   : one complete `irls` solve of that graph from its `init_mst` initialisation (rotations
+         restored on the device before every step; the restore is inside the timed region).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--p-loop P] [--views n] [--edges m]
+
+For N > 1 the driver launches one process per GPU through torch.distributed.run; rank 0 prints
+ONE JSON line. The line also carries `roofline` (dominant kernel + the edge-residual kernel the
+north star names, HIP-event timed on the handle's stream) and `cpu_baseline` (the CPU oracle --
+a port, not Eigen+SuiteSparse, which cannot be built in this image -- on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SIG = 5 * np.pi / 180
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_problem(n, m, p_loop, seed):
+    from irotavg_amd import ral, synth
+    S = synth.make_graph(n, m, p_loop, seed=seed)
+    Q0 = np.zeros((n, 4))
+    Q0[:, 3] = 1
+    Q0[0] = S["Qgt"][0]
+    ral.init_mst(Q0, S["QQ"], S["I"], 1)   # host, outside the timed region (as in the reference)
+    return S, Q0
+
+
+def kernel_rooflines(G, S, st):
+    """HIP-event timed kernels -> algorithmic GB/s (formulas: SURVEY.md 8(d))."""
+    m, n_t = S["m"], S["n"]
+    nu = n_t - 1
+    nnz0 = st["level_nnz"][0]
+    alg = {
+        "edge_residual": m * (8 + 32 + 24) + 32 * n_t,
+        "update_weights": m * (8 + 24 + 8) + 24 * nu,
+        "assemble": m * (8 + 8 + 24) + nu * (8 + 24) + 8 * nnz0,
+        "spmv": nnz0 * (8 + 4) + 4 * (nu + 1) + 2 * 24 * nu,
+    }
+    which = {"edge_residual": 1, "update_weights": 2, "assemble": 3, "spmv": 4}
+    out = {}
+    for name, w in which.items():
+        ms = G.time_kernel(w, 50)
+        out[name] = dict(ms=ms, bytes=alg[name], gbs=alg[name] / (ms * 1e-3) / 1e9)
+    out["vcycle"] = dict(ms=G.time_kernel(5, 50))
+    return out
+
+
+def cpu_baseline(S, Q0, p_loop, budget_s=25.0):
+    """The CPU oracle (oracle/, single thread, own sparse Cholesky) on a bounded sample."""
+    from oracle import oracle as O
+    from irotavg_amd import synth
+    cores = 1
+    if p_loop == 0.0 or S["m"] <= 200000:
+        iters = 3
+        t = time.time()
+        r = O.irls(S["QQ"], S["I"], Q0, 1, 4, SIG, iters, 1e-3)
+        dt = time.time() - t
+        return dict(value=S["m"] * r["iters"] / dt, unit="edge-updates/s", cores=cores, kind="port",
+                    sample="first %d IRLS iterations of the same %d-view/%d-edge graph "
+                           "(incl. one symbolic analysis), %.1f s" % (r["iters"], S["n"], S["m"], dt),
+                    note="oracle = C restatement + own sparse Cholesky; NOT Eigen+SuiteSparse "
+                         "(unbuildable here)")
+    # loop-closure-rich graphs: fill of the direct factorisation explodes; sample a 10x smaller graph
+    n2, m2 = S["n"] // 10, S["m"] // 10
+    S2 = synth.make_graph(n2, m2, p_loop, seed=0)
+    Q2 = np.zeros((n2, 4)); Q2[:, 3] = 1; Q2[0] = S2["Qgt"][0]
+    rc, Q2 = O.init_mst(Q2, S2["QQ"], S2["I"], 1)
+    t = time.time()
+    r = O.irls(S2["QQ"], S2["I"], Q2, 1, 4, SIG, 1, 1e-3)
+    dt = time.time() - t
+    return dict(value=S2["m"] * r["iters"] / dt, unit="edge-updates/s", cores=cores, kind="port",
+                sample="1 IRLS iteration of a %d-view/%d-edge graph with the same p_loop "
+                       "(the full-size factorisation does not finish in minutes), %.1f s" % (n2, m2, dt),
+                note="oracle = C restatement + own sparse Cholesky; NOT Eigen+SuiteSparse")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--views", type=int, default=100000)
+    ap.add_argument("--edges", type=int, default=2000000)
+    ap.add_argument("--p-loop", type=float, default=0.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from irotavg_amd import capi
+
+    S, Q0 = build_problem(args.views, args.edges, args.p_loop, args.seed)
+    dev = local_rank if world > 1 else -1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Multi-GPU: see DESIGN.md "Multi-GPU". Until the vertex-range sharded solver lands, ranks
+    # > 0 idle and rank 0 solves the whole graph (reported honestly: scaling "strong").
+    G = None
+    if rank == 0 or world == 1:
+        G = capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=args.rtol, device=dev)
+        G.set_rotations(Q0)
+        G.snapshot_rotations()
+
+    def step():
+        G.restore_rotations()
+        return G.irls(4, SIG, 100, 1e-3)
+
+    res = None
+    for _ in range(args.warmup):
+        if G is not None:
+            res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if G is not None:
+            res = step()
+            G.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        iters = res["iters"]
+        st = G.stats()
+        value = S["m"] * iters * args.steps / dt
+        line = {
+            "metric": "IRLS edge-updates/sec (+ iters-to-converge)",
+            "value": value, "unit": "edge-updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "iters_to_converge": iters,
+            "config": {"workload": "synthetic SO(3) view-graph, %d views / %d edges, p_loop=%g, "
+                                   "sigma_n=0.01 rad, 5%% outliers among loop edges, seed %d; "
+                                   "f=1, init_mst start, Geman-McClure sigma=5deg, change_th=1e-3, "
+                                   "max_iters=100" % (S["n"], S["m"], args.p_loop, args.seed),
+                       "pcg_rtol": args.rtol, "pcg_iters_per_solve": st["pcg_iters"] / max(st["pcg_solves"], 1),
+                       "mg_level_rows": st["level_rows"], "parallelism": "1 GPU" if world == 1 else
+                       "rank 0 solves, %d ranks idle (sharded solver pending)" % (world - 1)},
+            "final_scores": [float(x) for x in res["scores"]],
+        }
+        kr = kernel_rooflines(G, S, st)
+        dom = "spmv"
+        line["roofline"] = {"kernel": "k_spmv_dot (level-0 CSR SpMV + fused dot, dominant PCG kernel)",
+                            "bound": "hbm", "achieved": kr[dom]["gbs"], "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": kr[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                            "ms_per_launch": kr[dom]["ms"], "algorithmic_bytes": kr[dom]["bytes"]}
+        line["roofline_edge_residual"] = {
+            "kernel": "k_edge_residual (K1, the kernel north_star names)", "bound": "hbm",
+            "achieved": kr["edge_residual"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": kr["edge_residual"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+            "ms_per_launch": kr["edge_residual"]["ms"], "algorithmic_bytes": kr["edge_residual"]["bytes"]}
+        line["kernels"] = {k: {kk: (float(vv) if not isinstance(vv, int) else vv) for kk, vv in v.items()}
+                           for k, v in kr.items()}
+        if not args.no_extra and world == 1 and args.p_loop == 0.0 and args.views == 100000:
+            # the other topology SURVEY.md 8(d) asks for: 2 % random loop-closure edges
+            S2, Q2 = build_problem(args.views, args.edges, 0.02, args.seed)
+            with capi.Graph(S2["I"], S2["QQ"], S2["n"], 1, pcg_rtol=args.rtol) as G2:
+                G2.set_rotations(Q2)
+                G2.snapshot_rotations()
+                G2.irls(4, SIG, 100, 1e-3)
+                t1 = time.perf_counter()
+                reps = 5
+                for _ in range(reps):
+                    G2.restore_rotations()
+                    r2 = G2.irls(4, SIG, 100, 1e-3)
+                G2.synchronize()
+                d2 = time.perf_counter() - t1
+                s2 = G2.stats()
+            line["also_p_loop_0.02"] = {"value": S2["m"] * r2["iters"] * reps / d2, "unit": "edge-updates/s",
+                                        "iters_to_converge": r2["iters"], "ms_per_step": 1e3 * d2 / reps,
+                                        "pcg_iters_per_solve": s2["pcg_iters"] / max(s2["pcg_solves"], 1)}
+        if not args.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline(S, Q0, args.p_loop)
+        G.close()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

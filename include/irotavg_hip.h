@@ -120,6 +120,10 @@ void irotavg_graph_destroy(irotavg_graph *g);
 
 int irotavg_graph_set_rotations(irotavg_graph *g, const double *Q, int64_t ldq); /* H2D, all n_total rows */
 int irotavg_graph_get_rotations(irotavg_graph *g, double *Q, int64_t ldq);       /* D2H */
+/* device-side snapshot / restore of the n_total rotations (e.g. to re-run a solve from the same
+ * initial rotations without a host round trip) */
+int irotavg_graph_snapshot_rotations(irotavg_graph *g);
+int irotavg_graph_restore_rotations(irotavg_graph *g);
 int irotavg_graph_get_weights(irotavg_graph *g, double *weights);                /* D2H, m */
 int irotavg_graph_set_weights(irotavg_graph *g, const double *weights);          /* H2D, m */
 

@@ -17,7 +17,8 @@ ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_CONVERGED = -5, -6, -7, -8
 SYMBOLS = [
     "irotavg_default_options", "irotavg_init_mst", "irotavg_make_A", "irotavg_l1ra", "irotavg_irls",
     "irotavg_quat_normalised", "irotavg_graph_create", "irotavg_graph_destroy",
-    "irotavg_graph_set_rotations", "irotavg_graph_get_rotations", "irotavg_graph_get_weights",
+    "irotavg_graph_set_rotations", "irotavg_graph_get_rotations",
+    "irotavg_graph_snapshot_rotations", "irotavg_graph_restore_rotations", "irotavg_graph_get_weights",
     "irotavg_graph_set_weights", "irotavg_graph_irls", "irotavg_graph_l1ra",
     "irotavg_graph_quat_normalised", "irotavg_graph_get_stats", "irotavg_graph_reset_stats",
     "irotavg_graph_synchronize", "irotavg_graph_edge_residual", "irotavg_graph_get_residuals",
@@ -86,6 +87,8 @@ def lib():
     L.irotavg_graph_destroy.restype = None
     L.irotavg_graph_set_rotations.argtypes = [vp, _dp, C.c_int64]
     L.irotavg_graph_get_rotations.argtypes = [vp, _dp, C.c_int64]
+    L.irotavg_graph_snapshot_rotations.argtypes = [vp]
+    L.irotavg_graph_restore_rotations.argtypes = [vp]
     L.irotavg_graph_get_weights.argtypes = [vp, _dp]
     L.irotavg_graph_set_weights.argtypes = [vp, _dp]
     L.irotavg_graph_irls.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_double,
@@ -184,6 +187,12 @@ class Graph:
         Q = np.zeros((self.n_total, 4), order="F")
         check(lib().irotavg_graph_get_rotations(self._h, _d(Q), Q.shape[0]), "get_rotations")
         return Q
+
+    def snapshot_rotations(self):
+        check(lib().irotavg_graph_snapshot_rotations(self._h), "snapshot_rotations")
+
+    def restore_rotations(self):
+        check(lib().irotavg_graph_restore_rotations(self._h), "restore_rotations")
 
     def get_weights(self):
         w = np.zeros(self.m)

@@ -267,6 +267,28 @@ int irotavg_graph_get_rotations(irotavg_graph *h, double *Q, int64_t ldq) {
     API_CATCH
 }
 
+int irotavg_graph_snapshot_rotations(irotavg_graph *h) {
+    if (!h) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    if (g.Qsnap.n < (size_t)g.n_total) g.Qsnap.alloc((size_t)g.n_total);
+    IRH_CHECK(hipMemcpyAsync(g.Qsnap.p, g.Q.p, sizeof(double4) * (size_t)g.n_total,
+                             hipMemcpyDeviceToDevice, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_graph_restore_rotations(irotavg_graph *h) {
+    if (!h || h->g.Qsnap.n < (size_t)h->g.n_total) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    IRH_CHECK(hipMemcpyAsync(g.Q.p, g.Qsnap.p, sizeof(double4) * (size_t)g.n_total,
+                             hipMemcpyDeviceToDevice, g.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+
 int irotavg_graph_get_weights(irotavg_graph *h, double *w) {
     if (!h || !w) return IROTAVG_ERR_BAD_ARG;
     API_TRY
@@ -444,22 +466,14 @@ int irotavg_l1ra(int64_t m, int64_t n_total, int f, const int32_t *I, const doub
     return rc;
 }
 
-// O(n) normalisation of host data: Eigen normalized() per row (ral/l1_irls.cpp:982-991). The
-// device-resident variant is irotavg_graph_quat_normalised.
+// replaces irotavg::quat_normalised for host-resident rows: Eigen normalized() per row
+// (ral/l1_irls.cpp:982-991), evaluated by the same device kernel as the resident variant.
 int irotavg_quat_normalised(int64_t n, double *Q, int64_t ldq, int f) {
-    if (!Q || n < 0 || ldq < n || f < 0) return IROTAVG_ERR_BAD_ARG;
-    for (int64_t i = f; i < n; i++) {
-        const double x = Q[i], y = Q[ldq + i], z = Q[2 * ldq + i], w = Q[3 * ldq + i];
-        const double n2 = x * x + y * y + z * z + w * w;
-        if (n2 > 0.0) {
-            const double nn = std::sqrt(n2);
-            Q[i] = x / nn;
-            Q[ldq + i] = y / nn;
-            Q[2 * ldq + i] = z / nn;
-            Q[3 * ldq + i] = w / nn;
-        }
-    }
-    return IROTAVG_OK;
+    if (!Q || n < 0 || ldq < n || f < 0 || n > 0x7fffffffLL) return IROTAVG_ERR_BAD_ARG;
+    if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
+    API_TRY
+    return normalise_host_rows(n, Q, ldq, f);
+    API_CATCH
 }
 
 }  // extern "C"

@@ -36,6 +36,7 @@ struct Graph {
     DevBuf<double> dw;  // IRLS weights d_k (m)
     // views
     DevBuf<double4> Q;  // n_total quaternions [x y z w], gather-friendly AoS
+    DevBuf<double4> Qsnap;
 
     // level-0 adjacency extras (CSR itself lives in levels[0])
     DevBuf<uint32_t> slot_eid;  // per inner slot: (edge id << 1) | (row is the j endpoint)
@@ -85,6 +86,7 @@ void normalise_rotations(Graph &g);
 void fill(Graph &g, double *p, long long n, double v);
 void assemble(Graph &g, int mode, const double *wsrc);
 int pcg_solve(Graph &g);
+int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f);
 
 inline double now_seconds() {
     using namespace std::chrono;

@@ -1,12 +1,528 @@
-// l1pd.hip -- L1RA: primal-dual interior point per coordinate (ral/l1_irls.cpp:228-468, 851-912).
+// l1pd.hip -- L1RA: the primal-dual interior-point LP of ral/l1_irls.cpp:228-468 (one coordinate
+// of min ||A x - y||_1 per call, x0 = 0) and its outer loop, ral/l1_irls.cpp:851-912.
+//
+// Edge-length vectors (u, Ax, fu1, fu2, lamu1, lamu2, ...) live as planes of `pd`; the ~25
+// element-wise statements of one primal-dual iteration are grouped into a handful of streaming
+// kernels; A x is an edge-parallel gather, A' y a view-parallel walk over the incident-edge
+// slots (no atomics), and H11p dx = w1p (UMFPACK in the reference, :308-319) is solved by the
+// same multigrid-PCG as the IRLS step with the matrix values refreshed from sigx under
+// make_AtA's boundary rule (:825-843). Control flow (step length, backtracking, stopping) runs on
+// the host from fixed-order reductions, statement for statement as the reference.
 #include "graph.hpp"
 #include "kernels.hpp"
 
 namespace irh {
 
-int l1decode_pd_dev(Graph &, int, const double *, int, double *, int *, int) {
-    return IROTAVG_ERR_BAD_ARG;  // placeholder, implemented next
+enum PdPlane : int {
+    P_Y = 0, P_U, P_AX, P_F1, P_F2, P_L1, P_L2, P_SIGX, P_T1, P_T2, P_ADX, P_DU, P_DL1, P_DL2,
+    P_COUNT
+};
+enum PdnPlane : int { N_X = 0, N_ATV, N_ATDV, N_X0, N_X1, N_X2, N_COUNT };
+
+static void pd_prepare(Graph &g) {
+    if (g.pd_ready) return;
+    g.pd.alloc((size_t)P_COUNT * g.mpad);
+    g.pd.zero(g.stream);
+    g.pdn.alloc((size_t)N_COUNT * g.nu);
+    g.pdn.zero(g.stream);
+    g.pd_part.alloc((size_t)kMaxParts * 4);
+    g.pd_part.zero(g.stream);
+    g.pd_ready = true;
 }
-int run_l1ra(Graph &, int, double, int *, double *, double *) { return IROTAVG_ERR_BAD_ARG; }
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// workgroup min/max -> part[0]
+template <bool MAX>
+__device__ __forceinline__ void block_ext_store(double v, double *part) {
+    __shared__ double sm[kBlock / 64];
+    v = MAX ? wave_max(v) : wave_min(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = MAX ? fmax(r, sm[i]) : fmin(r, sm[i]);
+        part[0] = r;
+        part[1] = part[2] = part[3] = 0.0;
+    }
+    __syncthreads();
+}
+
+#define EDGE_LOOP(k) \
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += (long long)gridDim.x * blockDim.x)
+
+// max_k |y - Ax|   (ral/l1_irls.cpp:250-253)
+__global__ __launch_bounds__(kBlock) void k_pd_absmax(long long m, const double *__restrict__ y,
+                                                      const double *__restrict__ Ax,
+                                                      double *__restrict__ part) {
+    double v = -HUGE_VAL;
+    EDGE_LOOP(k) v = fmax(v, fabs(y[k] - Ax[k]));
+    block_ext_store<true>(v, part + 4 * blockIdx.x);
+}
+
+// :252-259, 262 (operand of A'), 264, 272-276 (tail of rdual)
+__global__ __launch_bounds__(kBlock) void k_pd_init(long long m, const double *__restrict__ y,
+                                                    const double *__restrict__ Ax, double maxabs,
+                                                    double *__restrict__ u, double *__restrict__ f1,
+                                                    double *__restrict__ f2, double *__restrict__ l1,
+                                                    double *__restrict__ l2, double *__restrict__ t,
+                                                    double *__restrict__ part) {
+    double a0 = 0, a1 = 0, a2 = 0;
+    EDGE_LOOP(k) {
+        const double ax = Ax[k], yy = y[k];
+        const double uu = fabs(yy - ax) * 0.95 + maxabs * 0.10;
+        const double g1 = ax - yy - uu, g2 = -ax + yy - uu;
+        const double m1 = -(1.0 / g1), m2 = -(1.0 / g2);
+        u[k] = uu;
+        f1[k] = g1;
+        f2[k] = g2;
+        l1[k] = m1;
+        l2[k] = m2;
+        t[k] = m1 - m2;
+        a0 += g1 * m1;
+        a1 += g2 * m2;
+        const double rd = 1.0 - m1 - m2;
+        a2 += rd * rd;
+    }
+    block_sum3_store(a0, a1, a2, part + 4 * blockIdx.x);
+}
+
+// sum of squares of rcent = [-lamu1.*fu1; -lamu2.*fu2] - 1/tau  (:267-270, 450-453)
+__global__ __launch_bounds__(kBlock) void k_pd_rcent(long long m, const double *__restrict__ f1,
+                                                     const double *__restrict__ f2,
+                                                     const double *__restrict__ l1,
+                                                     const double *__restrict__ l2, double itau,
+                                                     double *__restrict__ part) {
+    double a0 = 0;
+    EDGE_LOOP(k) {
+        const double c1 = -l1[k] * f1[k] - itau, c2 = -l2[k] * f2[k] - itau;
+        a0 += c1 * c1 + c2 * c2;
+    }
+    block_sum3_store(a0, 0.0, 0.0, part + 4 * blockIdx.x);
+}
+
+// :292-305 -- sigx and the two operands of A' (t1 for w1, t2 for w1p)
+__global__ __launch_bounds__(kBlock) void k_pd_sig(long long m, const double *__restrict__ f1,
+                                                   const double *__restrict__ f2,
+                                                   const double *__restrict__ l1,
+                                                   const double *__restrict__ l2, double itau,
+                                                   double *__restrict__ sigx, double *__restrict__ t1,
+                                                   double *__restrict__ t2) {
+    EDGE_LOOP(k) {
+        const double if1 = 1.0 / f1[k], if2 = 1.0 / f2[k];
+        const double w2 = -1 - itau * (if1 + if2);
+        const double a = l1[k] / f1[k], b = l2[k] / f2[k];
+        const double s1 = -a - b, s2 = a - b;
+        sigx[k] = s1 - (s2 * s2) / s1;
+        t1[k] = -if1 + if2;
+        t2[k] = (s2 / s1) * w2;
+    }
+}
+
+// view-parallel A' y over the incident-edge slots (make_A coefficients: +1 for the j endpoint,
+// -1 for the i endpoint, boundary slots only when make_A kept the coefficient).
+template <int G>
+__device__ __forceinline__ double at_row(int row, int l, const int *__restrict__ rowptr,
+                                         const uint32_t *__restrict__ slot_eid,
+                                         const int *__restrict__ bptr,
+                                         const uint32_t *__restrict__ beid,
+                                         const uint8_t *__restrict__ bflag,
+                                         const double *__restrict__ t) {
+    double s = 0.0;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int q = beg + l; q < end; q += G) {
+        const uint32_t se = slot_eid[q];
+        const double v = t[se >> 1];
+        s += (se & 1u) ? v : -v;
+    }
+    const int bb = bptr[row], be = bptr[row + 1];
+    for (int q = bb + l; q < be; q += G) {
+        if (!(bflag[q] & BF_IRLS)) continue;
+        const uint32_t se = beid[q];
+        const double v = t[se >> 1];
+        s += (se & 1u) ? v : -v;
+    }
+    return s;
+}
+
+// out = A' t, partial sum of out^2
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_at_mul(int n, const int *__restrict__ rowptr,
+                                                   const uint32_t *__restrict__ slot_eid,
+                                                   const int *__restrict__ bptr,
+                                                   const uint32_t *__restrict__ beid,
+                                                   const uint8_t *__restrict__ bflag,
+                                                   const double *__restrict__ t,
+                                                   double *__restrict__ out,
+                                                   double *__restrict__ part) {
+    constexpr int R = kBlock / G;
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int ntiles = (n + R - 1) / R;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    double acc = 0.0;
+    for (int tt = t0; tt < t1; tt++) {
+        const int row = tt * R + grp;
+        double s = row < n ? at_row<G>(row, l, rowptr, slot_eid, bptr, beid, bflag, t) : 0.0;
+        s = group_sum<G>(s);
+        if (l == 0 && row < n) {
+            out[row] = s;
+            acc += s * s;
+        }
+    }
+    block_sum3_store(acc, 0.0, 0.0, part + 4 * blockIdx.x);
+}
+
+// rhs = w1p = -(1/tau) A' t1 - A' t2   (:300-306), stored in component 0 of the PCG rhs
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_pd_rhs(int n, const int *__restrict__ rowptr,
+                                                   const uint32_t *__restrict__ slot_eid,
+                                                   const int *__restrict__ bptr,
+                                                   const uint32_t *__restrict__ beid,
+                                                   const uint8_t *__restrict__ bflag,
+                                                   const double *__restrict__ t1,
+                                                   const double *__restrict__ t2, double itau,
+                                                   double4 *__restrict__ rhs) {
+    constexpr int R = kBlock / G;
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int ntiles = (n + R - 1) / R;
+    int t0, t1r;
+    tile_range(ntiles, t0, t1r);
+    for (int tt = t0; tt < t1r; tt++) {
+        const int row = tt * R + grp;
+        double a = 0.0, b = 0.0;
+        if (row < n) {
+            a = at_row<G>(row, l, rowptr, slot_eid, bptr, beid, bflag, t1);
+            b = at_row<G>(row, l, rowptr, slot_eid, bptr, beid, bflag, t2);
+        }
+        a = group_sum<G>(a);
+        b = group_sum<G>(b);
+        if (l == 0 && row < n) {
+            const double w1 = -itau * a;
+            rhs[row] = make_double4(w1 - b, 0.0, 0.0, 0.0);
+        }
+    }
+}
+
+// :324-381 -- Adx, du, dlamu1, dlamu2, operand of A' (Atdv), and the four guarded step bounds
+__global__ __launch_bounds__(kBlock) void k_pd_dir(
+    long long m, int f, const int *__restrict__ ei, const int *__restrict__ ej,
+    const uint8_t *__restrict__ eflag, const double4 *__restrict__ DX,
+    const double *__restrict__ f1, const double *__restrict__ f2, const double *__restrict__ l1,
+    const double *__restrict__ l2, double itau, double *__restrict__ Adx, double *__restrict__ du,
+    double *__restrict__ dl1, double *__restrict__ dl2, double *__restrict__ t3,
+    double *__restrict__ part) {
+    double smin = HUGE_VAL;
+    EDGE_LOOP(k) {
+        const uint8_t fl = eflag[k];
+        double adx = 0.0;
+        if (fl & EF_CJ) adx += DX[ej[k] - f].x;
+        if (fl & EF_CI) adx -= DX[ei[k] - f].x;
+        const double g1 = f1[k], g2 = f2[k], m1 = l1[k], m2 = l2[k];
+        const double if1 = 1.0 / g1, if2 = 1.0 / g2;
+        const double w2 = -1 - itau * (if1 + if2);
+        const double a = m1 / g1, b = m2 / g2;
+        const double s1 = -a - b, s2 = a - b;
+        const double d_u = (w2 - s2 * adx) / s1;
+        double d1 = -m1 / g1;
+        d1 *= (adx - d_u);
+        d1 -= m1;
+        d1 -= itau * if1;
+        double d2 = m2 / g2;
+        d2 *= (adx + d_u);
+        d2 -= m2;
+        d2 -= itau * if2;
+        Adx[k] = adx;
+        du[k] = d_u;
+        dl1[k] = d1;
+        dl2[k] = d2;
+        t3[k] = d1 - d2;
+        if (d1 < 0) smin = fmin(smin, -m1 / d1);
+        if (d2 < 0) smin = fmin(smin, -m2 / d2);
+        const double p = adx - d_u;
+        if (p > 0) smin = fmin(smin, -g1 / p);
+        const double q = -adx - d_u;
+        if (q > 0) smin = fmin(smin, -g2 / q);
+    }
+    block_ext_store<false>(smin, part + 4 * blockIdx.x);
+}
+
+// trial point at step s: sums of squares of the m-tail of rdp (:407-410) and of rcp (:412-416)
+__global__ __launch_bounds__(kBlock) void k_pd_trial_edge(
+    long long m, const double *__restrict__ y, double s, double itau, const double *__restrict__ u,
+    const double *__restrict__ du, const double *__restrict__ Ax, const double *__restrict__ Adx,
+    const double *__restrict__ l1, const double *__restrict__ dl1, const double *__restrict__ l2,
+    const double *__restrict__ dl2, double *__restrict__ part) {
+    double a0 = 0, a1 = 0;
+    EDGE_LOOP(k) {
+        const double up = u[k] + s * du[k];
+        const double axp = Ax[k] + s * Adx[k];
+        const double m1 = l1[k] + s * dl1[k], m2 = l2[k] + s * dl2[k];
+        const double g1 = axp - y[k] - up, g2 = -axp + y[k] - up;
+        const double r = 1.0 + (-m1 - m2);
+        a0 += r * r;
+        const double c1 = -m1 * g1 - itau, c2 = -m2 * g2 - itau;
+        a1 += c1 * c1 + c2 * c2;
+    }
+    block_sum3_store(a0, a1, 0.0, part + 4 * blockIdx.x);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pd_trial_vert(int n, double s,
+                                                          const double *__restrict__ Atv,
+                                                          const double *__restrict__ Atdv,
+                                                          double *__restrict__ part) {
+    double a0 = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double v = Atv[i] + s * Atdv[i];
+        a0 += v * v;
+    }
+    block_sum3_store(a0, 0.0, 0.0, part + 4 * blockIdx.x);
+}
+
+// accept the trial point (:432-442) and produce the new surrogate duality gap sums (:446)
+__global__ __launch_bounds__(kBlock) void k_pd_commit_edge(
+    long long m, const double *__restrict__ y, double s, double *__restrict__ u,
+    const double *__restrict__ du, double *__restrict__ Ax, const double *__restrict__ Adx,
+    double *__restrict__ l1, const double *__restrict__ dl1, double *__restrict__ l2,
+    const double *__restrict__ dl2, double *__restrict__ f1, double *__restrict__ f2,
+    double *__restrict__ part) {
+    double a0 = 0, a1 = 0;
+    EDGE_LOOP(k) {
+        const double up = u[k] + s * du[k];
+        const double axp = Ax[k] + s * Adx[k];
+        const double m1 = l1[k] + s * dl1[k], m2 = l2[k] + s * dl2[k];
+        const double g1 = axp - y[k] - up, g2 = -axp + y[k] - up;
+        u[k] = up;
+        Ax[k] = axp;
+        l1[k] = m1;
+        l2[k] = m2;
+        f1[k] = g1;
+        f2[k] = g2;
+        a0 += g1 * m1;
+        a1 += g2 * m2;
+    }
+    block_sum3_store(a0, a1, 0.0, part + 4 * blockIdx.x);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pd_commit_vert(int n, double s, double *__restrict__ x,
+                                                           const double4 *__restrict__ DX,
+                                                           double *__restrict__ Atv,
+                                                           const double *__restrict__ Atdv) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        x[i] += s * DX[i].x;
+        Atv[i] += s * Atdv[i];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pack3(int n, const double *__restrict__ x0,
+                                                  const double *__restrict__ x1,
+                                                  const double *__restrict__ x2,
+                                                  double4 *__restrict__ X) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        X[i] = make_double4(x0[i], x1[i], x2[i], 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+static int grid_edges(long long m) {
+    long long gsz = std::min<long long>((m + kBlock - 1) / kBlock, kMaxParts);
+    if (gsz >= 8) gsz &= ~7ll;
+    return (int)std::max<long long>(gsz, 1);
+}
+static int grid_elems(int n) { return grid_edges(n); }
+static int grid_rows(int n, int lanes) {
+    const int R = kBlock / lanes;
+    int gsz = std::min((n + R - 1) / R, (int)kMaxParts);
+    if (gsz >= 8) gsz &= ~7;
+    return std::max(gsz, 1);
+}
+
+// fixed-order host sum of the first `cols` columns of a partial array
+static void fetch_parts(Graph &g, int nparts, double out[3]) {
+    IRH_CHECK(hipMemcpyAsync(g.h_part.data(), g.pd_part.p, sizeof(double) * 4 * (size_t)nparts,
+                             hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    out[0] = out[1] = out[2] = 0.0;
+    for (int b = 0; b < nparts; b++)
+        for (int c = 0; c < 3; c++) out[c] += g.h_part[4 * (size_t)b + c];
+}
+static double fetch_ext(Graph &g, int nparts, bool is_max) {
+    IRH_CHECK(hipMemcpyAsync(g.h_part.data(), g.pd_part.p, sizeof(double) * 4 * (size_t)nparts,
+                             hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    double r = g.h_part[0];
+    for (int b = 1; b < nparts; b++)
+        r = is_max ? std::max(r, g.h_part[4 * (size_t)b]) : std::min(r, g.h_part[4 * (size_t)b]);
+    return r;
+}
+
+#define PD_LANES(lanes, CALL)                        \
+    switch (lanes) {                                 \
+    case 2: { constexpr int G = 2; CALL; } break;    \
+    case 4: { constexpr int G = 4; CALL; } break;    \
+    case 8: { constexpr int G = 8; CALL; } break;    \
+    case 16: { constexpr int G = 16; CALL; } break;  \
+    case 32: { constexpr int G = 32; CALL; } break;  \
+    default: { constexpr int G = 64; CALL; } break;  \
+    }
+
+// One coordinate. y: device pointer (plane of er, or P_Y). Result in pdn plane `xplane`.
+static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, int *stuck) {
+    const double PDTOL = 1e-3, alpha = 0.01, beta = 0.5, mu = 10;  // :231-238
+    const long long m = g.m;
+    const int n = g.nu;
+    Level &L0 = g.levels[0];
+    const int ge = grid_edges(m), gv = grid_elems(n), gr = grid_rows(n, L0.lanes);
+    hipStream_t st = g.stream;
+    double *P = g.pd.p;
+    auto pl = [&](int i) { return P + (size_t)i * g.mpad; };
+    double *x = g.pdn.p + (size_t)xplane * n;
+    double *Atv = g.pdn.p + (size_t)N_ATV * n, *Atdv = g.pdn.p + (size_t)N_ATDV * n;
+    double s3[3];
+    if (stuck) *stuck = 0;
+
+    IRH_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, st));             // x0 = 0
+    IRH_CHECK(hipMemsetAsync(pl(P_AX), 0, sizeof(double) * (size_t)g.mpad, st));  // Ax = A*0
+    hipLaunchKernelGGL(k_pd_absmax, dim3(ge), dim3(kBlock), 0, st, m, y, pl(P_AX), g.pd_part.p);
+    const double maxabs = fetch_ext(g, ge, true);
+    hipLaunchKernelGGL(k_pd_init, dim3(ge), dim3(kBlock), 0, st, m, y, pl(P_AX), maxabs, pl(P_U),
+                       pl(P_F1), pl(P_F2), pl(P_L1), pl(P_L2), pl(P_T1), g.pd_part.p);
+    fetch_parts(g, ge, s3);
+    double sdg = -(s3[0] + s3[1]);           // :264
+    double tau = mu * 2 * (double)m / sdg;   // :265
+    double rd_tail2 = s3[2];
+    PD_LANES(L0.lanes, hipLaunchKernelGGL((k_at_mul<G>), dim3(gr), dim3(kBlock), 0, st, n,
+                                          L0.rowptr.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p,
+                                          pl(P_T1), Atv, g.pd_part.p));
+    fetch_parts(g, gr, s3);
+    const double atv2 = s3[0];
+    hipLaunchKernelGGL(k_pd_rcent, dim3(ge), dim3(kBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
+                       pl(P_L2), 1.0 / tau, g.pd_part.p);
+    fetch_parts(g, ge, s3);
+    double resnorm = std::sqrt(atv2 + rd_tail2 + s3[0]);  // :278-281
+
+    int pditer = 0;
+    bool done = (sdg < PDTOL) || (pditer >= pdmaxiter);  // :284
+    while (!done) {
+        pditer++;
+        const double itau = 1.0 / tau;
+        hipLaunchKernelGGL(k_pd_sig, dim3(ge), dim3(kBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
+                           pl(P_L2), itau, pl(P_SIGX), pl(P_T1), pl(P_T2));
+        assemble(g, 1, pl(P_SIGX));
+        PD_LANES(L0.lanes, hipLaunchKernelGGL((k_pd_rhs<G>), dim3(gr), dim3(kBlock), 0, st, n,
+                                              L0.rowptr.p, g.slot_eid.p, g.bptr.p, g.beid.p,
+                                              g.bflag.p, pl(P_T1), pl(P_T2), itau, L0.b.p));
+        int rc = pcg_solve(g);  // dx in g.X component 0
+        if (rc != IROTAVG_OK) return rc == IROTAVG_ERR_NOT_CONVERGED ? rc : IROTAVG_ERR_SOLVER;
+        hipLaunchKernelGGL(k_pd_dir, dim3(ge), dim3(kBlock), 0, st, m, g.f, g.ei.p, g.ej.p,
+                           g.eflag.p, g.X.p, pl(P_F1), pl(P_F2), pl(P_L1), pl(P_L2), itau, pl(P_ADX),
+                           pl(P_DU), pl(P_DL1), pl(P_DL2), pl(P_T1), g.pd_part.p);
+        double s = std::fmin(1.0, fetch_ext(g, ge, false));  // :347-380
+        if (!(s == s)) return IROTAVG_ERR_SOLVER;
+        s *= 0.99;                                            // :381
+        PD_LANES(L0.lanes, hipLaunchKernelGGL((k_at_mul<G>), dim3(gr), dim3(kBlock), 0, st, n,
+                                              L0.rowptr.p, g.slot_eid.p, g.bptr.p, g.beid.p,
+                                              g.bflag.p, pl(P_T1), Atdv, g.pd_part.p));
+        // backtracking (:384-429)
+        bool suffdec = false;
+        int backiter = 0;
+        double s_acc = s, rdp2 = 0.0;
+        while (!suffdec) {
+            hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv), dim3(kBlock), 0, st, n, s, Atv, Atdv,
+                               g.pd_part.p);
+            fetch_parts(g, gv, s3);
+            const double rdv = s3[0];
+            hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge), dim3(kBlock), 0, st, m, y, s, itau,
+                               pl(P_U), pl(P_DU), pl(P_AX), pl(P_ADX), pl(P_L1), pl(P_DL1), pl(P_L2),
+                               pl(P_DL2), g.pd_part.p);
+            fetch_parts(g, ge, s3);
+            rdp2 = rdv + s3[0];
+            suffdec = std::sqrt(rdp2 + s3[1]) <= (1 - alpha * s) * resnorm;  // :419
+            s_acc = s;
+            s *= beta;
+            backiter++;
+            if (backiter > 32) {  // :423-428 -- return the previous iterate
+                if (stuck) *stuck = 1;
+                return IROTAVG_OK;
+            }
+        }
+        hipLaunchKernelGGL(k_pd_commit_vert, dim3(gv), dim3(kBlock), 0, st, n, s_acc, x, g.X.p, Atv,
+                           Atdv);
+        hipLaunchKernelGGL(k_pd_commit_edge, dim3(ge), dim3(kBlock), 0, st, m, y, s_acc, pl(P_U),
+                           pl(P_DU), pl(P_AX), pl(P_ADX), pl(P_L1), pl(P_DL1), pl(P_L2), pl(P_DL2),
+                           pl(P_F1), pl(P_F2), g.pd_part.p);
+        fetch_parts(g, ge, s3);
+        sdg = -(s3[0] + s3[1]);             // :446
+        tau = mu * 2 * (double)m / sdg;     // :448
+        hipLaunchKernelGGL(k_pd_rcent, dim3(ge), dim3(kBlock), 0, st, m, pl(P_F1), pl(P_F2),
+                           pl(P_L1), pl(P_L2), 1.0 / tau, g.pd_part.p);
+        fetch_parts(g, ge, s3);
+        resnorm = std::sqrt(rdp2 + s3[0]);  // :455-458
+        done = (sdg < PDTOL) || (pditer >= pdmaxiter);  // :460
+    }
+    return IROTAVG_OK;
+}
+
+int l1decode_pd_dev(Graph &g, int er_plane, const double *y_host, int pdmaxiter, double *x_host,
+                    int *stuck, int /*unused*/) {
+    pd_prepare(g);
+    const double *y;
+    if (er_plane >= 0) {
+        y = g.er.p + (size_t)er_plane * g.mpad;
+    } else {
+        double *yp = g.pd.p + (size_t)P_Y * g.mpad;
+        IRH_CHECK(hipMemcpyAsync(yp, y_host, sizeof(double) * (size_t)g.m, hipMemcpyHostToDevice,
+                                 g.stream));
+        y = yp;
+    }
+    const int rc = l1decode_core(g, y, pdmaxiter, N_X, stuck);
+    if (x_host) {
+        IRH_CHECK(hipMemcpyAsync(x_host, g.pdn.p + (size_t)N_X * g.nu, sizeof(double) * (size_t)g.nu,
+                                 hipMemcpyDeviceToHost, g.stream));
+        IRH_CHECK(hipStreamSynchronize(g.stream));
+    }
+    return rc;
+}
+
+// ral/l1_irls.cpp:851-912
+int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runtime,
+             double *trace) {
+    pd_prepare(g);
+    const double tic = now_seconds();
+    double score = HUGE_VAL;
+    int l1_step = 2;  // :868
+    int it = 0, rc = IROTAVG_OK;
+    const int n = g.nu;
+    while (((score >= change_th) || (l1_step < 2)) && (it < max_iters)) {  // :877, >=
+        if (score < change_th) {  // :879-883 -- unreachable under the guard above; kept literal
+            l1_step *= 4;
+            change_th /= 100.0;
+        }
+        launch_edge_residual(g);
+        for (int c = 0; c < 3 && rc == IROTAVG_OK; c++)  // :889-892
+            rc = l1decode_core(g, g.er.p + (size_t)c * g.mpad, l1_step, N_X0 + c, nullptr);
+        if (rc != IROTAVG_OK) break;
+        hipLaunchKernelGGL(k_pack3, dim3(grid_elems(n)), dim3(kBlock), 0, g.stream, n,
+                           g.pdn.p + (size_t)N_X0 * n, g.pdn.p + (size_t)N_X1 * n,
+                           g.pdn.p + (size_t)N_X2 * n, g.X.p);
+        score = apply_step(g);  // :894-902
+        if (trace) trace[it] = score;
+        it++;
+    }
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    const double toc = now_seconds();
+    *iters = it;
+    *runtime = toc - tic;
+    g.stats.outer_iters += it;
+    g.stats.seconds_l1ra += toc - tic;
+    return rc;
+}
 
 }  // namespace irh

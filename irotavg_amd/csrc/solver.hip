@@ -710,6 +710,27 @@ void normalise_rotations(Graph &g) {
                        (int)g.n_total, g.f, g.Q.p);
 }
 
+// one-shot variant for host-resident rows (irotavg_quat_normalised): staged through HBM so the
+// arithmetic is the same kernel as the resident path
+int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f) {
+    if (n - f <= 0) return IROTAVG_OK;
+    DevBuf<double4> d;
+    std::vector<double4> h((size_t)n);
+    for (int64_t i = 0; i < n; i++) h[i] = make_double4(Q[i], Q[ldq + i], Q[2 * ldq + i], Q[3 * ldq + i]);
+    d.alloc((size_t)n);
+    IRH_CHECK(hipMemcpy(d.p, h.data(), sizeof(double4) * (size_t)n, hipMemcpyHostToDevice));
+    const int cnt = (int)(n - f);
+    hipLaunchKernelGGL(k_normalise, dim3((cnt + 255) / 256), dim3(256), 0, 0, (int)n, f, d.p);
+    IRH_CHECK(hipMemcpy(h.data(), d.p, sizeof(double4) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int64_t i = f; i < n; i++) {
+        Q[i] = h[i].x;
+        Q[ldq + i] = h[i].y;
+        Q[2 * ldq + i] = h[i].z;
+        Q[3 * ldq + i] = h[i].w;
+    }
+    return IROTAVG_OK;
+}
+
 // =============================================================================================
 // host drivers
 // =============================================================================================
