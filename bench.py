@@ -57,7 +57,8 @@ def kernel_rooflines(G, S, st):
     for name, w in which.items():
         ms = G.time_kernel(w, 50)
         out[name] = dict(ms=ms, bytes=alg[name], gbs=alg[name] / (ms * 1e-3) / 1e9)
-    out["vcycle"] = dict(ms=G.time_kernel(5, 50))
+    out["precondition"] = dict(ms=G.time_kernel(5, 50))
+    out["dense_inversion"] = dict(ms=G.time_kernel(7, 5))
     return out
 
 

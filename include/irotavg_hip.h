@@ -51,12 +51,14 @@ typedef struct irotavg_options {
     int pcg_check_every; /* PCG iterations enqueued between host polls of the done flag; default 8 */
     int mg_levels_max;   /* cap on multigrid levels (1 = plain Jacobi-PCG); default 16 */
     int mg_agg0;         /* aggregate size of the finest level (0 = choose from the mean degree) */
-    int mg_agg;          /* aggregate size of the other levels; default 4 */
-    int mg_dense_max;    /* coarsest level is inverted densely once it has <= this many rows; default 64 */
+    int mg_agg;          /* aggregate size of the other levels (0 = choose; default) */
+    int mg_dense_max;    /* coarsening stops at <= this many rows; that level is inverted densely
+                            (blocked Gauss-Jordan on the GPU) and applied exactly; default and cap 2048 */
     double mg_omega;     /* damped-Jacobi factor; default 0.7 */
     double mg_kc;        /* coarse-correction scale; default 1.0 */
     int device;          /* HIP device ordinal; -1 = current device */
-    int reserved[7];
+    int reserved[7];     /* reserved[0] = 1: multiplicative V-cycle on level 0 (default: additive top level);
+                            reserved[1] = 1: re-invert the dense coarse level at every solve (default: adaptive) */
 } irotavg_options;
 
 void irotavg_default_options(irotavg_options *opt);
@@ -161,8 +163,9 @@ int irotavg_graph_l1decode_pd(irotavg_graph *g, const double *y, int pdmaxiter, 
 
 /* Times `reps` back-to-back launches of one kernel with HIP events on the handle's stream and
  * returns the mean milliseconds per launch. which: 1 = K1 edge_residual, 2 = K2 weight update
- * (Geman-McClure), 3 = level-0 assembly, 4 = level-0 SpMV (q = L p), 5 = one multigrid V-cycle,
- * 6 = so(3) step kernel (non-destructive variant). */
+ * (Geman-McClure), 3 = matrix assembly (all levels, without the dense inversion), 4 = level-0 SpMV
+ * (q = L p), 5 = one preconditioner application, 6 = so(3) step kernel (non-destructive variant),
+ * 7 = dense coarse-level inversion (blocked Gauss-Jordan). */
 int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_per_launch);
 
 /* library / device info */

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libirotavg_hip.so")
-SOURCES = ["build.cpp", "solver.hip", "l1pd.hip", "capi.cpp"]
+SOURCES = ["build.cpp", "solver.hip", "dense.hip", "l1pd.hip", "capi.cpp"]
 HEADERS = ["common.hpp", "graph.hpp", "kernels.hpp", "../../include/irotavg_hip.h"]
 
 

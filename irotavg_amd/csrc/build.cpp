@@ -21,10 +21,31 @@ static int pow2floor(int v) {
     return p;
 }
 
-static int choose_lanes(int64_t nnz, int n) {
-    int avg = n > 0 ? (int)((nnz + n - 1) / n) : 1;
-    int l = pow2floor(std::max(avg / 2, 1));
-    return std::min(std::max(l, 2), 64);
+// SELL-64 positions of a CSR pattern: pos[t] for every CSR slot t, slice offsets, padded length
+struct SellMap {
+    int nsl = 0;
+    std::vector<int> sl_off;  // nsl + 1
+    std::vector<int> pos;     // per CSR slot
+    long long len = 0;        // 64 * sl_off[nsl]
+};
+static SellMap sell_map(int n, const std::vector<int> &rowptr) {
+    SellMap M;
+    M.nsl = (n + 63) / 64;
+    M.sl_off.assign((size_t)M.nsl + 1, 0);
+    for (int sl = 0; sl < M.nsl; sl++) {
+        int w = 0;
+        for (int r = sl * 64; r < std::min(n, sl * 64 + 64); r++) w = std::max(w, rowptr[r + 1] - rowptr[r]);
+        w = (w + kSellUnroll - 1) / kSellUnroll * kSellUnroll;  // whole batches of the row loops
+        M.sl_off[sl + 1] = M.sl_off[sl] + w;
+    }
+    M.len = 64ll * M.sl_off[M.nsl];
+    M.pos.resize((size_t)rowptr[n]);
+    for (int r = 0; r < n; r++) {
+        const int sl = r >> 6, lane = r & 63;
+        for (int t = rowptr[r]; t < rowptr[r + 1]; t++)
+            M.pos[t] = (M.sl_off[sl] + (t - rowptr[r])) * 64 + lane;
+    }
+    return M;
 }
 
 int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
@@ -134,17 +155,16 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     ents.clear();
     ents.shrink_to_fit();
 
-    g.slot_eid.upload(slot_eid, s);
     g.bptr.upload(bptr, s);
     g.beid.upload(beid, s);
     g.bflag.upload(bflag, s);
 
     // ---- hierarchy ----------------------------------------------------------------------
-    // Host patterns of every level first, uploads second.
+    // Host CSR patterns of every level first, SELL conversion + uploads second.
     struct HostLevel {
         int n = 0, agg = 0;
-        std::vector<int> rowptr, col;  // off-diagonal pattern
-        std::vector<int> cptr, cidx;   // value refresh from the finer level (empty on level 0)
+        std::vector<int> rowptr, col;  // off-diagonal pattern (CSR, host only)
+        std::vector<int> cptr, cidx;   // value refresh from the finer level (CSR slots of the finer level)
     };
     std::vector<HostLevel> H;
     H.emplace_back();
@@ -155,15 +175,19 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     while ((int)H.size() < max_levels && H.back().n > g.opt.mg_dense_max) {
         HostLevel &F = H.back();
         const int64_t fnnz = F.rowptr[F.n];
-        const int lanes = choose_lanes(fnnz, F.n);
-        // aggregate = `agg` contiguous rows; agg divides the rows-per-block of the row kernels
+        // aggregate = `agg` contiguous rows, a power of two <= 64 so it never straddles a slice
         int agg = (H.size() == 1) ? g.opt.mg_agg0 : g.opt.mg_agg;
-        if (H.size() == 1 && agg <= 0) {
-            const int avg = F.n > 0 ? (int)(fnnz / F.n) : 0;
-            agg = avg >= 16 ? 8 : (avg >= 6 ? 4 : 2);
+        if (agg <= 0) {
+            (void)fnnz;
+            agg = 8;  // few, large steps: every extra level costs two latency-bound sweeps per cycle
+            // do not overshoot the dense level: the smallest factor that reaches it
+            for (int s2 = 2; s2 < agg; s2 *= 2)
+                if ((F.n + s2 - 1) / s2 <= g.opt.mg_dense_max) {
+                    agg = s2;
+                    break;
+                }
         }
-        agg = pow2floor(std::max(agg, 2));
-        agg = std::min(agg, kBlock / lanes);
+        agg = std::min(pow2floor(std::max(agg, 2)), 64);
         F.agg = agg;
         HostLevel C;
         C.n = (F.n + agg - 1) / agg;
@@ -197,56 +221,88 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.levels.clear();
     g.levels.resize(H.size());
     g.stats.levels = (int)H.size();
+    SellMap prev;
     for (size_t lev = 0; lev < H.size(); lev++) {
         Level &L = g.levels[lev];
         HostLevel &h = H[lev];
+        SellMap M = sell_map(h.n, h.rowptr);
         L.n = h.n;
         L.nnz = h.rowptr[h.n];
         L.agg = h.agg;
-        L.lanes = choose_lanes(L.nnz, L.n);
-        L.rowptr.upload(h.rowptr, s);
-        L.col.upload(h.col, s);
-        L.val.alloc((size_t)L.nnz);
+        L.nsl = M.nsl;
+        L.sell_len = M.len;
+        std::vector<int> scol((size_t)M.len);
+        for (int sl = 0; sl < M.nsl; sl++)  // padding: a valid column (row 0 of the slice), value 0
+            for (int k = M.sl_off[sl]; k < M.sl_off[sl + 1]; k++)
+                for (int lane = 0; lane < 64; lane++) scol[(size_t)k * 64 + lane] = sl * 64;
+        for (size_t t = 0; t < h.col.size(); t++) scol[M.pos[t]] = h.col[t];
+        L.sl_off.upload(M.sl_off, s);
+        L.col.upload(scol, s);
+        L.val.alloc((size_t)M.len);
         L.val.zero(s);
-        L.excess.alloc((size_t)L.n);
+        if (lev == 0) {
+            std::vector<uint32_t> seid((size_t)M.len, 0xffffffffu);
+            for (size_t t = 0; t < slot_eid.size(); t++) seid[M.pos[t]] = slot_eid[t];
+            g.slot_eid.upload(seid, s);
+            IRH_CHECK(hipStreamSynchronize(s));
+        }
+        L.excess.alloc((size_t)M.nsl * 64);
+        L.diag.alloc((size_t)M.nsl * 64);
+        L.idg.alloc((size_t)M.nsl * 64);
         L.excess.zero(s);
-        L.diag.alloc((size_t)L.n);
-        L.idg.alloc((size_t)L.n);
         L.diag.zero(s);
         L.idg.zero(s);
         if (lev > 0) {
+            std::vector<int> cidx2(h.cidx.size());
+            for (size_t q = 0; q < h.cidx.size(); q++) cidx2[q] = prev.pos[h.cidx[q]];
             L.cptr.upload(h.cptr, s);
-            L.cidx.upload(h.cidx, s);
+            L.cidx.upload(cidx2, s);
+            L.cpos.upload(M.pos, s);
+            IRH_CHECK(hipStreamSynchronize(s));
         }
-        L.b.alloc((size_t)L.n);
-        L.x.alloc((size_t)L.n);
-        L.y.alloc((size_t)L.n);
+        // vectors are padded to whole slices so that tail lanes may load harmlessly
+        const size_t nv = (size_t)M.nsl * 64 + 64;
+        L.b.alloc(nv);
+        L.x.alloc(nv);
+        L.y.alloc(nv);
+        L.e.alloc(nv);
         L.b.zero(s);
         L.x.zero(s);
         L.y.zero(s);
+        L.e.zero(s);
         if (lev < (size_t)kMaxLevels) {
             g.stats.level_rows[lev] = L.n;
             g.stats.level_nnz[lev] = L.nnz;
         }
+        IRH_CHECK(hipStreamSynchronize(s));  // scol goes out of scope
+        prev = std::move(M);
     }
     // dense inverse of the coarsest level (only when it is small enough and there is a hierarchy)
     g.ndense = 0;
-    if (g.levels.size() > 1 && g.levels.back().n <= std::min(g.opt.mg_dense_max, 88)) {
+    g.ndense_pad = 0;
+    if (g.levels.back().n <= std::min(g.opt.mg_dense_max, 2048) && g.opt.mg_levels_max > 1) {
         g.ndense = g.levels.back().n;
-        g.dense_inv.alloc((size_t)g.ndense * g.ndense);
+        g.ndense_pad = (g.ndense + 63) / 64 * 64;
+        g.dense_inv.alloc((size_t)g.ndense_pad * g.ndense_pad);
         g.dense_inv.zero(s);
+        g.dense_wr.alloc((size_t)32 * g.ndense_pad);
+        g.dense_wc.alloc((size_t)32 * g.ndense_pad);
+        g.dense_ref_diag.alloc((size_t)g.ndense_pad);
     }
-
+    g.additive_top = g.opt.reserved[0] == 1 ? 0 : 1;
     // ---- PCG state ----------------------------------------------------------------------
-    g.X.alloc((size_t)nu);
-    g.P.alloc((size_t)nu);
-    g.AP.alloc((size_t)nu);
+    const size_t nv0 = (size_t)g.levels[0].nsl * 64 + 64;
+    g.X.alloc(nv0);
+    g.P.alloc(nv0);
+    g.AP.alloc(nv0);
     g.X.zero(s);
     g.P.zero(s);
     g.AP.zero(s);
     g.part_pq.alloc((size_t)kMaxParts * 4);
     g.part_rr.alloc((size_t)kMaxParts * 4);
     g.part_rz.alloc((size_t)kMaxParts * 4);
+    g.part_rz2.alloc((size_t)kMaxParts * 4);
+    g.part_rz2.zero(s);
     g.part_score.alloc((size_t)kMaxParts * 4);
     g.part_pq.zero(s);
     g.part_rr.zero(s);

@@ -57,8 +57,8 @@ void irotavg_default_options(irotavg_options *o) {
     o->pcg_check_every = 8;
     o->mg_levels_max = 16;
     o->mg_agg0 = 0;
-    o->mg_agg = 4;
-    o->mg_dense_max = 64;
+    o->mg_agg = 0;
+    o->mg_dense_max = 2048;
     o->mg_omega = 0.7;
     o->mg_kc = 1.0;
     o->device = -1;
@@ -193,8 +193,7 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
     if (g.opt.pcg_rtol <= 0) g.opt.pcg_rtol = 1e-10;
     if (g.opt.mg_omega <= 0) g.opt.mg_omega = 0.7;
     if (g.opt.mg_kc <= 0) g.opt.mg_kc = 1.0;
-    if (g.opt.mg_agg <= 0) g.opt.mg_agg = 4;
-    if (g.opt.mg_dense_max <= 0) g.opt.mg_dense_max = 64;
+    if (g.opt.mg_dense_max <= 0) g.opt.mg_dense_max = 2048;
     if (g.opt.mg_levels_max <= 0) g.opt.mg_levels_max = 16;
     if (g.opt.pcg_max_iters <= 0) g.opt.pcg_max_iters = 2000;
     if (g.opt.pcg_check_every <= 0) g.opt.pcg_check_every = 8;

@@ -70,9 +70,11 @@ struct DevBuf {
     }
 };
 
-constexpr int kBlock = 1024;  // threads per workgroup of the row/edge kernels (16 waves)
-constexpr int kMaxParts = 256;  // dot-product partials (= max grid of a reducing kernel)
+constexpr int kBlock = 1024;   // threads of the single-workgroup coarse-cycle kernel
+constexpr int kRowBlock = 256;  // threads per workgroup of the row / edge / vector kernels (4 waves)
+constexpr int kMaxParts = 512;  // dot-product partials (= max grid of a reducing kernel)
 constexpr int kMaxLevels = 16;
+constexpr int kSellUnroll = 8;  // slice widths are multiples of this (batch size of the row loops)
 
 // per-edge flag bits (host-built; see build.cpp)
 enum : uint8_t {
@@ -86,19 +88,42 @@ enum : uint8_t {
     BF_NEG = 4,   // self loop: make_AtA ends with -1 on the diagonal (see oracle lap_fill_AtA_times)
 };
 
+// scalar block shared by the PCG kernels (device memory, doubles)
+enum ScalIdx : int {
+    SC_RZ0 = 0,   // rz of parity 0 (3 values, padded to 4)
+    SC_RZ1 = 4,   // rz of parity 1
+    SC_BB = 8,    // ||b||^2 per column
+    SC_RELRES = 12,  // ||r||/||b|| per column at the last check
+    SC_COUNT = 16
+};
+// int flags block
+enum FlagIdx : int {
+    FL_DONE = 0,   // 0 running, 1 converged, 2 breakdown (non-finite scalar)
+    FL_ITERS = 1,  // PCG iterations performed
+    FL_COUNT = 4
+};
+
+// One multigrid level. The off-diagonal part of the weighted Laplacian is held in SELL-64:
+// rows are cut into slices of 64 consecutive rows (one wavefront), slice s is `sl_off[s+1] -
+// sl_off[s]` entry-columns wide (its longest row), and entry k of the row in lane l sits at
+// (sl_off[s] + k) * 64 + l. One lane owns one row, so every wave-level load of col/val is a
+// contiguous 256/512-byte run, the inner loop has a wave-uniform trip count, and no cross-lane
+// reduction is needed. Padding entries have val = 0 and col = a valid row.
 struct Level {
     int n = 0;        // rows
-    int nnz = 0;      // off-diagonal entries
+    int nnz = 0;      // real off-diagonal entries
     int agg = 0;      // rows per aggregate towards the next (coarser) level; 0 on the coarsest
-    int lanes = 16;   // lanes cooperating on one row in the row kernels
-    DevBuf<int> rowptr, col;
+    int nsl = 0;      // slices
+    long long sell_len = 0;  // 64 * total entry-columns
+    DevBuf<int> sl_off, col;
     DevBuf<double> val;     // off-diagonal values (<= 0 for a Laplacian)
     DevBuf<double> excess;  // diag - sum|offdiag| : Dirichlet mass from fixed neighbours
     DevBuf<double> diag, idg;  // diagonal and its inverse (0 where the diagonal is 0)
-    // value refresh from the finer level: coarse slot c sums finer slots cidx[cptr[c]..cptr[c+1])
-    DevBuf<int> cptr, cidx;
+    // value refresh from the finer level: coarse entry c (CSR order) sums the finer SELL
+    // positions cidx[cptr[c]..cptr[c+1]) and is stored at SELL position cpos[c]
+    DevBuf<int> cptr, cidx, cpos;
     // multigrid work vectors (double4 with 3 active components)
-    DevBuf<double4> b, x, y;
+    DevBuf<double4> b, x, y, e;
 };
 
 }  // namespace irh

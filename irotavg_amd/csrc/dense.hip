@@ -1,0 +1,309 @@
+// dense.hip -- the coarsest multigrid level as a DENSE explicit inverse.
+//
+// Many tiny sparse levels are launch/latency bound on a 256-CU GPU (each costs ~5 us per sweep
+// whatever its size), while one dense n_c x n_c mat-vec with n_c <= 2048 streams at most 32 MB and
+// costs about the same as ONE of them. So the hierarchy stops early (n_c ~ 1-2k rows) and the
+// coarse operator E = P'LP is inverted explicitly once per matrix refresh by a blocked, in-place
+// Gauss-Jordan sweep (E is SPD: no pivoting), and applied exactly in every V-cycle.
+//
+// Blocked in-place Gauss-Jordan, block size B = 32, for block step k (D = A_kk):
+//   A'_kk = D^-1,  A'_kj = D^-1 A_kj,  A'_ik = -A_ik D^-1,  A'_ij = A_ij - A_ik D^-1 A_kj.
+// With Rt = [D^-1 A_k,: with its block k replaced by D^-1] and C = A_:,k this is
+//   rows of block k:  A' = Rt;     other rows:  A'_ij = (j in block k ? 0 : A_ij) - C_i Rt_j,
+// i.e. one panel kernel (builds Rt and copies C) + one rank-32 update kernel per step.
+#include "graph.hpp"
+#include "kernels.hpp"
+
+namespace irh {
+
+constexpr int GJB = 32;   // block size of the Gauss-Jordan sweep
+constexpr int GJT = 64;   // tile edge of the update kernel
+
+// broadcast of lane `lane` (wave-uniform, here a compile-time constant) through SGPRs
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// E (npad x npad, row-major, zeroed beforehand) from the SELL level: E = diag + offdiag;
+// identity on the padding rows. One lane per row: a row's entries are written by its owner only.
+__global__ __launch_bounds__(kRowBlock) void k_dense_build(LevelView C, int npad,
+                                                           double *__restrict__ E) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    double *row = E + (size_t)i * npad;
+    if (i >= C.n) {
+        row[i] = 1.0;
+        return;
+    }
+    row[i] = C.diag[i];
+    const int sl = i >> 6, lane = i & 63;
+    const int o0 = C.sl_off[sl], w = C.sl_off[sl + 1] - o0;
+    for (int k = 0; k < w; k++) {
+        const size_t p = (size_t)(o0 + k) * 64 + lane;
+        const double v = C.val[p];
+        if (v != 0.0) row[C.col[p]] += v;
+    }
+}
+
+// panel kernel of block step k: every workgroup inverts D = A_kk (32 x 32) by itself -- ONE wave,
+// one lane per row, the row in registers, 32 fully unrolled scalar Gauss-Jordan steps with the
+// pivot row broadcast by lane reads: no barriers, ~3 us (a barrier-per-step LDS version costs
+// ten times that, and this sits on the critical path of all npad/32 steps). A non-positive pivot
+// zeroes its row/column: that unknown solves to 0. Then the workgroup builds a 32 x 64 chunk of
+// Rt, or copies a 64 x 32 chunk of the column panel C.
+__global__ __launch_bounds__(256) void k_gj_panel(int npad, int k0, const double *__restrict__ A,
+                                                  double *__restrict__ Wr, double *__restrict__ Wc) {
+    const int nchunk = npad / GJT;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nchunk) {  // column panel copy
+        const int r0 = ((int)blockIdx.x - nchunk) * GJT;
+        for (int e = tid; e < GJT * GJB; e += 256) {
+            const int r = e / GJB, q = e % GJB;
+            Wc[(size_t)(r0 + r) * GJB + q] = A[(size_t)(r0 + r) * npad + k0 + q];
+        }
+        return;
+    }
+    __shared__ double D[GJB][GJB + 1];
+    __shared__ double Ak[GJB][GJT + 1];
+    const int c0 = blockIdx.x * GJT;
+    for (int e = tid; e < GJB * GJT; e += 256) Ak[e / GJT][e % GJT] = A[(size_t)(k0 + e / GJT) * npad + c0 + e % GJT];
+    if (tid < 64) {
+        const int l = tid & 31;  // lanes 32..63 mirror lanes 0..31 (keeps the wave uniform)
+        double d[GJB];
+#pragma unroll
+        for (int j = 0; j < GJB; j++) d[j] = A[(size_t)(k0 + l) * npad + k0 + j];
+#pragma unroll
+        for (int k = 0; k < GJB; k++) {
+            const double piv = readlane_d(d[k], k);
+            const double ip = piv > 0.0 ? 1.0 / piv : 0.0;
+            const double ck = (l == k) ? 0.0 : d[k];
+#pragma unroll
+            for (int j = 0; j < GJB; j++) {
+                const double pr = readlane_d(d[j], k);              // pivot row entry j (pre-update)
+                const double rk = (j == k) ? ip : pr * ip;          // scaled pivot row
+                const double old = (j == k) ? 0.0 : d[j];
+                d[j] = (l == k) ? rk : old - ck * rk;
+            }
+        }
+        if (tid < GJB) {
+#pragma unroll
+            for (int j = 0; j < GJB; j++) D[l][j] = d[j];
+        }
+    }
+    __syncthreads();
+    // Rt chunk = D^-1 * A_k,chunk, except columns inside block k, which receive D^-1 itself
+    for (int e = tid; e < GJB * GJT; e += 256) {
+        const int q = e / GJT, c = e % GJT;
+        const int gc = c0 + c;
+        double s;
+        if (gc >= k0 && gc < k0 + GJB) {
+            s = D[q][gc - k0];
+        } else {
+            s = 0.0;
+#pragma unroll 8
+            for (int t = 0; t < GJB; t++) s += D[q][t] * Ak[t][c];
+        }
+        Wr[(size_t)q * npad + gc] = s;
+    }
+}
+
+// rank-32 update of one 64 x 64 tile (see file header); 256 threads, 4 x 4 outputs each
+__global__ __launch_bounds__(256) void k_gj_update(int npad, int k0, double *__restrict__ A,
+                                                   const double *__restrict__ Wr,
+                                                   const double *__restrict__ Wc) {
+    __shared__ double Cs[GJT][GJB + 1];
+    __shared__ double Rs[GJB][GJT + 4];
+    const int nt = npad / GJT;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    const int r0 = ti * GJT, c0 = tj * GJT;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < GJT * GJB; e += 256) Cs[e / GJB][e % GJB] = Wc[(size_t)(r0 + e / GJB) * GJB + e % GJB];
+    for (int e = tid; e < GJB * GJT; e += 256) Rs[e / GJT][e % GJT] = Wr[(size_t)(e / GJT) * npad + c0 + e % GJT];
+    __syncthreads();
+    const int ty = tid / 16, tx = tid % 16;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < GJB; q++) {
+        double cv[4], rv[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) cv[a] = Cs[ty * 4 + a][q];
+#pragma unroll
+        for (int b = 0; b < 4; b++) rv[b] = Rs[q][tx * 4 + b];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] += cv[a] * rv[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int r = r0 + ty * 4 + a;
+        const bool in_k_row = r >= k0 && r < k0 + GJB;
+        double *arow = A + (size_t)r * npad + c0 + tx * 4;
+        double out[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int c = c0 + tx * 4 + b;
+            if (in_k_row) {
+                out[b] = Rs[r - k0][tx * 4 + b];
+            } else {
+                const double old = (c >= k0 && c < k0 + GJB) ? 0.0 : arow[b];
+                out[b] = old - acc[a][b];
+            }
+        }
+        *reinterpret_cast<double2 *>(arow) = make_double2(out[0], out[1]);
+        *reinterpret_cast<double2 *>(arow + 2) = make_double2(out[2], out[3]);
+    }
+}
+
+// min / max over the coarse rows of diag_now / diag_ref (rows with a zero reference are skipped)
+__global__ __launch_bounds__(1024) void k_diag_ratio(int n, const double *__restrict__ now,
+                                                     const double *__restrict__ ref,
+                                                     double *__restrict__ out) {
+    __shared__ double smin[16], smax[16];
+    double lo = HUGE_VAL, hi = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double r = ref[i], v = now[i];
+        if (r > 0.0 && v > 0.0) {
+            lo = fmin(lo, v / r);
+            hi = fmax(hi, v / r);
+        } else if ((r > 0.0) != (v > 0.0)) {
+            hi = HUGE_VAL;  // a row appeared or vanished: force a refresh
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, o, 64));
+        hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = lo;
+        smax[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+            lo = fmin(lo, smin[w]);
+            hi = fmax(hi, smax[w]);
+        }
+        out[0] = lo;
+        out[1] = hi;
+    }
+}
+
+// Is the inverse computed at the last refresh still a good coarse solver for the CURRENT coarse
+// operator? If the coarse diagonal moved by (nearly) one common factor c, E_now ~ c E_ref and
+// E_ref^-1 / c is reused; otherwise the caller re-inverts. Returns true when a refresh is needed.
+bool dense_is_stale(Graph &g) {
+    if (g.ndense <= 0) return false;
+    if (!g.dense_valid) return true;
+    Level &C = g.levels.back();
+    hipLaunchKernelGGL(k_diag_ratio, dim3(1), dim3(1024), 0, g.stream, C.n, C.diag.p,
+                       g.dense_ref_diag.p, g.part_score.p);
+    double h[2];
+    IRH_CHECK(hipMemcpyAsync(h, g.part_score.p, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    const double lo = h[0], hi = h[1];
+    if (!(lo > 0.0) || !(hi < HUGE_VAL) || hi > g.stale_spread * lo) return true;
+    g.dense_scale = 1.0 / std::sqrt(lo * hi);
+    return false;
+}
+
+void dense_refresh(Graph &g) {
+    if (g.ndense <= 0) return;
+    g.dense_scale = 1.0;
+    IRH_CHECK(hipMemcpyAsync(g.dense_ref_diag.p, g.levels.back().diag.p,
+                             sizeof(double) * (size_t)g.levels.back().n, hipMemcpyDeviceToDevice,
+                             g.stream));
+    Level &C = g.levels.back();
+    const int npad = g.ndense_pad;
+    LevelView V{C.n, C.nsl, C.agg, C.sl_off.p, C.col.p, C.val.p, C.diag.p, C.idg.p};
+    IRH_CHECK(hipMemsetAsync(g.dense_inv.p, 0, sizeof(double) * (size_t)npad * npad, g.stream));
+    hipLaunchKernelGGL(k_dense_build, dim3((npad + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,
+                       g.stream, V, npad, g.dense_inv.p);
+    const int nchunk = npad / GJT;
+    for (int k0 = 0; k0 < npad; k0 += GJB) {
+        hipLaunchKernelGGL(k_gj_panel, dim3(2 * nchunk), dim3(256), 0, g.stream, npad, k0,
+                           g.dense_inv.p, g.dense_wr.p, g.dense_wc.p);
+        hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
+                           g.dense_inv.p, g.dense_wr.p, g.dense_wc.p);
+    }
+}
+
+// y = E^-1 b on the dense level (3 columns). One wave per row, 16 rows per workgroup; b lives in
+// LDS (one wave per row, 4 rows per workgroup so that ~n/4 workgroups spread over the chip). CHECK: PCG convergence prologue (when this is the first kernel after the PCG update).
+// DOT: partial sums of b.y (the coarse part of r.z in the additive variant / the whole r.z when
+// the dense level is level 0).
+template <bool CHECK, bool DOT>
+__global__ __launch_bounds__(kRowBlock) void k_dense_apply(
+    int n, int npad, const double *__restrict__ Einv, double scale, const double4 *__restrict__ b,
+    double4 *__restrict__ y, double *__restrict__ part_dot, const double *__restrict__ part_rr,
+    int nparts, int first, double rtol2, double *__restrict__ scal, int *__restrict__ flags) {
+    if (flags[FL_DONE]) return;
+    if (CHECK && pcg_check(part_rr, nparts, first, rtol2, scal, flags)) return;
+    extern __shared__ double sb[];  // 3 * npad
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        double4 v = make_double4(0, 0, 0, 0);
+        if (i < n) v = b[i];
+        sb[i] = v.x;
+        sb[npad + i] = v.y;
+        sb[2 * npad + i] = v.z;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int rr = 0; rr < 1; rr++) {
+        const int r = blockIdx.x * 4 + wv;
+        double s0 = 0, s1 = 0, s2 = 0;
+        if (r < n) {
+            const double *row = Einv + (size_t)r * npad;
+#pragma unroll 4
+            for (int c = lane; c < npad; c += 64) {
+                const double e = row[c];
+                s0 += e * sb[c];
+                s1 += e * sb[npad + c];
+                s2 += e * sb[2 * npad + c];
+            }
+        }
+        s0 = wave_sum(s0) * scale;
+        s1 = wave_sum(s1) * scale;
+        s2 = wave_sum(s2) * scale;
+        if (lane == 0 && r < n) {
+            y[r] = make_double4(s0, s1, s2, 0.0);
+            if (DOT) {
+                a0 += sb[r] * s0;
+                a1 += sb[npad + r] * s1;
+                a2 += sb[2 * npad + r] * s2;
+            }
+        }
+    }
+    if (DOT) block_sum3_store(a0, a1, a2, part_dot + 4 * blockIdx.x);
+}
+
+int dense_apply_grid(const Graph &g) { return (g.ndense + 3) / 4; }
+
+void dense_apply(Graph &g, const double4 *b, double4 *y, bool check, bool dot, double *part_dot,
+                 int np_rr, int first, double rtol2) {
+    const int grid = dense_apply_grid(g);
+    const size_t shm = sizeof(double) * 3 * (size_t)g.ndense_pad;
+#define DA_LAUNCH(CH, DT)                                                                            \
+    hipLaunchKernelGGL((k_dense_apply<CH, DT>), dim3(grid), dim3(kRowBlock), shm, g.stream, g.ndense, \
+                       g.ndense_pad, g.dense_inv.p, g.dense_scale, b, y, part_dot, g.part_rr.p, np_rr, first, rtol2, \
+                       g.scal.p, g.flags.p)
+    if (check && dot)
+        DA_LAUNCH(true, true);
+    else if (check)
+        DA_LAUNCH(true, false);
+    else if (dot)
+        DA_LAUNCH(false, true);
+    else
+        DA_LAUNCH(false, false);
+#undef DA_LAUNCH
+}
+
+}  // namespace irh

@@ -6,21 +6,6 @@
 
 namespace irh {
 
-// scalar block shared by the PCG kernels (device memory, doubles)
-enum ScalIdx : int {
-    SC_RZ0 = 0,   // rz of parity 0 (3 values, padded to 4)
-    SC_RZ1 = 4,   // rz of parity 1
-    SC_BB = 8,    // ||b||^2 per column
-    SC_RELRES = 12,  // ||r||/||b|| per column at the last check
-    SC_COUNT = 16
-};
-// int flags block
-enum FlagIdx : int {
-    FL_DONE = 0,   // 0 running, 1 converged, 2 breakdown (non-finite scalar)
-    FL_ITERS = 1,  // PCG iterations performed
-    FL_COUNT = 4
-};
-
 struct Graph {
     int64_t m = 0, n_total = 0, mpad = 0;
     int f = 0, nu = 0;
@@ -39,19 +24,25 @@ struct Graph {
     DevBuf<double4> Qsnap;
 
     // level-0 adjacency extras (CSR itself lives in levels[0])
-    DevBuf<uint32_t> slot_eid;  // per inner slot: (edge id << 1) | (row is the j endpoint)
+    DevBuf<uint32_t> slot_eid;  // SELL layout of level 0: (edge id << 1) | (row is the j endpoint); ~0u = padding
     DevBuf<int> bptr;           // per row: boundary slots (other endpoint fixed / self loop)
     DevBuf<uint32_t> beid;
     DevBuf<uint8_t> bflag;
 
     std::vector<Level> levels;
-    DevBuf<double> dense_inv;  // coarsest level inverse, n x n row-major
-    int ndense = 0;
+    DevBuf<double> dense_inv;  // explicit inverse of the coarsest level, ndense_pad^2 row-major
+    DevBuf<double> dense_wr, dense_wc;  // Gauss-Jordan panels (32 x npad, npad x 32)
+    int ndense = 0, ndense_pad = 0;
+    bool dense_valid = false, dense_fresh = false;
+    double dense_scale = 1.0, stale_spread = 1.5;
+    DevBuf<double> dense_ref_diag;
+    int64_t iters_after_refresh = 0;
+    int additive_top = 1;  // level 0 enters the preconditioner additively (no fine matrix pass)
 
     // PCG (level-0 sized). levels[0].b is the residual r, levels[0].x the pre-smoothed
     // iterate, levels[0].y the preconditioned residual z.
     DevBuf<double4> X, P, AP;
-    DevBuf<double> part_pq, part_rr, part_rz, part_score;  // kMaxParts x 4
+    DevBuf<double> part_pq, part_rr, part_rz, part_rz2, part_score;  // kMaxParts x 4
     DevBuf<double> scal;
     DevBuf<int> flags;
 
@@ -72,7 +63,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
 
 // solver entry points (solver.hip)
 void launch_edge_residual(Graph &g);
-int ls_solve(Graph &g);  // assemble (IRLS weights) + PCG; result in g.X
+int ls_solve(Graph &g, int seq_index = 0);  // assemble (IRLS weights) + PCG; result in g.X
 void launch_update_weights(Graph &g, int cost, double sigma);
 double apply_step(Graph &g);
 int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, int *iters,
@@ -84,9 +75,15 @@ int l1decode_pd_dev(Graph &g, int coord_plane_from_er, const double *y_host, int
 int time_kernel(Graph &g, int which, int reps, double *ms);
 void normalise_rotations(Graph &g);
 void fill(Graph &g, double *p, long long n, double v);
-void assemble(Graph &g, int mode, const double *wsrc);
+void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true);
 int pcg_solve(Graph &g);
 int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f);
+// dense.hip
+void dense_refresh(Graph &g);
+bool dense_is_stale(Graph &g);
+int dense_apply_grid(const Graph &g);
+void dense_apply(Graph &g, const double4 *b, double4 *y, bool check, bool dot, double *part_dot,
+                 int np_rr, int first, double rtol2);
 
 inline double now_seconds() {
     using namespace std::chrono;

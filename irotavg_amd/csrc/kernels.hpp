@@ -1,9 +1,11 @@
-// kernels.hpp -- gfx950 device code of the rotation-averaging core. Wave = 64 lanes; all row
-// kernels run 1024-thread workgroups (16 waves) on a grid of <= kMaxParts workgroups, each
-// looping over a CONTIGUOUS chunk of row tiles. Workgroups that share blockIdx % 8 sit on one
-// XCD (observed dispatch order), so chunks are assigned such that one XCD's workgroups cover
-// adjacent row ranges: neighbour gathers of the band-dominated view-graph then hit that XCD's
-// own L2. Placement only affects speed, never results.
+// kernels.hpp -- gfx950 device helpers of the rotation-averaging core. Wave = 64 lanes.
+//
+// Row kernels: one lane owns one matrix row (SELL-64, see common.hpp), 256-thread workgroups =
+// 4 slices. The grid is at most kMaxParts workgroups; each takes a CONTIGUOUS chunk of
+// 4-slice tiles. Workgroups that share blockIdx % 8 sit on one XCD (observed dispatch order),
+// so chunks are dealt such that one XCD's workgroups cover adjacent row ranges: neighbour
+// gathers of the band-dominated view-graph then hit that XCD's own L2. Placement only affects
+// speed, never results.
 //
 // Every reduction is evaluated in a fixed order (lane -> wave -> workgroup -> partial array ->
 // fixed-order re-reduction in the consumer), so results are bitwise reproducible run to run.
@@ -13,30 +15,26 @@
 namespace irh {
 
 struct LevelView {
-    int n, nnz, agg;
-    const int *rowptr, *col;
+    int n, nsl, agg;
+    const int *sl_off, *col;
     const double *val, *diag, *idg;
 };
 
-// ---------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;  // lane 0
 }
 
-template <int G>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;  // all lanes of the G-lane group
+// sum over aligned groups of `g` consecutive lanes (g a power of two <= 64); every lane gets it
+__device__ __forceinline__ double seg_sum(double v, int g) {
+    for (int o = 1; o < g; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
-// workgroup sum of three accumulators -> part[0..2] (written by thread 0)
+// workgroup sum of three accumulators -> part[0..2] (written by thread 0). Any blockDim <= 1024.
 __device__ __forceinline__ void block_sum3_store(double a0, double a1, double a2, double *part) {
-    __shared__ double sm[3][kBlock / 64];
+    __shared__ double sm[3][16];
     a0 = wave_sum(a0);
     a1 = wave_sum(a1);
     a2 = wave_sum(a2);
@@ -64,7 +62,7 @@ __device__ __forceinline__ void block_sum3_store(double a0, double a1, double a2
 }
 
 // every thread of the workgroup obtains the fixed-order sum of the partial array
-// (nparts <= kMaxParts rows of 4 doubles)
+// (nparts <= kMaxParts = 512 rows of 4 doubles); blockDim >= 256
 __device__ __forceinline__ void load_reduced3(const double *part, int nparts, double out[3]) {
     __shared__ double sm[3][4];
     const int t = threadIdx.x;
@@ -74,6 +72,11 @@ __device__ __forceinline__ void load_reduced3(const double *part, int nparts, do
             a0 = part[4 * t + 0];
             a1 = part[4 * t + 1];
             a2 = part[4 * t + 2];
+        }
+        if (t + 256 < nparts) {
+            a0 += part[4 * (t + 256) + 0];
+            a1 += part[4 * (t + 256) + 1];
+            a2 += part[4 * (t + 256) + 2];
         }
         a0 = wave_sum(a0);
         a1 = wave_sum(a1);
@@ -91,6 +94,27 @@ __device__ __forceinline__ void load_reduced3(const double *part, int nparts, do
     __syncthreads();
 }
 
+// convergence decision from the ||r||^2 partials of the last PCG update (every workgroup takes
+// the same decision; workgroup 0 publishes it)
+__device__ __forceinline__ bool pcg_check(const double *part_rr, int nparts, int first,
+                                          double rtol2, double *scal, int *flags) {
+    double rr[3], bb[3];
+    load_reduced3(part_rr, nparts, rr);
+    for (int c = 0; c < 3; c++) bb[c] = first ? rr[c] : scal[SC_BB + c];
+    const bool finite = isfinite(rr[0]) && isfinite(rr[1]) && isfinite(rr[2]);
+    const bool conv = rr[0] <= rtol2 * bb[0] && rr[1] <= rtol2 * bb[1] && rr[2] <= rtol2 * bb[2];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (first)
+            for (int c = 0; c < 3; c++) scal[SC_BB + c] = bb[c];
+        for (int c = 0; c < 3; c++) scal[SC_RELRES + c] = bb[c] > 0.0 ? sqrt(rr[c] / bb[c]) : 0.0;
+        if (!finite)
+            flags[FL_DONE] = 2;
+        else if (conv)
+            flags[FL_DONE] = 1;
+    }
+    return !finite || conv;
+}
+
 // contiguous tile chunk of this workgroup, XCD-aware (see file header)
 __device__ __forceinline__ void tile_range(int ntiles, int &t0, int &t1) {
     const int nb = gridDim.x, b = blockIdx.x;
@@ -98,6 +122,80 @@ __device__ __forceinline__ void tile_range(int ntiles, int &t0, int &t1) {
     if ((nb & 7) == 0) lb = (b & 7) * (nb >> 3) + (b >> 3);
     t0 = (int)(((long long)ntiles * lb) / nb);
     t1 = (int)(((long long)ntiles * (lb + 1)) / nb);
+}
+
+// Off-diagonal part of (L x)_row for the lane's own row. The slice width is a multiple of
+// kSellUnroll and uniform across the wave; the loop is software-pipelined by hand: the col/val
+// loads of batch k+1 are issued before the gathers of batch k are consumed, so each batch of 8
+// entries costs one memory round trip instead of two (col -> gather dependency).
+template <bool PROLONG>
+__device__ __forceinline__ void row_offdiag_t(const LevelView &L, int row, const double4 *__restrict__ x,
+                                              const double4 *__restrict__ xc, int sh, double kc,
+                                              double &s0, double &s1, double &s2) {
+    constexpr int U = kSellUnroll;
+    const int sl = row >> 6, lane = row & 63;
+    const int o0 = L.sl_off[sl], w = L.sl_off[sl + 1] - o0;
+    const int *__restrict__ c = L.col + (size_t)o0 * 64 + lane;
+    const double *__restrict__ v = L.val + (size_t)o0 * 64 + lane;
+    s0 = s1 = s2 = 0.0;
+    if (w == 0) return;
+    int cc[U];
+    double vv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        cc[u] = c[(size_t)u * 64];
+        vv[u] = v[(size_t)u * 64];
+    }
+    for (int k0 = 0; k0 < w; k0 += U) {
+        double4 xx[U], xk[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            xx[u] = x[cc[u]];
+            if (PROLONG) xk[u] = xc[cc[u] >> sh];
+        }
+        int cn[U];
+        double vn[U];
+        const bool more = k0 + U < w;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                cn[u] = c[(size_t)(k0 + U + u) * 64];
+                vn[u] = v[(size_t)(k0 + U + u) * 64];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (PROLONG) {
+                s0 += vv[u] * (xx[u].x + kc * xk[u].x);
+                s1 += vv[u] * (xx[u].y + kc * xk[u].y);
+                s2 += vv[u] * (xx[u].z + kc * xk[u].z);
+            } else {
+                s0 += vv[u] * xx[u].x;
+                s1 += vv[u] * xx[u].y;
+                s2 += vv[u] * xx[u].z;
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                cc[u] = cn[u];
+                vv[u] = vn[u];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void row_offdiag(const LevelView &L, int row, const double4 *__restrict__ x,
+                                            double &s0, double &s1, double &s2) {
+    row_offdiag_t<false>(L, row, x, nullptr, 0, 0.0, s0, s1, s2);
+}
+
+// same with the prolongated iterate x + kc * xc[col >> sh] gathered on the fly
+__device__ __forceinline__ void row_offdiag_prolong(const LevelView &L, int row,
+                                                    const double4 *__restrict__ x,
+                                                    const double4 *__restrict__ xc, int sh, double kc,
+                                                    double &s0, double &s1, double &s2) {
+    row_offdiag_t<true>(L, row, x, xc, sh, kc, s0, s1, s2);
 }
 
 // Hamilton product, [x y z w] (ral/l1_irls.cpp:99-105)

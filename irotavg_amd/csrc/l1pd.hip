@@ -43,7 +43,7 @@ __device__ __forceinline__ double wave_max(double v) {
 // workgroup min/max -> part[0]
 template <bool MAX>
 __device__ __forceinline__ void block_ext_store(double v, double *part) {
-    __shared__ double sm[kBlock / 64];
+    __shared__ double sm[16];
     v = MAX ? wave_max(v) : wave_min(v);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -60,7 +60,7 @@ __device__ __forceinline__ void block_ext_store(double v, double *part) {
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += (long long)gridDim.x * blockDim.x)
 
 // max_k |y - Ax|   (ral/l1_irls.cpp:250-253)
-__global__ __launch_bounds__(kBlock) void k_pd_absmax(long long m, const double *__restrict__ y,
+__global__ __launch_bounds__(kRowBlock) void k_pd_absmax(long long m, const double *__restrict__ y,
                                                       const double *__restrict__ Ax,
                                                       double *__restrict__ part) {
     double v = -HUGE_VAL;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_absmax(long long m, const double 
 }
 
 // :252-259, 262 (operand of A'), 264, 272-276 (tail of rdual)
-__global__ __launch_bounds__(kBlock) void k_pd_init(long long m, const double *__restrict__ y,
+__global__ __launch_bounds__(kRowBlock) void k_pd_init(long long m, const double *__restrict__ y,
                                                     const double *__restrict__ Ax, double maxabs,
                                                     double *__restrict__ u, double *__restrict__ f1,
                                                     double *__restrict__ f2, double *__restrict__ l1,
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_init(long long m, const double *_
 }
 
 // sum of squares of rcent = [-lamu1.*fu1; -lamu2.*fu2] - 1/tau  (:267-270, 450-453)
-__global__ __launch_bounds__(kBlock) void k_pd_rcent(long long m, const double *__restrict__ f1,
+__global__ __launch_bounds__(kRowBlock) void k_pd_rcent(long long m, const double *__restrict__ f1,
                                                      const double *__restrict__ f2,
                                                      const double *__restrict__ l1,
                                                      const double *__restrict__ l2, double itau,
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_rcent(long long m, const double *
 }
 
 // :292-305 -- sigx and the two operands of A' (t1 for w1, t2 for w1p)
-__global__ __launch_bounds__(kBlock) void k_pd_sig(long long m, const double *__restrict__ f1,
+__global__ __launch_bounds__(kRowBlock) void k_pd_sig(long long m, const double *__restrict__ f1,
                                                    const double *__restrict__ f2,
                                                    const double *__restrict__ l1,
                                                    const double *__restrict__ l2, double itau,
@@ -127,53 +127,59 @@ __global__ __launch_bounds__(kBlock) void k_pd_sig(long long m, const double *__
     }
 }
 
-// view-parallel A' y over the incident-edge slots (make_A coefficients: +1 for the j endpoint,
-// -1 for the i endpoint, boundary slots only when make_A kept the coefficient).
-template <int G>
-__device__ __forceinline__ double at_row(int row, int l, const int *__restrict__ rowptr,
+// view-parallel A' y: the lane that owns a view walks its incident-edge entries (SELL layout of
+// level 0; make_A coefficients: +1 for the j endpoint, -1 for the i endpoint; boundary slots
+// only when make_A kept the coefficient).
+__device__ __forceinline__ double at_row(int row, int n, const int *__restrict__ sl_off,
                                          const uint32_t *__restrict__ slot_eid,
                                          const int *__restrict__ bptr,
                                          const uint32_t *__restrict__ beid,
                                          const uint8_t *__restrict__ bflag,
                                          const double *__restrict__ t) {
+    const int sl = row >> 6, lane = row & 63;
+    const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
+    const uint32_t *__restrict__ se_p = slot_eid + (size_t)o0 * 64 + lane;
     double s = 0.0;
-    const int beg = rowptr[row], end = rowptr[row + 1];
-    for (int q = beg + l; q < end; q += G) {
-        const uint32_t se = slot_eid[q];
-        const double v = t[se >> 1];
-        s += (se & 1u) ? v : -v;
+#pragma unroll 4
+    for (int k = 0; k < w; k++) {
+        const uint32_t se = se_p[(size_t)k * 64];
+        if (se != 0xffffffffu) {
+            const double v = t[se >> 1];
+            s += (se & 1u) ? v : -v;
+        }
     }
-    const int bb = bptr[row], be = bptr[row + 1];
-    for (int q = bb + l; q < be; q += G) {
-        if (!(bflag[q] & BF_IRLS)) continue;
-        const uint32_t se = beid[q];
-        const double v = t[se >> 1];
-        s += (se & 1u) ? v : -v;
+    if (row < n) {
+        for (int q = bptr[row]; q < bptr[row + 1]; q++) {
+            if (!(bflag[q] & BF_IRLS)) continue;
+            const uint32_t se = beid[q];
+            const double v = t[se >> 1];
+            s += (se & 1u) ? v : -v;
+        }
     }
     return s;
 }
 
+#define PD_ROW_LOOP(nsl)                                       \
+    const int ntiles_ = ((nsl) + 3) / 4;                       \
+    int t0_, t1_;                                              \
+    tile_range(ntiles_, t0_, t1_);                             \
+    for (int t_ = t0_; t_ < t1_; t_++)                         \
+        if (const int sl_ = t_ * 4 + (threadIdx.x >> 6); sl_ < (nsl))
+
 // out = A' t, partial sum of out^2
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_at_mul(int n, const int *__restrict__ rowptr,
-                                                   const uint32_t *__restrict__ slot_eid,
-                                                   const int *__restrict__ bptr,
-                                                   const uint32_t *__restrict__ beid,
-                                                   const uint8_t *__restrict__ bflag,
-                                                   const double *__restrict__ t,
-                                                   double *__restrict__ out,
-                                                   double *__restrict__ part) {
-    constexpr int R = kBlock / G;
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int ntiles = (n + R - 1) / R;
-    int t0, t1;
-    tile_range(ntiles, t0, t1);
+__global__ __launch_bounds__(kRowBlock) void k_at_mul(int n, int nsl, const int *__restrict__ sl_off,
+                                                      const uint32_t *__restrict__ slot_eid,
+                                                      const int *__restrict__ bptr,
+                                                      const uint32_t *__restrict__ beid,
+                                                      const uint8_t *__restrict__ bflag,
+                                                      const double *__restrict__ t,
+                                                      double *__restrict__ out,
+                                                      double *__restrict__ part) {
     double acc = 0.0;
-    for (int tt = t0; tt < t1; tt++) {
-        const int row = tt * R + grp;
-        double s = row < n ? at_row<G>(row, l, rowptr, slot_eid, bptr, beid, bflag, t) : 0.0;
-        s = group_sum<G>(s);
-        if (l == 0 && row < n) {
+    PD_ROW_LOOP(nsl) {
+        const int row = sl_ * 64 + (threadIdx.x & 63);
+        const double s = at_row(row, n, sl_off, slot_eid, bptr, beid, bflag, t);
+        if (row < n) {
             out[row] = s;
             acc += s * s;
         }
@@ -182,30 +188,19 @@ __global__ __launch_bounds__(kBlock) void k_at_mul(int n, const int *__restrict_
 }
 
 // rhs = w1p = -(1/tau) A' t1 - A' t2   (:300-306), stored in component 0 of the PCG rhs
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_pd_rhs(int n, const int *__restrict__ rowptr,
-                                                   const uint32_t *__restrict__ slot_eid,
-                                                   const int *__restrict__ bptr,
-                                                   const uint32_t *__restrict__ beid,
-                                                   const uint8_t *__restrict__ bflag,
-                                                   const double *__restrict__ t1,
-                                                   const double *__restrict__ t2, double itau,
-                                                   double4 *__restrict__ rhs) {
-    constexpr int R = kBlock / G;
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int ntiles = (n + R - 1) / R;
-    int t0, t1r;
-    tile_range(ntiles, t0, t1r);
-    for (int tt = t0; tt < t1r; tt++) {
-        const int row = tt * R + grp;
-        double a = 0.0, b = 0.0;
+__global__ __launch_bounds__(kRowBlock) void k_pd_rhs(int n, int nsl, const int *__restrict__ sl_off,
+                                                      const uint32_t *__restrict__ slot_eid,
+                                                      const int *__restrict__ bptr,
+                                                      const uint32_t *__restrict__ beid,
+                                                      const uint8_t *__restrict__ bflag,
+                                                      const double *__restrict__ t1,
+                                                      const double *__restrict__ t2, double itau,
+                                                      double4 *__restrict__ rhs) {
+    PD_ROW_LOOP(nsl) {
+        const int row = sl_ * 64 + (threadIdx.x & 63);
+        const double a = at_row(row, n, sl_off, slot_eid, bptr, beid, bflag, t1);
+        const double b = at_row(row, n, sl_off, slot_eid, bptr, beid, bflag, t2);
         if (row < n) {
-            a = at_row<G>(row, l, rowptr, slot_eid, bptr, beid, bflag, t1);
-            b = at_row<G>(row, l, rowptr, slot_eid, bptr, beid, bflag, t2);
-        }
-        a = group_sum<G>(a);
-        b = group_sum<G>(b);
-        if (l == 0 && row < n) {
             const double w1 = -itau * a;
             rhs[row] = make_double4(w1 - b, 0.0, 0.0, 0.0);
         }
@@ -213,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_rhs(int n, const int *__restrict_
 }
 
 // :324-381 -- Adx, du, dlamu1, dlamu2, operand of A' (Atdv), and the four guarded step bounds
-__global__ __launch_bounds__(kBlock) void k_pd_dir(
+__global__ __launch_bounds__(kRowBlock) void k_pd_dir(
     long long m, int f, const int *__restrict__ ei, const int *__restrict__ ej,
     const uint8_t *__restrict__ eflag, const double4 *__restrict__ DX,
     const double *__restrict__ f1, const double *__restrict__ f2, const double *__restrict__ l1,
@@ -256,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_dir(
 }
 
 // trial point at step s: sums of squares of the m-tail of rdp (:407-410) and of rcp (:412-416)
-__global__ __launch_bounds__(kBlock) void k_pd_trial_edge(
+__global__ __launch_bounds__(kRowBlock) void k_pd_trial_edge(
     long long m, const double *__restrict__ y, double s, double itau, const double *__restrict__ u,
     const double *__restrict__ du, const double *__restrict__ Ax, const double *__restrict__ Adx,
     const double *__restrict__ l1, const double *__restrict__ dl1, const double *__restrict__ l2,
@@ -275,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_trial_edge(
     block_sum3_store(a0, a1, 0.0, part + 4 * blockIdx.x);
 }
 
-__global__ __launch_bounds__(kBlock) void k_pd_trial_vert(int n, double s,
+__global__ __launch_bounds__(kRowBlock) void k_pd_trial_vert(int n, double s,
                                                           const double *__restrict__ Atv,
                                                           const double *__restrict__ Atdv,
                                                           double *__restrict__ part) {
@@ -288,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_trial_vert(int n, double s,
 }
 
 // accept the trial point (:432-442) and produce the new surrogate duality gap sums (:446)
-__global__ __launch_bounds__(kBlock) void k_pd_commit_edge(
+__global__ __launch_bounds__(kRowBlock) void k_pd_commit_edge(
     long long m, const double *__restrict__ y, double s, double *__restrict__ u,
     const double *__restrict__ du, double *__restrict__ Ax, const double *__restrict__ Adx,
     double *__restrict__ l1, const double *__restrict__ dl1, double *__restrict__ l2,
@@ -312,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_commit_edge(
     block_sum3_store(a0, a1, 0.0, part + 4 * blockIdx.x);
 }
 
-__global__ __launch_bounds__(kBlock) void k_pd_commit_vert(int n, double s, double *__restrict__ x,
+__global__ __launch_bounds__(kRowBlock) void k_pd_commit_vert(int n, double s, double *__restrict__ x,
                                                            const double4 *__restrict__ DX,
                                                            double *__restrict__ Atv,
                                                            const double *__restrict__ Atdv) {
@@ -322,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_pd_commit_vert(int n, double s, doub
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_pack3(int n, const double *__restrict__ x0,
+__global__ __launch_bounds__(kRowBlock) void k_pack3(int n, const double *__restrict__ x0,
                                                   const double *__restrict__ x1,
                                                   const double *__restrict__ x2,
                                                   double4 *__restrict__ X) {
@@ -332,16 +327,15 @@ __global__ __launch_bounds__(kBlock) void k_pack3(int n, const double *__restric
 
 // ---------------------------------------------------------------------------------------------
 static int grid_edges(long long m) {
-    long long gsz = std::min<long long>((m + kBlock - 1) / kBlock, kMaxParts);
+    long long gsz = std::min<long long>((m + kRowBlock - 1) / kRowBlock, kMaxParts);
     if (gsz >= 8) gsz &= ~7ll;
     return (int)std::max<long long>(gsz, 1);
 }
 static int grid_elems(int n) { return grid_edges(n); }
-static int grid_rows(int n, int lanes) {
-    const int R = kBlock / lanes;
-    int gsz = std::min((n + R - 1) / R, (int)kMaxParts);
-    if (gsz >= 8) gsz &= ~7;
-    return std::max(gsz, 1);
+static int grid_rows(const Level &L) {
+    long long gsz = std::min<long long>((L.nsl + 3) / 4, kMaxParts);
+    if (gsz >= 8) gsz &= ~7ll;
+    return (int)std::max<long long>(gsz, 1);
 }
 
 // fixed-order host sum of the first `cols` columns of a partial array
@@ -363,23 +357,13 @@ static double fetch_ext(Graph &g, int nparts, bool is_max) {
     return r;
 }
 
-#define PD_LANES(lanes, CALL)                        \
-    switch (lanes) {                                 \
-    case 2: { constexpr int G = 2; CALL; } break;    \
-    case 4: { constexpr int G = 4; CALL; } break;    \
-    case 8: { constexpr int G = 8; CALL; } break;    \
-    case 16: { constexpr int G = 16; CALL; } break;  \
-    case 32: { constexpr int G = 32; CALL; } break;  \
-    default: { constexpr int G = 64; CALL; } break;  \
-    }
-
 // One coordinate. y: device pointer (plane of er, or P_Y). Result in pdn plane `xplane`.
 static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, int *stuck) {
     const double PDTOL = 1e-3, alpha = 0.01, beta = 0.5, mu = 10;  // :231-238
     const long long m = g.m;
     const int n = g.nu;
     Level &L0 = g.levels[0];
-    const int ge = grid_edges(m), gv = grid_elems(n), gr = grid_rows(n, L0.lanes);
+    const int ge = grid_edges(m), gv = grid_elems(n), gr = grid_rows(L0);
     hipStream_t st = g.stream;
     double *P = g.pd.p;
     auto pl = [&](int i) { return P + (size_t)i * g.mpad; };
@@ -390,20 +374,19 @@ static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, i
 
     IRH_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, st));             // x0 = 0
     IRH_CHECK(hipMemsetAsync(pl(P_AX), 0, sizeof(double) * (size_t)g.mpad, st));  // Ax = A*0
-    hipLaunchKernelGGL(k_pd_absmax, dim3(ge), dim3(kBlock), 0, st, m, y, pl(P_AX), g.pd_part.p);
+    hipLaunchKernelGGL(k_pd_absmax, dim3(ge), dim3(kRowBlock), 0, st, m, y, pl(P_AX), g.pd_part.p);
     const double maxabs = fetch_ext(g, ge, true);
-    hipLaunchKernelGGL(k_pd_init, dim3(ge), dim3(kBlock), 0, st, m, y, pl(P_AX), maxabs, pl(P_U),
+    hipLaunchKernelGGL(k_pd_init, dim3(ge), dim3(kRowBlock), 0, st, m, y, pl(P_AX), maxabs, pl(P_U),
                        pl(P_F1), pl(P_F2), pl(P_L1), pl(P_L2), pl(P_T1), g.pd_part.p);
     fetch_parts(g, ge, s3);
     double sdg = -(s3[0] + s3[1]);           // :264
     double tau = mu * 2 * (double)m / sdg;   // :265
     double rd_tail2 = s3[2];
-    PD_LANES(L0.lanes, hipLaunchKernelGGL((k_at_mul<G>), dim3(gr), dim3(kBlock), 0, st, n,
-                                          L0.rowptr.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p,
-                                          pl(P_T1), Atv, g.pd_part.p));
+    hipLaunchKernelGGL(k_at_mul, dim3(gr), dim3(kRowBlock), 0, st, n, L0.nsl, L0.sl_off.p,
+                       g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(P_T1), Atv, g.pd_part.p);
     fetch_parts(g, gr, s3);
     const double atv2 = s3[0];
-    hipLaunchKernelGGL(k_pd_rcent, dim3(ge), dim3(kBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
+    hipLaunchKernelGGL(k_pd_rcent, dim3(ge), dim3(kRowBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
                        pl(P_L2), 1.0 / tau, g.pd_part.p);
     fetch_parts(g, ge, s3);
     double resnorm = std::sqrt(atv2 + rd_tail2 + s3[0]);  // :278-281
@@ -413,33 +396,32 @@ static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, i
     while (!done) {
         pditer++;
         const double itau = 1.0 / tau;
-        hipLaunchKernelGGL(k_pd_sig, dim3(ge), dim3(kBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
+        hipLaunchKernelGGL(k_pd_sig, dim3(ge), dim3(kRowBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
                            pl(P_L2), itau, pl(P_SIGX), pl(P_T1), pl(P_T2));
         assemble(g, 1, pl(P_SIGX));
-        PD_LANES(L0.lanes, hipLaunchKernelGGL((k_pd_rhs<G>), dim3(gr), dim3(kBlock), 0, st, n,
-                                              L0.rowptr.p, g.slot_eid.p, g.bptr.p, g.beid.p,
-                                              g.bflag.p, pl(P_T1), pl(P_T2), itau, L0.b.p));
+        hipLaunchKernelGGL(k_pd_rhs, dim3(gr), dim3(kRowBlock), 0, st, n, L0.nsl, L0.sl_off.p,
+                           g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(P_T1), pl(P_T2), itau,
+                           L0.b.p);
         int rc = pcg_solve(g);  // dx in g.X component 0
         if (rc != IROTAVG_OK) return rc == IROTAVG_ERR_NOT_CONVERGED ? rc : IROTAVG_ERR_SOLVER;
-        hipLaunchKernelGGL(k_pd_dir, dim3(ge), dim3(kBlock), 0, st, m, g.f, g.ei.p, g.ej.p,
+        hipLaunchKernelGGL(k_pd_dir, dim3(ge), dim3(kRowBlock), 0, st, m, g.f, g.ei.p, g.ej.p,
                            g.eflag.p, g.X.p, pl(P_F1), pl(P_F2), pl(P_L1), pl(P_L2), itau, pl(P_ADX),
                            pl(P_DU), pl(P_DL1), pl(P_DL2), pl(P_T1), g.pd_part.p);
         double s = std::fmin(1.0, fetch_ext(g, ge, false));  // :347-380
         if (!(s == s)) return IROTAVG_ERR_SOLVER;
         s *= 0.99;                                            // :381
-        PD_LANES(L0.lanes, hipLaunchKernelGGL((k_at_mul<G>), dim3(gr), dim3(kBlock), 0, st, n,
-                                              L0.rowptr.p, g.slot_eid.p, g.bptr.p, g.beid.p,
-                                              g.bflag.p, pl(P_T1), Atdv, g.pd_part.p));
+        hipLaunchKernelGGL(k_at_mul, dim3(gr), dim3(kRowBlock), 0, st, n, L0.nsl, L0.sl_off.p,
+                           g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(P_T1), Atdv, g.pd_part.p);
         // backtracking (:384-429)
         bool suffdec = false;
         int backiter = 0;
         double s_acc = s, rdp2 = 0.0;
         while (!suffdec) {
-            hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv), dim3(kBlock), 0, st, n, s, Atv, Atdv,
+            hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv), dim3(kRowBlock), 0, st, n, s, Atv, Atdv,
                                g.pd_part.p);
             fetch_parts(g, gv, s3);
             const double rdv = s3[0];
-            hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge), dim3(kBlock), 0, st, m, y, s, itau,
+            hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge), dim3(kRowBlock), 0, st, m, y, s, itau,
                                pl(P_U), pl(P_DU), pl(P_AX), pl(P_ADX), pl(P_L1), pl(P_DL1), pl(P_L2),
                                pl(P_DL2), g.pd_part.p);
             fetch_parts(g, ge, s3);
@@ -453,15 +435,15 @@ static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, i
                 return IROTAVG_OK;
             }
         }
-        hipLaunchKernelGGL(k_pd_commit_vert, dim3(gv), dim3(kBlock), 0, st, n, s_acc, x, g.X.p, Atv,
+        hipLaunchKernelGGL(k_pd_commit_vert, dim3(gv), dim3(kRowBlock), 0, st, n, s_acc, x, g.X.p, Atv,
                            Atdv);
-        hipLaunchKernelGGL(k_pd_commit_edge, dim3(ge), dim3(kBlock), 0, st, m, y, s_acc, pl(P_U),
+        hipLaunchKernelGGL(k_pd_commit_edge, dim3(ge), dim3(kRowBlock), 0, st, m, y, s_acc, pl(P_U),
                            pl(P_DU), pl(P_AX), pl(P_ADX), pl(P_L1), pl(P_DL1), pl(P_L2), pl(P_DL2),
                            pl(P_F1), pl(P_F2), g.pd_part.p);
         fetch_parts(g, ge, s3);
         sdg = -(s3[0] + s3[1]);             // :446
         tau = mu * 2 * (double)m / sdg;     // :448
-        hipLaunchKernelGGL(k_pd_rcent, dim3(ge), dim3(kBlock), 0, st, m, pl(P_F1), pl(P_F2),
+        hipLaunchKernelGGL(k_pd_rcent, dim3(ge), dim3(kRowBlock), 0, st, m, pl(P_F1), pl(P_F2),
                            pl(P_L1), pl(P_L2), 1.0 / tau, g.pd_part.p);
         fetch_parts(g, ge, s3);
         resnorm = std::sqrt(rdp2 + s3[0]);  // :455-458
@@ -509,7 +491,7 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
         for (int c = 0; c < 3 && rc == IROTAVG_OK; c++)  // :889-892
             rc = l1decode_core(g, g.er.p + (size_t)c * g.mpad, l1_step, N_X0 + c, nullptr);
         if (rc != IROTAVG_OK) break;
-        hipLaunchKernelGGL(k_pack3, dim3(grid_elems(n)), dim3(kBlock), 0, g.stream, n,
+        hipLaunchKernelGGL(k_pack3, dim3(grid_elems(n)), dim3(kRowBlock), 0, g.stream, n,
                            g.pdn.p + (size_t)N_X0 * n, g.pdn.p + (size_t)N_X1 * n,
                            g.pdn.p + (size_t)N_X2 * n, g.X.p);
         score = apply_step(g);  // :894-902

@@ -169,69 +169,79 @@ void launch_update_weights(Graph &g, int cost, double sigma) {
 }
 
 // =============================================================================================
-// K3 -- level-0 assembly. One G-lane group per free view walks the view's incident-edge slots:
-// off-diagonal value -w, diagonal sum, Dirichlet excess and (IRLS) the right-hand side
-// b_v = sum_k +-w_k r_k. MODE 0: w = d_k^2 from the IRLS weights, rhs built.
-// MODE 1: w = s[k] (sigx of the primal-dual step), no rhs, make_AtA boundary rule.
+// K3 -- level-0 assembly. The lane that owns a free view walks the view's incident-edge entries
+// (SELL layout, wave-uniform trip count): off-diagonal value -w, diagonal sum, Dirichlet excess
+// and (IRLS) the right-hand side b_v = sum_k +-w_k r_k. MODE 0: w = d_k^2 from the IRLS weights,
+// rhs built. MODE 1: w = s[k] (sigx of the primal-dual step), no rhs, make_AtA boundary rule.
 // =============================================================================================
-template <int G, int MODE>
-__global__ __launch_bounds__(kBlock) void k_assemble0(
-    int n, const int *__restrict__ rowptr, const uint32_t *__restrict__ slot_eid,
+template <int MODE>
+__global__ __launch_bounds__(kRowBlock) void k_assemble0(
+    int n, int nsl, const int *__restrict__ sl_off, const uint32_t *__restrict__ slot_eid,
     const int *__restrict__ bptr, const uint32_t *__restrict__ beid,
     const uint8_t *__restrict__ bflag, const double *__restrict__ wsrc,
     const double *__restrict__ er, long long mpad, double *__restrict__ val,
     double *__restrict__ excess, double *__restrict__ diag, double *__restrict__ idg,
     double4 *__restrict__ rhs) {
-    constexpr int R = kBlock / G;
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int ntiles = (n + R - 1) / R;
+    const int ntiles = (nsl + 3) / 4;
     int t0, t1;
     tile_range(ntiles, t0, t1);
     for (int t = t0; t < t1; t++) {
-        const int row = t * R + grp;
+        const int sl = t * 4 + (threadIdx.x >> 6);
+        if (sl >= nsl) break;
+        const int lane = threadIdx.x & 63, row = sl * 64 + lane;
+        const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
+        const uint32_t *__restrict__ se_p = slot_eid + (size_t)o0 * 64 + lane;
+        double *__restrict__ v_p = val + (size_t)o0 * 64 + lane;
         double sw = 0.0, ex = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
-        if (row < n) {
-            const int beg = rowptr[row], end = rowptr[row + 1];
-            for (int s = beg + l; s < end; s += G) {
-                const uint32_t se = slot_eid[s];
-                const uint32_t k = se >> 1;
-                double w = wsrc[k];
-                if (MODE == 0) w = w * w;
-                val[s] = -w;
-                sw += w;
+        constexpr int U = kSellUnroll;
+        for (int k0 = 0; k0 < w; k0 += U) {  // w is a multiple of U: whole batches, loads first
+            uint32_t se[U];
+            double wk[U], r0[U], r1[U], r2[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) se[u] = se_p[(size_t)(k0 + u) * 64];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool live = se[u] != 0xffffffffu;
+                const uint32_t e = live ? (se[u] >> 1) : 0u;
+                wk[u] = wsrc[e];
                 if (MODE == 0) {
-                    const double sg = (se & 1u) ? w : -w;
-                    b0 += sg * er[k];
-                    b1 += sg * er[mpad + k];
-                    b2 += sg * er[2 * mpad + k];
+                    r0[u] = er[e];
+                    r1[u] = er[mpad + e];
+                    r2[u] = er[2 * mpad + e];
                 }
+                if (!live) wk[u] = 0.0;
             }
-            const int bb = bptr[row], be = bptr[row + 1];
-            for (int s = bb + l; s < be; s += G) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                double ww = wk[u];
+                if (MODE == 0) ww = ww * ww;
+                if (MODE == 0) {
+                    const double sg = (se[u] & 1u) ? ww : -ww;
+                    b0 += sg * r0[u];
+                    b1 += sg * r1[u];
+                    b2 += sg * r2[u];
+                }
+                v_p[(size_t)(k0 + u) * 64] = -ww;
+                sw += ww;
+            }
+        }
+        if (row < n) {
+            for (int s = bptr[row]; s < bptr[row + 1]; s++) {
                 const uint8_t fl = bflag[s];
                 if (!(fl & (MODE == 0 ? BF_IRLS : BF_L1H))) continue;
                 const uint32_t se = beid[s];
-                const uint32_t k = se >> 1;
-                double w = wsrc[k];
-                if (MODE == 0) w = w * w;
-                if (MODE == 1 && (fl & BF_NEG)) w = -w;
-                ex += w;
+                const uint32_t e = se >> 1;
+                double wk = wsrc[e];
+                if (MODE == 0) wk = wk * wk;
+                if (MODE == 1 && (fl & BF_NEG)) wk = -wk;
+                ex += wk;
                 if (MODE == 0) {
-                    const double sg = (se & 1u) ? w : -w;
-                    b0 += sg * er[k];
-                    b1 += sg * er[mpad + k];
-                    b2 += sg * er[2 * mpad + k];
+                    const double sg = (se & 1u) ? wk : -wk;
+                    b0 += sg * er[e];
+                    b1 += sg * er[mpad + e];
+                    b2 += sg * er[2 * mpad + e];
                 }
             }
-        }
-        sw = group_sum<G>(sw);
-        ex = group_sum<G>(ex);
-        if (MODE == 0) {
-            b0 = group_sum<G>(b0);
-            b1 = group_sum<G>(b1);
-            b2 = group_sum<G>(b2);
-        }
-        if (l == 0 && row < n) {
             const double d = sw + ex;
             excess[row] = ex;
             diag[row] = d;
@@ -241,151 +251,75 @@ __global__ __launch_bounds__(kBlock) void k_assemble0(
     }
 }
 
-// coarse off-diagonal values: val_c[c] = sum of the finer slots listed for c
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_coarse_vals(int nslots, const int *__restrict__ cptr,
-                                                        const int *__restrict__ cidx,
-                                                        const double *__restrict__ fval,
-                                                        double *__restrict__ cval) {
-    constexpr int R = kBlock / G;
+// coarse off-diagonal values: entry c (CSR order) = sum of the finer SELL positions listed for
+// it, stored at its own SELL position. 8 lanes per entry.
+__global__ __launch_bounds__(kRowBlock) void k_coarse_vals(int nent, const int *__restrict__ cptr,
+                                                           const int *__restrict__ cidx,
+                                                           const int *__restrict__ cpos,
+                                                           const double *__restrict__ fval,
+                                                           double *__restrict__ cval) {
+    constexpr int G = 8, R = kRowBlock / G;
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int ntiles = (nslots + R - 1) / R;
+    const int ntiles = (nent + R - 1) / R;
     int t0, t1;
     tile_range(ntiles, t0, t1);
     for (int t = t0; t < t1; t++) {
         const int c = t * R + grp;
         double s = 0.0;
-        if (c < nslots) {
+        if (c < nent) {
             const int beg = cptr[c], end = cptr[c + 1];
             for (int q = beg + l; q < end; q += G) s += fval[cidx[q]];
         }
-        s = group_sum<G>(s);
-        if (l == 0 && c < nslots) cval[c] = s;
+        s = seg_sum(s, G);
+        if (l == 0 && c < nent) cval[cpos[c]] = s;
     }
 }
 
-// coarse diagonal: excess_c = sum of the aggregate's excess, diag_c = excess_c - sum(val_c)
-__global__ __launch_bounds__(256) void k_coarse_diag(int nc, int nf, int agg,
-                                                     const double *__restrict__ fexcess,
-                                                     const int *__restrict__ rowptr,
-                                                     const double *__restrict__ cval,
-                                                     double *__restrict__ cexcess,
-                                                     double *__restrict__ cdiag,
-                                                     double *__restrict__ cidg) {
+// coarse diagonal: excess_c = sum of the aggregate's excess, diag_c = excess_c - sum(row values)
+__global__ __launch_bounds__(kRowBlock) void k_coarse_diag(LevelView C, int nf, int agg,
+                                                           const double *__restrict__ fexcess,
+                                                           double *__restrict__ cexcess,
+                                                           double *__restrict__ cdiag,
+                                                           double *__restrict__ cidg) {
     const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= nc) return;
+    if (I >= C.nsl * 64) return;
+    const int sl = I >> 6, lane = I & 63;
+    const int o0 = C.sl_off[sl], w = C.sl_off[sl + 1] - o0;
+    const double *__restrict__ v = C.val + (size_t)o0 * 64 + lane;
+    double sv = 0.0;
+    for (int k = 0; k < w; k++) sv += v[(size_t)k * 64];
+    if (I >= C.n) return;
     double ex = 0.0;
     const int v0 = I * agg, v1 = min(nf, v0 + agg);
-    for (int v = v0; v < v1; v++) ex += fexcess[v];
-    double sv = 0.0;
-    for (int s = rowptr[I]; s < rowptr[I + 1]; s++) sv += cval[s];
+    for (int q = v0; q < v1; q++) ex += fexcess[q];
     const double d = ex - sv;
     cexcess[I] = ex;
     cdiag[I] = d;
     cidg[I] = d > 0.0 ? 1.0 / d : 0.0;
 }
 
-// dense inverse of the coarsest level (n <= 128) by in-place Gauss-Jordan in LDS. The matrix is
-// SPD for a connected graph with f >= 1; a non-positive pivot (isolated coarse vertex) is
-// replaced by 1 after its row/column were zeroed, i.e. that unknown solves to 0.
-__global__ __launch_bounds__(1024) void k_dense_invert(int n, const int *__restrict__ rowptr,
-                                                       const int *__restrict__ col,
-                                                       const double *__restrict__ val,
-                                                       const double *__restrict__ diag,
-                                                       double *__restrict__ inv) {
-    extern __shared__ double A[];  // n*n + 2n
-    double *rowk = A + n * n, *colk = rowk + n;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int e = tid; e < n * n; e += nt) A[e] = 0.0;
-    __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-        A[i * n + i] = diag[i];
-        for (int s = rowptr[i]; s < rowptr[i + 1]; s++) A[i * n + col[s]] += val[s];
-    }
-    __syncthreads();
-    for (int k = 0; k < n; k++) {
-        const double piv = A[k * n + k];
-        const bool dead = !(piv > 0.0);
-        const double ip = dead ? 0.0 : 1.0 / piv;
-        for (int j = tid; j < n; j += nt) {
-            rowk[j] = (j == k) ? ip : A[k * n + j] * ip;
-            colk[j] = (j == k) ? 0.0 : A[j * n + k];
-        }
-        __syncthreads();
-        for (int e = tid; e < n * n; e += nt) {
-            const int i = e / n, j = e - i * n;
-            if (i == k)
-                A[e] = rowk[j];
-            else
-                A[e] = (j == k ? 0.0 : A[e]) - colk[i] * rowk[j];
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < n * n; e += nt) inv[e] = A[e];
-}
-
-__global__ __launch_bounds__(256) void k_dense_solve(int n, const double *__restrict__ inv,
-                                                     const double4 *__restrict__ b,
-                                                     double4 *__restrict__ x,
-                                                     const int *__restrict__ flags) {
-    if (flags[FL_DONE]) return;
-    extern __shared__ double4 sb[];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) sb[i] = b[i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        double s0 = 0, s1 = 0, s2 = 0;
-        for (int j = 0; j < n; j++) {
-            const double a = inv[i * n + j];
-            s0 += a * sb[j].x;
-            s1 += a * sb[j].y;
-            s2 += a * sb[j].z;
-        }
-        x[i] = make_double4(s0, s1, s2, 0.0);
-    }
-}
-
 // =============================================================================================
-// K4 -- row kernels on a level: y = L x variants. One G-lane group per row.
+// K4 -- row kernels on a level (one lane per row, SELL-64)
 // =============================================================================================
-template <int G>
-__device__ __forceinline__ void row_offdiag(const LevelView &L, int row, int l,
-                                            const double4 *__restrict__ x, double &s0, double &s1,
-                                            double &s2) {
-    s0 = s1 = s2 = 0.0;
-    if (row < L.n) {
-        const int beg = L.rowptr[row], end = L.rowptr[row + 1];
-        for (int s = beg + l; s < end; s += G) {
-            const int c = L.col[s];
-            const double v = L.val[s];
-            const double4 xc = x[c];
-            s0 += v * xc.x;
-            s1 += v * xc.y;
-            s2 += v * xc.z;
-        }
-    }
-    s0 = group_sum<G>(s0);
-    s1 = group_sum<G>(s1);
-    s2 = group_sum<G>(s2);
-}
+#define ROW_TILE_LOOP(L)                                       \
+    const int ntiles_ = ((L).nsl + 3) / 4;                     \
+    int t0_, t1_;                                              \
+    tile_range(ntiles_, t0_, t1_);                             \
+    for (int t_ = t0_; t_ < t1_; t_++)                         \
+        if (const int sl_ = t_ * 4 + (threadIdx.x >> 6); sl_ < (L).nsl)
 
 // q = L p, partial dot products p.q
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_spmv_dot(LevelView L, const double4 *__restrict__ p,
-                                                     double4 *__restrict__ q,
-                                                     double *__restrict__ part_pq,
-                                                     const int *__restrict__ flags) {
+__global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const double4 *__restrict__ p,
+                                                        double4 *__restrict__ q,
+                                                        double *__restrict__ part_pq,
+                                                        const int *__restrict__ flags) {
     if (flags[FL_DONE]) return;
-    constexpr int R = kBlock / G;
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int ntiles = (L.n + R - 1) / R;
-    int t0, t1;
-    tile_range(ntiles, t0, t1);
     double a0 = 0, a1 = 0, a2 = 0;
-    for (int t = t0; t < t1; t++) {
-        const int row = t * R + grp;
+    ROW_TILE_LOOP(L) {
+        const int row = sl_ * 64 + (threadIdx.x & 63);
         double s0, s1, s2;
-        row_offdiag<G>(L, row, l, p, s0, s1, s2);
-        if (l == 0 && row < L.n) {
+        row_offdiag(L, row, p, s0, s1, s2);
+        if (row < L.n) {
             const double4 pr = p[row];
             const double d = L.diag[row];
             s0 += d * pr.x;
@@ -400,134 +334,82 @@ __global__ __launch_bounds__(kBlock) void k_spmv_dot(LevelView L, const double4 
     block_sum3_store(a0, a1, a2, part_pq + 4 * blockIdx.x);
 }
 
-// Down-sweep on level l: r = b - L x (x = omega D^-1 b already stored), restricted by summing
-// each aggregate of `agg` consecutive rows: bc = P' r, and the coarse pre-smoothed iterate
-// xc = omega Dc^-1 bc. On level 0 (CHECK) the prologue turns the ||r||^2 partials of the last
-// PCG update into the convergence decision.
-template <int G, bool CHECK>
-__global__ __launch_bounds__(kBlock) void k_residual_restrict(
-    LevelView L, const double4 *__restrict__ b, const double4 *__restrict__ x,
-    double4 *__restrict__ bc, double4 *__restrict__ xc, const double *__restrict__ cidg, int nc,
-    double omega, const double *__restrict__ part_rr, int nparts, int first, double rtol2,
-    double *__restrict__ scal, int *__restrict__ flags) {
-    if (flags[FL_DONE]) return;
-    if (CHECK) {
-        double rr[3];
-        load_reduced3(part_rr, nparts, rr);
-        double bb[3];
-        if (first) {
-            bb[0] = rr[0];
-            bb[1] = rr[1];
-            bb[2] = rr[2];
-        } else {
-            bb[0] = scal[SC_BB];
-            bb[1] = scal[SC_BB + 1];
-            bb[2] = scal[SC_BB + 2];
-        }
-        const bool finite = isfinite(rr[0]) && isfinite(rr[1]) && isfinite(rr[2]);
-        const bool conv = rr[0] <= rtol2 * bb[0] && rr[1] <= rtol2 * bb[1] && rr[2] <= rtol2 * bb[2];
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            if (first) {
-                scal[SC_BB] = bb[0];
-                scal[SC_BB + 1] = bb[1];
-                scal[SC_BB + 2] = bb[2];
-            }
-            for (int c = 0; c < 3; c++) scal[SC_RELRES + c] = bb[c] > 0.0 ? sqrt(rr[c] / bb[c]) : 0.0;
-            if (!finite)
-                flags[FL_DONE] = 2;
-            else if (conv)
-                flags[FL_DONE] = 1;
-        }
-        if (!finite || conv) return;
+// r = b - L x for the lane's row, summed over each aggregate of `agg` consecutive lanes:
+// bc = P' r, and the coarse pre-smoothed iterate xc = omega Dc^-1 bc
+__device__ __forceinline__ void down_row(const LevelView &L, int row, const double4 *b,
+                                         const double4 *x, double4 *bc, double4 *xc,
+                                         const double *cidg, double omega) {
+    double s0, s1, s2;
+    row_offdiag(L, row, x, s0, s1, s2);
+    double r0 = 0, r1 = 0, r2 = 0;
+    if (row < L.n) {
+        const double4 xr = x[row], br = b[row];
+        const double d = L.diag[row];
+        r0 = br.x - (s0 + d * xr.x);
+        r1 = br.y - (s1 + d * xr.y);
+        r2 = br.z - (s2 + d * xr.z);
     }
-    constexpr int R = kBlock / G;
-    __shared__ double sr[3][R];
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int ntiles = (L.n + R - 1) / R;
-    int t0, t1;
-    tile_range(ntiles, t0, t1);
-    for (int t = t0; t < t1; t++) {
-        const int row = t * R + grp;
-        double s0, s1, s2;
-        row_offdiag<G>(L, row, l, x, s0, s1, s2);
-        if (l == 0) {
-            double r0 = 0, r1 = 0, r2 = 0;
-            if (row < L.n) {
-                const double4 xr = x[row], br = b[row];
-                const double d = L.diag[row];
-                r0 = br.x - (s0 + d * xr.x);
-                r1 = br.y - (s1 + d * xr.y);
-                r2 = br.z - (s2 + d * xr.z);
-            }
-            sr[0][grp] = r0;
-            sr[1][grp] = r1;
-            sr[2][grp] = r2;
-        }
-        __syncthreads();
-        const int nagg = R / L.agg;
-        if ((int)threadIdx.x < nagg) {
-            const int I = (t * R) / L.agg + threadIdx.x;
-            if (I < nc) {
-                double c0 = 0, c1 = 0, c2 = 0;
-                for (int q = 0; q < L.agg; q++) {
-                    c0 += sr[0][threadIdx.x * L.agg + q];
-                    c1 += sr[1][threadIdx.x * L.agg + q];
-                    c2 += sr[2][threadIdx.x * L.agg + q];
-                }
-                bc[I] = make_double4(c0, c1, c2, 0.0);
-                const double w = omega * cidg[I];
-                xc[I] = make_double4(w * c0, w * c1, w * c2, 0.0);
-            }
-        }
-        __syncthreads();
+    r0 = seg_sum(r0, L.agg);
+    r1 = seg_sum(r1, L.agg);
+    r2 = seg_sum(r2, L.agg);
+    if ((row & (L.agg - 1)) == 0 && row < L.n) {
+        const int I = row / L.agg;
+        bc[I] = make_double4(r0, r1, r2, 0.0);
+        const double w = omega * cidg[I];
+        xc[I] = make_double4(w * r0, w * r1, w * r2, 0.0);
     }
 }
 
-// Up-sweep on level l: x' = x + kc * P xc; y = x' + omega D^-1 (b - L x'). On level 0 (DOT) the
-// partial dot products r.z (r = b) are produced for the PCG beta.
-template <int G, bool DOT>
-__global__ __launch_bounds__(kBlock) void k_prolong_smooth(
+// x' = x + kc * P xc; y = x' + omega D^-1 (b - L x') for the lane's row; returns y
+__device__ __forceinline__ double4 up_row(const LevelView &L, int row, const double4 *b,
+                                          const double4 *x, const double4 *xc, double omega,
+                                          double kc, int sh) {
+    double s0, s1, s2;
+    row_offdiag_prolong(L, row, x, xc, sh, kc, s0, s1, s2);
+    double4 y = make_double4(0, 0, 0, 0);
+    if (row < L.n) {
+        const double4 xf = x[row], xk = xc[row >> sh], br = b[row];
+        const double d = L.diag[row], w = omega * L.idg[row];
+        const double p0 = xf.x + kc * xk.x, p1 = xf.y + kc * xk.y, p2 = xf.z + kc * xk.z;
+        y.x = p0 + w * (br.x - (s0 + d * p0));
+        y.y = p1 + w * (br.y - (s1 + d * p1));
+        y.z = p2 + w * (br.z - (s2 + d * p2));
+    }
+    return y;
+}
+
+template <bool CHECK>
+__global__ __launch_bounds__(kRowBlock) void k_residual_restrict(
+    LevelView L, const double4 *__restrict__ b, const double4 *__restrict__ x,
+    double4 *__restrict__ bc, double4 *__restrict__ xc, const double *__restrict__ cidg,
+    double omega, const double *__restrict__ part_rr, int nparts, int first, double rtol2,
+    double *__restrict__ scal, int *__restrict__ flags) {
+    if (flags[FL_DONE]) return;
+    if (CHECK && pcg_check(part_rr, nparts, first, rtol2, scal, flags)) return;
+    ROW_TILE_LOOP(L) {
+        const int row = sl_ * 64 + (threadIdx.x & 63);
+        down_row(L, row, b, x, bc, xc, cidg, omega);
+    }
+}
+
+template <bool DOT>
+__global__ __launch_bounds__(kRowBlock) void k_prolong_smooth(
     LevelView L, const double4 *__restrict__ b, const double4 *__restrict__ x,
     const double4 *__restrict__ xc, double4 *__restrict__ y, double omega, double kc,
     double *__restrict__ part_rz, const int *__restrict__ flags) {
     if (flags[FL_DONE]) return;
-    constexpr int R = kBlock / G;
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int ntiles = (L.n + R - 1) / R;
-    int t0, t1;
-    tile_range(ntiles, t0, t1);
     const int sh = __ffs(L.agg) - 1;  // agg is a power of two
     double a0 = 0, a1 = 0, a2 = 0;
-    for (int t = t0; t < t1; t++) {
-        const int row = t * R + grp;
-        double s0 = 0, s1 = 0, s2 = 0;
+    ROW_TILE_LOOP(L) {
+        const int row = sl_ * 64 + (threadIdx.x & 63);
+        const double4 yy = up_row(L, row, b, x, xc, omega, kc, sh);
         if (row < L.n) {
-            const int beg = L.rowptr[row], end = L.rowptr[row + 1];
-            for (int s = beg + l; s < end; s += G) {
-                const int c = L.col[s];
-                const double v = L.val[s];
-                const double4 xf = x[c];
-                const double4 xk = xc[c >> sh];
-                s0 += v * (xf.x + kc * xk.x);
-                s1 += v * (xf.y + kc * xk.y);
-                s2 += v * (xf.z + kc * xk.z);
-            }
-        }
-        s0 = group_sum<G>(s0);
-        s1 = group_sum<G>(s1);
-        s2 = group_sum<G>(s2);
-        if (l == 0 && row < L.n) {
-            const double4 xf = x[row], xk = xc[row >> sh], br = b[row];
-            const double d = L.diag[row], w = omega * L.idg[row];
-            const double p0 = xf.x + kc * xk.x, p1 = xf.y + kc * xk.y, p2 = xf.z + kc * xk.z;
-            const double y0 = p0 + w * (br.x - (s0 + d * p0));
-            const double y1 = p1 + w * (br.y - (s1 + d * p1));
-            const double y2 = p2 + w * (br.z - (s2 + d * p2));
-            y[row] = make_double4(y0, y1, y2, 0.0);
+            y[row] = yy;
             if (DOT) {
-                a0 += br.x * y0;
-                a1 += br.y * y1;
-                a2 += br.z * y2;
+                const double4 br = b[row];
+                a0 += br.x * yy.x;
+                a1 += br.y * yy.y;
+                a2 += br.z * yy.z;
             }
         }
     }
@@ -535,30 +417,16 @@ __global__ __launch_bounds__(kBlock) void k_prolong_smooth(
 }
 
 // single-level preconditioner (plain Jacobi): z = D^-1 r, with the convergence prologue
-__global__ __launch_bounds__(kBlock) void k_jacobi_z(int n, const double *__restrict__ idg,
-                                                     const double4 *__restrict__ r,
-                                                     double4 *__restrict__ z,
-                                                     double *__restrict__ part_rz,
-                                                     const double *__restrict__ part_rr,
-                                                     int nparts, int first, double rtol2,
-                                                     double *__restrict__ scal,
-                                                     int *__restrict__ flags) {
+__global__ __launch_bounds__(kRowBlock) void k_jacobi_z(int n, const double *__restrict__ idg,
+                                                        const double4 *__restrict__ r,
+                                                        double4 *__restrict__ z,
+                                                        double *__restrict__ part_rz,
+                                                        const double *__restrict__ part_rr,
+                                                        int nparts, int first, double rtol2,
+                                                        double *__restrict__ scal,
+                                                        int *__restrict__ flags) {
     if (flags[FL_DONE]) return;
-    double rr[3], bb[3];
-    load_reduced3(part_rr, nparts, rr);
-    for (int c = 0; c < 3; c++) bb[c] = first ? rr[c] : scal[SC_BB + c];
-    const bool finite = isfinite(rr[0]) && isfinite(rr[1]) && isfinite(rr[2]);
-    const bool conv = rr[0] <= rtol2 * bb[0] && rr[1] <= rtol2 * bb[1] && rr[2] <= rtol2 * bb[2];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (first)
-            for (int c = 0; c < 3; c++) scal[SC_BB + c] = bb[c];
-        for (int c = 0; c < 3; c++) scal[SC_RELRES + c] = bb[c] > 0.0 ? sqrt(rr[c] / bb[c]) : 0.0;
-        if (!finite)
-            flags[FL_DONE] = 2;
-        else if (conv)
-            flags[FL_DONE] = 1;
-    }
-    if (!finite || conv) return;
+    if (pcg_check(part_rr, nparts, first, rtol2, scal, flags)) return;
     double a0 = 0, a1 = 0, a2 = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double w = idg[i];
@@ -578,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void k_jacobi_z(int n, const double *__rest
 // INIT: x = 0, r = b (already in R), x0 = omega D^-1 r, partials of ||r||^2.
 // else: alpha = rz/pq; x += alpha p; r -= alpha q; x0 = omega D^-1 r; partials of ||r||^2.
 template <bool INIT>
-__global__ __launch_bounds__(kBlock) void k_pcg_update(
+__global__ __launch_bounds__(kRowBlock) void k_pcg_update(
     int n, const double *__restrict__ scal, int par, const double *__restrict__ part_pq, int nparts,
     double4 *__restrict__ X, double4 *__restrict__ R, const double4 *__restrict__ P,
     const double4 *__restrict__ AP, const double *__restrict__ idg, double4 *__restrict__ x0,
@@ -621,12 +489,12 @@ __global__ __launch_bounds__(kBlock) void k_pcg_update(
 }
 
 // beta = rz_new / rz_old (0 on the first pass); p = z + beta p; rz_new stored under the other parity
-__global__ __launch_bounds__(kBlock) void k_pcg_pupdate(int n, double *__restrict__ scal, int par,
-                                                        int first,
-                                                        const double *__restrict__ part_rz,
-                                                        int nparts, const double4 *__restrict__ Z,
-                                                        double4 *__restrict__ P,
-                                                        int *__restrict__ flags) {
+__global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate(int n, double *__restrict__ scal, int par,
+                                                           int first,
+                                                           const double *__restrict__ part_rz,
+                                                           int nparts, const double4 *__restrict__ Z,
+                                                           double4 *__restrict__ P,
+                                                           int *__restrict__ flags) {
     if (flags[FL_DONE]) return;
     double rzn[3], be[3];
     load_reduced3(part_rz, nparts, rzn);
@@ -655,9 +523,116 @@ __global__ __launch_bounds__(kBlock) void k_pcg_pupdate(int n, double *__restric
 }
 
 // =============================================================================================
+// K5' -- additive top level. Level 0 enters the preconditioner additively:
+//   z = omega D0^-1 r + kc * P0 M1^-1 P0' r      (M1 = multiplicative cycle on levels >= 1)
+// so the preconditioner needs NO pass over the fine matrix (the multiplicative variant needs
+// two). The PCG update restricts r on the fly, r.z is assembled from two partial sets
+// (r.z0 here, b1.y1 on level 1) and the p-update prolongs on the fly.
+// =============================================================================================
+template <bool INIT>
+__global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict(
+    int n, int nsl, int agg, const double *__restrict__ scal, int par,
+    const double *__restrict__ part_pq, int nparts, double4 *__restrict__ X, double4 *__restrict__ R,
+    const double4 *__restrict__ P, const double4 *__restrict__ AP, const double *__restrict__ idg,
+    double4 *__restrict__ bc, double4 *__restrict__ xc, const double *__restrict__ cidg,
+    double omega, double *__restrict__ part_rr, double *__restrict__ part_rz,
+    int *__restrict__ flags) {
+    if (flags[FL_DONE]) return;
+    double al[3] = {0, 0, 0};
+    if (!INIT) {
+        double pq[3];
+        load_reduced3(part_pq, nparts, pq);
+        for (int c = 0; c < 3; c++) {
+            const double rz = scal[(par ? SC_RZ1 : SC_RZ0) + c];
+            al[c] = pq[c] > 0.0 ? rz / pq[c] : 0.0;
+        }
+    }
+    double a0 = 0, a1 = 0, a2 = 0, z0 = 0, z1 = 0, z2 = 0;
+    const int ntiles = (nsl + 3) / 4;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    for (int t = t0; t < t1; t++) {
+        const int sl = t * 4 + (threadIdx.x >> 6);
+        if (sl < nsl) {
+            const int i = sl * 64 + (threadIdx.x & 63);
+            double4 r = make_double4(0, 0, 0, 0);
+            if (i < n) {
+                r = R[i];
+                if (INIT) {
+                    X[i] = make_double4(0, 0, 0, 0);
+                } else {
+                    const double4 p = P[i], q = AP[i];
+                    double4 x = X[i];
+                    x.x += al[0] * p.x;
+                    x.y += al[1] * p.y;
+                    x.z += al[2] * p.z;
+                    X[i] = x;
+                    r.x -= al[0] * q.x;
+                    r.y -= al[1] * q.y;
+                    r.z -= al[2] * q.z;
+                    R[i] = r;
+                }
+                const double w = omega * idg[i];
+                a0 += r.x * r.x;
+                a1 += r.y * r.y;
+                a2 += r.z * r.z;
+                z0 += w * r.x * r.x;
+                z1 += w * r.y * r.y;
+                z2 += w * r.z * r.z;
+            }
+            const double c0 = seg_sum(r.x, agg), c1 = seg_sum(r.y, agg), c2 = seg_sum(r.z, agg);
+            if ((i & (agg - 1)) == 0 && i < n) {
+                const int I = i / agg;
+                bc[I] = make_double4(c0, c1, c2, 0.0);
+                const double w = omega * cidg[I];
+                xc[I] = make_double4(w * c0, w * c1, w * c2, 0.0);
+            }
+        }
+    }
+    block_sum3_store(a0, a1, a2, part_rr + 4 * blockIdx.x);
+    block_sum3_store(z0, z1, z2, part_rz + 4 * blockIdx.x);
+    if (!INIT && blockIdx.x == 0 && threadIdx.x == 0) flags[FL_ITERS] += 1;
+}
+
+// beta from r.z = (r.z0 partials) + kc * (b1.y1 partials); p = omega D^-1 r + kc * P y1 + beta p
+__global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate_add(
+    int n, int sh, double *__restrict__ scal, int par, int first, const double *__restrict__ part_rz,
+    int np0, const double *__restrict__ part_rz2, int np1, const double4 *__restrict__ R,
+    const double *__restrict__ idg, const double4 *__restrict__ yc, double omega, double kc,
+    double4 *__restrict__ P, int *__restrict__ flags) {
+    if (flags[FL_DONE]) return;
+    double ra[3], rb[3], rzn[3], be[3];
+    load_reduced3(part_rz, np0, ra);
+    load_reduced3(part_rz2, np1, rb);
+    bool finite = true;
+    for (int c = 0; c < 3; c++) {
+        rzn[c] = ra[c] + kc * rb[c];
+        const double rzo = scal[(par ? SC_RZ1 : SC_RZ0) + c];
+        be[c] = (first || !(rzo > 0.0)) ? 0.0 : rzn[c] / rzo;
+        finite = finite && isfinite(rzn[c]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int c = 0; c < 3; c++) scal[(par ? SC_RZ0 : SC_RZ1) + c] = rzn[c];
+        if (!finite) flags[FL_DONE] = 2;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double4 r = R[i], y = yc[i >> sh];
+        const double w = omega * idg[i];
+        double4 p = make_double4(w * r.x + kc * y.x, w * r.y + kc * y.y, w * r.z + kc * y.z, 0.0);
+        if (!first) {
+            const double4 po = P[i];
+            p.x += be[0] * po.x;
+            p.y += be[1] * po.y;
+            p.z += be[2] * po.z;
+        }
+        P[i] = p;
+    }
+}
+
+// =============================================================================================
 // K6 -- score, exp map and rotation update (one free view per thread)
 // =============================================================================================
-__global__ __launch_bounds__(kBlock) void k_apply_step(int n, int f, const double4 *__restrict__ X,
+__global__ __launch_bounds__(kRowBlock) void k_apply_step(int n, int f, const double4 *__restrict__ X,
                                                        double4 *__restrict__ Q,
                                                        double *__restrict__ part_score,
                                                        int write) {
@@ -735,191 +710,215 @@ int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f) {
 // host drivers
 // =============================================================================================
 static LevelView view_of(const Level &L) {
-    return LevelView{L.n, L.nnz, L.agg, L.rowptr.p, L.col.p, L.val.p, L.diag.p, L.idg.p};
+    return LevelView{L.n, L.nsl, L.agg, L.sl_off.p, L.col.p, L.val.p, L.diag.p, L.idg.p};
 }
 
-static int grid_for_rows(int n, int lanes) {
-    const int R = kBlock / lanes;
-    const int ntiles = (n + R - 1) / R;
-    int gsz = std::min(ntiles, (int)kMaxParts);
-    if (gsz >= 8) gsz &= ~7;
-    return std::max(gsz, 1);
+static int round_grid(long long gsz) {
+    gsz = std::min<long long>(gsz, kMaxParts);
+    if (gsz >= 8) gsz &= ~7ll;
+    return (int)std::max<long long>(gsz, 1);
 }
-static int grid_for_elems(int n) {
-    int gsz = std::min((n + kBlock - 1) / kBlock, (int)kMaxParts);
-    if (gsz >= 8) gsz &= ~7;
-    return std::max(gsz, 1);
-}
-
-#define DISPATCH_LANES(lanes, CALL)      \
-    switch (lanes) {                     \
-    case 2: { constexpr int G = 2; CALL; } break;   \
-    case 4: { constexpr int G = 4; CALL; } break;   \
-    case 8: { constexpr int G = 8; CALL; } break;   \
-    case 16: { constexpr int G = 16; CALL; } break; \
-    case 32: { constexpr int G = 32; CALL; } break; \
-    default: { constexpr int G = 64; CALL; } break; \
-    }
+static int grid_for_rows(const Level &L) { return round_grid((L.nsl + 3) / 4); }
+static int grid_for_elems(long long n) { return round_grid((n + kRowBlock - 1) / kRowBlock); }
 
 // refresh all matrix values from per-edge weights: mode 0 = IRLS (d^2, rhs), mode 1 = L1 Hessian
-void assemble(Graph &g, int mode, const double *wsrc) {
+void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
     Level &L0 = g.levels[0];
-    const int grid = grid_for_rows(L0.n, L0.lanes);
+    const int grid = grid_for_rows(L0);
     if (mode == 0) {
-        DISPATCH_LANES(L0.lanes,
-                       hipLaunchKernelGGL((k_assemble0<G, 0>), dim3(grid), dim3(kBlock), 0, g.stream,
-                                          L0.n, L0.rowptr.p, g.slot_eid.p, g.bptr.p, g.beid.p,
-                                          g.bflag.p, wsrc, g.er.p, (long long)g.mpad, L0.val.p,
-                                          L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p));
+        hipLaunchKernelGGL((k_assemble0<0>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl,
+                           L0.sl_off.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, wsrc, g.er.p,
+                           (long long)g.mpad, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p);
     } else {
-        DISPATCH_LANES(L0.lanes,
-                       hipLaunchKernelGGL((k_assemble0<G, 1>), dim3(grid), dim3(kBlock), 0, g.stream,
-                                          L0.n, L0.rowptr.p, g.slot_eid.p, g.bptr.p, g.beid.p,
-                                          g.bflag.p, wsrc, g.er.p, (long long)g.mpad, L0.val.p,
-                                          L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p));
+        hipLaunchKernelGGL((k_assemble0<1>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl,
+                           L0.sl_off.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, wsrc, g.er.p,
+                           (long long)g.mpad, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p);
     }
     for (size_t l = 1; l < g.levels.size(); l++) {
         Level &F = g.levels[l - 1];
         Level &C = g.levels[l];
         if (C.nnz > 0) {
-            constexpr int G = 8;
-            const int grid2 = grid_for_rows(C.nnz, G);
-            hipLaunchKernelGGL((k_coarse_vals<G>), dim3(grid2), dim3(kBlock), 0, g.stream, C.nnz,
-                               C.cptr.p, C.cidx.p, F.val.p, C.val.p);
+            const int grid2 = round_grid((C.nnz + 31) / 32);
+            hipLaunchKernelGGL(k_coarse_vals, dim3(grid2), dim3(kRowBlock), 0, g.stream, C.nnz,
+                               C.cptr.p, C.cidx.p, C.cpos.p, F.val.p, C.val.p);
         }
-        hipLaunchKernelGGL(k_coarse_diag, dim3((C.n + 255) / 256), dim3(256), 0, g.stream, C.n,
-                           F.n, F.agg, F.excess.p, C.rowptr.p, C.val.p, C.excess.p, C.diag.p,
-                           C.idg.p);
+        hipLaunchKernelGGL(k_coarse_diag, dim3((C.nsl * 64 + kRowBlock - 1) / kRowBlock),
+                           dim3(kRowBlock), 0, g.stream, view_of(C), F.n, F.agg, F.excess.p,
+                           C.excess.p, C.diag.p, C.idg.p);
     }
-    if (g.ndense > 0) {
-        Level &C = g.levels.back();
-        const size_t shm = sizeof(double) * ((size_t)g.ndense * g.ndense + 2 * (size_t)g.ndense);
-        hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(1024), shm, g.stream, g.ndense,
-                           C.rowptr.p, C.col.p, C.val.p, C.diag.p, g.dense_inv.p);
+    if (refresh_dense || dense_is_stale(g)) {
+        dense_refresh(g);
+        g.dense_valid = true;
+        g.dense_fresh = true;
+    } else {
+        g.dense_fresh = false;
     }
 }
 
-// one V-cycle: z = M^-1 r with r = levels[0].b, x0 = levels[0].x (pre-smoothed) -> levels[0].y
-static void vcycle(Graph &g, int first, double rtol2) {
+// Multiplicative part of the cycle on levels [from, nl): down-sweeps, exact dense solve (or one
+// Jacobi sweep when no dense inverse exists), up-sweeps. Input: levels[from].b and .x (pre-
+// smoothed iterate omega D^-1 b); output: levels[from].y. `check_first`: the first kernel
+// launched carries the PCG convergence prologue. `dot_from`: the kernel producing
+// levels[from].y also emits partial sums of b.y into `part_dot`.
+static void cycle_from(Graph &g, int from, bool check_first, bool dot_from, double *part_dot,
+                       int np_rr, int first, double rtol2, int *np_dot) {
     const int nl = (int)g.levels.size();
     const double omega = g.opt.mg_omega, kc = g.opt.mg_kc;
-    Level &L0 = g.levels[0];
-    const int np_rr = grid_for_elems(L0.n);
-    if (nl == 1) {
-        const int grid = grid_for_elems(L0.n);
-        hipLaunchKernelGGL(k_jacobi_z, dim3(grid), dim3(kBlock), 0, g.stream, L0.n, L0.idg.p,
-                           L0.b.p, L0.y.p, g.part_rz.p, g.part_rr.p, np_rr, first, rtol2,
-                           g.scal.p, g.flags.p);
-        return;
-    }
-    for (int l = 0; l < nl - 1; l++) {
+    bool check = check_first;
+    for (int l = from; l < nl - 1; l++) {
         Level &F = g.levels[l];
         Level &C = g.levels[l + 1];
-        const int grid = grid_for_rows(F.n, F.lanes);
-        LevelView V = view_of(F);
-        if (l == 0) {
-            DISPATCH_LANES(F.lanes, hipLaunchKernelGGL((k_residual_restrict<G, true>), dim3(grid),
-                                                       dim3(kBlock), 0, g.stream, V, F.b.p, F.x.p,
-                                                       C.b.p, C.x.p, C.idg.p, C.n, omega,
-                                                       g.part_rr.p, np_rr, first, rtol2, g.scal.p,
-                                                       g.flags.p));
-        } else {
-            DISPATCH_LANES(F.lanes, hipLaunchKernelGGL((k_residual_restrict<G, false>), dim3(grid),
-                                                       dim3(kBlock), 0, g.stream, V, F.b.p, F.x.p,
-                                                       C.b.p, C.x.p, C.idg.p, C.n, omega,
-                                                       g.part_rr.p, np_rr, first, rtol2, g.scal.p,
-                                                       g.flags.p));
-        }
+        const int grid = grid_for_rows(F);
+        if (check)
+            hipLaunchKernelGGL((k_residual_restrict<true>), dim3(grid), dim3(kRowBlock), 0, g.stream,
+                               view_of(F), F.b.p, F.x.p, C.b.p, C.x.p, C.idg.p, omega, g.part_rr.p,
+                               np_rr, first, rtol2, g.scal.p, g.flags.p);
+        else
+            hipLaunchKernelGGL((k_residual_restrict<false>), dim3(grid), dim3(kRowBlock), 0,
+                               g.stream, view_of(F), F.b.p, F.x.p, C.b.p, C.x.p, C.idg.p, omega,
+                               g.part_rr.p, np_rr, first, rtol2, g.scal.p, g.flags.p);
+        check = false;
     }
     Level &CL = g.levels[nl - 1];
+    const bool last_is_from = (from == nl - 1);
     if (g.ndense > 0) {
-        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(256), sizeof(double4) * (size_t)g.ndense,
-                           g.stream, g.ndense, g.dense_inv.p, CL.b.p, CL.y.p, g.flags.p);
+        dense_apply(g, CL.b.p, CL.y.p, check, dot_from && last_is_from, part_dot, np_rr, first, rtol2);
+        if (dot_from && last_is_from && np_dot) *np_dot = dense_apply_grid(g);
     } else {
-        // no dense inverse (level cap reached): the coarsest correction is its Jacobi sweep
+        // level cap reached without a dense level: its correction is the Jacobi sweep already in x.
+        // (check/dot are handled by the caller's k_jacobi_z path when nl == 1.)
         IRH_CHECK(hipMemcpyAsync(CL.y.p, CL.x.p, sizeof(double4) * (size_t)CL.n,
                                  hipMemcpyDeviceToDevice, g.stream));
     }
-    for (int l = nl - 2; l >= 0; l--) {
+    for (int l = nl - 2; l >= from; l--) {
         Level &F = g.levels[l];
         Level &C = g.levels[l + 1];
-        const int grid = grid_for_rows(F.n, F.lanes);
-        LevelView V = view_of(F);
-        if (l == 0) {
-            DISPATCH_LANES(F.lanes, hipLaunchKernelGGL((k_prolong_smooth<G, true>), dim3(grid),
-                                                       dim3(kBlock), 0, g.stream, V, F.b.p, F.x.p,
-                                                       C.y.p, F.y.p, omega, kc, g.part_rz.p,
-                                                       g.flags.p));
+        const int grid = grid_for_rows(F);
+        if (l == from && dot_from) {
+            hipLaunchKernelGGL((k_prolong_smooth<true>), dim3(grid), dim3(kRowBlock), 0, g.stream,
+                               view_of(F), F.b.p, F.x.p, C.y.p, F.y.p, omega, kc, part_dot, g.flags.p);
+            if (np_dot) *np_dot = grid;
         } else {
-            DISPATCH_LANES(F.lanes, hipLaunchKernelGGL((k_prolong_smooth<G, false>), dim3(grid),
-                                                       dim3(kBlock), 0, g.stream, V, F.b.p, F.x.p,
-                                                       C.y.p, F.y.p, omega, kc, g.part_rz.p,
-                                                       g.flags.p));
+            hipLaunchKernelGGL((k_prolong_smooth<false>), dim3(grid), dim3(kRowBlock), 0, g.stream,
+                               view_of(F), F.b.p, F.x.p, C.y.p, F.y.p, omega, kc, part_dot, g.flags.p);
         }
     }
 }
 
-static int nparts_rz(Graph &g) {
+// Preconditioner application. Multiplicative mode: z = levels[0].y, r.z partials in part_rz
+// (np_rz of them). Additive-top mode: levels[1].y = M1^-1 P0' r and b1.y1 partials in part_rz2
+// (np_rz2); z itself is formed inside the p-update.
+struct PrecInfo {
+    int np_rz = 0, np_rz2 = 0;
+};
+static PrecInfo precondition(Graph &g, int first, double rtol2) {
+    PrecInfo pi;
+    const int nl = (int)g.levels.size();
     Level &L0 = g.levels[0];
-    return g.levels.size() == 1 ? grid_for_elems(L0.n) : grid_for_rows(L0.n, L0.lanes);
+    const int np_rr = g.additive_top && nl > 1 ? grid_for_rows(L0) : grid_for_elems(L0.n);
+    if (nl == 1) {
+        if (g.ndense > 0) {  // the whole system is the dense level: z = L^-1 r exactly
+            dense_apply(g, L0.b.p, L0.y.p, true, true, g.part_rz.p, np_rr, first, rtol2);
+            pi.np_rz = dense_apply_grid(g);
+        } else {
+            pi.np_rz = grid_for_elems(L0.n);
+            hipLaunchKernelGGL(k_jacobi_z, dim3(pi.np_rz), dim3(kRowBlock), 0, g.stream, L0.n,
+                               L0.idg.p, L0.b.p, L0.y.p, g.part_rz.p, g.part_rr.p, np_rr, first,
+                               rtol2, g.scal.p, g.flags.p);
+        }
+        return pi;
+    }
+    if (g.additive_top) {
+        pi.np_rz = np_rr;  // r.z0 partials were written by the update kernel
+        cycle_from(g, 1, true, true, g.part_rz2.p, np_rr, first, rtol2, &pi.np_rz2);
+    } else {
+        cycle_from(g, 0, true, true, g.part_rz.p, np_rr, first, rtol2, &pi.np_rz);
+    }
+    return pi;
+}
+
+static void launch_update(Graph &g, bool init, int par, int np_pq) {
+    Level &L0 = g.levels[0];
+    const int nl = (int)g.levels.size();
+    if (g.additive_top && nl > 1) {
+        Level &L1 = g.levels[1];
+        const int grid = grid_for_rows(L0);
+        if (init)
+            hipLaunchKernelGGL((k_pcg_update_restrict<true>), dim3(grid), dim3(kRowBlock), 0, g.stream,
+                               L0.n, L0.nsl, L0.agg, g.scal.p, par, g.part_pq.p, np_pq, g.X.p, L0.b.p,
+                               g.P.p, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p, g.opt.mg_omega,
+                               g.part_rr.p, g.part_rz.p, g.flags.p);
+        else
+            hipLaunchKernelGGL((k_pcg_update_restrict<false>), dim3(grid), dim3(kRowBlock), 0,
+                               g.stream, L0.n, L0.nsl, L0.agg, g.scal.p, par, g.part_pq.p, np_pq,
+                               g.X.p, L0.b.p, g.P.p, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p,
+                               g.opt.mg_omega, g.part_rr.p, g.part_rz.p, g.flags.p);
+    } else {
+        const int ge = grid_for_elems(L0.n);
+        if (init)
+            hipLaunchKernelGGL((k_pcg_update<true>), dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n,
+                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p, L0.b.p, g.P.p, g.AP.p,
+                               L0.idg.p, L0.x.p, g.opt.mg_omega, g.part_rr.p, g.flags.p);
+        else
+            hipLaunchKernelGGL((k_pcg_update<false>), dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n,
+                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p, L0.b.p, g.P.p, g.AP.p,
+                               L0.idg.p, L0.x.p, g.opt.mg_omega, g.part_rr.p, g.flags.p);
+    }
+}
+
+static void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi) {
+    Level &L0 = g.levels[0];
+    const int nl = (int)g.levels.size();
+    const int ge = grid_for_elems(L0.n);
+    if (g.additive_top && nl > 1) {
+        const int sh = __builtin_ctz((unsigned)L0.agg);
+        hipLaunchKernelGGL(k_pcg_pupdate_add, dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n, sh,
+                           g.scal.p, par, first, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2,
+                           L0.b.p, L0.idg.p, g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, g.P.p,
+                           g.flags.p);
+    } else {
+        hipLaunchKernelGGL(k_pcg_pupdate, dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n, g.scal.p, par,
+                           first, g.part_rz.p, pi.np_rz, L0.y.p, g.P.p, g.flags.p);
+    }
 }
 
 // PCG on L X = levels[0].b (three columns). Matrix values must be assembled. Result in g.X.
+// Iteration k: [precondition (its first kernel tests convergence of the previous update)] ->
+// p-update -> q = L p -> x/r update. The host polls the done flag every pcg_check_every
+// iterations; kernels enqueued past convergence return immediately.
 int pcg_solve(Graph &g) {
     Level &L0 = g.levels[0];
-    const int n = L0.n;
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
-    const int ge = grid_for_elems(n);
-    const int gr = grid_for_rows(n, L0.lanes);
+    const int gr = grid_for_rows(L0);
     LevelView V0 = view_of(L0);
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
-    hipLaunchKernelGGL((k_pcg_update<true>), dim3(ge), dim3(kBlock), 0, g.stream, n, g.scal.p, 0,
-                       g.part_pq.p, gr, g.X.p, L0.b.p, g.P.p, g.AP.p, L0.idg.p, L0.x.p,
-                       g.opt.mg_omega, g.part_rr.p, g.flags.p);
-    const double omega1 = g.levels.size() == 1 ? 1.0 : g.opt.mg_omega;
-    (void)omega1;
+    launch_update(g, true, 0, gr);
     int h_flags[FL_COUNT] = {0, 0, 0, 0};
     int it = 0;
     const int check = std::max(1, g.opt.pcg_check_every);
     const int maxit = std::max(1, g.opt.pcg_max_iters);
-    const int np_rz = nparts_rz(g);
+    auto iteration_tail = [&](const PrecInfo &pi) {
+        const int first = (it == 0);
+        const int par = it & 1;
+        launch_pupdate(g, par, first, pi);
+        hipLaunchKernelGGL(k_spmv_dot, dim3(gr), dim3(kRowBlock), 0, g.stream, V0, g.P.p, g.AP.p,
+                           g.part_pq.p, g.flags.p);
+        launch_update(g, false, par ^ 1, gr);
+        it++;
+    };
     while (true) {
-        for (int c = 0; c < check; c++, it++) {
-            const int first = (it == 0);
-            const int par = it & 1;
-            vcycle(g, first, rtol2);
-            hipLaunchKernelGGL(k_pcg_pupdate, dim3(ge), dim3(kBlock), 0, g.stream, n, g.scal.p, par,
-                               first, g.part_rz.p, np_rz, L0.y.p, g.P.p, g.flags.p);
-            DISPATCH_LANES(L0.lanes,
-                           hipLaunchKernelGGL((k_spmv_dot<G>), dim3(gr), dim3(kBlock), 0, g.stream,
-                                              V0, g.P.p, g.AP.p, g.part_pq.p, g.flags.p));
-            hipLaunchKernelGGL((k_pcg_update<false>), dim3(ge), dim3(kBlock), 0, g.stream, n,
-                               g.scal.p, par ^ 1, g.part_pq.p, gr, g.X.p, L0.b.p, g.P.p, g.AP.p,
-                               L0.idg.p, L0.x.p, g.opt.mg_omega, g.part_rr.p, g.flags.p);
+        for (int c = 0; c < check; c++) {
+            PrecInfo pi = precondition(g, it == 0, rtol2);
+            iteration_tail(pi);
         }
-        // the convergence test of the last update runs in the next V-cycle prologue; enqueue a
-        // bare check so the flag is current when the host reads it
-        vcycle(g, it == 0, rtol2);
+        // the convergence test of the last update runs in the next preconditioner prologue
+        PrecInfo pi = precondition(g, it == 0, rtol2);
         IRH_CHECK(hipMemcpyAsync(h_flags, g.flags.p, sizeof(int) * FL_COUNT, hipMemcpyDeviceToHost,
                                  g.stream));
         IRH_CHECK(hipStreamSynchronize(g.stream));
         if (h_flags[FL_DONE] != 0) break;
         if (it >= maxit) break;
-        // not converged: the V-cycle just run is exactly the one the next iteration needs
-        // -> continue with its p-update
-        {
-            const int first = (it == 0);
-            const int par = it & 1;
-            hipLaunchKernelGGL(k_pcg_pupdate, dim3(ge), dim3(kBlock), 0, g.stream, n, g.scal.p, par,
-                               first, g.part_rz.p, np_rz, L0.y.p, g.P.p, g.flags.p);
-            DISPATCH_LANES(L0.lanes,
-                           hipLaunchKernelGGL((k_spmv_dot<G>), dim3(gr), dim3(kBlock), 0, g.stream,
-                                              V0, g.P.p, g.AP.p, g.part_pq.p, g.flags.p));
-            hipLaunchKernelGGL((k_pcg_update<false>), dim3(ge), dim3(kBlock), 0, g.stream, n,
-                               g.scal.p, par ^ 1, g.part_pq.p, gr, g.X.p, L0.b.p, g.P.p, g.AP.p,
-                               L0.idg.p, L0.x.p, g.opt.mg_omega, g.part_rr.p, g.flags.p);
-            it++;
-        }
+        iteration_tail(pi);  // not converged: that preconditioner pass is the next iteration's
     }
     double h_scal[SC_COUNT];
     IRH_CHECK(hipMemcpyAsync(h_scal, g.scal.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost,
@@ -934,15 +933,23 @@ int pcg_solve(Graph &g) {
     return IROTAVG_OK;
 }
 
-int ls_solve(Graph &g) {
-    assemble(g, 0, g.dw.p);
-    return pcg_solve(g);
+// Dense-inverse refresh policy: the inverse of the coarse operator is only a preconditioner
+// component, so a stale one costs PCG iterations, never accuracy, while a refresh costs about as
+// much as ~25 PCG iterations. After the coarse values are refreshed, dense_is_stale() compares the
+// coarse diagonal with the one the inverse was computed from; the inverse is re-used (rescaled)
+// when the change is a nearly uniform factor. Depends on data only (deterministic).
+int ls_solve(Graph &g, int seq_index) {
+    (void)seq_index;
+    assemble(g, 0, g.dw.p, g.opt.reserved[1] == 1);
+    const int rc = pcg_solve(g);
+    if (g.dense_fresh) g.iters_after_refresh = g.stats.pcg_iters_last;
+    return rc;
 }
 
 double apply_step(Graph &g) {
     const int n = g.nu;
     const int grid = grid_for_elems(n);
-    hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kBlock), 0, g.stream, n, g.f, g.X.p, g.Q.p,
+    hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kRowBlock), 0, g.stream, n, g.f, g.X.p, g.Q.p,
                        g.part_score.p, 1);
     IRH_CHECK(hipMemcpyAsync(g.h_part.data(), g.part_score.p, sizeof(double) * 4 * (size_t)grid,
                              hipMemcpyDeviceToHost, g.stream));
@@ -962,7 +969,7 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     fill(g, g.dw.p, (long long)g.mpad, 1.0);  // weights.setOnes() (:577)
     while (score > change_th && it < max_iters) {  // :590, strict >
         launch_edge_residual(g);
-        rc = ls_solve(g);
+        rc = ls_solve(g, it);
         if (rc != IROTAVG_OK) break;
         launch_update_weights(g, cost, sigma);
         score = apply_step(g);
@@ -987,27 +994,27 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
     IRH_CHECK(hipEventCreate(&e0));
     IRH_CHECK(hipEventCreate(&e1));
     Level &L0 = g.levels[0];
-    const int gr = grid_for_rows(L0.n, L0.lanes);
+    const int gr = grid_for_rows(L0);
     LevelView V0 = view_of(L0);
     auto once = [&]() {
         switch (which) {
         case 1: launch_edge_residual(g); break;
         case 2: launch_update_weights(g, IROTAVG_GEMAN_MCCLURE, 5 * IRH_PI / 180.0); break;
-        case 3: assemble(g, 0, g.dw.p); break;
+        case 3: assemble(g, 0, g.dw.p, false); break;
+        case 7: dense_refresh(g); break;
         case 4:
-            DISPATCH_LANES(L0.lanes,
-                           hipLaunchKernelGGL((k_spmv_dot<G>), dim3(gr), dim3(kBlock), 0, g.stream,
-                                              V0, g.P.p, g.AP.p, g.part_pq.p, g.flags.p));
+            hipLaunchKernelGGL(k_spmv_dot, dim3(gr), dim3(kRowBlock), 0, g.stream, V0, g.P.p, g.AP.p,
+                               g.part_pq.p, g.flags.p);
             break;
-        case 5: vcycle(g, 0, -1.0); break;
+        case 5: (void)precondition(g, 0, -1.0); break;
         case 6:
-            hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kBlock), 0, g.stream,
+            hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kRowBlock), 0, g.stream,
                                g.nu, g.f, g.X.p, g.Q.p, g.part_score.p, 0);
             break;
         default: break;
         }
     };
-    if (which < 1 || which > 6) return IROTAVG_ERR_BAD_ARG;
+    if (which < 1 || which > 7) return IROTAVG_ERR_BAD_ARG;
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
     once();  // warm-up
     IRH_CHECK(hipEventRecord(e0, g.stream));
