@@ -168,6 +168,41 @@ int irotavg_graph_l1decode_pd(irotavg_graph *g, const double *y, int pdmaxiter, 
  * 7 = dense coarse-level inversion (blocked Gauss-Jordan). */
 int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_per_launch);
 
+/* ---------------------------------------------------------------------------------------------
+ * View-graph side: OpenCV-free counterpart of ViewGraph / Pose (src/ViewGraph.hpp:54-75,
+ * src/Pose.hpp:35-59). Rotations are row-major 3x3 doubles (cv::Matx33d layout). Connections
+ * carry R_ij with R_j = R_ij R_i for the pair (i < j). The ORB / essential-matrix front-end that
+ * produces them is not part of this library.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct irotavg_viewgraph irotavg_viewgraph;
+
+typedef struct irotavg_rotavg_info {
+    int skipped;       /* 0 solved; 1 fewer than 2 views (:1270); 2 too few edges (:1313);
+                          3 too few vertices (:1318); 4 no free view left */
+    int n_views, n_edges, n_fixed;  /* size of the extracted sub-problem */
+    int l1_iters, irls_iters;
+    double l1_runtime, irls_runtime;
+} irotavg_rotavg_info;
+
+int irotavg_viewgraph_create(irotavg_viewgraph **vg, const irotavg_options *opt /* may be NULL */);
+void irotavg_viewgraph_destroy(irotavg_viewgraph *vg);
+/* appends a view with absolute rotation R (NULL = identity, Pose() default); returns its index,
+ * which plays the role of frame().id() (ids only advance for admitted frames, src/IRotAvg.cpp:280-284) */
+int irotavg_viewgraph_add_view(irotavg_viewgraph *vg, const double R[9]);
+int irotavg_viewgraph_num_views(const irotavg_viewgraph *vg);
+/* replaces View::connect (src/View.hpp:92, src/ViewGraph.cpp:1438-1455): returns 1 if the
+ * connection was added, 0 if the pair was already connected */
+int irotavg_viewgraph_connect(irotavg_viewgraph *vg, int i, int j, const double Rij[9]);
+/* replace ViewGraph::fixPose / isPoseFixed / countFixedPoses (src/ViewGraph.hpp:69-73) */
+int irotavg_viewgraph_fix_pose(irotavg_viewgraph *vg, int idx, const double R[9]);
+int irotavg_viewgraph_is_pose_fixed(const irotavg_viewgraph *vg, int idx);
+int irotavg_viewgraph_count_fixed_poses(const irotavg_viewgraph *vg);
+/* Pose::R() / Pose::setR() (src/Pose.hpp:47-51) */
+int irotavg_viewgraph_get_pose(const irotavg_viewgraph *vg, int idx, double R[9]);
+int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]);
+/* replaces ViewGraph::rotAvg(int winSize) (src/ViewGraph.hpp:75, src/ViewGraph.cpp:1263-1435) */
+int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotavg_info *info);
+
 /* library / device info */
 const char *irotavg_version(void);
 int irotavg_device_count(void);

@@ -5,8 +5,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+CLI = os.path.join(HERE, "bin", "l1_irls")
 LIB = os.path.join(HERE, "libirotavg_hip.so")
-SOURCES = ["build.cpp", "solver.hip", "dense.hip", "l1pd.hip", "capi.cpp"]
+SOURCES = ["build.cpp", "solver.hip", "dense.hip", "l1pd.hip", "capi.cpp", "viewgraph.cpp"]
 HEADERS = ["common.hpp", "graph.hpp", "kernels.hpp", "../../include/irotavg_hip.h"]
 
 
@@ -21,6 +22,10 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
+    extra = [os.path.join(os.path.dirname(HERE), "tools", "l1_irls.cpp"),
+             os.path.join(os.path.dirname(HERE), "include", "irotavg", "l1_irls.hpp")]
+    if not os.path.exists(CLI) or any(os.path.getmtime(e) > t for e in extra if os.path.exists(e)):
+        return True
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS
                if os.path.exists(os.path.join(CSRC, f)))
 
@@ -45,7 +50,23 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_cli(verbose)
     return LIB
+
+
+CLI = os.path.join(HERE, "bin", "l1_irls")
+
+
+def build_cli(verbose=False):
+    """The `l1_irls`-compatible driver (tools/l1_irls.cpp over include/irotavg/l1_irls.hpp)."""
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    src = os.path.join(os.path.dirname(HERE), "tools", "l1_irls.cpp")
+    cmd = ["g++", "-O2", "-std=c++11", "-DIROTAVG_SHIM_NO_EIGEN", src, "-o", CLI, "-L" + HERE,
+           "-lirotavg_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":

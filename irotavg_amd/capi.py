@@ -25,6 +25,10 @@ SYMBOLS = [
     "irotavg_graph_ls_solve", "irotavg_graph_update_weights", "irotavg_graph_apply_step",
     "irotavg_graph_l1decode_pd", "irotavg_graph_time_kernel", "irotavg_version",
     "irotavg_device_count", "irotavg_error_string",
+    "irotavg_viewgraph_create", "irotavg_viewgraph_destroy", "irotavg_viewgraph_add_view",
+    "irotavg_viewgraph_num_views", "irotavg_viewgraph_connect", "irotavg_viewgraph_fix_pose",
+    "irotavg_viewgraph_is_pose_fixed", "irotavg_viewgraph_count_fixed_poses",
+    "irotavg_viewgraph_get_pose", "irotavg_viewgraph_set_pose", "irotavg_viewgraph_rot_avg",
 ]
 
 
@@ -41,6 +45,12 @@ class Stats(C.Structure):
                 ("seconds_irls", C.c_double), ("seconds_l1ra", C.c_double), ("levels", C.c_int),
                 ("level_rows", C.c_int64 * 16), ("level_nnz", C.c_int64 * 16),
                 ("last_relres", C.c_double * 3)]
+
+
+class RotAvgInfo(C.Structure):
+    _fields_ = [("skipped", C.c_int), ("n_views", C.c_int), ("n_edges", C.c_int), ("n_fixed", C.c_int),
+                ("l1_iters", C.c_int), ("irls_iters", C.c_int), ("l1_runtime", C.c_double),
+                ("irls_runtime", C.c_double)]
 
 
 class IrotavgError(RuntimeError):
@@ -106,6 +116,18 @@ def lib():
     L.irotavg_graph_apply_step.argtypes = [vp, _dp]
     L.irotavg_graph_l1decode_pd.argtypes = [vp, _dp, C.c_int, _dp, C.POINTER(C.c_int)]
     L.irotavg_graph_time_kernel.argtypes = [vp, C.c_int, C.c_int, _dp]
+    L.irotavg_viewgraph_create.argtypes = [C.POINTER(vp), C.POINTER(Options)]
+    L.irotavg_viewgraph_destroy.argtypes = [vp]
+    L.irotavg_viewgraph_destroy.restype = None
+    L.irotavg_viewgraph_add_view.argtypes = [vp, _dp]
+    L.irotavg_viewgraph_num_views.argtypes = [vp]
+    L.irotavg_viewgraph_connect.argtypes = [vp, C.c_int, C.c_int, _dp]
+    L.irotavg_viewgraph_fix_pose.argtypes = [vp, C.c_int, _dp]
+    L.irotavg_viewgraph_is_pose_fixed.argtypes = [vp, C.c_int]
+    L.irotavg_viewgraph_count_fixed_poses.argtypes = [vp]
+    L.irotavg_viewgraph_get_pose.argtypes = [vp, C.c_int, _dp]
+    L.irotavg_viewgraph_set_pose.argtypes = [vp, C.c_int, _dp]
+    L.irotavg_viewgraph_rot_avg.argtypes = [vp, C.c_int, C.POINTER(RotAvgInfo)]
     _LIB = L
     return L
 

@@ -1,0 +1,274 @@
+// viewgraph.cpp -- OpenCV-free counterpart of the rotation side of the reference's ViewGraph /
+// Pose API (src/ViewGraph.hpp:54-75, src/Pose.hpp:35-59): views hold a row-major 3x3 rotation and
+// a fixed flag, connections hold the relative rotation R_ij (R_j = R_ij R_i, stored once with
+// i < j), and rot_avg(win_size) reproduces ViewGraph::rotAvg (src/ViewGraph.cpp:1263-1435):
+// window extraction, fixed/free relabelling, R -> quaternion, l1ra + irls on the GPU core,
+// quaternion -> R write-back. The vision front-end that produces the edges is out of scope.
+//
+// One deliberate difference: the reference walks `std::map<View*, ViewConnection*>`, i.e. in
+// pointer order (run-to-run non-deterministic edge order, src/View.hpp:66); here a view's
+// connections are walked by ascending neighbour id.
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "graph.hpp"
+
+namespace {
+
+struct Mat3 {
+    double m[9];
+};
+
+// src/ViewGraph.cpp:1175-1203, row-major R -> [x y z w]
+void rmat2quat(const double *R, double q[4]) {
+    auto at = [&](int r, int c) { return R[3 * r + c]; };
+    const double trace = at(0, 0) + at(1, 1) + at(2, 2);
+    if (trace > 0.0) {
+        double s = std::sqrt(trace + 1.0);
+        q[3] = s * 0.5;
+        s = 0.5 / s;
+        q[0] = (at(2, 1) - at(1, 2)) * s;
+        q[1] = (at(0, 2) - at(2, 0)) * s;
+        q[2] = (at(1, 0) - at(0, 1)) * s;
+    } else {
+        const int i = at(0, 0) < at(1, 1) ? (at(1, 1) < at(2, 2) ? 2 : 1) : (at(0, 0) < at(2, 2) ? 2 : 0);
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        double s = std::sqrt(at(i, i) - at(j, j) - at(k, k) + 1.0);
+        q[i] = s * 0.5;
+        s = 0.5 / s;
+        q[3] = (at(k, j) - at(j, k)) * s;
+        q[j] = (at(j, i) + at(i, j)) * s;
+        q[k] = (at(k, i) + at(i, k)) * s;
+    }
+}
+
+// src/ViewGraph.cpp:1426-1433: q.normalized().toRotationMatrix(), row-major
+void quat2rmat(const double qin[4], double *R) {
+    double x = qin[0], y = qin[1], z = qin[2], w = qin[3];
+    const double n2 = x * x + y * y + z * z + w * w;
+    if (n2 > 0.0) {
+        const double nn = std::sqrt(n2);
+        x /= nn;
+        y /= nn;
+        z /= nn;
+        w /= nn;
+    }
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz);
+    R[1] = txy - twz;
+    R[2] = txz + twy;
+    R[3] = txy + twz;
+    R[4] = 1 - (txx + tzz);
+    R[5] = tyz - twx;
+    R[6] = txz - twy;
+    R[7] = tyz + twx;
+    R[8] = 1 - (txx + tyy);
+}
+
+}  // namespace
+
+struct irotavg_viewgraph {
+    std::vector<Mat3> pose;                      // absolute rotation per view (Pose::R)
+    std::vector<char> fixed;                     // m_fixed_mask
+    std::vector<std::map<int, Mat3>> conn;       // per view: neighbour id -> R_ij of the pair (min,max)
+    irotavg_options opt;
+    irotavg_rotavg_info last{};
+};
+
+extern "C" {
+
+int irotavg_viewgraph_create(irotavg_viewgraph **vg, const irotavg_options *opt) {
+    if (!vg) return IROTAVG_ERR_BAD_ARG;
+    try {
+        *vg = new irotavg_viewgraph();
+        if (opt)
+            (*vg)->opt = *opt;
+        else
+            irotavg_default_options(&(*vg)->opt);
+    } catch (...) {
+        return IROTAVG_ERR_NOMEM;
+    }
+    return IROTAVG_OK;
+}
+
+void irotavg_viewgraph_destroy(irotavg_viewgraph *vg) { delete vg; }
+
+int irotavg_viewgraph_add_view(irotavg_viewgraph *vg, const double R[9]) {
+    if (!vg) return IROTAVG_ERR_BAD_ARG;
+    Mat3 M;
+    if (R) {
+        std::copy(R, R + 9, M.m);
+    } else {  // Pose() default: identity (src/Pose.hpp)
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::copy(I, I + 9, M.m);
+    }
+    vg->pose.push_back(M);
+    vg->fixed.push_back(0);
+    vg->conn.emplace_back();
+    return (int)vg->pose.size() - 1;
+}
+
+int irotavg_viewgraph_num_views(const irotavg_viewgraph *vg) { return vg ? (int)vg->pose.size() : 0; }
+
+// View::connect (src/ViewGraph.cpp:1438-1455): undirected, one ViewConnection per pair, a second
+// connect of the same pair is refused. Rij relates the lower to the higher id: R_j = R_ij R_i.
+int irotavg_viewgraph_connect(irotavg_viewgraph *vg, int a, int b, const double Rij[9]) {
+    if (!vg || !Rij || a == b || a < 0 || b < 0 || a >= (int)vg->pose.size() || b >= (int)vg->pose.size())
+        return IROTAVG_ERR_BAD_ARG;
+    if (vg->conn[a].count(b)) return 0;
+    Mat3 M;
+    std::copy(Rij, Rij + 9, M.m);
+    vg->conn[a][b] = M;
+    vg->conn[b][a] = M;
+    return 1;
+}
+
+// ViewGraph::fixPose / isPoseFixed / countFixedPoses (src/ViewGraph.cpp:1234-1260)
+int irotavg_viewgraph_fix_pose(irotavg_viewgraph *vg, int idx, const double R[9]) {
+    if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
+    vg->fixed[idx] = 1;
+    std::copy(R, R + 9, vg->pose[idx].m);
+    return IROTAVG_OK;
+}
+int irotavg_viewgraph_is_pose_fixed(const irotavg_viewgraph *vg, int idx) {
+    if (!vg || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
+    return vg->fixed[idx] ? 1 : 0;
+}
+int irotavg_viewgraph_count_fixed_poses(const irotavg_viewgraph *vg) {
+    if (!vg) return IROTAVG_ERR_BAD_ARG;
+    int c = 0;
+    for (char f : vg->fixed) c += f ? 1 : 0;
+    return c;
+}
+int irotavg_viewgraph_get_pose(const irotavg_viewgraph *vg, int idx, double R[9]) {
+    if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
+    std::copy(vg->pose[idx].m, vg->pose[idx].m + 9, R);
+    return IROTAVG_OK;
+}
+int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]) {
+    if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
+    std::copy(R, R + 9, vg->pose[idx].m);
+    return IROTAVG_OK;
+}
+
+// ViewGraph::rotAvg(winSize), src/ViewGraph.cpp:1263-1435. Returns IROTAVG_OK also for the
+// reference's silent early-outs (info->skipped tells which).
+int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotavg_info *info) {
+    if (!vg || win_size <= 2) return IROTAVG_ERR_BAD_ARG;  // assert(winSize > 2) :1265
+    irotavg_rotavg_info loc{};
+    const long m = (long)vg->pose.size();
+    int win = (int)std::min<long>(m, win_size);  // :1269
+    if (win < 2) {
+        loc.skipped = 1;
+        if (info) *info = loc;
+        return IROTAVG_OK;  // :1270-1273
+    }
+    // ---- local connections (:1282-1307): for the last `win` views, edges with i < j
+    std::vector<int32_t> I;
+    std::vector<double> qq;  // per edge [x y z w]
+    std::set<int> vertices;
+    for (long t = m - win; t < m; t++) {
+        const int j = (int)t;  // frame id == view index (src/IRotAvg.cpp:280-284)
+        for (const auto &kv : vg->conn[j]) {
+            const int i = kv.first;
+            if (i < j) {
+                I.push_back(i);
+                I.push_back(j);
+                vertices.insert(i);
+                vertices.insert(j);
+                double q[4];
+                rmat2quat(kv.second.m, q);
+                qq.insert(qq.end(), q, q + 4);
+            }
+        }
+    }
+    const long ne = (long)qq.size() / 4, nv = (long)vertices.size();
+    if (ne < win) {  // :1313-1316
+        loc.skipped = 2;
+        if (info) *info = loc;
+        return IROTAVG_OK;
+    }
+    if (nv < win) {  // :1318-1321
+        loc.skipped = 3;
+        if (info) *info = loc;
+        return IROTAVG_OK;
+    }
+    // ---- fixed count and relabelling (:1323-1363)
+    int f = (int)nv - win;
+    for (int x : vertices)
+        if (x >= m - win && vg->fixed[x]) f++;
+    std::map<int, int> v2i;
+    std::vector<int> i2v((size_t)nv);
+    int t = 0, k = f;
+    for (int x : vertices) {
+        if (x >= m - win && !vg->fixed[x]) {
+            i2v[k] = x;
+            v2i[x] = k++;
+        } else {
+            i2v[t] = x;
+            v2i[x] = t++;
+        }
+    }
+    for (auto &e : I) e = v2i[e];
+    // ---- Q (:1365-1386)
+    std::vector<double> Q((size_t)4 * nv);
+    for (int x : vertices) {
+        double q[4];
+        rmat2quat(vg->pose[x].m, q);
+        const int r = v2i[x];
+        for (int c = 0; c < 4; c++) Q[(size_t)c * nv + r] = q[c];
+    }
+    if (f == 0) {  // :1382-1386
+        Q[0] = 0;
+        Q[nv] = 0;
+        Q[2 * nv] = 0;
+        Q[3 * nv] = 1;
+        f = 1;
+    }
+    // make_A asserts n - f > 1 (ral/l1_irls.cpp:758); fewer unknowns cannot be solved
+    if (nv - f < 1) {
+        loc.skipped = 4;
+        if (info) *info = loc;
+        return IROTAVG_OK;
+    }
+    std::vector<double> QQ((size_t)4 * ne);
+    for (long e = 0; e < ne; e++)
+        for (int c = 0; c < 4; c++) QQ[(size_t)c * ne + e] = qq[(size_t)4 * e + c];
+    // ---- solve (:1396-1417): no init_mst (refine from the current poses); l1ra 100 iterations,
+    // then irls Geman-McClure, sigma 5 deg, 100 iterations, change_th 1e-3
+    const double change_th = .001;
+    irotavg_graph *g = nullptr;
+    int rc = irotavg_graph_create(&g, ne, nv, f, I.data(), QQ.data(), ne, &vg->opt);
+    if (rc != IROTAVG_OK) return rc;
+    rc = irotavg_graph_set_rotations(g, Q.data(), nv);
+    if (rc == IROTAVG_OK)
+        rc = irotavg_graph_l1ra(g, 100, change_th, &loc.l1_iters, &loc.l1_runtime, nullptr);
+    if (rc == IROTAVG_OK)
+        rc = irotavg_graph_irls(g, IROTAVG_GEMAN_MCCLURE, 5 * M_PI / 180.0, 100, change_th,
+                                &loc.irls_iters, &loc.irls_runtime, nullptr);
+    if (rc == IROTAVG_OK) rc = irotavg_graph_get_rotations(g, Q.data(), nv);
+    irotavg_graph_destroy(g);
+    loc.n_views = (int)nv;
+    loc.n_edges = (int)ne;
+    loc.n_fixed = f;
+    if (rc != IROTAVG_OK) {
+        if (info) *info = loc;
+        return rc;
+    }
+    // ---- write-back for k >= f (:1420-1434)
+    for (long r = f; r < nv; r++) {
+        const double q[4] = {Q[r], Q[nv + r], Q[2 * nv + r], Q[3 * nv + r]};
+        quat2rmat(q, vg->pose[i2v[r]].m);
+    }
+    vg->last = loc;
+    if (info) *info = loc;
+    return IROTAVG_OK;
+}
+
+}  // extern "C"

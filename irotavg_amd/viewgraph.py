@@ -1,0 +1,81 @@
+"""Python mirror of the rotation side of the reference's ViewGraph / Pose API
+(src/ViewGraph.hpp:54-75, src/Pose.hpp:35-59) over the C ABI (irotavg_viewgraph_*): same method
+names and meaning (processFrame's vision front-end is out of scope -- views and connections are
+fed in directly, cf. View::connect, src/ViewGraph.cpp:1438-1455)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class ViewGraph:
+    def __init__(self, **opts):
+        self._h = C.c_void_p()
+        o = capi.default_options(**opts)
+        capi.check(capi.lib().irotavg_viewgraph_create(C.byref(self._h), C.byref(o)), "viewgraph_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            capi.lib().irotavg_viewgraph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _r(R):
+        return np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+
+    def addView(self, R=None):
+        """Appends a view (the rotation part of processFrame's `m_views.push_back`). Returns its id."""
+        if R is None:
+            rc = capi.lib().irotavg_viewgraph_add_view(self._h, None)
+        else:
+            r = self._r(R)
+            rc = capi.lib().irotavg_viewgraph_add_view(self._h, capi._d(r))
+        if rc < 0:
+            raise capi.IrotavgError(rc, "add_view")
+        return rc
+
+    def numViews(self):
+        return capi.lib().irotavg_viewgraph_num_views(self._h)
+
+    def connect(self, i, j, Rij):
+        """View::connect: R_j = R_ij R_i for i < j. True if added, False if already connected."""
+        r = self._r(Rij)
+        rc = capi.lib().irotavg_viewgraph_connect(self._h, int(i), int(j), capi._d(r))
+        if rc < 0:
+            raise capi.IrotavgError(rc, "connect")
+        return bool(rc)
+
+    def fixPose(self, idx, R):
+        r = self._r(R)
+        capi.check(capi.lib().irotavg_viewgraph_fix_pose(self._h, int(idx), capi._d(r)), "fixPose")
+
+    def isPoseFixed(self, idx):
+        rc = capi.lib().irotavg_viewgraph_is_pose_fixed(self._h, int(idx))
+        if rc < 0:
+            raise capi.IrotavgError(rc, "isPoseFixed")
+        return bool(rc)
+
+    def countFixedPoses(self):
+        return capi.lib().irotavg_viewgraph_count_fixed_poses(self._h)
+
+    def R(self, idx):
+        r = np.zeros(9)
+        capi.check(capi.lib().irotavg_viewgraph_get_pose(self._h, int(idx), capi._d(r)), "get_pose")
+        return r.reshape(3, 3)
+
+    def setR(self, idx, R):
+        r = self._r(R)
+        capi.check(capi.lib().irotavg_viewgraph_set_pose(self._h, int(idx), capi._d(r)), "set_pose")
+
+    def rotAvg(self, winSize):
+        """ViewGraph::rotAvg (src/ViewGraph.cpp:1263-1435). Returns the info record as a dict."""
+        info = capi.RotAvgInfo()
+        capi.check(capi.lib().irotavg_viewgraph_rot_avg(self._h, int(winSize), C.byref(info)), "rotAvg")
+        return {k: getattr(info, k) for k, _ in capi.RotAvgInfo._fields_}

@@ -1,0 +1,63 @@
+"""The l1_irls-compatible driver (tools/l1_irls.cpp, ral/test.cpp's arguments and formats)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from irotavg_amd import buildlib, capi, graphio, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "tests", "golden", "ravg_input.txt")
+
+
+def cli():
+    if not os.path.exists(buildlib.CLI):
+        buildlib.build()
+    return buildlib.CLI
+
+
+def test_usage_and_argument_errors():
+    r = subprocess.run([cli()], capture_output=True, text=True)
+    assert r.returncode == 255 and "Usage" in r.stderr       # exit(-1) in the reference
+    r = subprocess.run([cli(), "/nonexistent/file"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Unable to open file" in r.stderr
+    r = subprocess.run([cli(), FIX, "/tmp/_o.txt", "not-a-cost"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Unknown string" in r.stderr
+
+
+def test_fails_loudly_without_a_device(tmp_path):
+    if capi.lib().irotavg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([cli(), FIX, str(tmp_path / "o.txt")], capture_output=True, text=True)
+    assert r.returncode == 255 and "no usable HIP device" in r.stderr
+    assert not (tmp_path / "o.txt").exists()
+
+
+@pytest.mark.gpu
+def test_fixture_end_to_end_matches_golden(tmp_path):
+    out = tmp_path / "l1_irls_out.txt"
+    r = subprocess.run([cli(), FIX, str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "L1-RA iterations = 1" in r.stdout and "IRLS  iterations = 2" in r.stdout
+    Q, w = graphio.read_l1_irls_out(str(out), 1832)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "fixture_expected.npz"))
+    assert len(w) == 3655
+    assert synth.angular_distance(Q, gold["Q"]).max() < 1e-8
+    np.testing.assert_allclose(w, gold["weights"], rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_all_arguments(tmp_path):
+    out = tmp_path / "o.txt"
+    r = subprocess.run([cli(), FIX, str(out), "L1", "3", "7", "2", "0.0005"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "cost: L1" in r.stdout and "sigma [deg]: 3" in r.stdout
+    from oracle import oracle as O
+    g = graphio.read_ravg_input(FIX)
+    rc, Q0 = O.init_mst(g["Q"], g["QQ"], g["I"], 1)
+    a = O.l1ra(g["QQ"], g["I"], Q0, 1, 2, 0.0005)
+    b = O.irls(g["QQ"], g["I"], a["Q"], 1, 1, 3 * np.pi / 180, 7, 0.0005)
+    Q, w = graphio.read_l1_irls_out(str(out), 1832)
+    assert synth.angular_distance(Q, O.quat_normalised(b["Q"], 1)).max() < 1e-8
+    np.testing.assert_allclose(w, b["weights"], rtol=1e-7)

@@ -1,0 +1,116 @@
+"""The ViewGraph / Pose counterpart (irotavg_viewgraph_*): container semantics on the CPU, and
+rotAvg against the oracle's literal restatement of src/ViewGraph.cpp:1263-1435 on the GPU."""
+import numpy as np
+import pytest
+
+from irotavg_amd import capi, synth
+from irotavg_amd.viewgraph import ViewGraph
+from oracle import oracle as O
+from oracle.viewgraph_oracle import ViewGraphOracle
+
+
+def rot(q):
+    return O.quat2rmat(np.asarray(q, dtype=np.float64))
+
+
+def test_container_semantics_without_gpu():
+    vg = ViewGraph()
+    a, b, c = vg.addView(), vg.addView(rot([0, 0, np.sin(.1), np.cos(.1)])), vg.addView()
+    assert (a, b, c) == (0, 1, 2) and vg.numViews() == 3
+    np.testing.assert_array_equal(vg.R(0), np.eye(3))            # Pose() default
+    assert vg.connect(0, 1, np.eye(3)) is True
+    assert vg.connect(1, 0, np.eye(3)) is False                   # View::connect refuses duplicates
+    with pytest.raises(capi.IrotavgError):
+        vg.connect(1, 1, np.eye(3))
+    assert vg.countFixedPoses() == 0 and not vg.isPoseFixed(1)
+    R = rot([0.1, 0.2, 0.3, 0.9])
+    vg.fixPose(1, R)                                              # sets the pose AND the mask
+    assert vg.isPoseFixed(1) and vg.countFixedPoses() == 1
+    np.testing.assert_array_equal(vg.R(1), R)
+    with pytest.raises(capi.IrotavgError):
+        vg.rotAvg(2)                                              # assert(winSize > 2)
+    # early-outs of rotAvg never reach the GPU
+    assert vg.rotAvg(10)["skipped"] == 2                          # 1 edge < winSize 3
+    one = ViewGraph(); one.addView()
+    assert one.rotAvg(10)["skipped"] == 1
+
+
+def build_sequence(n, seed, k_prev=4, n_loops=6, noise=0.01):
+    """A small SLAM-like stream: each view linked to up to k_prev predecessors + a few loop closures."""
+    rng = np.random.default_rng(seed)
+    Qgt = rng.normal(size=(n, 4)); Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+    edges = []
+    for j in range(1, n):
+        for d in range(1, min(k_prev, j) + 1):
+            edges.append((j - d, j))
+    for _ in range(n_loops):
+        a, b = sorted(rng.choice(n, size=2, replace=False))
+        if b - a > k_prev:
+            edges.append((a, b))
+    rel = {}
+    for (i, j) in edges:
+        e = synth.qexp(rng.normal(scale=noise, size=(1, 3)))[0]
+        rel[(i, j)] = rot(synth.qmul(e, synth.qmul(Qgt[j], synth.qconj(Qgt[i]))))
+    return Qgt, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("win", [10, 5000000])
+def test_rotavg_matches_oracle(win):
+    n = 40
+    Qgt, rel = build_sequence(n, seed=7)
+    vg, vo = ViewGraph(), ViewGraphOracle()
+    rng = np.random.default_rng(1)
+    for v in range(n):
+        # initial poses: ground truth perturbed by ~0.05 rad (what the front-end would hand over)
+        R0 = rot(synth.qmul(synth.qexp(rng.normal(scale=0.05, size=(1, 3)))[0], Qgt[v]))
+        vg.addView(R0); vo.addView(R0)
+    for (i, j), R in rel.items():
+        assert vg.connect(i, j, R) == vo.connect(i, j, R)
+    for idx in (0, 20, 35):                                        # GT corrections (src/IRotAvg.cpp:360-368)
+        vg.fixPose(idx, rot(Qgt[idx])); vo.fixPose(idx, rot(Qgt[idx]))
+    a, b = vg.rotAvg(win), vo.rotAvg(win)
+    assert a["skipped"] == b["skipped"] == 0
+    assert (a["n_views"], a["n_edges"], a["n_fixed"]) == (b["n_views"], b["n_edges"], b["n_fixed"])
+    assert (a["l1_iters"], a["irls_iters"]) == (b["l1_iters"], b["irls_iters"])
+    for v in range(n):
+        np.testing.assert_allclose(vg.R(v), vo.R[v], atol=1e-8)
+    for idx in (0, 20, 35):
+        np.testing.assert_array_equal(vg.R(idx), rot(Qgt[idx]))   # fixed poses untouched
+    if win >= n:
+        err = [synth.angular_distance(O.rmat2quat(vg.R(v)), Qgt[v]) for v in range(n)]
+        assert max(err) < 0.05
+
+
+@pytest.mark.gpu
+def test_incremental_stream_matches_oracle():
+    """Config-5 call pattern (src/IRotAvg.cpp:360-378): local rotAvg(10) per admitted view, global
+    re-solve when a loop closure arrives, a ground-truth fix every 20 frames."""
+    n = 60
+    Qgt, rel = build_sequence(n, seed=11, n_loops=5)
+    vg, vo = ViewGraph(), ViewGraphOracle()
+    by_new = {}
+    for (i, j), R in rel.items():
+        by_new.setdefault(j, []).append((i, R))
+    for v in range(n):
+        # the front-end's initial pose of a new view: chain the first relative rotation
+        if v == 0:
+            R0 = rot(Qgt[0])
+        else:
+            i, R = sorted(by_new[v], key=lambda t: -t[0])[0]
+            R0 = R @ vo.R[i]
+        vg.addView(R0); vo.addView(R0)
+        loop = False
+        for (i, R) in by_new.get(v, []):
+            vg.connect(i, v, R); vo.connect(i, v, R)
+            loop = loop or (v - i > 4)
+        if v % 20 == 0:
+            vg.fixPose(v, rot(Qgt[v])); vo.fixPose(v, rot(Qgt[v]))
+        a = vg.rotAvg(5000000 if loop else 10)
+        b = vo.rotAvg(5000000 if loop else 10)
+        assert a["skipped"] == b["skipped"]
+        if not a["skipped"]:
+            assert (a["n_views"], a["n_fixed"], a["l1_iters"], a["irls_iters"]) == \
+                   (b["n_views"], b["n_fixed"], b["l1_iters"], b["irls_iters"]), (v, a, b)
+    for v in range(n):
+        np.testing.assert_allclose(vg.R(v), vo.R[v], atol=1e-7)
