@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="use the sharded (RCCL) path even with one rank (exercises it on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,52 +112,70 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from irotavg_amd import capi
 
     S, Q0 = build_problem(args.views, args.edges, args.p_loop, args.seed)
-    dev = local_rank if world > 1 else -1
+    dev = local_rank if dist is not None else -1
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Multi-GPU: see DESIGN.md "Multi-GPU". Until the vertex-range sharded solver lands, ranks
-    # > 0 idle and rank 0 solves the whole graph (reported honestly: scaling "strong").
-    G = None
-    if rank == 0 or world == 1:
+    # N = 1: the resident single-GPU handle. N > 1: the SAME graph sharded by contiguous view
+    # ranges, one shard per process/GPU, RCCL over xGMI (halo exchange of the PCG direction +
+    # all-reduced dot products; see DESIGN.md "Multi-GPU") -- strong scaling.
+    G = D = None
+    if dist is None:
         G = capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=args.rtol, device=dev)
         G.set_rotations(Q0)
         G.snapshot_rotations()
 
-    def step():
-        G.restore_rotations()
-        return G.irls(4, SIG, 100, 1e-3)
+        def step():
+            G.restore_rotations()
+            r = G.irls(4, SIG, 100, 1e-3)
+            G.synchronize()
+            return r
+    else:
+        uid = [capi.DistGraph.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        D = capi.DistGraph(S["I"], S["QQ"], S["n"], 1, world, rank=rank, unique_id=uid[0],
+                           pcg_rtol=args.rtol, device=dev)
+
+        def step():
+            D.set_rotations(Q0)          # H2D of the shard's rows (inside the timed region)
+            return D.irls(4, SIG, 100, 1e-3)
 
     res = None
     for _ in range(args.warmup):
-        if G is not None:
-            res = step()
+        res = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if G is not None:
-            res = step()
-            G.synchronize()
+        res = step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    dstats = D.stats() if D is not None else None
+    if D is not None:
+        D.close()
+        if rank == 0:   # kernel rooflines are measured on a single-GPU handle of the same graph
+            G = capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=args.rtol, device=dev)
+            G.set_rotations(Q0)
+            G.irls(4, SIG, 100, 1e-3)
 
     if rank == 0:
         iters = res["iters"]
         st = G.stats()
+        if dstats is not None:
+            st = dict(st, pcg_iters=dstats["pcg_iters"], pcg_solves=dstats["pcg_solves"])
         value = S["m"] * iters * args.steps / dt
         line = {
             "metric": "IRLS edge-updates/sec (+ iters-to-converge)",
@@ -168,8 +188,9 @@ def main():
                                    "f=1, init_mst start, Geman-McClure sigma=5deg, change_th=1e-3, "
                                    "max_iters=100" % (S["n"], S["m"], args.p_loop, args.seed),
                        "pcg_rtol": args.rtol, "pcg_iters_per_solve": st["pcg_iters"] / max(st["pcg_solves"], 1),
-                       "mg_level_rows": st["level_rows"], "parallelism": "1 GPU" if world == 1 else
-                       "rank 0 solves, %d ranks idle (sharded solver pending)" % (world - 1)},
+                       "mg_level_rows": st["level_rows"] if dstats is None else dstats["level_rows"],
+                       "parallelism": "1 GPU" if world == 1 else
+                       "views sharded in %d contiguous ranges, 1 shard/GPU, RCCL halo + all-reduce" % world},
             "final_scores": [float(x) for x in res["scores"]],
         }
         kr = kernel_rooflines(G, S, st)

@@ -203,6 +203,35 @@ int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]
 /* replaces ViewGraph::rotAvg(int winSize) (src/ViewGraph.hpp:75, src/ViewGraph.cpp:1263-1435) */
 int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotavg_info *info);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: the IRLS solve sharded by contiguous ranges of free views; one
+ * process per GPU, RCCL over xGMI for the halo exchanges and the scalar all-reduces. Every
+ * process passes the SAME global graph; each keeps its shard. Bootstrap: rank 0 calls
+ * irotavg_dist_unique_id and broadcasts the 128 bytes (e.g. with torch.distributed), then every
+ * rank calls irotavg_dist_create(world, rank, id, ...). With unique_id128 == NULL the handle holds
+ * ALL `world` shards in this process on the current GPU and exchanges through an in-process
+ * loopback (no RCCL): the sharded algebra can then be checked on a single GPU.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct irotavg_dist irotavg_dist;
+int irotavg_dist_unique_id(void *out128);
+int irotavg_dist_create(irotavg_dist **d, int world, int rank, const void *unique_id128, int64_t m,
+                        int64_t n_total, int f, const int32_t *I, const double *QQ, int64_t ldqq,
+                        const irotavg_options *opt);
+void irotavg_dist_destroy(irotavg_dist *d);
+int irotavg_dist_set_rotations(irotavg_dist *d, const double *Q, int64_t ldq); /* GLOBAL n_total x 4 */
+int irotavg_dist_get_rotations(irotavg_dist *d, double *Q, int64_t ldq); /* writes the rows this process owns */
+int irotavg_dist_get_weights(irotavg_dist *d, double *weights);          /* writes its local edges */
+int irotavg_dist_irls(irotavg_dist *d, int cost, double sigma, int max_iters, double change_th,
+                      int *iters, double *runtime, double *score_trace);
+int irotavg_dist_get_stats(irotavg_dist *d, irotavg_stats *out);
+int irotavg_dist_plan(irotavg_dist *d, int local_index, int64_t counts[6], int *peers, int *send_cnt,
+                      int *recv_cnt, int cap);
+/* host-only partition plan of one rank (no GPU): see irotavg_amd/csrc/dist.hip */
+int irotavg_dist_plan_host(int world, int rank, int64_t m, int64_t n_total, int f, const int32_t *I,
+                           int64_t counts[6], int32_t *ghosts_out, int64_t ghosts_cap,
+                           int32_t *send_out, int64_t send_cap, int32_t *edges_out, int64_t edges_cap,
+                           int *peers, int *send_cnt, int *recv_cnt, int peers_cap);
+
 /* library / device info */
 const char *irotavg_version(void);
 int irotavg_device_count(void);

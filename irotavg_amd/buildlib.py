@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 CLI = os.path.join(HERE, "bin", "l1_irls")
 LIB = os.path.join(HERE, "libirotavg_hip.so")
-SOURCES = ["build.cpp", "solver.hip", "dense.hip", "l1pd.hip", "capi.cpp", "viewgraph.cpp"]
+SOURCES = ["build.cpp", "solver.hip", "dense.hip", "l1pd.hip", "capi.cpp", "viewgraph.cpp", "dist.hip"]
 HEADERS = ["common.hpp", "graph.hpp", "kernels.hpp", "../../include/irotavg_hip.h"]
 
 
@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -29,6 +29,9 @@ SYMBOLS = [
     "irotavg_viewgraph_num_views", "irotavg_viewgraph_connect", "irotavg_viewgraph_fix_pose",
     "irotavg_viewgraph_is_pose_fixed", "irotavg_viewgraph_count_fixed_poses",
     "irotavg_viewgraph_get_pose", "irotavg_viewgraph_set_pose", "irotavg_viewgraph_rot_avg",
+    "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
+    "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
+    "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_plan", "irotavg_dist_plan_host",
 ]
 
 
@@ -128,6 +131,23 @@ def lib():
     L.irotavg_viewgraph_get_pose.argtypes = [vp, C.c_int, _dp]
     L.irotavg_viewgraph_set_pose.argtypes = [vp, C.c_int, _dp]
     L.irotavg_viewgraph_rot_avg.argtypes = [vp, C.c_int, C.POINTER(RotAvgInfo)]
+    L.irotavg_dist_unique_id.argtypes = [C.c_void_p]
+    L.irotavg_dist_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
+                                      C.c_int, _ip, _dp, C.c_int64, C.POINTER(Options)]
+    L.irotavg_dist_destroy.argtypes = [vp]
+    L.irotavg_dist_destroy.restype = None
+    L.irotavg_dist_set_rotations.argtypes = [vp, _dp, C.c_int64]
+    L.irotavg_dist_get_rotations.argtypes = [vp, _dp, C.c_int64]
+    L.irotavg_dist_get_weights.argtypes = [vp, _dp]
+    L.irotavg_dist_irls.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int),
+                                    _dp, _dp]
+    L.irotavg_dist_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.irotavg_dist_plan.argtypes = [vp, C.c_int, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.c_int]
+    L.irotavg_dist_plan_host.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _ip, _i64p,
+                                         _ip, C.c_int64, _ip, C.c_int64, _ip, C.c_int64,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.c_int]
     _LIB = L
     return L
 
@@ -302,3 +322,105 @@ class Graph:
         ms = C.c_double(0)
         check(lib().irotavg_graph_time_kernel(self._h, which, reps, C.byref(ms)), "time_kernel")
         return ms.value
+
+
+def plan_host(world, rank, I, n_total, f):
+    """Host-only partition plan of one rank (irotavg_dist_plan_host): dict with the owned range,
+    ghost ids, per-peer send ids (GLOBAL view ids), local edge ids."""
+    I = edges(I)
+    m = len(I)
+    counts = (C.c_int64 * 6)()
+    cap = 2 * m + 8
+    ghosts = np.zeros(cap, dtype=np.int32)
+    send = np.zeros(cap, dtype=np.int32)
+    led = np.zeros(m + 8, dtype=np.int32)
+    pc = max(world, 1)
+    peers = (C.c_int * pc)()
+    sc = (C.c_int * pc)()
+    rc_ = (C.c_int * pc)()
+    rc = lib().irotavg_dist_plan_host(world, rank, m, n_total, f, _i(I), counts, _i(ghosts), cap, _i(send),
+                                      cap, _i(led), m + 8, peers, sc, rc_, pc)
+    check(rc, "dist_plan_host")
+    lo, hi, ng, ml, npeers, ns = [int(x) for x in counts]
+    out = dict(lo=lo, hi=hi, ghosts=ghosts[:ng].copy(), edges=led[:ml].copy(), peers=list(peers)[:npeers],
+               send_cnt=list(sc)[:npeers], recv_cnt=list(rc_)[:npeers])
+    off, per = 0, {}
+    for q, h in enumerate(out["peers"]):
+        per[h] = send[off:off + out["send_cnt"][q]].copy()
+        off += out["send_cnt"][q]
+    out["send"] = per
+    return out
+
+
+class DistGraph:
+    """Sharded IRLS (irotavg_dist_*). unique_id=None: all `world` shards in this process on one GPU
+    (loopback transport); otherwise this process holds shard `rank` and talks RCCL."""
+
+    def __init__(self, I, QQ, n_total, f, world, rank=0, unique_id=None, **opts):
+        I = edges(I)
+        QQ = fmat(QQ)
+        self.m, self.n_total, self.f, self.world, self.rank = len(I), int(n_total), int(f), world, rank
+        self._h = C.c_void_p()
+        o = default_options(**opts)
+        uid = None
+        if unique_id is not None:
+            uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        rc = lib().irotavg_dist_create(C.byref(self._h), world, rank, uid, self.m, self.n_total, self.f,
+                                       _i(I), _d(QQ), QQ.shape[0], C.byref(o))
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise IrotavgError(rc, "irotavg_dist_create")
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        check(lib().irotavg_dist_unique_id(buf), "dist_unique_id")
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().irotavg_dist_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_rotations(self, Q):
+        Q = fmat(Q)
+        check(lib().irotavg_dist_set_rotations(self._h, _d(Q), Q.shape[0]), "dist_set_rotations")
+
+    def get_rotations(self, into=None):
+        Q = np.zeros((self.n_total, 4), order="F") if into is None else fmat(into)
+        check(lib().irotavg_dist_get_rotations(self._h, _d(Q), Q.shape[0]), "dist_get_rotations")
+        return Q
+
+    def get_weights(self):
+        w = np.full(self.m, np.nan)
+        check(lib().irotavg_dist_get_weights(self._h, _d(w)), "dist_get_weights")
+        return w
+
+    def irls(self, cost=4, sigma=5 * np.pi / 180, max_iters=50, change_th=1e-3, allow_rc=()):
+        iters = C.c_int(0)
+        rt = C.c_double(0)
+        trace = np.full(max(max_iters, 1), np.nan)
+        rc = lib().irotavg_dist_irls(self._h, cost, sigma, max_iters, change_th, C.byref(iters),
+                                     C.byref(rt), _d(trace))
+        if rc != OK and rc not in allow_rc:
+            raise IrotavgError(rc, "irotavg_dist_irls")
+        return dict(rc=rc, iters=iters.value, runtime=rt.value, scores=trace[:iters.value].copy())
+
+    def stats(self):
+        s = Stats()
+        check(lib().irotavg_dist_get_stats(self._h, C.byref(s)), "dist_get_stats")
+        return dict(pcg_solves=s.pcg_solves, pcg_iters=s.pcg_iters, pcg_iters_last=s.pcg_iters_last,
+                    outer_iters=s.outer_iters, edge_updates=s.edge_updates, seconds_irls=s.seconds_irls,
+                    levels=s.levels, level_rows=list(s.level_rows)[:s.levels])

@@ -51,7 +51,8 @@ static SellMap sell_map(int n, const std::vector<int> &rowptr) {
 int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     const int64_t m = g.m;
     const int f = g.f;
-    const int nu = g.nu;
+    const int fo = g.f + g.ng;  // operator offset: fixed and ghost views have no row
+    const int nu = g.no;        // rows of the operator (owned free views)
     hipStream_t s = g.stream;
 
     // ---- edge streams -------------------------------------------------------------------
@@ -94,18 +95,23 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.Q.zero(s);
 
     // ---- level-0 adjacency --------------------------------------------------------------
+    // Endpoint classes by local index: [0,f) fixed, [f,fo) ghost (free, owned by another shard),
+    // [fo, n_total) owned. Owned-owned edges become matrix entries; an edge from an owned view
+    // to a fixed or ghost view is a "boundary slot" of the owned row.
+    auto cls = [&](int v) { return v < f ? 0 : (v < fo ? 1 : 2); };
     std::vector<int> rowptr((size_t)nu + 1, 0), bptr((size_t)nu + 1, 0);
     for (int64_t k = 0; k < m; k++) {
-        const int i = ei[k] - f, j = ej[k] - f;
-        if (i >= 0 && j >= 0 && i != j) {
+        const int ci = cls(ei[k]), cj = cls(ej[k]);
+        const int i = ei[k] - fo, j = ej[k] - fo;
+        if (ci == 2 && cj == 2 && i != j) {
             rowptr[i + 1]++;
             rowptr[j + 1]++;
-        } else if (i >= 0 && j >= 0) {
+        } else if (ci == 2 && cj == 2) {
             bptr[i + 1]++;  // self loop
-        } else if (j >= 0) {
-            bptr[j + 1]++;  // i fixed
-        } else if (i >= 0) {
-            bptr[i + 1]++;  // j fixed (dropped by make_A, kept by make_AtA)
+        } else if (cj == 2) {
+            bptr[j + 1]++;  // i fixed or ghost
+        } else if (ci == 2) {
+            bptr[i + 1]++;  // j fixed (dropped by make_A, kept by make_AtA) or ghost
         }
     }
     for (int v = 0; v < nu; v++) {
@@ -122,22 +128,26 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     std::vector<Ent> ents((size_t)nnz0);
     std::vector<uint32_t> beid((size_t)nb);
     std::vector<uint8_t> bflag((size_t)nb);
+    std::vector<int> bghost((size_t)nb, -1);
     {
         std::vector<int> pos(rowptr.begin(), rowptr.end() - 1), bpos(bptr.begin(), bptr.end() - 1);
         for (int64_t k = 0; k < m; k++) {
-            const int i = ei[k] - f, j = ej[k] - f;
-            if (i >= 0 && j >= 0 && i != j) {
+            const int ci = cls(ei[k]), cj = cls(ej[k]);
+            const int i = ei[k] - fo, j = ej[k] - fo;
+            if (ci == 2 && cj == 2 && i != j) {
                 ents[pos[j]++] = Ent{i, (uint32_t)(k << 1) | 1u};  // row j: +1 coefficient
                 ents[pos[i]++] = Ent{j, (uint32_t)(k << 1)};       // row i: -1 coefficient
-            } else if (i >= 0 && j >= 0) {
+            } else if (ci == 2 && cj == 2) {
                 beid[bpos[i]] = (uint32_t)(k << 1);
                 bflag[bpos[i]++] = BF_IRLS | BF_L1H | BF_NEG;
-            } else if (j >= 0) {
+            } else if (cj == 2) {  // row j, other endpoint i fixed or ghost
                 beid[bpos[j]] = (uint32_t)(k << 1) | 1u;
+                bghost[bpos[j]] = ci == 1 ? ei[k] - f : -1;
                 bflag[bpos[j]++] = BF_IRLS | BF_L1H;
-            } else if (i >= 0) {
+            } else if (ci == 2) {  // row i, other endpoint j fixed (make_A drops it) or ghost
                 beid[bpos[i]] = (uint32_t)(k << 1);
-                bflag[bpos[i]++] = BF_L1H;
+                bghost[bpos[i]] = cj == 1 ? ej[k] - f : -1;
+                bflag[bpos[i]++] = cj == 1 ? (BF_IRLS | BF_L1H) : BF_L1H;
             }
         }
     }
@@ -158,6 +168,11 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.bptr.upload(bptr, s);
     g.beid.upload(beid, s);
     g.bflag.upload(bflag, s);
+    g.bghost.upload(bghost, s);
+    g.bval.alloc((size_t)nb);
+    g.bval.zero(s);
+    g.PG.alloc((size_t)g.ng + 1);
+    g.PG.zero(s);
 
     // ---- hierarchy ----------------------------------------------------------------------
     // Host CSR patterns of every level first, SELL conversion + uploads second.
@@ -292,7 +307,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.additive_top = g.opt.reserved[0] == 1 ? 0 : 1;
     // ---- PCG state ----------------------------------------------------------------------
     const size_t nv0 = (size_t)g.levels[0].nsl * 64 + 64;
-    g.X.alloc(nv0);
+    g.X.alloc(nv0 + (size_t)g.ng);
     g.P.alloc(nv0);
     g.AP.alloc(nv0);
     g.X.zero(s);

@@ -204,6 +204,8 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
     g.n_total = n_total;
     g.f = f;
     g.nu = (int)(n_total - f);
+    g.ng = 0;
+    g.no = g.nu;
     const int rc = build_graph(g, I, QQ, ldqq);
     if (rc != IROTAVG_OK) {
         irotavg_graph_destroy(h);

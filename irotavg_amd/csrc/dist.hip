@@ -1,0 +1,681 @@
+// dist.hip -- vertex-range sharding of the IRLS solve across the GPUs of one node.
+//
+// The free views are cut into `world` contiguous ranges (multiples of 64 views). A shard owns its
+// range's rows of the normal matrix and every edge with an endpoint in the range; cross-shard
+// edges are held by both shards (their residuals and weights are computed redundantly and
+// identically), the remote endpoint is a GHOST view: free, but without a local row. Locally the
+// vertex order is [fixed | ghost | owned], so K1/K2/K6 run unchanged over X = [ghost | owned].
+//
+// Per PCG iteration: one halo exchange (the direction p of ghost views, 32 B each) and three small
+// all-reduces (p.Lp; ||r||^2 with r.z0; b1.y1) of 3-8 doubles. Per IRLS iteration: one halo
+// exchange of the solution X and one all-reduce of the score. The preconditioner is the
+// single-GPU one built on the shard's own diagonal block (ghost couplings act as Dirichlet mass):
+// block-Jacobi across shards, no communication inside it.
+//
+// Transport: RCCL over xGMI when each process holds one shard (ncclSend/ncclRecv groups for the
+// halos, ncclAllReduce for the scalars, all on the shard's stream), or an in-process loopback when
+// one process holds all shards on one GPU (used by the tests to verify the sharded algebra
+// against the unsharded solve without multi-GPU hardware).
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+
+#include "graph.hpp"
+#include "kernels.hpp"
+
+namespace irh {
+
+struct Shard {
+    Graph g;
+    int rank = 0;
+    int64_t lo = 0, hi = 0;          // owned range in global free-view index space
+    std::vector<int64_t> gvert;      // local vertex -> global vertex id
+    std::vector<int64_t> gedge;      // local edge   -> global edge id
+    std::vector<int> peers;          // ranks this shard exchanges halos with
+    std::vector<int> send_off, send_cnt, recv_off, recv_cnt;
+    DevBuf<int> send_idx;            // owned-local indices to pack, grouped by peer
+    DevBuf<double4> sendbuf;
+    DevBuf<double> gsum;             // 16 doubles: staging of the all-reduced scalars
+    int send_total = 0;
+};
+
+struct Dist {
+    int world = 1;
+    int64_t m = 0, n_total = 0, nu = 0, chunk = 0;
+    int f = 0;
+    std::vector<std::unique_ptr<Shard>> shards;  // local shards (all of them in loopback mode)
+    bool use_rccl = false;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    irotavg_options opt{};
+    irotavg_stats stats{};
+};
+
+#define NCCL_CHECK(expr)                                                                      \
+    do {                                                                                      \
+        ncclResult_t _r = (expr);                                                             \
+        if (_r != ncclSuccess) {                                                              \
+            std::fprintf(stderr, "[irotavg_hip] %s failed: %s (%s:%d)\n", #expr,              \
+                         ncclGetErrorString(_r), __FILE__, __LINE__);                         \
+            throw ::irh::HipError{hipErrorUnknown};                                           \
+        }                                                                                     \
+    } while (0)
+
+// ---- small kernels ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(int cnt, const int *__restrict__ idx,
+                                              const double4 *__restrict__ src,
+                                              double4 *__restrict__ dst) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < cnt) dst[t] = src[idx[t]];
+}
+
+// fixed-order reduction of up to two partial arrays into gsum[0..3] and gsum[4..7]
+__global__ __launch_bounds__(256) void k_reduce_parts(const double *__restrict__ pa, int na,
+                                                      const double *__restrict__ pb, int nb,
+                                                      double *__restrict__ gsum) {
+    double a[3], b[3] = {0, 0, 0};
+    load_reduced3(pa, na, a);
+    if (pb) load_reduced3(pb, nb, b);
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < 3; c++) {
+            gsum[c] = a[c];
+            gsum[4 + c] = b[c];
+        }
+        gsum[3] = gsum[7] = 0.0;
+    }
+}
+
+__global__ void k_scatter_parts(const double *__restrict__ gsum, double *__restrict__ pa,
+                                double *__restrict__ pb) {
+    const int t = threadIdx.x;
+    if (t < 4) {
+        pa[t] = gsum[t];
+        if (pb) pb[t] = gsum[4 + t];
+    }
+}
+
+__global__ void k_add_small(int n, double *__restrict__ dst, const double *__restrict__ src) {
+    const int t = threadIdx.x;
+    if (t < n) dst[t] += src[t];
+}
+
+// ---- collectives ------------------------------------------------------------------------------
+static void allreduce(Dist &D, int count) {  // over every shard's gsum[0..count)
+    if (D.use_rccl) {
+        Shard &S = *D.shards[0];
+        NCCL_CHECK(ncclAllReduce(S.gsum.p, S.gsum.p, (size_t)count, ncclDouble, ncclSum, D.comm,
+                                 D.stream));
+        return;
+    }
+    if (D.shards.size() == 1) return;
+    Shard &S0 = *D.shards[0];
+    for (size_t s = 1; s < D.shards.size(); s++)  // fixed shard order
+        hipLaunchKernelGGL(k_add_small, dim3(1), dim3(64), 0, D.stream, count, S0.gsum.p,
+                           D.shards[s]->gsum.p);
+    for (size_t s = 1; s < D.shards.size(); s++)
+        IRH_CHECK(hipMemcpyAsync(D.shards[s]->gsum.p, S0.gsum.p, sizeof(double) * (size_t)count,
+                                 hipMemcpyDeviceToDevice, D.stream));
+}
+
+// halo exchange: owned values `src_of(shard)` -> ghost slots `dst_of(peer shard)`
+enum HaloWhat { HALO_P, HALO_X };
+static const double4 *halo_src(Shard &S, HaloWhat w) {
+    return w == HALO_P ? S.g.P.p : S.g.X.p + S.g.ng;
+}
+static double4 *halo_dst(Shard &S, HaloWhat w) { return w == HALO_P ? S.g.PG.p : S.g.X.p; }
+
+static void halo_exchange(Dist &D, HaloWhat what) {
+    for (auto &sp : D.shards) {
+        Shard &S = *sp;
+        if (S.send_total > 0)
+            hipLaunchKernelGGL(k_pack, dim3((S.send_total + 255) / 256), dim3(256), 0, D.stream,
+                               S.send_total, S.send_idx.p, halo_src(S, what), S.sendbuf.p);
+    }
+    if (D.use_rccl) {
+        Shard &S = *D.shards[0];
+        NCCL_CHECK(ncclGroupStart());
+        for (size_t q = 0; q < S.peers.size(); q++) {
+            if (S.send_cnt[q] > 0)
+                NCCL_CHECK(ncclSend(S.sendbuf.p + S.send_off[q], (size_t)S.send_cnt[q] * 4, ncclDouble,
+                                    S.peers[q], D.comm, D.stream));
+            if (S.recv_cnt[q] > 0)
+                NCCL_CHECK(ncclRecv(halo_dst(S, what) + S.recv_off[q], (size_t)S.recv_cnt[q] * 4,
+                                    ncclDouble, S.peers[q], D.comm, D.stream));
+        }
+        NCCL_CHECK(ncclGroupEnd());
+        return;
+    }
+    for (auto &sp : D.shards) {  // loopback: copy each send segment into the peer's ghost slots
+        Shard &S = *sp;
+        for (size_t q = 0; q < S.peers.size(); q++) {
+            Shard &T = *D.shards[S.peers[q]];
+            // T's receive slot for data coming from S
+            size_t r = 0;
+            while (r < T.peers.size() && T.peers[r] != S.rank) r++;
+            if (r == T.peers.size() || T.recv_cnt[r] != S.send_cnt[q]) throw HipError{hipErrorUnknown};
+            IRH_CHECK(hipMemcpyAsync(halo_dst(T, what) + T.recv_off[r], S.sendbuf.p + S.send_off[q],
+                                     sizeof(double4) * (size_t)S.send_cnt[q], hipMemcpyDeviceToDevice,
+                                     D.stream));
+        }
+    }
+}
+
+// ---- partition (pure host) ---------------------------------------------------------------------
+struct ShardPlan {
+    int rank = 0;
+    int64_t lo = 0, hi = 0, chunk = 0;
+    std::vector<int64_t> ledge;        // global edge ids of the shard's edges (ascending)
+    std::vector<int> fixed_used;       // global ids of the fixed views its edges touch (ascending)
+    std::vector<int> ghosts;           // global ids of its ghost views (ascending => grouped by owner)
+    std::vector<int> peers, send_off, send_cnt, recv_off, recv_cnt;
+    std::vector<int> send_idx;         // owned-local indices to pack, grouped by peer, ascending
+};
+
+static int64_t chunk_of(int64_t nu, int world) { return ((nu + world - 1) / world + 63) / 64 * 64; }
+
+static int plan_shard(int world, int rank, int64_t m, int64_t n_total, int f, const int32_t *I,
+                      ShardPlan &P) {
+    const int64_t nu = n_total - f;
+    P.rank = rank;
+    P.chunk = chunk_of(nu, world);
+    if ((int64_t)(world - 1) * P.chunk >= nu) return IROTAVG_ERR_BAD_ARG;  // a shard would be empty
+    P.lo = (int64_t)rank * P.chunk;
+    P.hi = rank == world - 1 ? nu : (int64_t)(rank + 1) * P.chunk;
+    auto owner = [&](int64_t gfree) { return (int)std::min<int64_t>(gfree / P.chunk, world - 1); };
+    auto owned = [&](int v) { return v >= f && v - f >= P.lo && v - f < P.hi; };
+    std::map<int, std::vector<int>> send_to;  // peer -> my owned-local indices
+    for (int64_t k = 0; k < m; k++) {
+        const int i = I[2 * k], j = I[2 * k + 1];
+        if (i < 0 || j < 0 || i >= n_total || j >= n_total) return IROTAVG_ERR_BAD_ARG;
+        // local edges: any endpoint owned; edges without a free endpoint go to rank 0
+        const bool mine = owned(i) || owned(j) || (rank == 0 && i < f && j < f);
+        if (!mine) continue;
+        P.ledge.push_back(k);
+        for (int v : {i, j}) {
+            if (v < f)
+                P.fixed_used.push_back(v);
+            else if (!owned(v))
+                P.ghosts.push_back(v);
+        }
+        if (owned(i) && j >= f && !owned(j)) send_to[owner(j - f)].push_back((int)(i - f - P.lo));
+        if (owned(j) && i >= f && !owned(i)) send_to[owner(i - f)].push_back((int)(j - f - P.lo));
+    }
+    std::sort(P.fixed_used.begin(), P.fixed_used.end());
+    P.fixed_used.erase(std::unique(P.fixed_used.begin(), P.fixed_used.end()), P.fixed_used.end());
+    std::sort(P.ghosts.begin(), P.ghosts.end());
+    P.ghosts.erase(std::unique(P.ghosts.begin(), P.ghosts.end()), P.ghosts.end());
+    // Halo plan. Ghosts are sorted by global id, hence grouped by owner. What I send to peer h is
+    // the set of my views adjacent to h's views, sorted by global id -- exactly h's ghost list
+    // for me, so the two sides agree without a handshake.
+    std::map<int, std::pair<int, int>> recv_from;  // peer -> (offset, count) in the ghost array
+    for (int q = 0; q < (int)P.ghosts.size(); q++) {
+        const int h = owner(P.ghosts[q] - f);
+        auto it = recv_from.find(h);
+        if (it == recv_from.end())
+            recv_from[h] = {q, 1};
+        else
+            it->second.second++;
+    }
+    std::vector<int> all_peers;
+    for (auto &kv : send_to) {
+        auto &v = kv.second;
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        all_peers.push_back(kv.first);
+    }
+    for (auto &kv : recv_from) all_peers.push_back(kv.first);
+    std::sort(all_peers.begin(), all_peers.end());
+    all_peers.erase(std::unique(all_peers.begin(), all_peers.end()), all_peers.end());
+    for (int h : all_peers) {
+        P.peers.push_back(h);
+        P.send_off.push_back((int)P.send_idx.size());
+        auto it = send_to.find(h);
+        const int sc = it == send_to.end() ? 0 : (int)it->second.size();
+        if (sc) P.send_idx.insert(P.send_idx.end(), it->second.begin(), it->second.end());
+        P.send_cnt.push_back(sc);
+        auto ir = recv_from.find(h);
+        P.recv_off.push_back(ir == recv_from.end() ? 0 : ir->second.first);
+        P.recv_cnt.push_back(ir == recv_from.end() ? 0 : ir->second.second);
+    }
+    return IROTAVG_OK;
+}
+
+static int build_shard(Dist &D, Shard &S, const int32_t *I, const double *QQ, int64_t ldqq) {
+    const int f = D.f;
+    ShardPlan P;
+    int rc = plan_shard(D.world, S.rank, D.m, D.n_total, f, I, P);
+    if (rc != IROTAVG_OK) return rc;
+    S.lo = P.lo;
+    S.hi = P.hi;
+    const int64_t no = S.hi - S.lo;
+    const int ft = (int)P.fixed_used.size(), ng = (int)P.ghosts.size();
+    std::map<int, int> lid;
+    S.gvert.clear();
+    for (int v : P.fixed_used) {
+        lid[v] = (int)S.gvert.size();
+        S.gvert.push_back(v);
+    }
+    for (int v : P.ghosts) {
+        lid[v] = (int)S.gvert.size();
+        S.gvert.push_back(v);
+    }
+    for (int64_t q = 0; q < no; q++) S.gvert.push_back(f + S.lo + q);
+    auto owned = [&](int v) { return v >= f && v - f >= S.lo && v - f < S.hi; };
+    auto local_id = [&](int v) { return owned(v) ? (int)(ft + ng + (v - f - S.lo)) : lid[v]; };
+    const int64_t ml = (int64_t)P.ledge.size();
+    if (ml == 0) return IROTAVG_ERR_BAD_ARG;
+    std::vector<int32_t> Il((size_t)2 * ml);
+    std::vector<double> QQl((size_t)4 * ml);
+    for (int64_t t = 0; t < ml; t++) {
+        const int64_t k = P.ledge[t];
+        Il[2 * t] = local_id(I[2 * k]);
+        Il[2 * t + 1] = local_id(I[2 * k + 1]);
+        for (int c = 0; c < 4; c++) QQl[(size_t)c * ml + t] = QQ[(size_t)c * ldqq + k];
+    }
+    S.gedge = P.ledge;
+    Graph &g = S.g;
+    g.opt = D.opt;
+    g.stream = D.stream;
+    g.m = ml;
+    g.n_total = ft + ng + no;
+    g.f = ft;
+    g.ng = ng;
+    g.no = (int)no;
+    g.nu = ng + (int)no;
+    g.force_np = 1;
+    rc = build_graph(g, Il.data(), QQl.data(), ml);
+    if (rc != IROTAVG_OK) return rc;
+    S.peers = P.peers;
+    S.send_off = P.send_off;
+    S.send_cnt = P.send_cnt;
+    S.recv_off = P.recv_off;
+    S.recv_cnt = P.recv_cnt;
+    S.send_total = (int)P.send_idx.size();
+    S.send_idx.upload(P.send_idx, D.stream);
+    S.sendbuf.alloc((size_t)S.send_total + 1);
+    S.gsum.alloc(16);
+    S.gsum.zero(D.stream);
+    IRH_CHECK(hipStreamSynchronize(D.stream));
+    return IROTAVG_OK;
+}
+
+// ---- sharded PCG ----------------------------------------------------------------------------------
+static void reduce_pair(Dist &D, Shard &S, double *pa, int na, double *pb, int nb) {
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, D.stream, pa, na, pb, nb, S.gsum.p);
+}
+static void scatter_pair(Dist &D, Shard &S, double *pa, double *pb) {
+    hipLaunchKernelGGL(k_scatter_parts, dim3(1), dim3(64), 0, D.stream, S.gsum.p, pa, pb);
+}
+
+static int pcg_dist(Dist &D) {
+    const double rtol2 = D.opt.pcg_rtol * D.opt.pcg_rtol;
+    auto rows_grid = [](Graph &g) { return grid_for_rows(g.levels[0]); };
+    auto upd_parts = [](Graph &g) {  // grid of the update kernel = producer count of part_rr / part_rz
+        return (g.additive_top && g.levels.size() > 1) ? grid_for_rows(g.levels[0])
+                                                        : grid_for_elems(g.levels[0].n);
+    };
+    // init: r = b, x = 0, first restriction
+    for (auto &sp : D.shards) {
+        Graph &g = sp->g;
+        IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, D.stream));
+        launch_update(g, true, 0, 1);
+        reduce_pair(D, *sp, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
+    }
+    allreduce(D, 8);
+    for (auto &sp : D.shards) scatter_pair(D, *sp, sp->g.part_rr.p, sp->g.part_rz.p);
+    int it = 0;
+    int h_flags[FL_COUNT] = {0, 0, 0, 0};
+    const int check = std::max(1, D.opt.pcg_check_every);
+    const int maxit = std::max(1, D.opt.pcg_max_iters);
+    auto prec_all = [&]() {
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            PrecInfo pi = precondition(g, it == 0, rtol2);
+            const bool additive = g.additive_top && g.levels.size() > 1;
+            // the coarse (additive) or full (multiplicative) r.z partials of this shard
+            if (additive)
+                reduce_pair(D, *sp, g.part_rz2.p, pi.np_rz2, nullptr, 0);
+            else
+                reduce_pair(D, *sp, g.part_rz.p, pi.np_rz, nullptr, 0);
+        }
+        allreduce(D, 4);
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            const bool additive = g.additive_top && g.levels.size() > 1;
+            scatter_pair(D, *sp, additive ? g.part_rz2.p : g.part_rz.p, nullptr);
+        }
+    };
+    auto tail_all = [&]() {
+        const int first = (it == 0), par = it & 1;
+        PrecInfo one;
+        one.np_rz = 1;
+        one.np_rz2 = 1;
+        for (auto &sp : D.shards) launch_pupdate(sp->g, par, first, one);
+        halo_exchange(D, HALO_P);
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            launch_spmv(g);
+            reduce_pair(D, *sp, g.part_pq.p, rows_grid(g), nullptr, 0);
+        }
+        allreduce(D, 4);
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            scatter_pair(D, *sp, g.part_pq.p, nullptr);
+            launch_update(g, false, par ^ 1, 1);
+            reduce_pair(D, *sp, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
+        }
+        allreduce(D, 8);
+        for (auto &sp : D.shards) scatter_pair(D, *sp, sp->g.part_rr.p, sp->g.part_rz.p);
+        it++;
+    };
+    while (true) {
+        for (int c = 0; c < check; c++) {
+            prec_all();
+            tail_all();
+        }
+        prec_all();
+        IRH_CHECK(hipMemcpyAsync(h_flags, D.shards[0]->g.flags.p, sizeof(int) * FL_COUNT,
+                                 hipMemcpyDeviceToHost, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+        if (h_flags[FL_DONE] != 0) break;
+        if (it >= maxit) break;
+        tail_all();
+    }
+    D.stats.pcg_solves += 1;
+    D.stats.pcg_iters += h_flags[FL_ITERS];
+    D.stats.pcg_iters_last = h_flags[FL_ITERS];
+    if (h_flags[FL_DONE] == 2) return IROTAVG_ERR_SOLVER;
+    if (h_flags[FL_DONE] == 0) return IROTAVG_ERR_NOT_CONVERGED;
+    return IROTAVG_OK;
+}
+
+static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double change_th, int *iters,
+                     double *runtime, double *trace) {
+    if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
+    const double tic = now_seconds();
+    double score = HUGE_VAL;
+    int it = 0, rc = IROTAVG_OK;
+    for (auto &sp : D.shards) fill(sp->g, sp->g.dw.p, (long long)sp->g.mpad, 1.0);
+    while (score > change_th && it < max_iters) {
+        for (auto &sp : D.shards) {
+            launch_edge_residual(sp->g);
+            assemble(sp->g, 0, sp->g.dw.p, D.opt.reserved[1] == 1);
+        }
+        rc = pcg_dist(D);
+        if (rc != IROTAVG_OK) break;
+        halo_exchange(D, HALO_X);  // ghost views receive their owners' steps
+        double local = 0.0;
+        for (auto &sp : D.shards) {
+            launch_update_weights(sp->g, cost, sigma);
+            (void)apply_step(sp->g);  // updates owned AND ghost rotations; scores owned views only
+            local += sp->g.last_score_sum;
+        }
+        if (D.use_rccl) {
+            Shard &S = *D.shards[0];
+            IRH_CHECK(hipMemcpyAsync(S.gsum.p, &local, sizeof(double), hipMemcpyHostToDevice, D.stream));
+            NCCL_CHECK(ncclAllReduce(S.gsum.p, S.gsum.p, 1, ncclDouble, ncclSum, D.comm, D.stream));
+            IRH_CHECK(hipMemcpyAsync(&local, S.gsum.p, sizeof(double), hipMemcpyDeviceToHost, D.stream));
+            IRH_CHECK(hipStreamSynchronize(D.stream));
+        }
+        score = local / (double)D.nu;
+        if (trace) trace[it] = score;
+        it++;
+    }
+    IRH_CHECK(hipStreamSynchronize(D.stream));
+    const double toc = now_seconds();
+    *iters = it;
+    *runtime = toc - tic;
+    D.stats.outer_iters += it;
+    D.stats.edge_updates += (int64_t)it * D.m;
+    D.stats.seconds_irls += toc - tic;
+    return rc;
+}
+
+}  // namespace irh
+
+using namespace irh;
+
+struct irotavg_dist {
+    Dist D;
+};
+
+#define API_TRY try {
+#define API_CATCH                     \
+    }                                 \
+    catch (const HipError &) {        \
+        return IROTAVG_ERR_HIP;       \
+    }                                 \
+    catch (const std::bad_alloc &) {  \
+        return IROTAVG_ERR_NOMEM;     \
+    }                                 \
+    catch (...) {                     \
+        return IROTAVG_ERR_HIP;       \
+    }
+
+extern "C" {
+
+int irotavg_dist_unique_id(void *out128) {
+    if (!out128) return IROTAVG_ERR_BAD_ARG;
+    static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the ABI buffer");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return IROTAVG_ERR_HIP;
+    std::memset(out128, 0, 128);
+    std::memcpy(out128, &id, sizeof(id));
+    return IROTAVG_OK;
+}
+
+int irotavg_dist_create(irotavg_dist **out, int world, int rank, const void *unique_id128, int64_t m,
+                        int64_t n_total, int f, const int32_t *I, const double *QQ, int64_t ldqq,
+                        const irotavg_options *opt) {
+    if (!out || !I || !QQ || world < 1 || m <= 0 || n_total <= 0 || f < 0 || n_total - f < 1 ||
+        ldqq < m || n_total > 0x7fffffffLL)
+        return IROTAVG_ERR_BAD_ARG;
+    const bool loopback = unique_id128 == nullptr;
+    if (!loopback && (rank < 0 || rank >= world)) return IROTAVG_ERR_BAD_ARG;
+    *out = nullptr;
+    if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
+    irotavg_dist *h = nullptr;
+    try {
+        h = new irotavg_dist();
+        Dist &D = h->D;
+        if (opt)
+            D.opt = *opt;
+        else
+            irotavg_default_options(&D.opt);
+        if (D.opt.pcg_rtol <= 0) D.opt.pcg_rtol = 1e-10;
+        if (D.opt.mg_omega <= 0) D.opt.mg_omega = 0.7;
+        if (D.opt.mg_kc <= 0) D.opt.mg_kc = 1.0;
+        if (D.opt.mg_dense_max <= 0) D.opt.mg_dense_max = 2048;
+        if (D.opt.mg_levels_max <= 0) D.opt.mg_levels_max = 16;
+        if (D.opt.pcg_max_iters <= 0) D.opt.pcg_max_iters = 2000;
+        if (D.opt.pcg_check_every <= 0) D.opt.pcg_check_every = 8;
+        if (D.opt.device >= 0) IRH_CHECK(hipSetDevice(D.opt.device));
+        IRH_CHECK(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+        D.world = world;
+        D.m = m;
+        D.n_total = n_total;
+        D.f = f;
+        D.nu = n_total - f;
+        D.chunk = chunk_of(D.nu, world);
+        if ((int64_t)(world - 1) * D.chunk >= D.nu) {  // every shard needs at least one view
+            irotavg_dist_destroy(h);
+            return IROTAVG_ERR_BAD_ARG;
+        }
+        D.use_rccl = !loopback;
+        if (D.use_rccl) {
+            ncclUniqueId id;
+            std::memcpy(&id, unique_id128, sizeof(id));
+            NCCL_CHECK(ncclCommInitRank(&D.comm, world, id, rank));
+        }
+        const int first = loopback ? 0 : rank, last = loopback ? world : rank + 1;
+        for (int r = first; r < last; r++) {
+            D.shards.emplace_back(new Shard());
+            D.shards.back()->rank = r;
+            const int rc = build_shard(D, *D.shards.back(), I, QQ, ldqq);
+            if (rc != IROTAVG_OK) {
+                irotavg_dist_destroy(h);
+                return rc;
+            }
+        }
+        *out = h;
+        return IROTAVG_OK;
+    } catch (const std::bad_alloc &) {
+        if (h) irotavg_dist_destroy(h);
+        return IROTAVG_ERR_NOMEM;
+    } catch (...) {
+        if (h) irotavg_dist_destroy(h);
+        return IROTAVG_ERR_HIP;
+    }
+}
+
+void irotavg_dist_destroy(irotavg_dist *h) {
+    if (!h) return;
+    Dist &D = h->D;
+    if (D.stream) (void)hipStreamSynchronize(D.stream);
+    for (auto &sp : D.shards) sp->g.stream = nullptr;  // shards share D.stream
+    D.shards.clear();
+    if (D.comm) (void)ncclCommDestroy(D.comm);
+    if (D.stream) (void)hipStreamDestroy(D.stream);
+    delete h;
+}
+
+// Q: the GLOBAL n_total x 4 column-major matrix (every process passes the same one)
+int irotavg_dist_set_rotations(irotavg_dist *h, const double *Q, int64_t ldq) {
+    if (!h || !Q || ldq < h->D.n_total) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Dist &D = h->D;
+    for (auto &sp : D.shards) {
+        Shard &S = *sp;
+        std::vector<double4> aos(S.gvert.size());
+        for (size_t t = 0; t < S.gvert.size(); t++) {
+            const int64_t v = S.gvert[t];
+            aos[t] = make_double4(Q[v], Q[ldq + v], Q[2 * ldq + v], Q[3 * ldq + v]);
+        }
+        S.g.Q.upload(aos.data(), aos.size(), D.stream);
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+    }
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+// writes the rows OWNED by this process's shards into the global matrix (other rows untouched)
+int irotavg_dist_get_rotations(irotavg_dist *h, double *Q, int64_t ldq) {
+    if (!h || !Q || ldq < h->D.n_total) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Dist &D = h->D;
+    for (auto &sp : D.shards) {
+        Shard &S = *sp;
+        std::vector<double4> aos(S.gvert.size());
+        IRH_CHECK(hipMemcpyAsync(aos.data(), S.g.Q.p, sizeof(double4) * aos.size(),
+                                 hipMemcpyDeviceToHost, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+        for (size_t t = (size_t)(S.g.f + S.g.ng); t < S.gvert.size(); t++) {
+            const int64_t v = S.gvert[t];
+            Q[v] = aos[t].x;
+            Q[ldq + v] = aos[t].y;
+            Q[2 * ldq + v] = aos[t].z;
+            Q[3 * ldq + v] = aos[t].w;
+        }
+    }
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+// writes the weights of this process's local edges into the global m-vector
+int irotavg_dist_get_weights(irotavg_dist *h, double *w) {
+    if (!h || !w) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Dist &D = h->D;
+    for (auto &sp : D.shards) {
+        Shard &S = *sp;
+        std::vector<double> loc((size_t)S.g.m);
+        IRH_CHECK(hipMemcpyAsync(loc.data(), S.g.dw.p, sizeof(double) * loc.size(),
+                                 hipMemcpyDeviceToHost, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+        for (size_t t = 0; t < loc.size(); t++) w[S.gedge[t]] = loc[t];
+    }
+    return IROTAVG_OK;
+    API_CATCH
+}
+
+int irotavg_dist_irls(irotavg_dist *h, int cost, double sigma, int max_iters, double change_th,
+                      int *iters, double *runtime, double *trace) {
+    if (!h || !iters || !runtime) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    return irls_dist(h->D, cost, sigma, max_iters, change_th, iters, runtime, trace);
+    API_CATCH
+}
+
+int irotavg_dist_get_stats(irotavg_dist *h, irotavg_stats *out) {
+    if (!h || !out) return IROTAVG_ERR_BAD_ARG;
+    *out = h->D.stats;
+    out->levels = h->D.shards.empty() ? 0 : h->D.shards[0]->g.stats.levels;
+    for (int i = 0; i < 16; i++) {
+        out->level_rows[i] = h->D.shards.empty() ? 0 : h->D.shards[0]->g.stats.level_rows[i];
+        out->level_nnz[i] = h->D.shards.empty() ? 0 : h->D.shards[0]->g.stats.level_nnz[i];
+    }
+    return IROTAVG_OK;
+}
+
+// Host-only partition plan of rank `rank` (no GPU needed; used by the CPU tests of the N > 1
+// path). counts = {owned lo, owned hi, #ghosts, #local edges, #peers, #send entries}. ghosts_out
+// receives the ghost views' GLOBAL ids (ascending), send_out the GLOBAL ids this rank sends,
+// grouped by peer in `peers` order; the per-peer counts go to send_cnt / recv_cnt.
+int irotavg_dist_plan_host(int world, int rank, int64_t m, int64_t n_total, int f, const int32_t *I,
+                           int64_t counts[6], int32_t *ghosts_out, int64_t ghosts_cap,
+                           int32_t *send_out, int64_t send_cap, int32_t *edges_out, int64_t edges_cap,
+                           int *peers, int *send_cnt, int *recv_cnt, int peers_cap) {
+    if (!I || !counts || world < 1 || rank < 0 || rank >= world || n_total - f < 1)
+        return IROTAVG_ERR_BAD_ARG;
+    try {
+        ShardPlan P;
+        const int rc = plan_shard(world, rank, m, n_total, f, I, P);
+        if (rc != IROTAVG_OK) return rc;
+        counts[0] = P.lo;
+        counts[1] = P.hi;
+        counts[2] = (int64_t)P.ghosts.size();
+        counts[3] = (int64_t)P.ledge.size();
+        counts[4] = (int64_t)P.peers.size();
+        counts[5] = (int64_t)P.send_idx.size();
+        if (ghosts_out)
+            for (int64_t q = 0; q < (int64_t)P.ghosts.size() && q < ghosts_cap; q++) ghosts_out[q] = P.ghosts[q];
+        if (send_out)
+            for (int64_t q = 0; q < (int64_t)P.send_idx.size() && q < send_cap; q++)
+                send_out[q] = (int32_t)(f + P.lo + P.send_idx[q]);
+        if (edges_out)
+            for (int64_t q = 0; q < (int64_t)P.ledge.size() && q < edges_cap; q++) edges_out[q] = (int32_t)P.ledge[q];
+        for (int q = 0; q < (int)P.peers.size() && q < peers_cap; q++) {
+            if (peers) peers[q] = P.peers[q];
+            if (send_cnt) send_cnt[q] = P.send_cnt[q];
+            if (recv_cnt) recv_cnt[q] = P.recv_cnt[q];
+        }
+        return IROTAVG_OK;
+    } catch (...) {
+        return IROTAVG_ERR_NOMEM;
+    }
+}
+
+// partition plan of shard `local_index` (for the tests): counts[0..5] = rank, owned lo, owned hi,
+// ghosts, local edges, peers; the peer / send / recv tables are copied up to `cap` entries
+int irotavg_dist_plan(irotavg_dist *h, int local_index, int64_t counts[6], int *peers, int *send_cnt,
+                      int *recv_cnt, int cap) {
+    if (!h || !counts || local_index < 0 || local_index >= (int)h->D.shards.size())
+        return IROTAVG_ERR_BAD_ARG;
+    Shard &S = *h->D.shards[local_index];
+    counts[0] = S.rank;
+    counts[1] = S.lo;
+    counts[2] = S.hi;
+    counts[3] = S.g.ng;
+    counts[4] = S.g.m;
+    counts[5] = (int64_t)S.peers.size();
+    for (int q = 0; q < (int)S.peers.size() && q < cap; q++) {
+        if (peers) peers[q] = S.peers[q];
+        if (send_cnt) send_cnt[q] = S.send_cnt[q];
+        if (recv_cnt) recv_cnt[q] = S.recv_cnt[q];
+    }
+    return IROTAVG_OK;
+}
+
+}  // extern "C"

@@ -8,7 +8,10 @@ namespace irh {
 
 struct Graph {
     int64_t m = 0, n_total = 0, mpad = 0;
-    int f = 0, nu = 0;
+    // Local vertex order is [fixed | ghost | owned]. f = fixed views, ng = ghost views (free
+    // views owned by another shard; 0 on a single GPU), nu = n_total - f = ghost + owned (length
+    // of X), no = owned views = rows of the operator.
+    int f = 0, nu = 0, ng = 0, no = 0;
     irotavg_options opt{};
     hipStream_t stream = nullptr;
     int device = 0;
@@ -28,6 +31,9 @@ struct Graph {
     DevBuf<int> bptr;           // per row: boundary slots (other endpoint fixed / self loop)
     DevBuf<uint32_t> beid;
     DevBuf<uint8_t> bflag;
+    DevBuf<int> bghost;     // per boundary slot: ghost index of the other endpoint, or -1
+    DevBuf<double> bval;    // per boundary slot: current weight (refreshed by the assembly)
+    DevBuf<double4> PG;     // ghost values of the PCG direction p (filled by the halo exchange)
 
     std::vector<Level> levels;
     DevBuf<double> dense_inv;  // explicit inverse of the coarsest level, ndense_pad^2 row-major
@@ -55,7 +61,13 @@ struct Graph {
     // host staging
     std::vector<double> h_part;
 
+    double last_score_sum = 0.0;
+    int force_np = 0;  // sharded runs: consumers read this many pre-reduced partial rows (1)
     irotavg_stats stats{};
+};
+
+struct PrecInfo {
+    int np_rz = 0, np_rz2 = 0;
 };
 
 // build.cpp
@@ -77,6 +89,12 @@ void normalise_rotations(Graph &g);
 void fill(Graph &g, double *p, long long n, double v);
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true);
 int pcg_solve(Graph &g);
+void launch_spmv(Graph &g);
+void launch_update(Graph &g, bool init, int par, int np_pq);
+void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi);
+PrecInfo precondition(Graph &g, int first, double rtol2);
+int grid_for_rows(const Level &L);
+int grid_for_elems(long long n);
 int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f);
 // dense.hip
 void dense_refresh(Graph &g);

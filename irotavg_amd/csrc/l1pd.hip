@@ -361,7 +361,7 @@ static double fetch_ext(Graph &g, int nparts, bool is_max) {
 static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, int *stuck) {
     const double PDTOL = 1e-3, alpha = 0.01, beta = 0.5, mu = 10;  // :231-238
     const long long m = g.m;
-    const int n = g.nu;
+    const int n = g.no;
     Level &L0 = g.levels[0];
     const int ge = grid_edges(m), gv = grid_elems(n), gr = grid_rows(L0);
     hipStream_t st = g.stream;

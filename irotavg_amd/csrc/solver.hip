@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0(
     const uint8_t *__restrict__ bflag, const double *__restrict__ wsrc,
     const double *__restrict__ er, long long mpad, double *__restrict__ val,
     double *__restrict__ excess, double *__restrict__ diag, double *__restrict__ idg,
-    double4 *__restrict__ rhs) {
+    double4 *__restrict__ rhs, double *__restrict__ bval) {
     const int ntiles = (nsl + 3) / 4;
     int t0, t1;
     tile_range(ntiles, t0, t1);
@@ -228,12 +228,16 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0(
         if (row < n) {
             for (int s = bptr[row]; s < bptr[row + 1]; s++) {
                 const uint8_t fl = bflag[s];
-                if (!(fl & (MODE == 0 ? BF_IRLS : BF_L1H))) continue;
+                if (!(fl & (MODE == 0 ? BF_IRLS : BF_L1H))) {
+                    bval[s] = 0.0;
+                    continue;
+                }
                 const uint32_t se = beid[s];
                 const uint32_t e = se >> 1;
                 double wk = wsrc[e];
                 if (MODE == 0) wk = wk * wk;
                 if (MODE == 1 && (fl & BF_NEG)) wk = -wk;
+                bval[s] = wk;
                 ex += wk;
                 if (MODE == 0) {
                     const double sg = (se & 1u) ? wk : -wk;
@@ -309,10 +313,16 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_diag(LevelView C, int nf, 
         if (const int sl_ = t_ * 4 + (threadIdx.x >> 6); sl_ < (L).nsl)
 
 // q = L p, partial dot products p.q
+// (sharded runs: `pg` holds the halo-exchanged directions of the ghost views; boundary slots with
+// a ghost endpoint contribute -w * p_ghost; pg == nullptr on a single GPU)
 __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const double4 *__restrict__ p,
                                                         double4 *__restrict__ q,
                                                         double *__restrict__ part_pq,
-                                                        const int *__restrict__ flags) {
+                                                        const int *__restrict__ flags,
+                                                        const double4 *__restrict__ pg,
+                                                        const int *__restrict__ bptr,
+                                                        const int *__restrict__ bghost,
+                                                        const double *__restrict__ bval) {
     if (flags[FL_DONE]) return;
     double a0 = 0, a1 = 0, a2 = 0;
     ROW_TILE_LOOP(L) {
@@ -325,6 +335,18 @@ __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const doubl
             s0 += d * pr.x;
             s1 += d * pr.y;
             s2 += d * pr.z;
+            if (pg != nullptr) {
+                for (int s = bptr[row]; s < bptr[row + 1]; s++) {
+                    const int gi = bghost[s];
+                    if (gi >= 0) {
+                        const double w = bval[s];
+                        const double4 x = pg[gi];
+                        s0 -= w * x.x;
+                        s1 -= w * x.y;
+                        s2 -= w * x.z;
+                    }
+                }
+            }
             q[row] = make_double4(s0, s1, s2, 0.0);
             a0 += pr.x * s0;
             a1 += pr.y * s1;
@@ -632,7 +654,8 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate_add(
 // =============================================================================================
 // K6 -- score, exp map and rotation update (one free view per thread)
 // =============================================================================================
-__global__ __launch_bounds__(kRowBlock) void k_apply_step(int n, int f, const double4 *__restrict__ X,
+__global__ __launch_bounds__(kRowBlock) void k_apply_step(int n, int f, int nghost,
+                                                       const double4 *__restrict__ X,
                                                        double4 *__restrict__ Q,
                                                        double *__restrict__ part_score,
                                                        int write) {
@@ -640,7 +663,7 @@ __global__ __launch_bounds__(kRowBlock) void k_apply_step(int n, int f, const do
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double4 x = X[i];
         const double th = sqrt(x.x * x.x + x.y * x.y + x.z * x.z);
-        acc += th;  // score = mean ||W3 row|| BEFORE the exp map (ral/l1_irls.cpp:729)
+        if (i >= nghost) acc += th;  // score = mean ||W3 row|| BEFORE the exp map (ral/l1_irls.cpp:729); ghosts are scored by their owner
         double sn, cs;
         sincos(th / 2.0, &sn, &cs);
         const double coef = sn / th;
@@ -718,8 +741,8 @@ static int round_grid(long long gsz) {
     if (gsz >= 8) gsz &= ~7ll;
     return (int)std::max<long long>(gsz, 1);
 }
-static int grid_for_rows(const Level &L) { return round_grid((L.nsl + 3) / 4); }
-static int grid_for_elems(long long n) { return round_grid((n + kRowBlock - 1) / kRowBlock); }
+int grid_for_rows(const Level &L) { return round_grid((L.nsl + 3) / 4); }
+int grid_for_elems(long long n) { return round_grid((n + kRowBlock - 1) / kRowBlock); }
 
 // refresh all matrix values from per-edge weights: mode 0 = IRLS (d^2, rhs), mode 1 = L1 Hessian
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
@@ -728,11 +751,13 @@ void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
     if (mode == 0) {
         hipLaunchKernelGGL((k_assemble0<0>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl,
                            L0.sl_off.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, wsrc, g.er.p,
-                           (long long)g.mpad, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p);
+                           (long long)g.mpad, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p,
+                           g.bval.p);
     } else {
         hipLaunchKernelGGL((k_assemble0<1>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl,
                            L0.sl_off.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, wsrc, g.er.p,
-                           (long long)g.mpad, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p);
+                           (long long)g.mpad, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p,
+                           g.bval.p);
     }
     for (size_t l = 1; l < g.levels.size(); l++) {
         Level &F = g.levels[l - 1];
@@ -808,14 +833,12 @@ static void cycle_from(Graph &g, int from, bool check_first, bool dot_from, doub
 // Preconditioner application. Multiplicative mode: z = levels[0].y, r.z partials in part_rz
 // (np_rz of them). Additive-top mode: levels[1].y = M1^-1 P0' r and b1.y1 partials in part_rz2
 // (np_rz2); z itself is formed inside the p-update.
-struct PrecInfo {
-    int np_rz = 0, np_rz2 = 0;
-};
-static PrecInfo precondition(Graph &g, int first, double rtol2) {
+PrecInfo precondition(Graph &g, int first, double rtol2) {
     PrecInfo pi;
     const int nl = (int)g.levels.size();
     Level &L0 = g.levels[0];
-    const int np_rr = g.additive_top && nl > 1 ? grid_for_rows(L0) : grid_for_elems(L0.n);
+    int np_rr = g.additive_top && nl > 1 ? grid_for_rows(L0) : grid_for_elems(L0.n);
+    if (g.force_np) np_rr = g.force_np;  // sharded run: partials were reduced across shards into row 0
     if (nl == 1) {
         if (g.ndense > 0) {  // the whole system is the dense level: z = L^-1 r exactly
             dense_apply(g, L0.b.p, L0.y.p, true, true, g.part_rz.p, np_rr, first, rtol2);
@@ -829,7 +852,7 @@ static PrecInfo precondition(Graph &g, int first, double rtol2) {
         return pi;
     }
     if (g.additive_top) {
-        pi.np_rz = np_rr;  // r.z0 partials were written by the update kernel
+        pi.np_rz = g.additive_top && nl > 1 ? grid_for_rows(L0) : np_rr;  // r.z0 partials of the update kernel
         cycle_from(g, 1, true, true, g.part_rz2.p, np_rr, first, rtol2, &pi.np_rz2);
     } else {
         cycle_from(g, 0, true, true, g.part_rz.p, np_rr, first, rtol2, &pi.np_rz);
@@ -837,7 +860,15 @@ static PrecInfo precondition(Graph &g, int first, double rtol2) {
     return pi;
 }
 
-static void launch_update(Graph &g, bool init, int par, int np_pq) {
+void launch_spmv(Graph &g) {
+    Level &L0 = g.levels[0];
+    hipLaunchKernelGGL(k_spmv_dot, dim3(grid_for_rows(L0)), dim3(kRowBlock), 0, g.stream, view_of(L0),
+                       g.P.p, g.AP.p, g.part_pq.p, g.flags.p,
+                       g.ng > 0 ? (const double4 *)g.PG.p : (const double4 *)nullptr, g.bptr.p,
+                       g.bghost.p, g.bval.p);
+}
+
+void launch_update(Graph &g, bool init, int par, int np_pq) {
     Level &L0 = g.levels[0];
     const int nl = (int)g.levels.size();
     if (g.additive_top && nl > 1) {
@@ -845,28 +876,28 @@ static void launch_update(Graph &g, bool init, int par, int np_pq) {
         const int grid = grid_for_rows(L0);
         if (init)
             hipLaunchKernelGGL((k_pcg_update_restrict<true>), dim3(grid), dim3(kRowBlock), 0, g.stream,
-                               L0.n, L0.nsl, L0.agg, g.scal.p, par, g.part_pq.p, np_pq, g.X.p, L0.b.p,
+                               L0.n, L0.nsl, L0.agg, g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, L0.b.p,
                                g.P.p, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p, g.opt.mg_omega,
                                g.part_rr.p, g.part_rz.p, g.flags.p);
         else
             hipLaunchKernelGGL((k_pcg_update_restrict<false>), dim3(grid), dim3(kRowBlock), 0,
                                g.stream, L0.n, L0.nsl, L0.agg, g.scal.p, par, g.part_pq.p, np_pq,
-                               g.X.p, L0.b.p, g.P.p, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p,
+                               g.X.p + g.ng, L0.b.p, g.P.p, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p,
                                g.opt.mg_omega, g.part_rr.p, g.part_rz.p, g.flags.p);
     } else {
         const int ge = grid_for_elems(L0.n);
         if (init)
             hipLaunchKernelGGL((k_pcg_update<true>), dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n,
-                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p, L0.b.p, g.P.p, g.AP.p,
+                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, L0.b.p, g.P.p, g.AP.p,
                                L0.idg.p, L0.x.p, g.opt.mg_omega, g.part_rr.p, g.flags.p);
         else
             hipLaunchKernelGGL((k_pcg_update<false>), dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n,
-                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p, L0.b.p, g.P.p, g.AP.p,
+                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, L0.b.p, g.P.p, g.AP.p,
                                L0.idg.p, L0.x.p, g.opt.mg_omega, g.part_rr.p, g.flags.p);
     }
 }
 
-static void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi) {
+void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi) {
     Level &L0 = g.levels[0];
     const int nl = (int)g.levels.size();
     const int ge = grid_for_elems(L0.n);
@@ -901,8 +932,7 @@ int pcg_solve(Graph &g) {
         const int first = (it == 0);
         const int par = it & 1;
         launch_pupdate(g, par, first, pi);
-        hipLaunchKernelGGL(k_spmv_dot, dim3(gr), dim3(kRowBlock), 0, g.stream, V0, g.P.p, g.AP.p,
-                           g.part_pq.p, g.flags.p);
+        launch_spmv(g);
         launch_update(g, false, par ^ 1, gr);
         it++;
     };
@@ -949,14 +979,15 @@ int ls_solve(Graph &g, int seq_index) {
 double apply_step(Graph &g) {
     const int n = g.nu;
     const int grid = grid_for_elems(n);
-    hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kRowBlock), 0, g.stream, n, g.f, g.X.p, g.Q.p,
-                       g.part_score.p, 1);
+    hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kRowBlock), 0, g.stream, n, g.f, g.ng, g.X.p,
+                       g.Q.p, g.part_score.p, 1);
     IRH_CHECK(hipMemcpyAsync(g.h_part.data(), g.part_score.p, sizeof(double) * 4 * (size_t)grid,
                              hipMemcpyDeviceToHost, g.stream));
     IRH_CHECK(hipStreamSynchronize(g.stream));
     double s = 0.0;
     for (int b = 0; b < grid; b++) s += g.h_part[4 * (size_t)b];
-    return s / (double)n;
+    g.last_score_sum = s;
+    return s / (double)g.no;
 }
 
 // ral/l1_irls.cpp:559-752
@@ -1003,13 +1034,12 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         case 3: assemble(g, 0, g.dw.p, false); break;
         case 7: dense_refresh(g); break;
         case 4:
-            hipLaunchKernelGGL(k_spmv_dot, dim3(gr), dim3(kRowBlock), 0, g.stream, V0, g.P.p, g.AP.p,
-                               g.part_pq.p, g.flags.p);
+            launch_spmv(g);
             break;
         case 5: (void)precondition(g, 0, -1.0); break;
         case 6:
             hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kRowBlock), 0, g.stream,
-                               g.nu, g.f, g.X.p, g.Q.p, g.part_score.p, 0);
+                               g.nu, g.f, g.ng, g.X.p, g.Q.p, g.part_score.p, 0);
             break;
         default: break;
         }

@@ -1,0 +1,80 @@
+"""Sharded IRLS on the GPU: all `world` shards in one process on one GPU (loopback transport)
+against the unsharded handle, and the RCCL transport with a 1-rank communicator."""
+import numpy as np
+import pytest
+
+from irotavg_amd import capi, ral, synth
+
+pytestmark = pytest.mark.gpu
+SIG = 5 * np.pi / 180
+
+
+def problem(n, m, p, f=1, seed=0):
+    S = synth.make_graph(n, m, p, seed=seed)
+    Q = np.zeros((n, 4)); Q[:, 3] = 1; Q[:f] = S["Qgt"][:f]
+    ral.init_mst(Q, S["QQ"], S["I"], f)
+    return S, Q
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("p_loop", [0.0, 0.02])
+def test_loopback_sharded_equals_unsharded(world, p_loop):
+    n, m, f = 20000, 300000, 3
+    S, Q0 = problem(n, m, p_loop, f)
+    with capi.Graph(S["I"], S["QQ"], n, f) as G:
+        G.set_rotations(Q0)
+        a = G.irls(4, SIG, 50, 1e-3)
+        Qa, wa = G.get_rotations(), G.get_weights()
+    with capi.DistGraph(S["I"], S["QQ"], n, f, world) as D:
+        D.set_rotations(Q0)
+        b = D.irls(4, SIG, 50, 1e-3)
+        Qb, wb = D.get_rotations(into=Q0), D.get_weights()
+        st = D.stats()
+    assert a["iters"] == b["iters"]
+    np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-6)
+    assert synth.angular_distance(Qa, Qb).max() < 1e-8
+    assert not np.isnan(wb).any()                      # every edge belongs to some shard
+    np.testing.assert_allclose(wa, wb, rtol=1e-6)
+    np.testing.assert_array_equal(Qb[:f], Q0[:f])
+    assert st["pcg_iters"] > 0
+
+
+def test_loopback_every_cost_family():
+    n, m = 8000, 80000
+    S, Q0 = problem(n, m, 0.05, 1, seed=3)
+    for cost in (1, 5, 12):                            # L1, Huber (keeps old weights), Talwar (zeros)
+        with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+            G.set_rotations(Q0)
+            a = G.irls(cost, SIG, 8, 1e-3)
+            Qa, wa = G.get_rotations(), G.get_weights()
+        with capi.DistGraph(S["I"], S["QQ"], n, 1, 4) as D:
+            D.set_rotations(Q0)
+            b = D.irls(cost, SIG, 8, 1e-3)
+            Qb, wb = D.get_rotations(into=Q0), D.get_weights()
+        assert a["iters"] == b["iters"]
+        assert synth.angular_distance(Qa, Qb).max() < 1e-7
+        np.testing.assert_allclose(wa, wb, rtol=1e-5, atol=1e-9)
+
+
+def test_rccl_transport_single_rank():
+    """ncclCommInitRank / ncclAllReduce / send-recv groups with a 1-rank communicator: exercises
+    the RCCL code path on the one GPU a test box has."""
+    n, m = 20000, 300000
+    S, Q0 = problem(n, m, 0.02)
+    uid = capi.DistGraph.unique_id()
+    with capi.DistGraph(S["I"], S["QQ"], n, 1, 1, rank=0, unique_id=uid) as D:
+        D.set_rotations(Q0)
+        b = D.irls(4, SIG, 50, 1e-3)
+        Qb = D.get_rotations(into=Q0)
+    with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+        G.set_rotations(Q0)
+        a = G.irls(4, SIG, 50, 1e-3)
+        Qa = G.get_rotations()
+    assert a["iters"] == b["iters"]
+    assert synth.angular_distance(Qa, Qb).max() < 1e-8
+
+
+def test_bad_world_size():
+    S, Q0 = problem(200, 1200, 0.0)
+    with pytest.raises(capi.IrotavgError):
+        capi.DistGraph(S["I"], S["QQ"], 200, 1, 8)     # 199 free views cannot feed 8 shards
