@@ -62,6 +62,17 @@ def kernel_rooflines(G, S, st):
     return out
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (tools/profile_counters.sh + tools/summarize_pmc.py -> profiles/r01_pmc_summary.json)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as fh:
+            return float(json.load(fh)[kernel]["traffic_bytes"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(S, Q0, p_loop, budget_s=25.0):
     """The CPU oracle (oracle/, single thread, own sparse Cholesky) on a bounded sample."""
     from oracle import oracle as O
@@ -195,14 +206,15 @@ def main():
         }
         kr = kernel_rooflines(G, S, st)
         dom = "spmv"
-        line["roofline"] = {"kernel": "k_spmv_dot (level-0 CSR SpMV + fused dot, dominant PCG kernel)",
+        line["roofline"] = {"kernel": "k_spmv_dot (level-0 SELL-64 SpMV + fused dot, dominant PCG kernel)",
                             "bound": "hbm", "achieved": kr[dom]["gbs"], "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": kr[dom]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                            "unit": "GB/s", "frac": kr[dom]["gbs"] / HBM_PEAK_GBS,
+                            "traffic": pmc_traffic("k_spmv_dot"),
                             "ms_per_launch": kr[dom]["ms"], "algorithmic_bytes": kr[dom]["bytes"]}
         line["roofline_edge_residual"] = {
             "kernel": "k_edge_residual (K1, the kernel north_star names)", "bound": "hbm",
             "achieved": kr["edge_residual"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kr["edge_residual"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+            "frac": kr["edge_residual"]["gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic("k_edge_residual"),
             "ms_per_launch": kr["edge_residual"]["ms"], "algorithmic_bytes": kr["edge_residual"]["bytes"]}
         line["kernels"] = {k: {kk: (float(vv) if not isinstance(vv, int) else vv) for kk, vv in v.items()}
                            for k, v in kr.items()}
