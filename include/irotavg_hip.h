@@ -58,7 +58,8 @@ typedef struct irotavg_options {
     double mg_kc;        /* coarse-correction scale; default 1.0 */
     int device;          /* HIP device ordinal; -1 = current device */
     int reserved[7];     /* reserved[0] = 1: multiplicative V-cycle on level 0 (default: additive top level);
-                            reserved[1] = 1: re-invert the dense coarse level at every solve (default: adaptive) */
+                            reserved[1] = 1: re-invert the dense coarse level at every solve (default: adaptive);
+                            reserved[2] = 1: irotavg_viewgraph_rot_avg never uses the single-kernel window path */
 } irotavg_options;
 
 void irotavg_default_options(irotavg_options *opt);
@@ -200,8 +201,17 @@ int irotavg_viewgraph_count_fixed_poses(const irotavg_viewgraph *vg);
 /* Pose::R() / Pose::setR() (src/Pose.hpp:47-51) */
 int irotavg_viewgraph_get_pose(const irotavg_viewgraph *vg, int idx, double R[9]);
 int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]);
-/* replaces ViewGraph::rotAvg(int winSize) (src/ViewGraph.hpp:75, src/ViewGraph.cpp:1263-1435) */
+/* replaces ViewGraph::rotAvg(int winSize) (src/ViewGraph.hpp:75, src/ViewGraph.cpp:1263-1435).
+ * Sub-problems with <= 64 free views / <= 640 edges (every rotAvg(10) call) run as ONE kernel
+ * launch (irotavg_amd/csrc/window.hip); larger ones through the graph handle path. */
 int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotavg_info *info);
+
+/* The single-kernel window pipeline on caller data (layout as irotavg_l1ra / irotavg_irls):
+ * l1ra(l1_iters) then irls(cost, sigma, irls_iters), change_th for both, in one launch.
+ * IROTAVG_ERR_BAD_ARG if the problem does not fit the kernel's limits. */
+int irotavg_window_solve(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                         int64_t ldqq, double *Q, int64_t ldq, int cost, double sigma, int l1_iters,
+                         int irls_iters, double change_th, double *weights, int *l1_out, int *irls_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU: the IRLS solve sharded by contiguous ranges of free views; one

@@ -32,6 +32,7 @@ SYMBOLS = [
     "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
     "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_plan", "irotavg_dist_plan_host",
+    "irotavg_window_solve",
 ]
 
 
@@ -131,6 +132,9 @@ def lib():
     L.irotavg_viewgraph_get_pose.argtypes = [vp, C.c_int, _dp]
     L.irotavg_viewgraph_set_pose.argtypes = [vp, C.c_int, _dp]
     L.irotavg_viewgraph_rot_avg.argtypes = [vp, C.c_int, C.POINTER(RotAvgInfo)]
+    L.irotavg_window_solve.argtypes = [C.c_int64, C.c_int64, C.c_int, _ip, _dp, C.c_int64, _dp, C.c_int64,
+                                       C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.irotavg_dist_unique_id.argtypes = [C.c_void_p]
     L.irotavg_dist_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                       C.c_int, _ip, _dp, C.c_int64, C.POINTER(Options)]
@@ -322,6 +326,21 @@ class Graph:
         ms = C.c_double(0)
         check(lib().irotavg_graph_time_kernel(self._h, which, reps, C.byref(ms)), "time_kernel")
         return ms.value
+
+
+def window_solve(I, QQ, Q, f, cost=4, sigma=5 * np.pi / 180, l1_iters=100, irls_iters=100,
+                 change_th=1e-3):
+    """irotavg_window_solve: l1ra + irls of a small problem in one kernel launch."""
+    I = edges(I)
+    QQ = fmat(QQ)
+    Q = fmat(Q)
+    w = np.zeros(len(I))
+    a, b = C.c_int(0), C.c_int(0)
+    rc = lib().irotavg_window_solve(len(I), Q.shape[0], f, _i(I), _d(QQ), QQ.shape[0], _d(Q), Q.shape[0],
+                                    cost, sigma, l1_iters, irls_iters, change_th, _d(w), C.byref(a),
+                                    C.byref(b))
+    check(rc, "irotavg_window_solve")
+    return dict(Q=Q, weights=w, l1_iters=a.value, irls_iters=b.value)
 
 
 def plan_host(world, rank, I, n_total, f):

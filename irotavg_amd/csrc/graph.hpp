@@ -96,6 +96,14 @@ PrecInfo precondition(Graph &g, int first, double rtol2);
 int grid_for_rows(const Level &L);
 int grid_for_elems(long long n);
 int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f);
+// window.hip: single-kernel solve of small (sliding-window) problems
+struct WindowSolver;
+WindowSolver *window_solver_new();
+void window_solver_delete(WindowSolver *w);
+bool window_fits(int nv, int f, int ne);
+int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, const double *QQ_aos,
+                 double *Q_aos, double *weights, int l1_max, int irls_max, int cost, double sigma,
+                 double change_th, int *l1_iters, int *irls_iters);
 // dense.hip
 void dense_refresh(Graph &g);
 bool dense_is_stale(Graph &g);

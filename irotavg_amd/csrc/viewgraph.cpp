@@ -79,6 +79,10 @@ struct irotavg_viewgraph {
     std::vector<std::map<int, Mat3>> conn;       // per view: neighbour id -> R_ij of the pair (min,max)
     irotavg_options opt;
     irotavg_rotavg_info last{};
+    irh::WindowSolver *win = nullptr;  // persistent staging of the single-kernel window solve
+    ~irotavg_viewgraph() {
+        if (win) irh::window_solver_delete(win);
+    }
 };
 
 extern "C" {
@@ -243,17 +247,38 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     // ---- solve (:1396-1417): no init_mst (refine from the current poses); l1ra 100 iterations,
     // then irls Geman-McClure, sigma 5 deg, 100 iterations, change_th 1e-3
     const double change_th = .001;
-    irotavg_graph *g = nullptr;
-    int rc = irotavg_graph_create(&g, ne, nv, f, I.data(), QQ.data(), ne, &vg->opt);
-    if (rc != IROTAVG_OK) return rc;
-    rc = irotavg_graph_set_rotations(g, Q.data(), nv);
-    if (rc == IROTAVG_OK)
-        rc = irotavg_graph_l1ra(g, 100, change_th, &loc.l1_iters, &loc.l1_runtime, nullptr);
-    if (rc == IROTAVG_OK)
-        rc = irotavg_graph_irls(g, IROTAVG_GEMAN_MCCLURE, 5 * M_PI / 180.0, 100, change_th,
-                                &loc.irls_iters, &loc.irls_runtime, nullptr);
-    if (rc == IROTAVG_OK) rc = irotavg_graph_get_rotations(g, Q.data(), nv);
-    irotavg_graph_destroy(g);
+    int rc = IROTAVG_OK;
+    if (vg->opt.reserved[2] != 1 && irh::window_fits((int)nv, f, (int)ne)) {
+        // small (sliding-window) problem: the whole l1ra + irls pipeline in ONE kernel launch
+        if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
+        try {
+            if (!vg->win) vg->win = irh::window_solver_new();
+            std::vector<double> Qa((size_t)4 * nv);
+            for (long r = 0; r < nv; r++)
+                for (int c = 0; c < 4; c++) Qa[(size_t)4 * r + c] = Q[(size_t)c * nv + r];
+            const double t0 = irh::now_seconds();
+            rc = irh::window_solve(*vg->win, (int)nv, f, (int)ne, I.data(), qq.data(), Qa.data(), nullptr,
+                                   100, 100, IROTAVG_GEMAN_MCCLURE, 5 * M_PI / 180.0, change_th,
+                                   &loc.l1_iters, &loc.irls_iters);
+            loc.irls_runtime = irh::now_seconds() - t0;  // both stages run in the one launch
+            for (long r = 0; r < nv; r++)
+                for (int c = 0; c < 4; c++) Q[(size_t)c * nv + r] = Qa[(size_t)4 * r + c];
+        } catch (...) {
+            return IROTAVG_ERR_HIP;
+        }
+    } else {
+        irotavg_graph *g = nullptr;
+        rc = irotavg_graph_create(&g, ne, nv, f, I.data(), QQ.data(), ne, &vg->opt);
+        if (rc != IROTAVG_OK) return rc;
+        rc = irotavg_graph_set_rotations(g, Q.data(), nv);
+        if (rc == IROTAVG_OK)
+            rc = irotavg_graph_l1ra(g, 100, change_th, &loc.l1_iters, &loc.l1_runtime, nullptr);
+        if (rc == IROTAVG_OK)
+            rc = irotavg_graph_irls(g, IROTAVG_GEMAN_MCCLURE, 5 * M_PI / 180.0, 100, change_th,
+                                    &loc.irls_iters, &loc.irls_runtime, nullptr);
+        if (rc == IROTAVG_OK) rc = irotavg_graph_get_rotations(g, Q.data(), nv);
+        irotavg_graph_destroy(g);
+    }
     loc.n_views = (int)nv;
     loc.n_edges = (int)ne;
     loc.n_fixed = f;
@@ -269,6 +294,34 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     vg->last = loc;
     if (info) *info = loc;
     return IROTAVG_OK;
+}
+
+// The single-kernel window pipeline on caller data (same layout as irotavg_l1ra / irotavg_irls):
+// l1ra(l1_iters) then irls(cost, sigma, irls_iters) in one launch. Only for problems that fit
+// (<= 64 free views, <= 640 edges, <= 320 views): IROTAVG_ERR_BAD_ARG otherwise.
+int irotavg_window_solve(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                         int64_t ldqq, double *Q, int64_t ldq, int cost, double sigma, int l1_iters,
+                         int irls_iters, double change_th, double *weights, int *l1_out, int *irls_out) {
+    if (!I || !QQ || !Q || m <= 0 || n_total <= 0 || ldqq < m || ldq < n_total) return IROTAVG_ERR_BAD_ARG;
+    if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
+    if (!irh::window_fits((int)n_total, f, (int)m)) return IROTAVG_ERR_BAD_ARG;
+    if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
+    try {
+        std::vector<double> qa((size_t)4 * m), Qa((size_t)4 * n_total);
+        for (int64_t k = 0; k < m; k++)
+            for (int c = 0; c < 4; c++) qa[(size_t)4 * k + c] = QQ[(size_t)c * ldqq + k];
+        for (int64_t r = 0; r < n_total; r++)
+            for (int c = 0; c < 4; c++) Qa[(size_t)4 * r + c] = Q[(size_t)c * ldq + r];
+        irh::WindowSolver *ws = irh::window_solver_new();
+        const int rc = irh::window_solve(*ws, (int)n_total, f, (int)m, I, qa.data(), Qa.data(), weights,
+                                         l1_iters, irls_iters, cost, sigma, change_th, l1_out, irls_out);
+        irh::window_solver_delete(ws);
+        for (int64_t r = 0; r < n_total; r++)
+            for (int c = 0; c < 4; c++) Q[(size_t)c * ldq + r] = Qa[(size_t)4 * r + c];
+        return rc;
+    } catch (...) {
+        return IROTAVG_ERR_HIP;
+    }
 }
 
 }  // extern "C"

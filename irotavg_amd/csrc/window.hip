@@ -1,0 +1,604 @@
+// window.hip -- the sliding-window solve of ViewGraph::rotAvg(10) (src/ViewGraph.cpp:1263-1435,
+// called once per admitted frame, src/IRotAvg.cpp:371-378) as ONE kernel launch.
+//
+// A window problem has <= 64 free views and a few hundred edges: far too small for the
+// multi-kernel path (one l1ra + irls there is ~150 launches and ~40 host round trips, ~6 ms),
+// so the complete pipeline -- l1ra (primal-dual LP per coordinate, ral/l1_irls.cpp:228-468,
+// 851-912) followed by irls (:559-752) -- runs inside a single workgroup with every vector and
+// the dense normal matrix in LDS: one H2D, one launch, one D2H. The arithmetic follows the same
+// reference statements as solver.hip / l1pd.hip; the linear solves are exact (dense Gauss-Jordan
+// in LDS, dead pivots -> 0 like the oracle).
+#include "graph.hpp"
+#include "kernels.hpp"
+
+namespace irh {
+
+constexpr int WIN_MAX_NU = 64;    // free views
+constexpr int WIN_MAX_NV = 320;   // all views of the sub-problem
+constexpr int WIN_MAX_NE = 640;   // edges
+constexpr int WIN_THREADS = 256;
+
+struct WinParams {
+    int nv, f, ne;
+    int l1_max, irls_max, cost;
+    double change_th, sigma;
+};
+struct WinResult {
+    int l1_iters, irls_iters, status, pad;
+    double l1_score, irls_score;
+};
+
+#define W_PI 3.141592653589793238462643383279502884
+#define W_EPS 2.2204e-16
+
+struct WinShared {
+    double4 *Q;       // nv
+    double *r;        // 3 * ne (planes)
+    double *d;        // ne   IRLS weights
+    double *W;        // 3 * nu (planes): the step X
+    double *H;        // nu * (nu + 1)
+    double *B;        // nu * 3
+    double *pd;       // 12 * ne  primal-dual edge vectors
+    double *pn;       // 5 * nu   primal-dual view vectors
+    double *red;      // 16 reduction scratch
+    int2 *I;          // ne
+    unsigned char *fl;  // ne
+};
+
+// ---- workgroup reductions (result to every thread) -------------------------------------------
+__device__ __forceinline__ double wg_sum(double v, double *red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double s = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    return s;
+}
+__device__ __forceinline__ double wg_min(double v, double *red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double s = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    __syncthreads();
+    return s;
+}
+__device__ __forceinline__ double wg_max(double v, double *red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double s = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    return s;
+}
+
+// ---- dense SPD solve in LDS: H (n x n, leading dim n+1) X = B (n x nrhs, row-major) ----------
+// Gauss-Jordan without pivoting; a non-positive pivot marks a dead variable (row/column dropped,
+// solution 0), like the oracle's sparse Cholesky. Returns false if a non-finite value appears.
+__device__ bool dense_solve(double *H, int n, double *B, int nrhs, double *red) {
+    const int ld = n + 1;
+    for (int k = 0; k < n; k++) {
+        const double piv = H[k * ld + k];
+        const bool dead = !(piv > 0.0);
+        const double ip = dead ? 0.0 : 1.0 / piv;
+        __syncthreads();
+        // scale row k (entries j > k and the right-hand sides)
+        for (int j = threadIdx.x; j < n + nrhs; j += blockDim.x) {
+            if (j < n) {
+                if (j > k) H[k * ld + j] *= ip;
+            } else {
+                B[k * nrhs + (j - n)] *= ip;
+            }
+        }
+        __syncthreads();
+        // eliminate column k from every other row
+        const int cols = n - k - 1 + nrhs;
+        for (int e = threadIdx.x; e < n * cols; e += blockDim.x) {
+            const int i = e / cols, c = e - i * cols;
+            if (i == k) continue;
+            const double fk = H[i * ld + k];
+            if (fk == 0.0) continue;
+            if (c < n - k - 1)
+                H[i * ld + k + 1 + c] -= fk * H[k * ld + k + 1 + c];
+            else
+                B[i * nrhs + (c - (n - k - 1))] -= fk * B[k * nrhs + (c - (n - k - 1))];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if (i != k) H[i * ld + k] = 0.0;
+    }
+    __syncthreads();
+    double bad = 0.0;
+    for (int e = threadIdx.x; e < n * nrhs; e += blockDim.x)
+        if (!isfinite(B[e])) bad = 1.0;
+    return wg_sum(bad, red) == 0.0;
+}
+
+// ---- K1 on the window: r_k = log(Qinv_j (x) QQ_k (x) Q_i)  (ral/l1_irls.cpp:109-127,498-532) --
+__device__ void win_residual(const WinParams &P, const WinShared &S, const double4 *__restrict__ QQ) {
+    for (int k = threadIdx.x; k < P.ne; k += blockDim.x) {
+        double4 qj = S.Q[S.I[k].y];
+        qj.w = -qj.w;
+        const double4 d = qmul(qj, qmul(QQ[k], S.Q[S.I[k].x]));
+        const double s2 = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+        double th = 2.0 * atan2(s2, d.w);
+        if (th < -W_PI)
+            th += 2.0 * W_PI;
+        else if (th >= W_PI)
+            th -= 2.0 * W_PI;
+        const double aux = th / s2;
+        double ox = d.x * aux, oy = d.y * aux, oz = d.z * aux;
+        if (s2 < W_EPS) ox = oy = oz = 0.0;
+        S.r[k] = ox;
+        S.r[P.ne + k] = oy;
+        S.r[2 * P.ne + k] = oz;
+    }
+    __syncthreads();
+}
+
+// (A' t)_v with make_A's coefficients, v a free-view index
+__device__ __forceinline__ double at_dot(const WinParams &P, const WinShared &S, const double *t, int v) {
+    double s = 0.0;
+    for (int k = 0; k < P.ne; k++) {
+        const unsigned char fl = S.fl[k];
+        if ((fl & EF_CJ) && S.I[k].y - P.f == v) s += t[k];
+        if ((fl & EF_CI) && S.I[k].x - P.f == v) s -= t[k];
+    }
+    return s;
+}
+
+// score = mean ||W row|| (before the exp map), exp map, Q_{f+i} <- Q_{f+i} (x) W_i
+// (ral/l1_irls.cpp:729-737 / :894-902, :471-492)
+__device__ double win_apply_step(const WinParams &P, const WinShared &S) {
+    const int nu = P.nv - P.f;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) {
+        const double x = S.W[i], y = S.W[nu + i], z = S.W[2 * nu + i];
+        const double th = sqrt(x * x + y * y + z * z);
+        acc += th;
+        const double sn = sin(th / 2.0), cs = cos(th / 2.0);
+        const double coef = sn / th;
+        double4 w = make_double4(x * coef, y * coef, z * coef, cs);
+        if (!isfinite(w.x)) w.x = 0.0;
+        if (!isfinite(w.y)) w.y = 0.0;
+        if (!isfinite(w.z)) w.z = 0.0;
+        if (!isfinite(w.w)) w.w = 0.0;
+        S.Q[i + P.f] = qmul(S.Q[i + P.f], w);
+    }
+    const double s = wg_sum(acc, S.red);
+    return s / (double)nu;
+}
+
+// ---- one coordinate of the primal-dual LP, x0 = 0 (ral/l1_irls.cpp:228-468) -------------------
+// y: LDS vector of ne entries; result written to xout (nu entries). Returns 0 ok, 1 solver error.
+__device__ int win_l1decode(const WinParams &P, const WinShared &S, const double *y, int pdmaxiter,
+                            double *xout) {
+    const double PDTOL = 1e-3, alpha = 0.01, beta = 0.5, mu = 10;
+    const int m = P.ne, nu = P.nv - P.f, f = P.f;
+    double *u = S.pd, *Ax = u + m, *f1 = Ax + m, *f2 = f1 + m, *l1 = f2 + m, *l2 = l1 + m;
+    double *sigx = l2 + m, *t1 = sigx + m, *t2 = t1 + m, *Adx = t2 + m, *du = Adx + m, *dl1 = du + m;
+    double *dl2 = S.r + 3 * m;  // one spare plane behind the residuals (allocated 4 * ne)
+    double *x = S.pn, *Atv = x + nu, *Atdv = Atv + nu, *dx = Atdv + nu;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < nu; i += nt) x[i] = 0.0;
+    double loc = -HUGE_VAL;
+    for (int k = tid; k < m; k += nt) {
+        Ax[k] = 0.0;
+        loc = fmax(loc, fabs(y[k]));
+    }
+    const double maxabs = wg_max(loc, S.red);
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int k = tid; k < m; k += nt) {  // :252-276
+        const double uu = fabs(y[k] - Ax[k]) * 0.95 + maxabs * 0.10;
+        const double g1 = Ax[k] - y[k] - uu, g2 = -Ax[k] + y[k] - uu;
+        const double m1 = -(1.0 / g1), m2 = -(1.0 / g2);
+        u[k] = uu;
+        f1[k] = g1;
+        f2[k] = g2;
+        l1[k] = m1;
+        l2[k] = m2;
+        t1[k] = m1 - m2;
+        a0 += g1 * m1;
+        a1 += g2 * m2;
+        const double rd = 1.0 - m1 - m2;
+        a2 += rd * rd;
+    }
+    const double sa = wg_sum(a0, S.red), sb = wg_sum(a1, S.red), rd_tail2 = wg_sum(a2, S.red);
+    double sdg = -(sa + sb);
+    double tau = mu * 2 * (double)m / sdg;
+    double acc = 0.0;
+    for (int v = tid; v < nu; v += nt) {
+        const double s = at_dot(P, S, t1, v);
+        Atv[v] = s;
+        acc += s * s;
+    }
+    const double atv2 = wg_sum(acc, S.red);
+    acc = 0.0;
+    for (int k = tid; k < m; k += nt) {
+        const double c1 = -l1[k] * f1[k] - 1.0 / tau, c2 = -l2[k] * f2[k] - 1.0 / tau;
+        acc += c1 * c1 + c2 * c2;
+    }
+    double resnorm = sqrt(atv2 + rd_tail2 + wg_sum(acc, S.red));
+    int pditer = 0;
+    bool done = (sdg < PDTOL) || (pditer >= pdmaxiter);
+    while (!done) {
+        pditer++;
+        const double itau = 1.0 / tau;
+        for (int k = tid; k < m; k += nt) {  // :292-305
+            const double if1 = 1.0 / f1[k], if2 = 1.0 / f2[k];
+            const double w2 = -1 - itau * (if1 + if2);
+            const double a = l1[k] / f1[k], b = l2[k] / f2[k];
+            const double s1 = -a - b, s2 = a - b;
+            sigx[k] = s1 - (s2 * s2) / s1;
+            t1[k] = -if1 + if2;
+            t2[k] = (s2 / s1) * w2;
+        }
+        __syncthreads();
+        // H11p = reshape(AtA * sigx) (make_AtA: endpoints skipped independently, :825-843),
+        // right-hand side w1p = -(1/tau) A't1 - A't2
+        const int ld = nu + 1;
+        for (int e = tid; e < nu * ld; e += nt) S.H[e] = 0.0;
+        __syncthreads();
+        for (int v = tid; v < nu; v += nt) {
+            double *row = S.H + v * ld;
+            for (int k = 0; k < m; k++) {
+                const int i = S.I[k].x - f, j = S.I[k].y - f;
+                const double s = sigx[k];
+                if (i >= 0 && i == j) {
+                    if (i == v) row[v] -= s;
+                    continue;
+                }
+                if (i == v) {
+                    row[v] += s;
+                    if (j >= 0) row[j] -= s;
+                }
+                if (j == v) {
+                    row[v] += s;
+                    if (i >= 0) row[i] -= s;
+                }
+            }
+            const double w1 = -itau * at_dot(P, S, t1, v);
+            dx[v] = w1 - at_dot(P, S, t2, v);
+        }
+        __syncthreads();
+        if (!dense_solve(S.H, nu, dx, 1, S.red)) return 1;
+        double smin = HUGE_VAL;
+        for (int k = tid; k < m; k += nt) {  // :324-381
+            const unsigned char fl = S.fl[k];
+            double adx = 0.0;
+            if (fl & EF_CJ) adx += dx[S.I[k].y - f];
+            if (fl & EF_CI) adx -= dx[S.I[k].x - f];
+            const double g1 = f1[k], g2 = f2[k], m1 = l1[k], m2 = l2[k];
+            const double if1 = 1.0 / g1, if2 = 1.0 / g2;
+            const double w2 = -1 - itau * (if1 + if2);
+            const double a = m1 / g1, b = m2 / g2;
+            const double s1 = -a - b, s2 = a - b;
+            const double d_u = (w2 - s2 * adx) / s1;
+            double d1 = -m1 / g1;
+            d1 *= (adx - d_u);
+            d1 -= m1;
+            d1 -= itau * if1;
+            double d2 = m2 / g2;
+            d2 *= (adx + d_u);
+            d2 -= m2;
+            d2 -= itau * if2;
+            Adx[k] = adx;
+            du[k] = d_u;
+            dl1[k] = d1;
+            dl2[k] = d2;
+            t1[k] = d1 - d2;
+            if (d1 < 0) smin = fmin(smin, -m1 / d1);
+            if (d2 < 0) smin = fmin(smin, -m2 / d2);
+            const double p = adx - d_u;
+            if (p > 0) smin = fmin(smin, -g1 / p);
+            const double q = -adx - d_u;
+            if (q > 0) smin = fmin(smin, -g2 / q);
+        }
+        double s = fmin(1.0, wg_min(smin, S.red));
+        if (!(s == s)) return 1;
+        s *= 0.99;
+        for (int v = tid; v < nu; v += nt) Atdv[v] = at_dot(P, S, t1, v);
+        __syncthreads();
+        bool suffdec = false;
+        int backiter = 0;
+        double s_acc = s, rdp2 = 0.0;
+        while (!suffdec) {  // :384-429
+            double b0 = 0, b1 = 0;
+            for (int v = tid; v < nu; v += nt) {
+                const double q = Atv[v] + s * Atdv[v];
+                b0 += q * q;
+            }
+            for (int k = tid; k < m; k += nt) {
+                const double up = u[k] + s * du[k];
+                const double axp = Ax[k] + s * Adx[k];
+                const double m1 = l1[k] + s * dl1[k], m2 = l2[k] + s * dl2[k];
+                const double g1 = axp - y[k] - up, g2 = -axp + y[k] - up;
+                const double r = 1.0 + (-m1 - m2);
+                b0 += r * r;
+                const double c1 = -m1 * g1 - itau, c2 = -m2 * g2 - itau;
+                b1 += c1 * c1 + c2 * c2;
+            }
+            rdp2 = wg_sum(b0, S.red);
+            const double rcp2 = wg_sum(b1, S.red);
+            suffdec = sqrt(rdp2 + rcp2) <= (1 - alpha * s) * resnorm;
+            s_acc = s;
+            s *= beta;
+            backiter++;
+            if (backiter > 32) {  // "Stuck backtracking": the previous iterate is returned
+                for (int v = tid; v < nu; v += nt) xout[v] = x[v];
+                __syncthreads();
+                return 0;
+            }
+        }
+        for (int v = tid; v < nu; v += nt) {
+            x[v] += s_acc * dx[v];
+            Atv[v] += s_acc * Atdv[v];
+        }
+        a0 = a1 = 0;
+        for (int k = tid; k < m; k += nt) {
+            const double up = u[k] + s_acc * du[k];
+            const double axp = Ax[k] + s_acc * Adx[k];
+            const double m1 = l1[k] + s_acc * dl1[k], m2 = l2[k] + s_acc * dl2[k];
+            const double g1 = axp - y[k] - up, g2 = -axp + y[k] - up;
+            u[k] = up;
+            Ax[k] = axp;
+            l1[k] = m1;
+            l2[k] = m2;
+            f1[k] = g1;
+            f2[k] = g2;
+            a0 += g1 * m1;
+            a1 += g2 * m2;
+        }
+        sdg = -(wg_sum(a0, S.red) + wg_sum(a1, S.red));
+        tau = mu * 2 * (double)m / sdg;
+        acc = 0.0;
+        for (int k = tid; k < m; k += nt) {
+            const double c1 = -l1[k] * f1[k] - 1.0 / tau, c2 = -l2[k] * f2[k] - 1.0 / tau;
+            acc += c1 * c1 + c2 * c2;
+        }
+        resnorm = sqrt(rdp2 + wg_sum(acc, S.red));
+        done = (sdg < PDTOL) || (pditer >= pdmaxiter);
+    }
+    for (int v = tid; v < nu; v += nt) xout[v] = x[v];
+    __syncthreads();
+    return 0;
+}
+
+__device__ __forceinline__ double win_weight(int cost, double sigma, double e2, double prev);
+
+__global__ __launch_bounds__(WIN_THREADS) void k_window_solve(WinParams P, const int2 *__restrict__ Ig,
+                                                              const double4 *__restrict__ QQ,
+                                                              double4 *__restrict__ Qg,
+                                                              double *__restrict__ weights,
+                                                              WinResult *__restrict__ out) {
+    extern __shared__ double4 smem4[];
+    const int nv = P.nv, ne = P.ne, f = P.f, nu = nv - f;
+    WinShared S;
+    S.Q = smem4;
+    double *p = reinterpret_cast<double *>(S.Q + nv);
+    S.r = p;          p += 4 * ne;
+    S.d = p;          p += ne;
+    S.W = p;          p += 3 * nu;
+    S.H = p;          p += nu * (nu + 1);
+    S.B = p;          p += 3 * nu;
+    S.pd = p;         p += 12 * ne;
+    S.pn = p;         p += 5 * nu;
+    S.red = p;        p += 16;
+    S.I = reinterpret_cast<int2 *>(p);
+    S.fl = reinterpret_cast<unsigned char *>(S.I + ne);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < nv; i += nt) S.Q[i] = Qg[i];
+    for (int k = tid; k < ne; k += nt) {
+        const int2 e = Ig[k];
+        S.I[k] = e;
+        unsigned char fl = 0;  // make_A coefficients (ral/l1_irls.cpp:764-777)
+        if (e.y >= f) {
+            if (e.x >= f && e.x == e.y) {
+                fl = EF_CI;
+            } else {
+                fl |= EF_CJ;
+                if (e.x >= f) fl |= EF_CI;
+            }
+        }
+        S.fl[k] = fl;
+    }
+    __syncthreads();
+    int status = 0;
+    // ---------------- l1ra (ral/l1_irls.cpp:851-912) ----------------
+    double score = HUGE_VAL, change_th = P.change_th;
+    int iter = 0, l1_step = 2;
+    while (((score >= change_th) || (l1_step < 2)) && (iter < P.l1_max) && status == 0) {
+        if (score < change_th) {  // unreachable under the guard above; kept literal (:879-883)
+            l1_step *= 4;
+            change_th /= 100.0;
+        }
+        win_residual(P, S, QQ);
+        for (int c = 0; c < 3 && status == 0; c++)
+            status = win_l1decode(P, S, S.r + c * ne, l1_step, S.W + c * nu);
+        if (status) break;
+        score = win_apply_step(P, S);
+        iter++;
+    }
+    const int l1_iters = iter;
+    const double l1_score = score;
+    // ---------------- irls (ral/l1_irls.cpp:559-752) ----------------
+    for (int k = tid; k < ne; k += nt) S.d[k] = 1.0;
+    __syncthreads();
+    score = HUGE_VAL;
+    iter = 0;
+    while (score > P.change_th && iter < P.irls_max && status == 0) {
+        win_residual(P, S, QQ);
+        const int ld = nu + 1;
+        for (int e = tid; e < nu * ld; e += nt) S.H[e] = 0.0;
+        __syncthreads();
+        for (int v = tid; v < nu; v += nt) {  // A'D^2A and A'D^2 r with make_A's A
+            double *row = S.H + v * ld;
+            double b0 = 0, b1 = 0, b2 = 0;
+            for (int k = 0; k < ne; k++) {
+                const unsigned char fl = S.fl[k];
+                if (!fl) continue;
+                const int i = S.I[k].x - f, j = S.I[k].y - f;
+                const double s = S.d[k] * S.d[k];
+                if ((fl & EF_CJ) && j == v) {
+                    row[v] += s;
+                    if (fl & EF_CI) row[i] -= s;
+                    b0 += s * S.r[k];
+                    b1 += s * S.r[ne + k];
+                    b2 += s * S.r[2 * ne + k];
+                }
+                if ((fl & EF_CI) && i == v) {
+                    row[v] += s;
+                    if (fl & EF_CJ) row[j] -= s;
+                    b0 -= s * S.r[k];
+                    b1 -= s * S.r[ne + k];
+                    b2 -= s * S.r[2 * ne + k];
+                }
+            }
+            S.B[3 * v] = b0;
+            S.B[3 * v + 1] = b1;
+            S.B[3 * v + 2] = b2;
+        }
+        __syncthreads();
+        if (!dense_solve(S.H, nu, S.B, 3, S.red)) {
+            status = IROTAVG_ERR_SOLVER;
+            break;
+        }
+        for (int v = tid; v < nu; v += nt) {
+            S.W[v] = S.B[3 * v];
+            S.W[nu + v] = S.B[3 * v + 1];
+            S.W[2 * nu + v] = S.B[3 * v + 2];
+        }
+        __syncthreads();
+        for (int k = tid; k < ne; k += nt) {  // E = A W3 - w, weights (:614-727)
+            const unsigned char fl = S.fl[k];
+            double e0 = 0, e1 = 0, e2c = 0;
+            if (fl & EF_CJ) {
+                const int j = S.I[k].y - f;
+                e0 += S.W[j];
+                e1 += S.W[nu + j];
+                e2c += S.W[2 * nu + j];
+            }
+            if (fl & EF_CI) {
+                const int i = S.I[k].x - f;
+                e0 -= S.W[i];
+                e1 -= S.W[nu + i];
+                e2c -= S.W[2 * nu + i];
+            }
+            e0 -= S.r[k];
+            e1 -= S.r[ne + k];
+            e2c -= S.r[2 * ne + k];
+            S.d[k] = win_weight(P.cost, P.sigma, e0 * e0 + e1 * e1 + e2c * e2c, S.d[k]);
+        }
+        __syncthreads();
+        score = win_apply_step(P, S);
+        iter++;
+    }
+    if (status == 1) status = IROTAVG_ERR_SOLVER;
+    __syncthreads();
+    for (int i = tid; i < nv; i += nt) Qg[i] = S.Q[i];
+    for (int k = tid; k < ne; k += nt) weights[k] = S.d[k];
+    if (tid == 0) {
+        out->l1_iters = l1_iters;
+        out->irls_iters = iter;
+        out->status = status;
+        out->l1_score = l1_score;
+        out->irls_score = score;
+    }
+}
+
+// the 14 robust weights (ral/l1_irls.cpp:617-727); same statements as robust_weight() in solver.hip
+__device__ __forceinline__ double win_weight(int cost, double sigma, double e2, double prev) {
+    switch (cost) {
+    case IROTAVG_L2: return prev;
+    case IROTAVG_L05: { double w = 1.0 / pow(e2, 3. / 8.); return w > 1e4 ? 1e4 : w; }
+    case IROTAVG_L1: { double w = 1.0 / sqrt(sqrt(e2)); return w > 1e4 ? 1e4 : w; }
+    case IROTAVG_L15: { double w = 1.0 / sqrt(sqrt(sqrt(e2))); return w > 1e4 ? 1e4 : w; }
+    case IROTAVG_GEMAN_MCCLURE: return 1.0 / (e2 + sigma * sigma);
+    case IROTAVG_HUBER: { const double e = sqrt(e2) / (1.345 * sigma); return e >= 1 ? sqrt(1. / e) : prev; }
+    case IROTAVG_PSEUDO_HUBER: return 1.0 / sqrt(sqrt(1.0 + e2 / (sigma * sigma)));
+    case IROTAVG_ANDREWS: {
+        const double e = sqrt(e2) / (1.339 * sigma);
+        double w = sqrt(sin(e) / e);
+        if (e >= W_PI) w = 0; else if (e < .0001) w = 1;
+        return w < 0.0001 ? 0.0001 : w;
+    }
+    case IROTAVG_BISQUARE: { const double t = 4.685 * sigma; double w = 1.0 - e2 / (t * t); return w < 0.0001 ? 0.0001 : w; }
+    case IROTAVG_CAUCHY: { const double t = 2.385 * sigma; return 1.0 / sqrt(1.0 + e2 / (t * t)); }
+    case IROTAVG_FAIR: return 1.0 / sqrt(1.0 + sqrt(e2) / (1.400 * sigma));
+    case IROTAVG_LOGISTIC: { const double e = sqrt(e2) / (1.205 * sigma); return e < 0.0001 ? 1.0 : sqrt(tanh(e) / e); }
+    case IROTAVG_TALWAR: { const double t = 2.795 * sigma; return e2 < t * t ? 1.0001 : 0.0; }
+    default: { const double t = 2.985 * sigma; double w = exp(-.5 * e2 / (t * t)); return w < 0.0001 ? 0.0001 : w; }
+    }
+}
+
+// ---- host side: persistent staging, one H2D / launch / D2H per solve ---------------------------
+struct WindowSolver {
+    hipStream_t stream = nullptr;
+    DevBuf<unsigned char> dev;   // [I | QQ | Q | weights | result]
+    unsigned char *host = nullptr;
+    size_t cap = 0;
+    bool attr_set = false;
+    ~WindowSolver() {
+        if (host) (void)hipHostFree(host);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static size_t win_lds_bytes(int nv, int ne, int nu) {
+    return sizeof(double4) * (size_t)nv +
+           sizeof(double) * ((size_t)4 * ne + ne + 3 * nu + (size_t)nu * (nu + 1) + 3 * nu + 12 * (size_t)ne +
+                             5 * nu + 16) +
+           sizeof(int2) * (size_t)ne + (size_t)ne + 64;
+}
+
+bool window_fits(int nv, int f, int ne) {
+    const int nu = nv - f;
+    return nu >= 1 && nu <= WIN_MAX_NU && nv <= WIN_MAX_NV && ne >= 1 && ne <= WIN_MAX_NE &&
+           win_lds_bytes(nv, ne, nu) <= 160 * 1024;
+}
+
+int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, const double *QQ_aos,
+                 double *Q_aos, double *weights, int l1_max, int irls_max, int cost, double sigma,
+                 double change_th, int *l1_iters, int *irls_iters) {
+    if (!window_fits(nv, f, ne)) return IROTAVG_ERR_BAD_ARG;
+    if (!ws.stream) IRH_CHECK(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
+    const size_t oI = 0, oQQ = oI + sizeof(int2) * (size_t)WIN_MAX_NE;
+    const size_t oQ = oQQ + sizeof(double4) * (size_t)WIN_MAX_NE;
+    const size_t oW = oQ + sizeof(double4) * (size_t)WIN_MAX_NV;
+    const size_t oR = oW + sizeof(double) * (size_t)WIN_MAX_NE;
+    const size_t total = oR + sizeof(WinResult);
+    if (ws.cap < total) {
+        ws.dev.alloc(total);
+        if (ws.host) (void)hipHostFree(ws.host);
+        IRH_CHECK(hipHostMalloc((void **)&ws.host, total, hipHostMallocDefault));
+        ws.cap = total;
+    }
+    std::memcpy(ws.host + oI, I, sizeof(int32_t) * 2 * (size_t)ne);
+    std::memcpy(ws.host + oQQ, QQ_aos, sizeof(double) * 4 * (size_t)ne);
+    std::memcpy(ws.host + oQ, Q_aos, sizeof(double) * 4 * (size_t)nv);
+    IRH_CHECK(hipMemcpyAsync(ws.dev.p, ws.host, oW, hipMemcpyHostToDevice, ws.stream));
+    WinParams P{nv, f, ne, l1_max, irls_max, cost, change_th, sigma};
+    const size_t shm = win_lds_bytes(nv, ne, nv - f);
+    if (!ws.attr_set) {
+        IRH_CHECK(hipFuncSetAttribute((const void *)k_window_solve,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ws.attr_set = true;
+    }
+    hipLaunchKernelGGL(k_window_solve, dim3(1), dim3(WIN_THREADS), shm, ws.stream, P,
+                       (const int2 *)(ws.dev.p + oI), (const double4 *)(ws.dev.p + oQQ),
+                       (double4 *)(ws.dev.p + oQ), (double *)(ws.dev.p + oW),
+                       (WinResult *)(ws.dev.p + oR));
+    IRH_CHECK(hipMemcpyAsync(ws.host + oQ, ws.dev.p + oQ, total - oQ, hipMemcpyDeviceToHost, ws.stream));
+    IRH_CHECK(hipStreamSynchronize(ws.stream));
+    WinResult R;
+    std::memcpy(&R, ws.host + oR, sizeof(R));
+    std::memcpy(Q_aos, ws.host + oQ, sizeof(double) * 4 * (size_t)nv);
+    if (weights) std::memcpy(weights, ws.host + oW, sizeof(double) * (size_t)ne);
+    if (l1_iters) *l1_iters = R.l1_iters;
+    if (irls_iters) *irls_iters = R.irls_iters;
+    return R.status;
+}
+
+WindowSolver *window_solver_new() { return new WindowSolver(); }
+void window_solver_delete(WindowSolver *w) { delete w; }
+
+}  // namespace irh
