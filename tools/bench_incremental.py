@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Config 5 of BASELINE.json: incremental mode. A warm solution of the first
+`--warm` views, then `--stream` new views arrive one by one (each linked to its <= 4
+predecessors, `vg_win_size = 4` in src/IRotAvg.cpp:158-161) with sparse loop-closure edges; every
+new view triggers rotAvg(10), a loop closure triggers the global rotAvg(5000000), a ground-truth
+correction fixes a pose every `--fix-every` frames (src/IRotAvg.cpp:360-378).
+
+Prints one JSON line: views/s, local/global solve counts and latencies, final error vs ground truth.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from irotavg_amd import capi, synth  # noqa: E402
+from irotavg_amd.viewgraph import ViewGraph  # noqa: E402
+
+
+def quat2rmat(q):
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], axis=-1)
+    return R.reshape(q.shape[:-1] + (3, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--warm", type=int, default=50000)
+    ap.add_argument("--stream", type=int, default=50000)
+    ap.add_argument("--loops", type=int, default=10, help="loop closures among the streamed views")
+    ap.add_argument("--fix-every", type=int, default=20)
+    ap.add_argument("--noise", type=float, default=0.01)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    n = a.warm + a.stream
+    rng = np.random.default_rng(a.seed)
+    Qgt = rng.normal(size=(n, 4))
+    Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+    Rgt = quat2rmat(Qgt)
+
+    def rel(i, j):
+        e = synth.qexp(rng.normal(scale=a.noise, size=(1, 3)))[0]
+        return quat2rmat(synth.qmul(e, synth.qmul(Qgt[j], synth.qconj(Qgt[i]))))
+
+    loop_at = set(rng.choice(np.arange(a.warm + 100, n), size=a.loops, replace=False).tolist()) if a.loops else set()
+    vg = ViewGraph()
+    t_build = time.perf_counter()
+    # warm part: the first `warm` views with poses as a converged run would have left them
+    # (ground truth perturbed by the measurement noise level), fixes every fix_every frames
+    for v in range(a.warm):
+        R0 = quat2rmat(synth.qmul(synth.qexp(rng.normal(scale=a.noise, size=(1, 3)))[0], Qgt[v]))
+        vg.addView(R0)
+        for d in range(1, min(4, v) + 1):
+            vg.connect(v - d, v, rel(v - d, v))
+        if v % a.fix_every == 0:
+            vg.fixPose(v, Rgt[v])
+    t_build = time.perf_counter() - t_build
+    lat_local, lat_global = [], []
+    edges_solved = 0
+    t0 = time.perf_counter()
+    for v in range(a.warm, n):
+        Rprev = vg.R(v - 1)
+        Rij = rel(v - 1, v)
+        vg.addView(Rij @ Rprev)                    # the front-end's initial pose
+        vg.connect(v - 1, v, Rij)
+        for d in range(2, 5):
+            vg.connect(v - d, v, rel(v - d, v))
+        loop = v in loop_at
+        if loop:
+            u = int(rng.integers(0, v - 1000))
+            vg.connect(u, v, rel(u, v))
+        if v % a.fix_every == 0:
+            vg.fixPose(v, Rgt[v])
+        t = time.perf_counter()
+        info = vg.rotAvg(5000000 if loop else 10)
+        (lat_global if loop else lat_local).append(time.perf_counter() - t)
+        if not info["skipped"]:
+            edges_solved += info["n_edges"] * max(info["irls_iters"], 1)
+    dt = time.perf_counter() - t0
+    err = np.array([np.arccos(np.clip((np.trace(vg.R(v).T @ Rgt[v]) - 1) / 2, -1, 1)) for v in range(a.warm, n, 97)])
+    print(json.dumps({
+        "mode": "incremental", "warm_views": a.warm, "streamed_views": a.stream, "loop_closures": len(lat_global),
+        "views_per_s": a.stream / dt, "seconds": dt, "warm_build_seconds": t_build,
+        "local_rotavg_ms_mean": 1e3 * float(np.mean(lat_local)), "local_rotavg_ms_p99": 1e3 * float(np.percentile(lat_local, 99)),
+        "global_rotavg_ms_mean": 1e3 * float(np.mean(lat_global)) if lat_global else None,
+        "irls_edge_updates_per_s": edges_solved / dt,
+        "mean_angular_error_rad": float(err.mean()), "max_angular_error_rad": float(err.max())}))
+
+
+if __name__ == "__main__":
+    main()
