@@ -22,6 +22,7 @@ struct Graph {
     DevBuf<double> qq;  // 4 planes (x,y,z,w) of mpad doubles: the reference's col-major QQ
     DevBuf<double> er;  // 3 planes (rx,ry,rz) of mpad doubles: rotation-vector residual per edge
     DevBuf<double> dw;  // IRLS weights d_k (m)
+    DevBuf<double4> T;  // per edge (w r, w), w = d^2: the assembly's gather record (IRLS mode)
     // views
     DevBuf<double4> Q;  // n_total quaternions [x y z w], gather-friendly AoS
     DevBuf<double4> Qsnap;

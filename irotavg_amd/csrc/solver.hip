@@ -174,12 +174,25 @@ void launch_update_weights(Graph &g, int cost, double sigma) {
 // and (IRLS) the right-hand side b_v = sum_k +-w_k r_k. MODE 0: w = d_k^2 from the IRLS weights,
 // rhs built. MODE 1: w = s[k] (sigx of the primal-dual step), no rhs, make_AtA boundary rule.
 // =============================================================================================
+// Edge-parallel producer of the assembly's operands: T[e] = (w r_x, w r_y, w r_z, w), w = d_e^2, as
+// ONE 32-byte record per edge, so that the view-parallel assembly issues one gather per entry
+// instead of four (weights + three residual planes): PMC showed 5x the algorithmic traffic before.
+__global__ __launch_bounds__(256) void k_edge_pack(long long m, long long mpad,
+                                                   const double *__restrict__ d,
+                                                   const double *__restrict__ er,
+                                                   double4 *__restrict__ T) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const double w = d[k] * d[k];
+    T[k] = make_double4(w * er[k], w * er[mpad + k], w * er[2 * mpad + k], w);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kRowBlock) void k_assemble0(
     int n, int nsl, const int *__restrict__ sl_off, const uint32_t *__restrict__ slot_eid,
     const int *__restrict__ bptr, const uint32_t *__restrict__ beid,
     const uint8_t *__restrict__ bflag, const double *__restrict__ wsrc,
-    const double *__restrict__ er, long long mpad, double *__restrict__ val,
+    const double4 *__restrict__ T, double *__restrict__ val,
     double *__restrict__ excess, double *__restrict__ diag, double *__restrict__ idg,
     double4 *__restrict__ rhs, double *__restrict__ bval) {
     const int ntiles = (nsl + 3) / 4;
@@ -196,30 +209,27 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0(
         constexpr int U = kSellUnroll;
         for (int k0 = 0; k0 < w; k0 += U) {  // w is a multiple of U: whole batches, loads first
             uint32_t se[U];
-            double wk[U], r0[U], r1[U], r2[U];
+            double4 tt[U];
 #pragma unroll
             for (int u = 0; u < U; u++) se[u] = se_p[(size_t)(k0 + u) * 64];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const bool live = se[u] != 0xffffffffu;
                 const uint32_t e = live ? (se[u] >> 1) : 0u;
-                wk[u] = wsrc[e];
-                if (MODE == 0) {
-                    r0[u] = er[e];
-                    r1[u] = er[mpad + e];
-                    r2[u] = er[2 * mpad + e];
-                }
-                if (!live) wk[u] = 0.0;
+                if (MODE == 0)
+                    tt[u] = T[e];
+                else
+                    tt[u].w = wsrc[e];
+                if (!live) tt[u] = make_double4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                double ww = wk[u];
-                if (MODE == 0) ww = ww * ww;
+                const double ww = tt[u].w;
                 if (MODE == 0) {
-                    const double sg = (se[u] & 1u) ? ww : -ww;
-                    b0 += sg * r0[u];
-                    b1 += sg * r1[u];
-                    b2 += sg * r2[u];
+                    const double sg = (se[u] & 1u) ? 1.0 : -1.0;
+                    b0 += sg * tt[u].x;
+                    b1 += sg * tt[u].y;
+                    b2 += sg * tt[u].z;
                 }
                 v_p[(size_t)(k0 + u) * 64] = -ww;
                 sw += ww;
@@ -234,17 +244,20 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0(
                 }
                 const uint32_t se = beid[s];
                 const uint32_t e = se >> 1;
-                double wk = wsrc[e];
-                if (MODE == 0) wk = wk * wk;
-                if (MODE == 1 && (fl & BF_NEG)) wk = -wk;
+                double wk;
+                if (MODE == 0) {
+                    const double4 t = T[e];
+                    wk = t.w;
+                    const double sg = (se & 1u) ? 1.0 : -1.0;
+                    b0 += sg * t.x;
+                    b1 += sg * t.y;
+                    b2 += sg * t.z;
+                } else {
+                    wk = wsrc[e];
+                    if (fl & BF_NEG) wk = -wk;
+                }
                 bval[s] = wk;
                 ex += wk;
-                if (MODE == 0) {
-                    const double sg = (se & 1u) ? wk : -wk;
-                    b0 += sg * er[e];
-                    b1 += sg * er[mpad + e];
-                    b2 += sg * er[2 * mpad + e];
-                }
             }
             const double d = sw + ex;
             excess[row] = ex;
@@ -749,14 +762,16 @@ void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
     Level &L0 = g.levels[0];
     const int grid = grid_for_rows(L0);
     if (mode == 0) {
+        if (g.T.n < (size_t)g.mpad) g.T.alloc((size_t)g.mpad);
+        hipLaunchKernelGGL(k_edge_pack, dim3((unsigned)((g.m + 255) / 256)), dim3(256), 0, g.stream,
+                           (long long)g.m, (long long)g.mpad, wsrc, g.er.p, g.T.p);
         hipLaunchKernelGGL((k_assemble0<0>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl,
-                           L0.sl_off.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, wsrc, g.er.p,
-                           (long long)g.mpad, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p,
-                           g.bval.p);
+                           L0.sl_off.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, wsrc, g.T.p,
+                           L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p, g.bval.p);
     } else {
         hipLaunchKernelGGL((k_assemble0<1>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl,
-                           L0.sl_off.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, wsrc, g.er.p,
-                           (long long)g.mpad, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p,
+                           L0.sl_off.p, g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, wsrc,
+                           (const double4 *)nullptr, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p,
                            g.bval.p);
     }
     for (size_t l = 1; l < g.levels.size(); l++) {
