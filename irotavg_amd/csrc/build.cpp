@@ -21,29 +21,48 @@ static int pow2floor(int v) {
     return p;
 }
 
-// SELL-64 positions of a CSR pattern: pos[t] for every CSR slot t, slice offsets, padded length
+// SELL-64 positions of a CSR pattern (layout: common.hpp): pos[t] for every CSR slot t, slice
+// offsets, near widths, padded length. Near = column inside the LDS window of the row's tile.
 struct SellMap {
     int nsl = 0;
-    std::vector<int> sl_off;  // nsl + 1
-    std::vector<int> pos;     // per CSR slot
-    long long len = 0;        // 64 * sl_off[nsl]
+    std::vector<int> sl_off, sl_near;  // nsl + 1, nsl
+    std::vector<int> pos;              // per CSR slot
+    long long len = 0;                 // 64 * sl_off[nsl]
 };
-static SellMap sell_map(int n, const std::vector<int> &rowptr) {
+static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector<int> &col) {
     SellMap M;
     M.nsl = (n + 63) / 64;
     M.sl_off.assign((size_t)M.nsl + 1, 0);
+    M.sl_near.assign((size_t)M.nsl, 0);
+    auto is_near = [&](int r, int c) {
+        const int t0 = (r / 256) * 256;
+        return c >= t0 - kWinHalo && c < t0 + 256 + kWinHalo;
+    };
+    auto roundup = [](int w) { return (w + kSellUnroll - 1) / kSellUnroll * kSellUnroll; };
+    std::vector<int> nnear((size_t)n, 0);
     for (int sl = 0; sl < M.nsl; sl++) {
-        int w = 0;
-        for (int r = sl * 64; r < std::min(n, sl * 64 + 64); r++) w = std::max(w, rowptr[r + 1] - rowptr[r]);
-        w = (w + kSellUnroll - 1) / kSellUnroll * kSellUnroll;  // whole batches of the row loops
-        M.sl_off[sl + 1] = M.sl_off[sl] + w;
+        int wn = 0, wf = 0;
+        for (int r = sl * 64; r < std::min(n, sl * 64 + 64); r++) {
+            int nn = 0;
+            for (int t = rowptr[r]; t < rowptr[r + 1]; t++) nn += is_near(r, col[t]) ? 1 : 0;
+            nnear[r] = nn;
+            wn = std::max(wn, nn);
+            wf = std::max(wf, rowptr[r + 1] - rowptr[r] - nn);
+        }
+        wn = roundup(wn);
+        wf = roundup(wf);
+        M.sl_near[sl] = wn;
+        M.sl_off[sl + 1] = M.sl_off[sl] + wn + wf;
     }
     M.len = 64ll * M.sl_off[M.nsl];
     M.pos.resize((size_t)rowptr[n]);
     for (int r = 0; r < n; r++) {
         const int sl = r >> 6, lane = r & 63;
-        for (int t = rowptr[r]; t < rowptr[r + 1]; t++)
-            M.pos[t] = (M.sl_off[sl] + (t - rowptr[r])) * 64 + lane;
+        int kn = 0, kf = M.sl_near[sl];
+        for (int t = rowptr[r]; t < rowptr[r + 1]; t++) {
+            const int k = is_near(r, col[t]) ? kn++ : kf++;
+            M.pos[t] = (int)sell_pos(M.sl_off[sl], k, lane);
+        }
     }
     return M;
 }
@@ -240,18 +259,19 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     for (size_t lev = 0; lev < H.size(); lev++) {
         Level &L = g.levels[lev];
         HostLevel &h = H[lev];
-        SellMap M = sell_map(h.n, h.rowptr);
+        SellMap M = sell_map(h.n, h.rowptr, h.col);
         L.n = h.n;
         L.nnz = h.rowptr[h.n];
         L.agg = h.agg;
         L.nsl = M.nsl;
         L.sell_len = M.len;
         std::vector<int> scol((size_t)M.len);
-        for (int sl = 0; sl < M.nsl; sl++)  // padding: a valid column (row 0 of the slice), value 0
+        for (int sl = 0; sl < M.nsl; sl++)  // padding: a valid near column (row 0 of the slice), value 0
             for (int k = M.sl_off[sl]; k < M.sl_off[sl + 1]; k++)
                 for (int lane = 0; lane < 64; lane++) scol[(size_t)k * 64 + lane] = sl * 64;
         for (size_t t = 0; t < h.col.size(); t++) scol[M.pos[t]] = h.col[t];
         L.sl_off.upload(M.sl_off, s);
+        L.sl_near.upload(M.sl_near, s);
         L.col.upload(scol, s);
         L.val.alloc((size_t)M.len);
         L.val.zero(s);

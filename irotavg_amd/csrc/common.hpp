@@ -103,19 +103,28 @@ enum FlagIdx : int {
     FL_COUNT = 4
 };
 
-// One multigrid level. The off-diagonal part of the weighted Laplacian is held in SELL-64:
-// rows are cut into slices of 64 consecutive rows (one wavefront), slice s is `sl_off[s+1] -
-// sl_off[s]` entry-columns wide (its longest row), and entry k of the row in lane l sits at
-// (sl_off[s] + k) * 64 + l. One lane owns one row, so every wave-level load of col/val is a
-// contiguous 256/512-byte run, the inner loop has a wave-uniform trip count, and no cross-lane
-// reduction is needed. Padding entries have val = 0 and col = a valid row.
+// One multigrid level. The off-diagonal part of the weighted Laplacian is held in SELL-64 with
+// 2-entry interleave: rows are cut into slices of 64 consecutive rows (one wavefront), slice s is
+// `sl_off[s+1] - sl_off[s]` entry-columns wide (a multiple of 8), and entries 2q, 2q+1 of the row
+// in lane l sit next to each other at (sl_off[s] + 2q) * 64 + 2l (+1): one lane owns one row and
+// reads its entries two at a time, so a wave-level load of `val` is one contiguous 1 KiB run of
+// 16 B per lane (`col`: 512 B of 8 B per lane), the inner loop has a wave-uniform trip count and
+// no cross-lane reduction is needed. Within a row the entries whose column lies in the window of
+// the row's 256-row workgroup tile ([tile - 64, tile + 320)) come first -- the first `sl_near[s]`
+// entry-columns of the slice hold only such entries -- so the SpMV can serve them from an LDS copy
+// of that window instead of gathering from global memory. Padding: val = 0, col = a row of the slice.
+__host__ __device__ inline size_t sell_pos(int o0, int k, int lane) {
+    return (size_t)(o0 + (k & ~1)) * 64 + (size_t)lane * 2 + (size_t)(k & 1);
+}
+constexpr int kWinHalo = 64;   // rows on either side of a 256-row tile held in the LDS window
+constexpr int kWinLen = 256 + 2 * kWinHalo;
 struct Level {
     int n = 0;        // rows
     int nnz = 0;      // real off-diagonal entries
     int agg = 0;      // rows per aggregate towards the next (coarser) level; 0 on the coarsest
     int nsl = 0;      // slices
     long long sell_len = 0;  // 64 * total entry-columns
-    DevBuf<int> sl_off, col;
+    DevBuf<int> sl_off, sl_near, col;
     DevBuf<double> val;     // off-diagonal values (<= 0 for a Laplacian)
     DevBuf<double> excess;  // diag - sum|offdiag| : Dirichlet mass from fixed neighbours
     DevBuf<double> diag, idg;  // diagonal and its inverse (0 where the diagonal is 0)

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kRowBlock) void k_dense_build(LevelView C, int npad
     const int sl = i >> 6, lane = i & 63;
     const int o0 = C.sl_off[sl], w = C.sl_off[sl + 1] - o0;
     for (int k = 0; k < w; k++) {
-        const size_t p = (size_t)(o0 + k) * 64 + lane;
+        const size_t p = sell_pos(o0, k, lane);
         const double v = C.val[p];
         if (v != 0.0) row[C.col[p]] += v;
     }
@@ -222,7 +222,7 @@ void dense_refresh(Graph &g) {
                              g.stream));
     Level &C = g.levels.back();
     const int npad = g.ndense_pad;
-    LevelView V{C.n, C.nsl, C.agg, C.sl_off.p, C.col.p, C.val.p, C.diag.p, C.idg.p};
+    LevelView V{C.n, C.nsl, C.agg, C.sl_off.p, C.sl_near.p, C.col.p, C.val.p, C.diag.p, C.idg.p};
     IRH_CHECK(hipMemsetAsync(g.dense_inv.p, 0, sizeof(double) * (size_t)npad * npad, g.stream));
     hipLaunchKernelGGL(k_dense_build, dim3((npad + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,
                        g.stream, V, npad, g.dense_inv.p);

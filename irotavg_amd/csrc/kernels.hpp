@@ -16,7 +16,7 @@ namespace irh {
 
 struct LevelView {
     int n, nsl, agg;
-    const int *sl_off, *col;
+    const int *sl_off, *sl_near, *col;
     const double *val, *diag, *idg;
 };
 
@@ -125,62 +125,73 @@ __device__ __forceinline__ void tile_range(int ntiles, int &t0, int &t1) {
 }
 
 // Off-diagonal part of (L x)_row for the lane's own row. The slice width is a multiple of
-// kSellUnroll and uniform across the wave; the loop is software-pipelined by hand: the col/val
-// loads of batch k+1 are issued before the gathers of batch k are consumed, so each batch of 8
-// entries costs one memory round trip instead of two (col -> gather dependency).
+// kSellUnroll and uniform across the wave. The loop is software-pipelined by hand TWO batches
+// deep: while the gathers of batch k are in flight, the col/val loads of batch k+2 are issued
+// and those of batch k+1 are already underway. The matrix stream does not fit the 4 MB L2 of an
+// XCD, so every batch is a ~2 us trip to the Infinity Cache / HBM; with only ~6 waves per CU
+// (one lane per row) the bytes in flight per wave set the bandwidth (Little's law).
 template <bool PROLONG>
 __device__ __forceinline__ void row_offdiag_t(const LevelView &L, int row, const double4 *__restrict__ x,
                                               const double4 *__restrict__ xc, int sh, double kc,
-                                              double &s0, double &s1, double &s2) {
-    constexpr int U = kSellUnroll;
+                                              double &s0, double &s1, double &s2, int kbeg = 0) {
+    constexpr int U = kSellUnroll, H = kSellUnroll / 2;  // a batch = U entries = H pairs
     const int sl = row >> 6, lane = row & 63;
     const int o0 = L.sl_off[sl], w = L.sl_off[sl + 1] - o0;
-    const int *__restrict__ c = L.col + (size_t)o0 * 64 + lane;
-    const double *__restrict__ v = L.val + (size_t)o0 * 64 + lane;
+    // entry pairs: (o0 + 2q) * 64 + 2 lane  ==  int2/double2 index (o0/2 + q) * 64 + lane
+    const int2 *__restrict__ c = reinterpret_cast<const int2 *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+    const double2 *__restrict__ v = reinterpret_cast<const double2 *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
     s0 = s1 = s2 = 0.0;
-    if (w == 0) return;
-    int cc[U];
-    double vv[U];
+    if (kbeg >= w) return;
+    int2 ca[H], cb[H], cn[H];
+    double2 va[H], vb[H], vn[H];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        cc[u] = c[(size_t)u * 64];
-        vv[u] = v[(size_t)u * 64];
+    for (int u = 0; u < H; u++) {
+        ca[u] = c[(size_t)(kbeg / 2 + u) * 64];
+        va[u] = v[(size_t)(kbeg / 2 + u) * 64];
     }
-    for (int k0 = 0; k0 < w; k0 += U) {
+    if (kbeg + U < w) {
+#pragma unroll
+        for (int u = 0; u < H; u++) {
+            cb[u] = c[(size_t)((kbeg + U) / 2 + u) * 64];
+            vb[u] = v[(size_t)((kbeg + U) / 2 + u) * 64];
+        }
+    }
+    for (int k0 = kbeg; k0 < w; k0 += U) {
         double4 xx[U], xk[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            xx[u] = x[cc[u]];
-            if (PROLONG) xk[u] = xc[cc[u] >> sh];
-        }
-        int cn[U];
-        double vn[U];
-        const bool more = k0 + U < w;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                cn[u] = c[(size_t)(k0 + U + u) * 64];
-                vn[u] = v[(size_t)(k0 + U + u) * 64];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
+        for (int u = 0; u < H; u++) {
+            xx[2 * u] = x[ca[u].x];
+            xx[2 * u + 1] = x[ca[u].y];
             if (PROLONG) {
-                s0 += vv[u] * (xx[u].x + kc * xk[u].x);
-                s1 += vv[u] * (xx[u].y + kc * xk[u].y);
-                s2 += vv[u] * (xx[u].z + kc * xk[u].z);
-            } else {
-                s0 += vv[u] * xx[u].x;
-                s1 += vv[u] * xx[u].y;
-                s2 += vv[u] * xx[u].z;
+                xk[2 * u] = xc[ca[u].x >> sh];
+                xk[2 * u + 1] = xc[ca[u].y >> sh];
             }
         }
-        if (more) {
+        if (k0 + 2 * U < w) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                cc[u] = cn[u];
-                vv[u] = vn[u];
+            for (int u = 0; u < H; u++) {
+                cn[u] = c[(size_t)((k0 + 2 * U) / 2 + u) * 64];
+                vn[u] = v[(size_t)((k0 + 2 * U) / 2 + u) * 64];
             }
+        }
+#pragma unroll
+        for (int u = 0; u < H; u++) {
+            if (PROLONG) {
+                s0 += va[u].x * (xx[2 * u].x + kc * xk[2 * u].x) + va[u].y * (xx[2 * u + 1].x + kc * xk[2 * u + 1].x);
+                s1 += va[u].x * (xx[2 * u].y + kc * xk[2 * u].y) + va[u].y * (xx[2 * u + 1].y + kc * xk[2 * u + 1].y);
+                s2 += va[u].x * (xx[2 * u].z + kc * xk[2 * u].z) + va[u].y * (xx[2 * u + 1].z + kc * xk[2 * u + 1].z);
+            } else {
+                s0 += va[u].x * xx[2 * u].x + va[u].y * xx[2 * u + 1].x;
+                s1 += va[u].x * xx[2 * u].y + va[u].y * xx[2 * u + 1].y;
+                s2 += va[u].x * xx[2 * u].z + va[u].y * xx[2 * u + 1].z;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < H; u++) {
+            ca[u] = cb[u];
+            va[u] = vb[u];
+            cb[u] = cn[u];
+            vb[u] = vn[u];
         }
     }
 }

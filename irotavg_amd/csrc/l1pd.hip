@@ -138,11 +138,10 @@ __device__ __forceinline__ double at_row(int row, int n, const int *__restrict__
                                          const double *__restrict__ t) {
     const int sl = row >> 6, lane = row & 63;
     const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
-    const uint32_t *__restrict__ se_p = slot_eid + (size_t)o0 * 64 + lane;
     double s = 0.0;
 #pragma unroll 4
     for (int k = 0; k < w; k++) {
-        const uint32_t se = se_p[(size_t)k * 64];
+        const uint32_t se = slot_eid[sell_pos(o0, k, lane)];
         if (se != 0xffffffffu) {
             const double v = t[se >> 1];
             s += (se & 1u) ? v : -v;

@@ -203,15 +203,19 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0(
         if (sl >= nsl) break;
         const int lane = threadIdx.x & 63, row = sl * 64 + lane;
         const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
-        const uint32_t *__restrict__ se_p = slot_eid + (size_t)o0 * 64 + lane;
-        double *__restrict__ v_p = val + (size_t)o0 * 64 + lane;
+        const uint2 *__restrict__ se_p = reinterpret_cast<const uint2 *>(slot_eid) + (size_t)(o0 / 2) * 64 + lane;
+        double2 *__restrict__ v_p = reinterpret_cast<double2 *>(val) + (size_t)(o0 / 2) * 64 + lane;
         double sw = 0.0, ex = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
         constexpr int U = kSellUnroll;
         for (int k0 = 0; k0 < w; k0 += U) {  // w is a multiple of U: whole batches, loads first
             uint32_t se[U];
             double4 tt[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) se[u] = se_p[(size_t)(k0 + u) * 64];
+            for (int u = 0; u < U / 2; u++) {
+                const uint2 pr = se_p[(size_t)(k0 / 2 + u) * 64];
+                se[2 * u] = pr.x;
+                se[2 * u + 1] = pr.y;
+            }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const bool live = se[u] != 0xffffffffu;
@@ -231,9 +235,11 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0(
                     b1 += sg * tt[u].y;
                     b2 += sg * tt[u].z;
                 }
-                v_p[(size_t)(k0 + u) * 64] = -ww;
                 sw += ww;
             }
+#pragma unroll
+            for (int u = 0; u < U / 2; u++)
+                v_p[(size_t)(k0 / 2 + u) * 64] = make_double2(-tt[2 * u].w, -tt[2 * u + 1].w);
         }
         if (row < n) {
             for (int s = bptr[row]; s < bptr[row + 1]; s++) {
@@ -302,9 +308,8 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_diag(LevelView C, int nf, 
     if (I >= C.nsl * 64) return;
     const int sl = I >> 6, lane = I & 63;
     const int o0 = C.sl_off[sl], w = C.sl_off[sl + 1] - o0;
-    const double *__restrict__ v = C.val + (size_t)o0 * 64 + lane;
     double sv = 0.0;
-    for (int k = 0; k < w; k++) sv += v[(size_t)k * 64];
+    for (int k = 0; k < w; k++) sv += C.val[sell_pos(o0, k, lane)];
     if (I >= C.n) return;
     double ex = 0.0;
     const int v0 = I * agg, v1 = min(nf, v0 + agg);
@@ -325,7 +330,11 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_diag(LevelView C, int nf, 
     for (int t_ = t0_; t_ < t1_; t_++)                         \
         if (const int sl_ = t_ * 4 + (threadIdx.x >> 6); sl_ < (L).nsl)
 
-// q = L p, partial dot products p.q
+// q = L p, partial dot products p.q -- the dominant kernel of the PCG.
+// The 256-row tile's window of p (rows [tile - 64, tile + 320)) is copied into LDS once (12 KB,
+// coalesced); the near part of every row (all of it on a band graph) then reads p from LDS, so
+// the loop is a pure 16 B/lane matrix stream without dependent global gathers. Only the far
+// entries (loop closures) gather from global memory, through the pipelined loop of row_offdiag_t.
 // (sharded runs: `pg` holds the halo-exchanged directions of the ghost views; boundary slots with
 // a ghost endpoint contribute -w * p_ghost; pg == nullptr on a single GPU)
 __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const double4 *__restrict__ p,
@@ -336,34 +345,108 @@ __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const doubl
                                                         const int *__restrict__ bptr,
                                                         const int *__restrict__ bghost,
                                                         const double *__restrict__ bval) {
-    if (flags[FL_DONE]) return;
+    // every independent load of the prologue is issued before the first dependent use (the done
+    // flag included): a serial chain of ~1-2 us memory round trips is what this kernel is made of
+    const int done = flags[FL_DONE];
+    __shared__ double wx[kWinLen], wy[kWinLen], wz[kWinLen];
     double a0 = 0, a1 = 0, a2 = 0;
-    ROW_TILE_LOOP(L) {
-        const int row = sl_ * 64 + (threadIdx.x & 63);
-        double s0, s1, s2;
-        row_offdiag(L, row, p, s0, s1, s2);
-        if (row < L.n) {
-            const double4 pr = p[row];
-            const double d = L.diag[row];
-            s0 += d * pr.x;
-            s1 += d * pr.y;
-            s2 += d * pr.z;
-            if (pg != nullptr) {
-                for (int s = bptr[row]; s < bptr[row + 1]; s++) {
-                    const int gi = bghost[s];
-                    if (gi >= 0) {
-                        const double w = bval[s];
-                        const double4 x = pg[gi];
-                        s0 -= w * x.x;
-                        s1 -= w * x.y;
-                        s2 -= w * x.z;
-                    }
+    const int ntiles = (L.nsl + 3) / 4;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    const int lane = threadIdx.x & 63;
+    for (int t = t0; t < t1; t++) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo), whi = min(L.n, r0 + 256 + kWinHalo);
+        const int sl = min(t * 4 + (int)(threadIdx.x >> 6), L.nsl - 1);
+        const bool live = t * 4 + (int)(threadIdx.x >> 6) < L.nsl;
+        const int row = sl * 64 + lane;
+        const int o0 = L.sl_off[sl], wn = L.sl_near[sl];
+        const double4 pr = p[min(row, L.n - 1)];
+        const double d = L.diag[row];
+        double4 wv0 = make_double4(0, 0, 0, 0), wv1 = wv0;
+        const int i0w = threadIdx.x, i1w = threadIdx.x + kRowBlock;
+        if (i0w < whi - wlo) wv0 = p[wlo + i0w];
+        if (i1w < whi - wlo) wv1 = p[wlo + i1w];
+        if (done) return;  // uniform across the grid
+        __syncthreads();   // the previous tile's readers are done with the window
+        if (i0w < kWinLen) {
+            wx[i0w] = wv0.x;
+            wy[i0w] = wv0.y;
+            wz[i0w] = wv0.z;
+        }
+        if (i1w < kWinLen) {
+            wx[i1w] = wv1.x;
+            wy[i1w] = wv1.y;
+            wz[i1w] = wv1.z;
+        }
+        __syncthreads();
+        if (live) {
+            const int2 *__restrict__ c = reinterpret_cast<const int2 *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+            const double2 *__restrict__ v = reinterpret_cast<const double2 *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
+            double s0 = 0, s1 = 0, s2 = 0;
+            // wn is a multiple of 8: batches of 4 pairs, all 8 loads of a batch issued before use
+            // and the next batch's loads issued before the current batch is consumed
+            constexpr int HB = kSellUnroll / 2;
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2i *__restrict__ cs = reinterpret_cast<const v2i *>(c);
+            const v2d *__restrict__ vs = reinterpret_cast<const v2d *>(v);
+            v2i cc[HB], cn[HB];
+            v2d vv[HB], vn[HB];
+            if (wn > 0) {
+#pragma unroll
+                for (int u = 0; u < HB; u++) {
+                    cc[u] = __builtin_nontemporal_load(&cs[(size_t)u * 64]);
+                    vv[u] = __builtin_nontemporal_load(&vs[(size_t)u * 64]);
                 }
             }
-            q[row] = make_double4(s0, s1, s2, 0.0);
-            a0 += pr.x * s0;
-            a1 += pr.y * s1;
-            a2 += pr.z * s2;
+            for (int q0 = 0; q0 < wn / 2; q0 += HB) {
+                if (q0 + HB < wn / 2) {
+#pragma unroll
+                    for (int u = 0; u < HB; u++) {
+                        cn[u] = __builtin_nontemporal_load(&cs[(size_t)(q0 + HB + u) * 64]);
+                        vn[u] = __builtin_nontemporal_load(&vs[(size_t)(q0 + HB + u) * 64]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < HB; u++) {
+                    const int i0 = cc[u].x - wlo, i1 = cc[u].y - wlo;
+                    s0 += vv[u].x * wx[i0] + vv[u].y * wx[i1];
+                    s1 += vv[u].x * wy[i0] + vv[u].y * wy[i1];
+                    s2 += vv[u].x * wz[i0] + vv[u].y * wz[i1];
+                }
+#pragma unroll
+                for (int u = 0; u < HB; u++) {
+                    cc[u] = cn[u];
+                    vv[u] = vn[u];
+                }
+            }
+            double f0, f1, f2;
+            row_offdiag_t<false>(L, row, p, nullptr, 0, 0.0, f0, f1, f2, wn);  // far entries
+            s0 += f0;
+            s1 += f1;
+            s2 += f2;
+            if (row < L.n) {
+                s0 += d * pr.x;
+                s1 += d * pr.y;
+                s2 += d * pr.z;
+                if (pg != nullptr) {
+                    for (int s = bptr[row]; s < bptr[row + 1]; s++) {
+                        const int gi = bghost[s];
+                        if (gi >= 0) {
+                            const double w = bval[s];
+                            const double4 x = pg[gi];
+                            s0 -= w * x.x;
+                            s1 -= w * x.y;
+                            s2 -= w * x.z;
+                        }
+                    }
+                }
+                q[row] = make_double4(s0, s1, s2, 0.0);
+                a0 += pr.x * s0;
+                a1 += pr.y * s1;
+                a2 += pr.z * s2;
+            }
         }
     }
     block_sum3_store(a0, a1, a2, part_pq + 4 * blockIdx.x);
@@ -572,7 +655,28 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict(
     double4 *__restrict__ bc, double4 *__restrict__ xc, const double *__restrict__ cidg,
     double omega, double *__restrict__ part_rr, double *__restrict__ part_rz,
     int *__restrict__ flags) {
-    if (flags[FL_DONE]) return;
+    const int done = flags[FL_DONE];
+    const int ntiles = (nsl + 3) / 4;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    // The vectors of the first tile are requested BEFORE alpha is reduced from the partials: the
+    // reduction (dependent loads + two barriers) then overlaps the ~2 us the streams take to land.
+    double4 r_pre = make_double4(0, 0, 0, 0), p_pre = r_pre, q_pre = r_pre, x_pre = r_pre;
+    double w_pre = 0.0;
+    {
+        const int sl = t0 * 4 + (threadIdx.x >> 6);
+        const int i = sl * 64 + (threadIdx.x & 63);
+        if (t0 < t1 && sl < nsl && i < n) {
+            r_pre = R[i];
+            w_pre = idg[i];
+            if (!INIT) {
+                p_pre = P[i];
+                q_pre = AP[i];
+                x_pre = X[i];
+            }
+        }
+    }
+    if (done) return;
     double al[3] = {0, 0, 0};
     if (!INIT) {
         double pq[3];
@@ -583,21 +687,32 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict(
         }
     }
     double a0 = 0, a1 = 0, a2 = 0, z0 = 0, z1 = 0, z2 = 0;
-    const int ntiles = (nsl + 3) / 4;
-    int t0, t1;
-    tile_range(ntiles, t0, t1);
     for (int t = t0; t < t1; t++) {
         const int sl = t * 4 + (threadIdx.x >> 6);
         if (sl < nsl) {
             const int i = sl * 64 + (threadIdx.x & 63);
             double4 r = make_double4(0, 0, 0, 0);
             if (i < n) {
-                r = R[i];
+                double4 p, q, x;
+                double wi;
+                if (t == t0) {
+                    r = r_pre;
+                    p = p_pre;
+                    q = q_pre;
+                    x = x_pre;
+                    wi = w_pre;
+                } else {
+                    r = R[i];
+                    wi = idg[i];
+                    if (!INIT) {
+                        p = P[i];
+                        q = AP[i];
+                        x = X[i];
+                    }
+                }
                 if (INIT) {
                     X[i] = make_double4(0, 0, 0, 0);
                 } else {
-                    const double4 p = P[i], q = AP[i];
-                    double4 x = X[i];
                     x.x += al[0] * p.x;
                     x.y += al[1] * p.y;
                     x.z += al[2] * p.z;
@@ -607,7 +722,7 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict(
                     r.z -= al[2] * q.z;
                     R[i] = r;
                 }
-                const double w = omega * idg[i];
+                const double w = omega * wi;
                 a0 += r.x * r.x;
                 a1 += r.y * r.y;
                 a2 += r.z * r.z;
@@ -635,7 +750,17 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate_add(
     int np0, const double *__restrict__ part_rz2, int np1, const double4 *__restrict__ R,
     const double *__restrict__ idg, const double4 *__restrict__ yc, double omega, double kc,
     double4 *__restrict__ P, int *__restrict__ flags) {
-    if (flags[FL_DONE]) return;
+    const int done = flags[FL_DONE];
+    const int i_pre = blockIdx.x * blockDim.x + threadIdx.x;
+    double4 r_pre = make_double4(0, 0, 0, 0), y_pre = r_pre, p_pre = r_pre;
+    double w_pre = 0.0;
+    if (i_pre < n) {  // first grid-stride element: requested before beta is reduced (see update)
+        r_pre = R[i_pre];
+        y_pre = yc[i_pre >> sh];
+        w_pre = idg[i_pre];
+        if (!first) p_pre = P[i_pre];
+    }
+    if (done) return;
     double ra[3], rb[3], rzn[3], be[3];
     load_reduced3(part_rz, np0, ra);
     load_reduced3(part_rz2, np1, rb);
@@ -650,12 +775,13 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate_add(
         for (int c = 0; c < 3; c++) scal[(par ? SC_RZ0 : SC_RZ1) + c] = rzn[c];
         if (!finite) flags[FL_DONE] = 2;
     }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double4 r = R[i], y = yc[i >> sh];
-        const double w = omega * idg[i];
+    for (int i = i_pre; i < n; i += gridDim.x * blockDim.x) {
+        const bool pre = i == i_pre;
+        const double4 r = pre ? r_pre : R[i], y = pre ? y_pre : yc[i >> sh];
+        const double w = omega * (pre ? w_pre : idg[i]);
         double4 p = make_double4(w * r.x + kc * y.x, w * r.y + kc * y.y, w * r.z + kc * y.z, 0.0);
         if (!first) {
-            const double4 po = P[i];
+            const double4 po = pre ? p_pre : P[i];
             p.x += be[0] * po.x;
             p.y += be[1] * po.y;
             p.z += be[2] * po.z;
@@ -746,7 +872,7 @@ int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f) {
 // host drivers
 // =============================================================================================
 static LevelView view_of(const Level &L) {
-    return LevelView{L.n, L.nsl, L.agg, L.sl_off.p, L.col.p, L.val.p, L.diag.p, L.idg.p};
+    return LevelView{L.n, L.nsl, L.agg, L.sl_off.p, L.sl_near.p, L.col.p, L.val.p, L.diag.p, L.idg.p};
 }
 
 static int round_grid(long long gsz) {
