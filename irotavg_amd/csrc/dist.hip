@@ -370,11 +370,13 @@ static int pcg_dist(Dist &D) {
         for (auto &sp : D.shards) scatter_pair(D, *sp, sp->g.part_rr.p, sp->g.part_rz.p);
         it++;
     };
+    int chunk = D.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(D.stats.pcg_iters_last, maxit) : check;
     while (true) {
-        for (int c = 0; c < check; c++) {
+        for (int c = 0; c < chunk; c++) {
             prec_all();
             tail_all();
         }
+        chunk = std::max(2, check / 2);
         prec_all();
         IRH_CHECK(hipMemcpyAsync(h_flags, D.shards[0]->g.flags.p, sizeof(int) * FL_COUNT,
                                  hipMemcpyDeviceToHost, D.stream));

@@ -1077,11 +1077,16 @@ int pcg_solve(Graph &g) {
         launch_update(g, false, par ^ 1, gr);
         it++;
     };
+    // Poll schedule: consecutive solves of an IRLS run need almost the same number of iterations,
+    // so the first poll is placed where the previous solve converged and later ones every few
+    // iterations (each poll drains the stream; iterations enqueued past convergence are no-ops).
+    int chunk = g.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(g.stats.pcg_iters_last, maxit) : check;
     while (true) {
-        for (int c = 0; c < check; c++) {
+        for (int c = 0; c < chunk; c++) {
             PrecInfo pi = precondition(g, it == 0, rtol2);
             iteration_tail(pi);
         }
+        chunk = std::max(2, check / 2);
         // the convergence test of the last update runs in the next preconditioner prologue
         PrecInfo pi = precondition(g, it == 0, rtol2);
         IRH_CHECK(hipMemcpyAsync(h_flags, g.flags.p, sizeof(int) * FL_COUNT, hipMemcpyDeviceToHost,
