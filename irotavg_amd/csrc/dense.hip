@@ -162,19 +162,25 @@ __global__ __launch_bounds__(256) void k_gj_update(int npad, int k0, double *__r
     }
 }
 
-// min / max over the coarse rows of diag_now / diag_ref (rows with a zero reference are skipped)
-__global__ __launch_bounds__(1024) void k_diag_ratio(int n, const double *__restrict__ now,
-                                                     const double *__restrict__ ref,
-                                                     double *__restrict__ out) {
+// min / max of now[i] / ref[i] over an array (entries that are zero in both are skipped; an entry
+// that is zero in only one of them forces a refresh). One workgroup, fixed-order reduction.
+__global__ __launch_bounds__(1024) void k_value_ratio(long long n, const double *__restrict__ now,
+                                                      const double *__restrict__ ref,
+                                                      double *__restrict__ out, int accumulate) {
     __shared__ double smin[16], smax[16];
     double lo = HUGE_VAL, hi = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
         const double r = ref[i], v = now[i];
-        if (r > 0.0 && v > 0.0) {
-            lo = fmin(lo, v / r);
-            hi = fmax(hi, v / r);
-        } else if ((r > 0.0) != (v > 0.0)) {
-            hi = HUGE_VAL;  // a row appeared or vanished: force a refresh
+        if (r != 0.0 && v != 0.0) {
+            const double q = v / r;
+            if (q > 0.0) {
+                lo = fmin(lo, q);
+                hi = fmax(hi, q);
+            } else {
+                hi = HUGE_VAL;
+            }
+        } else if ((r != 0.0) != (v != 0.0)) {
+            hi = HUGE_VAL;  // an entry appeared or vanished: force a refresh
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -191,20 +197,30 @@ __global__ __launch_bounds__(1024) void k_diag_ratio(int n, const double *__rest
             lo = fmin(lo, smin[w]);
             hi = fmax(hi, smax[w]);
         }
+        if (accumulate) {
+            lo = fmin(lo, out[0]);
+            hi = fmax(hi, out[1]);
+        }
         out[0] = lo;
         out[1] = hi;
     }
 }
 
 // Is the inverse computed at the last refresh still a good coarse solver for the CURRENT coarse
-// operator? If the coarse diagonal moved by (nearly) one common factor c, E_now ~ c E_ref and
-// E_ref^-1 / c is reused; otherwise the caller re-inverts. Returns true when a refresh is needed.
+// operator? Every entry of E (diagonal AND off-diagonal: a re-weighted loop closure barely moves
+// a diagonal that sums ~2500 edges, but changes its own long-range entry by orders of magnitude)
+// is compared with the operator the inverse was computed from. If all ratios lie within a narrow
+// band around one factor c, E_now ~ c E_ref and E_ref^-1 / c is reused; otherwise the caller
+// re-inverts. Returns true when a refresh is needed.
 bool dense_is_stale(Graph &g) {
     if (g.ndense <= 0) return false;
     if (!g.dense_valid) return true;
     Level &C = g.levels.back();
-    hipLaunchKernelGGL(k_diag_ratio, dim3(1), dim3(1024), 0, g.stream, C.n, C.diag.p,
-                       g.dense_ref_diag.p, g.part_score.p);
+    hipLaunchKernelGGL(k_value_ratio, dim3(1), dim3(1024), 0, g.stream, (long long)C.n, C.diag.p,
+                       g.dense_ref_diag.p, g.part_score.p, 0);
+    if (C.sell_len > 0)
+        hipLaunchKernelGGL(k_value_ratio, dim3(1), dim3(1024), 0, g.stream, C.sell_len, C.val.p,
+                           g.dense_ref_val.p, g.part_score.p, 1);
     double h[2];
     IRH_CHECK(hipMemcpyAsync(h, g.part_score.p, sizeof(h), hipMemcpyDeviceToHost, g.stream));
     IRH_CHECK(hipStreamSynchronize(g.stream));
@@ -220,6 +236,13 @@ void dense_refresh(Graph &g) {
     IRH_CHECK(hipMemcpyAsync(g.dense_ref_diag.p, g.levels.back().diag.p,
                              sizeof(double) * (size_t)g.levels.back().n, hipMemcpyDeviceToDevice,
                              g.stream));
+    if (g.levels.back().sell_len > 0) {
+        if (g.dense_ref_val.n < (size_t)g.levels.back().sell_len)
+            g.dense_ref_val.alloc((size_t)g.levels.back().sell_len);
+        IRH_CHECK(hipMemcpyAsync(g.dense_ref_val.p, g.levels.back().val.p,
+                                 sizeof(double) * (size_t)g.levels.back().sell_len,
+                                 hipMemcpyDeviceToDevice, g.stream));
+    }
     Level &C = g.levels.back();
     const int npad = g.ndense_pad;
     LevelView V{C.n, C.nsl, C.agg, C.sl_off.p, C.sl_near.p, C.col.p, C.val.p, C.diag.p, C.idg.p};

@@ -41,8 +41,8 @@ struct Graph {
     DevBuf<double> dense_wr, dense_wc;  // Gauss-Jordan panels (32 x npad, npad x 32)
     int ndense = 0, ndense_pad = 0;
     bool dense_valid = false, dense_fresh = false;
-    double dense_scale = 1.0, stale_spread = 1.5;
-    DevBuf<double> dense_ref_diag;
+    double dense_scale = 1.0, stale_spread = 1.1;
+    DevBuf<double> dense_ref_diag, dense_ref_val;  // coarse operator the current inverse was computed from
     int64_t iters_after_refresh = 0;
     int additive_top = 1;  // level 0 enters the preconditioner additively (no fine matrix pass)
 

@@ -268,3 +268,46 @@ def test_determinism_bitwise(syn):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2]
+
+
+def test_isolated_view_single_unknown_and_self_loop():
+    """Ragged inputs: a free view without edges (zero diagonal -> stays put, like a dead SPQR
+    column / the oracle's dead pivot), a single unknown, and a self-loop edge (make_A keeps the
+    -1 coefficient, ral/l1_irls.cpp:770-776)."""
+    rng = np.random.default_rng(4)
+    # views 0 (fixed), 1..4 free; view 4 has no edges at all; edge (2,2) is a self loop
+    I = np.array([[0, 1], [1, 2], [0, 2], [2, 2], [1, 3], [0, 3]], dtype=np.int32)
+    Qgt = rng.normal(size=(5, 4)); Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+    QQ = synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(6, 3))), synth.qmul(Qgt[I[:, 1]], synth.qconj(Qgt[I[:, 0]])))
+    Q0 = synth.qmul(synth.qexp(rng.normal(scale=0.03, size=(5, 3))), Qgt); Q0[0] = Qgt[0]
+    for cost in (0, 4):
+        with capi.Graph(I, QQ, 5, 1) as G:
+            G.set_rotations(Q0)
+            r = G.irls(cost, SIG, 20, 1e-6)
+            Q = G.get_rotations(); w = G.get_weights()
+        ro = O.irls(QQ, I, Q0, 1, cost, SIG, 20, 1e-6)
+        assert r["iters"] == ro["iters"]
+        assert synth.angular_distance(Q, ro["Q"]).max() < 1e-9
+        np.testing.assert_allclose(w, ro["weights"], rtol=1e-8)
+        np.testing.assert_array_equal(Q[4], Q0[4])             # the isolated view never moves
+    # one unknown
+    I1 = np.array([[0, 1], [0, 1]], dtype=np.int32)
+    with capi.Graph(I1, QQ[:2], 2, 1) as G:
+        G.set_rotations(Q0[:2])
+        r = G.irls(4, SIG, 20, 1e-9)
+        Q = G.get_rotations()
+    ro = O.irls(QQ[:2], I1, Q0[:2], 1, 4, SIG, 20, 1e-9)
+    assert r["iters"] == ro["iters"] and synth.angular_distance(Q, ro["Q"]).max() < 1e-10
+
+
+def test_bad_inputs_are_rejected():
+    QQ = np.tile([0, 0, 0, 1.0], (2, 1))
+    with pytest.raises(capi.IrotavgError) as e:
+        capi.Graph(np.array([[0, 5], [1, 2]], dtype=np.int32), QQ, 3, 1)   # endpoint out of range
+    assert e.value.code == capi.ERR_BAD_ARG
+    with pytest.raises(capi.IrotavgError) as e:
+        capi.Graph(np.zeros((0, 2), dtype=np.int32), np.zeros((0, 4)), 3, 1)  # no edges
+    assert e.value.code == capi.ERR_BAD_ARG
+    with pytest.raises(capi.IrotavgError) as e:
+        capi.Graph(np.array([[0, 1]], dtype=np.int32), QQ[:1], 2, 2)          # no free view
+    assert e.value.code == capi.ERR_BAD_ARG
