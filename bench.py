@@ -79,13 +79,20 @@ def cpu_baseline(S, Q0, p_loop, budget_s=25.0):
     from irotavg_amd import synth
     cores = 1
     if p_loop == 0.0 or S["m"] <= 200000:
-        iters = 3
+        # the identical workload: complete IRLS solves (to convergence) of the same graph, repeated
+        # until ~10 s of CPU time have been spent
         t = time.time()
-        r = O.irls(S["QQ"], S["I"], Q0, 1, 4, SIG, iters, 1e-3)
+        updates, runs, iters = 0, 0, 0
+        while time.time() - t < 10.0 and runs < 50:
+            r = O.irls(S["QQ"], S["I"], Q0, 1, 4, SIG, 100, 1e-3)
+            updates += S["m"] * r["iters"]
+            iters = r["iters"]
+            runs += 1
         dt = time.time() - t
-        return dict(value=S["m"] * r["iters"] / dt, unit="edge-updates/s", cores=cores, kind="port",
-                    sample="first %d IRLS iterations of the same %d-view/%d-edge graph "
-                           "(incl. one symbolic analysis), %.1f s" % (r["iters"], S["n"], S["m"], dt),
+        return dict(value=updates / dt, unit="edge-updates/s", cores=cores, kind="port",
+                    sample="%d complete IRLS solves (%d iterations each, incl. symbolic analysis) of the "
+                           "same %d-view/%d-edge graph, %.1f s" % (runs, iters, S["n"], S["m"], dt),
+                    iters_to_converge=iters,
                     note="oracle = C restatement + own sparse Cholesky; NOT Eigen+SuiteSparse "
                          "(unbuildable here)")
     # loop-closure-rich graphs: fill of the direct factorisation explodes; sample a 10x smaller graph
