@@ -71,28 +71,22 @@ __global__ __launch_bounds__(256) void k_pack(int cnt, const int *__restrict__ i
     if (t < cnt) dst[t] = src[idx[t]];
 }
 
-// fixed-order reduction of up to two partial arrays into gsum[0..3] and gsum[4..7]
-__global__ __launch_bounds__(256) void k_reduce_parts(const double *__restrict__ pa, int na,
-                                                      const double *__restrict__ pb, int nb,
-                                                      double *__restrict__ gsum) {
+// fixed-order reduction of up to two partial arrays IN PLACE: row 0 of each array receives the
+// shard's sum (load_reduced3 ends with a barrier, so every row has been read before row 0 is
+// overwritten); the all-reduce then runs directly on row 0 and the consumers read it with
+// nparts = 1 -- no staging copies.
+__global__ __launch_bounds__(256) void k_reduce_parts(double *__restrict__ pa, int na,
+                                                      double *__restrict__ pb, int nb) {
     double a[3], b[3] = {0, 0, 0};
     load_reduced3(pa, na, a);
     if (pb) load_reduced3(pb, nb, b);
     if (threadIdx.x == 0) {
         for (int c = 0; c < 3; c++) {
-            gsum[c] = a[c];
-            gsum[4 + c] = b[c];
+            pa[c] = a[c];
+            if (pb) pb[c] = b[c];
         }
-        gsum[3] = gsum[7] = 0.0;
-    }
-}
-
-__global__ void k_scatter_parts(const double *__restrict__ gsum, double *__restrict__ pa,
-                                double *__restrict__ pb) {
-    const int t = threadIdx.x;
-    if (t < 4) {
-        pa[t] = gsum[t];
-        if (pb) pb[t] = gsum[4 + t];
+        pa[3] = 0.0;
+        if (pb) pb[3] = 0.0;
     }
 }
 
@@ -102,21 +96,28 @@ __global__ void k_add_small(int n, double *__restrict__ dst, const double *__res
 }
 
 // ---- collectives ------------------------------------------------------------------------------
-static void allreduce(Dist &D, int count) {  // over every shard's gsum[0..count)
+// sum over all shards of the 4-double rows `pa(shard)` (and `pb(shard)` when given), in place
+template <typename FA, typename FB>
+static void allreduce_rows(Dist &D, FA pa, FB pb, bool two) {
     if (D.use_rccl) {
         Shard &S = *D.shards[0];
-        NCCL_CHECK(ncclAllReduce(S.gsum.p, S.gsum.p, (size_t)count, ncclDouble, ncclSum, D.comm,
-                                 D.stream));
+        NCCL_CHECK(ncclGroupStart());
+        NCCL_CHECK(ncclAllReduce(pa(S), pa(S), 4, ncclDouble, ncclSum, D.comm, D.stream));
+        if (two) NCCL_CHECK(ncclAllReduce(pb(S), pb(S), 4, ncclDouble, ncclSum, D.comm, D.stream));
+        NCCL_CHECK(ncclGroupEnd());
         return;
     }
     if (D.shards.size() == 1) return;
     Shard &S0 = *D.shards[0];
-    for (size_t s = 1; s < D.shards.size(); s++)  // fixed shard order
-        hipLaunchKernelGGL(k_add_small, dim3(1), dim3(64), 0, D.stream, count, S0.gsum.p,
-                           D.shards[s]->gsum.p);
-    for (size_t s = 1; s < D.shards.size(); s++)
-        IRH_CHECK(hipMemcpyAsync(D.shards[s]->gsum.p, S0.gsum.p, sizeof(double) * (size_t)count,
-                                 hipMemcpyDeviceToDevice, D.stream));
+    for (int w = 0; w < (two ? 2 : 1); w++) {
+        double *d0 = w == 0 ? pa(S0) : pb(S0);
+        for (size_t s = 1; s < D.shards.size(); s++)  // fixed shard order
+            hipLaunchKernelGGL(k_add_small, dim3(1), dim3(64), 0, D.stream, 4, d0,
+                               w == 0 ? pa(*D.shards[s]) : pb(*D.shards[s]));
+        for (size_t s = 1; s < D.shards.size(); s++)
+            IRH_CHECK(hipMemcpyAsync(w == 0 ? pa(*D.shards[s]) : pb(*D.shards[s]), d0, sizeof(double) * 4,
+                                     hipMemcpyDeviceToDevice, D.stream));
+    }
 }
 
 // halo exchange: owned values `src_of(shard)` -> ghost slots `dst_of(peer shard)`
@@ -302,11 +303,8 @@ static int build_shard(Dist &D, Shard &S, const int32_t *I, const double *QQ, in
 }
 
 // ---- sharded PCG ----------------------------------------------------------------------------------
-static void reduce_pair(Dist &D, Shard &S, double *pa, int na, double *pb, int nb) {
-    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, D.stream, pa, na, pb, nb, S.gsum.p);
-}
-static void scatter_pair(Dist &D, Shard &S, double *pa, double *pb) {
-    hipLaunchKernelGGL(k_scatter_parts, dim3(1), dim3(64), 0, D.stream, S.gsum.p, pa, pb);
+static void reduce_pair(Dist &D, double *pa, int na, double *pb, int nb) {
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, D.stream, pa, na, pb, nb);
 }
 
 static int pcg_dist(Dist &D) {
@@ -316,15 +314,19 @@ static int pcg_dist(Dist &D) {
         return (g.additive_top && g.levels.size() > 1) ? grid_for_rows(g.levels[0])
                                                         : grid_for_elems(g.levels[0].n);
     };
+    auto additive = [](Graph &g) { return g.additive_top && g.levels.size() > 1; };
+    auto p_rr = [](Shard &S) { return S.g.part_rr.p; };
+    auto p_rz = [](Shard &S) { return S.g.part_rz.p; };
+    auto p_pq = [](Shard &S) { return S.g.part_pq.p; };
+    auto p_prec = [&](Shard &S) { return additive(S.g) ? S.g.part_rz2.p : S.g.part_rz.p; };
     // init: r = b, x = 0, first restriction
     for (auto &sp : D.shards) {
         Graph &g = sp->g;
         IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, D.stream));
         launch_update(g, true, 0, 1);
-        reduce_pair(D, *sp, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
+        reduce_pair(D, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
     }
-    allreduce(D, 8);
-    for (auto &sp : D.shards) scatter_pair(D, *sp, sp->g.part_rr.p, sp->g.part_rz.p);
+    allreduce_rows(D, p_rr, p_rz, true);
     int it = 0;
     int h_flags[FL_COUNT] = {0, 0, 0, 0};
     const int check = std::max(1, D.opt.pcg_check_every);
@@ -333,19 +335,13 @@ static int pcg_dist(Dist &D) {
         for (auto &sp : D.shards) {
             Graph &g = sp->g;
             PrecInfo pi = precondition(g, it == 0, rtol2);
-            const bool additive = g.additive_top && g.levels.size() > 1;
             // the coarse (additive) or full (multiplicative) r.z partials of this shard
-            if (additive)
-                reduce_pair(D, *sp, g.part_rz2.p, pi.np_rz2, nullptr, 0);
+            if (additive(g))
+                reduce_pair(D, g.part_rz2.p, pi.np_rz2, nullptr, 0);
             else
-                reduce_pair(D, *sp, g.part_rz.p, pi.np_rz, nullptr, 0);
+                reduce_pair(D, g.part_rz.p, pi.np_rz, nullptr, 0);
         }
-        allreduce(D, 4);
-        for (auto &sp : D.shards) {
-            Graph &g = sp->g;
-            const bool additive = g.additive_top && g.levels.size() > 1;
-            scatter_pair(D, *sp, additive ? g.part_rz2.p : g.part_rz.p, nullptr);
-        }
+        allreduce_rows(D, p_prec, p_prec, false);
     };
     auto tail_all = [&]() {
         const int first = (it == 0), par = it & 1;
@@ -357,17 +353,15 @@ static int pcg_dist(Dist &D) {
         for (auto &sp : D.shards) {
             Graph &g = sp->g;
             launch_spmv(g);
-            reduce_pair(D, *sp, g.part_pq.p, rows_grid(g), nullptr, 0);
+            reduce_pair(D, g.part_pq.p, rows_grid(g), nullptr, 0);
         }
-        allreduce(D, 4);
+        allreduce_rows(D, p_pq, p_pq, false);
         for (auto &sp : D.shards) {
             Graph &g = sp->g;
-            scatter_pair(D, *sp, g.part_pq.p, nullptr);
             launch_update(g, false, par ^ 1, 1);
-            reduce_pair(D, *sp, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
+            reduce_pair(D, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
         }
-        allreduce(D, 8);
-        for (auto &sp : D.shards) scatter_pair(D, *sp, sp->g.part_rr.p, sp->g.part_rz.p);
+        allreduce_rows(D, p_rr, p_rz, true);
         it++;
     };
     int chunk = D.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(D.stats.pcg_iters_last, maxit) : check;
