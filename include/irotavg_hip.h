@@ -206,6 +206,14 @@ int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]
  * launch (irotavg_amd/csrc/window.hip); larger ones through the graph handle path. */
 int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotavg_info *info);
 
+/* rmat2quat (src/ViewGraph.cpp:1175-1203) / q.normalized().toRotationMatrix() (:1426-1433);
+ * row-major R, q = [x y z w] */
+void irotavg_rmat2quat(const double R[9], double q[4]);
+void irotavg_quat2rmat(const double q[4], double R[9]);
+/* replaces ViewGraph::savePoses (src/ViewGraph.hpp:64, src/ViewGraph.cpp:1206-1231): lines
+ * `id \t qw \t qx \t qy \t qz \t tx \t ty \t tz`; t = 3 doubles per view or NULL (zeros) */
+int irotavg_viewgraph_save_poses(const irotavg_viewgraph *vg, const char *filename, const double *t);
+
 /* The single-kernel window pipeline on caller data (layout as irotavg_l1ra / irotavg_irls):
  * l1ra(l1_iters) then irls(cost, sigma, irls_iters), change_th for both, in one launch.
  * IROTAVG_ERR_BAD_ARG if the problem does not fit the kernel's limits. */

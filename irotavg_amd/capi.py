@@ -32,7 +32,7 @@ SYMBOLS = [
     "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
     "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_plan", "irotavg_dist_plan_host",
-    "irotavg_window_solve",
+    "irotavg_window_solve", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
 ]
 
 
@@ -135,6 +135,11 @@ def lib():
     L.irotavg_window_solve.argtypes = [C.c_int64, C.c_int64, C.c_int, _ip, _dp, C.c_int64, _dp, C.c_int64,
                                        C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.irotavg_rmat2quat.argtypes = [_dp, _dp]
+    L.irotavg_rmat2quat.restype = None
+    L.irotavg_quat2rmat.argtypes = [_dp, _dp]
+    L.irotavg_quat2rmat.restype = None
+    L.irotavg_viewgraph_save_poses.argtypes = [vp, C.c_char_p, _dp]
     L.irotavg_dist_unique_id.argtypes = [C.c_void_p]
     L.irotavg_dist_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                       C.c_int, _ip, _dp, C.c_int64, C.POINTER(Options)]

@@ -10,6 +10,7 @@
 // connections are walked by ascending neighbour id.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <map>
 #include <set>
 #include <vector>
@@ -293,6 +294,33 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     }
     vg->last = loc;
     if (info) *info = loc;
+    return IROTAVG_OK;
+}
+
+// rmat2quat (src/ViewGraph.cpp:1175-1203) and q.normalized().toRotationMatrix() (:1426-1433) for
+// callers that hold Pose-style 3x3 matrices; row-major R, q = [x y z w].
+void irotavg_rmat2quat(const double R[9], double q[4]) {
+    if (R && q) rmat2quat(R, q);
+}
+void irotavg_quat2rmat(const double q[4], double R[9]) {
+    if (R && q) quat2rmat(q, R);
+}
+
+// ViewGraph::savePoses (src/ViewGraph.cpp:1206-1231): one line per view,
+// `id \t qw \t qx \t qy \t qz \t tx \t ty \t tz`, 17 significant digits, scientific. Translations
+// belong to the vision front-end and are not tracked here: t (3 doubles per view) may be NULL (zeros).
+int irotavg_viewgraph_save_poses(const irotavg_viewgraph *vg, const char *filename, const double *t) {
+    if (!vg || !filename) return IROTAVG_ERR_BAD_ARG;
+    std::FILE *fs = std::fopen(filename, "w");
+    if (!fs) return IROTAVG_ERR_BAD_ARG;  // "Unable to save results."
+    for (size_t v = 0; v < vg->pose.size(); v++) {
+        double q[4];
+        rmat2quat(vg->pose[v].m, q);
+        const double tx = t ? t[3 * v] : 0.0, ty = t ? t[3 * v + 1] : 0.0, tz = t ? t[3 * v + 2] : 0.0;
+        std::fprintf(fs, "%zu\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\n", v, q[3], q[0], q[1],
+                     q[2], tx, ty, tz);
+    }
+    std::fclose(fs);
     return IROTAVG_OK;
 }
 

@@ -79,3 +79,26 @@ class ViewGraph:
         info = capi.RotAvgInfo()
         capi.check(capi.lib().irotavg_viewgraph_rot_avg(self._h, int(winSize), C.byref(info)), "rotAvg")
         return {k: getattr(info, k) for k, _ in capi.RotAvgInfo._fields_}
+
+    def savePoses(self, filename, t=None):
+        """ViewGraph::savePoses (src/ViewGraph.cpp:1206-1231); t: optional (n, 3) translations."""
+        tp = None
+        if t is not None:
+            t = np.ascontiguousarray(t, dtype=np.float64).reshape(-1)
+            tp = capi._d(t)
+        capi.check(capi.lib().irotavg_viewgraph_save_poses(self._h, str(filename).encode(), tp), "savePoses")
+
+
+def rmat2quat(R):
+    """src/ViewGraph.cpp:1175-1203; row-major 3x3 -> [x y z w]."""
+    r = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+    q = np.zeros(4)
+    capi.lib().irotavg_rmat2quat(capi._d(r), capi._d(q))
+    return q
+
+
+def quat2rmat(q):
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    r = np.zeros(9)
+    capi.lib().irotavg_quat2rmat(capi._d(q), capi._d(r))
+    return r.reshape(3, 3)

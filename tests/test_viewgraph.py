@@ -35,6 +35,30 @@ def test_container_semantics_without_gpu():
     assert one.rotAvg(10)["skipped"] == 1
 
 
+def test_pose_conversions_and_save_poses(tmp_path):
+    from irotavg_amd.viewgraph import quat2rmat, rmat2quat
+    rng = np.random.default_rng(0)
+    qs = list(rng.normal(size=(20, 4))) + [np.array([1, .01, .02, .01]), np.array([.01, 1, .02, .01]),
+                                           np.array([.01, .02, 1, .01])]
+    for q in qs:
+        q = q / np.linalg.norm(q)
+        np.testing.assert_array_equal(quat2rmat(q), O.quat2rmat(q))          # same statements as the oracle
+        np.testing.assert_array_equal(rmat2quat(O.quat2rmat(q)), O.rmat2quat(O.quat2rmat(q)))
+    vg = ViewGraph()
+    Rs = [O.quat2rmat(q / np.linalg.norm(q)) for q in qs[:3]]
+    for R in Rs:
+        vg.addView(R)
+    t = np.arange(9, dtype=np.float64).reshape(3, 3)
+    vg.savePoses(tmp_path / "rotavg_poses.txt", t)
+    rows = [l.rstrip("\n").split("\t") for l in open(tmp_path / "rotavg_poses.txt")]
+    assert [int(r[0]) for r in rows] == [0, 1, 2] and all(len(r) == 8 for r in rows)
+    for v, r in enumerate(rows):
+        q = O.rmat2quat(Rs[v])
+        np.testing.assert_allclose([float(x) for x in r[1:5]], [q[3], q[0], q[1], q[2]], rtol=1e-15)
+        np.testing.assert_array_equal([float(x) for x in r[5:]], t[v])
+        assert "e" in r[1]                                                    # std::scientific
+
+
 def build_sequence(n, seed, k_prev=4, n_loops=6, noise=0.01):
     """A small SLAM-like stream: each view linked to up to k_prev predecessors + a few loop closures."""
     rng = np.random.default_rng(seed)
