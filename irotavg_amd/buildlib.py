@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

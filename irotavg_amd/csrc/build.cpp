@@ -68,6 +68,14 @@ static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector
 }
 
 int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
+    const bool timing = getenv("IROTAVG_BUILD_TIMING") != nullptr;
+    double tlast = now_seconds();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t = now_seconds();
+        std::fprintf(stderr, "[irotavg_hip build] %-28s %8.2f ms\n", what, 1e3 * (t - tlast));
+        tlast = t;
+    };
     const int64_t m = g.m;
     const int f = g.f;
     const int fo = g.f + g.ng;  // operator offset: fixed and ghost views have no row
@@ -113,6 +121,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.Q.alloc((size_t)g.n_total);
     g.Q.zero(s);
 
+    lap("edge streams + upload");
     // ---- level-0 adjacency --------------------------------------------------------------
     // Endpoint classes by local index: [0,f) fixed, [f,fo) ghost (free, owned by another shard),
     // [fo, n_total) owned. Owned-owned edges become matrix entries; an edge from an owned view
@@ -170,6 +179,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
             }
         }
     }
+    lap("adjacency count/fill");
     // sort each row by column (edge order breaks ties): locality for the gathers and a
     // canonical order for the coarse-level maps
     for (int v = 0; v < nu; v++)
@@ -193,6 +203,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.PG.alloc((size_t)g.ng + 1);
     g.PG.zero(s);
 
+    lap("row sort + boundary upload");
     // ---- hierarchy ----------------------------------------------------------------------
     // Host CSR patterns of every level first, SELL conversion + uploads second.
     struct HostLevel {
@@ -252,6 +263,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         H.push_back(std::move(C));
     }
 
+    lap("coarse patterns (host)");
     g.levels.clear();
     g.levels.resize(H.size());
     g.stats.levels = (int)H.size();
@@ -312,6 +324,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         IRH_CHECK(hipStreamSynchronize(s));  // scol goes out of scope
         prev = std::move(M);
     }
+    lap("SELL conversion + uploads");
     // dense inverse of the coarsest level (only when it is small enough and there is a hierarchy)
     g.ndense = 0;
     g.ndense_pad = 0;
@@ -349,6 +362,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.flags.zero(s);
     g.h_part.assign((size_t)kMaxParts * 4, 0.0);
     IRH_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
+    lap("PCG state");
     return IROTAVG_OK;
 }
 

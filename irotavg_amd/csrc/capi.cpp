@@ -232,6 +232,7 @@ void irotavg_graph_destroy(irotavg_graph *h) {
     if (!h) return;
     hipStream_t s = h->g.stream;
     if (s) (void)hipStreamSynchronize(s);
+    release_l1_clones(h->g);
     h->g.stream = nullptr;
     delete h;
     if (s) (void)hipStreamDestroy(s);

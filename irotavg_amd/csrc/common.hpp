@@ -31,10 +31,11 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool own = true;  // false: a non-owning alias of another handle's buffer (read-only data)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) {
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), own(o.own) {
         o.p = nullptr;
         o.n = 0;
     }
@@ -43,6 +44,7 @@ struct DevBuf {
             release();
             p = o.p;
             n = o.n;
+            own = o.own;
             o.p = nullptr;
             o.n = 0;
         }
@@ -50,9 +52,20 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && own) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        own = true;
+    }
+    void alias(const DevBuf &o) {
+        release();
+        p = o.p;
+        n = o.n;
+        own = false;
+    }
+    void alloc_like(const DevBuf &o, hipStream_t s) {
+        alloc(o.n);
+        if (o.n) IRH_CHECK(hipMemsetAsync(p, 0, o.n * sizeof(T), s));
     }
     void alloc(size_t count) {
         release();

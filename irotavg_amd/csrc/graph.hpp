@@ -1,6 +1,7 @@
 // graph.hpp -- the device-resident view-graph handle behind the C ABI.
 #pragma once
 #include <chrono>
+#include <memory>
 
 #include "common.hpp"
 
@@ -58,6 +59,10 @@ struct Graph {
     DevBuf<double> pdn;     // nu-length planes
     DevBuf<double> pd_part; // reduction partials
     bool pd_ready = false;
+    // L1RA solves its three coordinates concurrently: three solver clones (own stream, own
+    // matrix values / vectors / dense level; static structure aliased from this handle)
+    std::vector<std::unique_ptr<Graph>> l1_clones;
+    bool is_clone = false;
 
     // host staging
     std::vector<double> h_part;
@@ -86,6 +91,7 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
 int l1decode_pd_dev(Graph &g, int coord_plane_from_er, const double *y_host, int pdmaxiter,
                     double *x_host, int *stuck, int out_component);
 int time_kernel(Graph &g, int which, int reps, double *ms);
+void release_l1_clones(Graph &g);
 void normalise_rotations(Graph &g);
 void fill(Graph &g, double *p, long long n, double v);
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true);

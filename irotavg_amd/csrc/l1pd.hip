@@ -8,6 +8,8 @@
 // same multigrid-PCG as the IRLS step with the matrix values refreshed from sigx under
 // make_AtA's boundary rule (:825-843). Control flow (step length, backtracking, stopping) runs on
 // the host from fixed-order reductions, statement for statement as the reference.
+#include <thread>
+
 #include "graph.hpp"
 #include "kernels.hpp"
 
@@ -472,6 +474,67 @@ int l1decode_pd_dev(Graph &g, int er_plane, const double *y_host, int pdmaxiter,
     return rc;
 }
 
+// A solver clone shares the handle's static structure (edges, patterns, maps) and owns every
+// array a solve writes: one clone per coordinate lets the three primal-dual LPs of an outer
+// iteration (ral/l1_irls.cpp:889-892, independent by construction) run concurrently on three
+// streams. Every kernel of this latency-bound path leaves most of the chip idle, so the three
+// chains overlap almost perfectly.
+static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
+    std::unique_ptr<Graph> c(new Graph());
+    Graph &q = *c;
+    q.is_clone = true;
+    q.m = g.m; q.n_total = g.n_total; q.mpad = g.mpad;
+    q.f = g.f; q.nu = g.nu; q.ng = g.ng; q.no = g.no;
+    q.opt = g.opt;
+    q.device = g.device;
+    IRH_CHECK(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+    hipStream_t s = q.stream;
+    q.ei.alias(g.ei); q.ej.alias(g.ej); q.eflag.alias(g.eflag);
+    q.qq.alias(g.qq); q.er.alias(g.er); q.dw.alias(g.dw); q.Q.alias(g.Q);
+    q.slot_eid.alias(g.slot_eid); q.bptr.alias(g.bptr); q.beid.alias(g.beid);
+    q.bflag.alias(g.bflag); q.bghost.alias(g.bghost);
+    q.bval.alloc_like(g.bval, s);
+    q.PG.alloc_like(g.PG, s);
+    q.levels.resize(g.levels.size());
+    for (size_t l = 0; l < g.levels.size(); l++) {
+        Level &A = g.levels[l];
+        Level &B = q.levels[l];
+        B.n = A.n; B.nnz = A.nnz; B.agg = A.agg; B.nsl = A.nsl; B.sell_len = A.sell_len;
+        B.sl_off.alias(A.sl_off); B.sl_near.alias(A.sl_near); B.col.alias(A.col);
+        B.cptr.alias(A.cptr); B.cidx.alias(A.cidx); B.cpos.alias(A.cpos);
+        B.val.alloc_like(A.val, s); B.excess.alloc_like(A.excess, s);
+        B.diag.alloc_like(A.diag, s); B.idg.alloc_like(A.idg, s);
+        B.b.alloc_like(A.b, s); B.x.alloc_like(A.x, s); B.y.alloc_like(A.y, s); B.e.alloc_like(A.e, s);
+    }
+    q.ndense = g.ndense; q.ndense_pad = g.ndense_pad; q.additive_top = g.additive_top;
+    q.stale_spread = g.stale_spread;
+    q.dense_inv.alloc_like(g.dense_inv, s); q.dense_wr.alloc_like(g.dense_wr, s);
+    q.dense_wc.alloc_like(g.dense_wc, s); q.dense_ref_diag.alloc_like(g.dense_ref_diag, s);
+    q.X.alloc_like(g.X, s); q.P.alloc_like(g.P, s); q.AP.alloc_like(g.AP, s);
+    q.part_pq.alloc_like(g.part_pq, s); q.part_rr.alloc_like(g.part_rr, s);
+    q.part_rz.alloc_like(g.part_rz, s); q.part_rz2.alloc_like(g.part_rz2, s);
+    q.part_score.alloc_like(g.part_score, s);
+    q.scal.alloc_like(g.scal, s); q.flags.alloc_like(g.flags, s);
+    q.h_part.assign(g.h_part.size(), 0.0);
+    q.stats = g.stats;
+    IRH_CHECK(hipStreamSynchronize(s));
+    return c;
+}
+
+static void destroy_clone_streams(Graph &g) {
+    for (auto &c : g.l1_clones)
+        if (c && c->stream) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamDestroy(c->stream);
+            c->stream = nullptr;
+        }
+}
+
+void release_l1_clones(Graph &g) {
+    destroy_clone_streams(g);
+    g.l1_clones.clear();
+}
+
 // ral/l1_irls.cpp:851-912
 int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runtime,
              double *trace) {
@@ -480,19 +543,46 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
     double score = HUGE_VAL;
     int l1_step = 2;  // :868
     int it = 0, rc = IROTAVG_OK;
-    const int n = g.nu;
+    const int n = g.no;
     while (((score >= change_th) || (l1_step < 2)) && (it < max_iters)) {  // :877, >=
         if (score < change_th) {  // :879-883 -- unreachable under the guard above; kept literal
             l1_step *= 4;
             change_th /= 100.0;
         }
         launch_edge_residual(g);
-        for (int c = 0; c < 3 && rc == IROTAVG_OK; c++)  // :889-892
-            rc = l1decode_core(g, g.er.p + (size_t)c * g.mpad, l1_step, N_X0 + c, nullptr);
+        IRH_CHECK(hipStreamSynchronize(g.stream));  // the clones read the residual planes
+        // :889-892 -- the three coordinates are independent LPs: one solver clone and one host
+        // thread per coordinate, three streams
+        if (g.l1_clones.empty())
+            for (int c = 0; c < 3; c++) g.l1_clones.push_back(make_solver_clone(g));
+        int rcs[3] = {IROTAVG_OK, IROTAVG_OK, IROTAVG_OK};
+        std::thread th[3];
+        for (int c = 0; c < 3; c++) {
+            th[c] = std::thread([&, c]() {
+                try {
+                    (void)hipSetDevice(g.device);
+                    Graph &q = *g.l1_clones[c];
+                    pd_prepare(q);
+                    rcs[c] = l1decode_core(q, g.er.p + (size_t)c * g.mpad, l1_step, N_X0, nullptr);
+                } catch (...) {
+                    rcs[c] = IROTAVG_ERR_HIP;
+                }
+            });
+        }
+        for (int c = 0; c < 3; c++) th[c].join();
+        for (int c = 0; c < 3; c++) {
+            if (rcs[c] != IROTAVG_OK && rc == IROTAVG_OK) rc = rcs[c];
+            Graph &q = *g.l1_clones[c];
+            g.stats.pcg_solves += q.stats.pcg_solves;
+            g.stats.pcg_iters += q.stats.pcg_iters;
+            g.stats.pcg_iters_last = q.stats.pcg_iters_last;
+            q.stats.pcg_solves = 0;
+            q.stats.pcg_iters = 0;
+        }
         if (rc != IROTAVG_OK) break;
         hipLaunchKernelGGL(k_pack3, dim3(grid_elems(n)), dim3(kRowBlock), 0, g.stream, n,
-                           g.pdn.p + (size_t)N_X0 * n, g.pdn.p + (size_t)N_X1 * n,
-                           g.pdn.p + (size_t)N_X2 * n, g.X.p);
+                           g.l1_clones[0]->pdn.p + (size_t)N_X0 * n, g.l1_clones[1]->pdn.p + (size_t)N_X0 * n,
+                           g.l1_clones[2]->pdn.p + (size_t)N_X0 * n, g.X.p + g.ng);
         score = apply_step(g);  // :894-902
         if (trace) trace[it] = score;
         it++;
