@@ -220,6 +220,13 @@ int irotavg_viewgraph_save_poses(const irotavg_viewgraph *vg, const char *filena
 int irotavg_window_solve(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
                          int64_t ldqq, double *Q, int64_t ldq, int cost, double sigma, int l1_iters,
                          int irls_iters, double change_th, double *weights, int *l1_out, int *irls_out);
+/* Same with an explicit kernel choice: 0 = automatic (what irotavg_window_solve and rot_avg do),
+ * 1 = the general LDS kernel (<= 64 free views, <= 640 edges, <= 320 views), 2 = the wave-resident
+ * kernel for the usual rotAvg(10) size (<= 16 free views, <= 64 edges; BAD_ARG beyond). */
+int irotavg_window_solve_kernel(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                                int64_t ldqq, double *Q, int64_t ldq, int cost, double sigma,
+                                int l1_iters, int irls_iters, double change_th, double *weights,
+                                int *l1_out, int *irls_out, int kernel);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU: the IRLS solve sharded by contiguous ranges of free views; one

@@ -32,7 +32,7 @@ SYMBOLS = [
     "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
     "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_plan", "irotavg_dist_plan_host",
-    "irotavg_window_solve", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
+    "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
 ]
 
 
@@ -135,6 +135,9 @@ def lib():
     L.irotavg_window_solve.argtypes = [C.c_int64, C.c_int64, C.c_int, _ip, _dp, C.c_int64, _dp, C.c_int64,
                                        C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.irotavg_window_solve_kernel.argtypes = [C.c_int64, C.c_int64, C.c_int, _ip, _dp, C.c_int64, _dp, C.c_int64,
+                                       C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     L.irotavg_rmat2quat.argtypes = [_dp, _dp]
     L.irotavg_rmat2quat.restype = None
     L.irotavg_quat2rmat.argtypes = [_dp, _dp]
@@ -334,16 +337,17 @@ class Graph:
 
 
 def window_solve(I, QQ, Q, f, cost=4, sigma=5 * np.pi / 180, l1_iters=100, irls_iters=100,
-                 change_th=1e-3):
-    """irotavg_window_solve: l1ra + irls of a small problem in one kernel launch."""
+                 change_th=1e-3, kernel=0):
+    """irotavg_window_solve[_kernel]: l1ra + irls of a small problem in one kernel launch
+    (kernel: 0 automatic, 1 general LDS kernel, 2 wave-resident kernel)."""
     I = edges(I)
     QQ = fmat(QQ)
     Q = fmat(Q)
     w = np.zeros(len(I))
     a, b = C.c_int(0), C.c_int(0)
-    rc = lib().irotavg_window_solve(len(I), Q.shape[0], f, _i(I), _d(QQ), QQ.shape[0], _d(Q), Q.shape[0],
-                                    cost, sigma, l1_iters, irls_iters, change_th, _d(w), C.byref(a),
-                                    C.byref(b))
+    rc = lib().irotavg_window_solve_kernel(len(I), Q.shape[0], f, _i(I), _d(QQ), QQ.shape[0], _d(Q),
+                                           Q.shape[0], cost, sigma, l1_iters, irls_iters, change_th,
+                                           _d(w), C.byref(a), C.byref(b), kernel)
     check(rc, "irotavg_window_solve")
     return dict(Q=Q, weights=w, l1_iters=a.value, irls_iters=b.value)
 

@@ -110,7 +110,8 @@ void window_solver_delete(WindowSolver *w);
 bool window_fits(int nv, int f, int ne);
 int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, const double *QQ_aos,
                  double *Q_aos, double *weights, int l1_max, int irls_max, int cost, double sigma,
-                 double change_th, int *l1_iters, int *irls_iters);
+                 double change_th, int *l1_iters, int *irls_iters, int kernel = 0);
+bool window_fits_wave(int nv, int f, int ne);
 // dense.hip
 void dense_refresh(Graph &g);
 bool dense_is_stale(Graph &g);

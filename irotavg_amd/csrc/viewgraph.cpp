@@ -327,12 +327,17 @@ int irotavg_viewgraph_save_poses(const irotavg_viewgraph *vg, const char *filena
 // The single-kernel window pipeline on caller data (same layout as irotavg_l1ra / irotavg_irls):
 // l1ra(l1_iters) then irls(cost, sigma, irls_iters) in one launch. Only for problems that fit
 // (<= 64 free views, <= 640 edges, <= 320 views): IROTAVG_ERR_BAD_ARG otherwise.
-int irotavg_window_solve(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
-                         int64_t ldqq, double *Q, int64_t ldq, int cost, double sigma, int l1_iters,
-                         int irls_iters, double change_th, double *weights, int *l1_out, int *irls_out) {
+// kernel: 0 = pick (wave-resident variant when <= 16 free views and <= 64 edges), 1 = the general
+// LDS kernel, 2 = the wave-resident kernel (BAD_ARG if the problem is too large for it).
+int irotavg_window_solve_kernel(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                                int64_t ldqq, double *Q, int64_t ldq, int cost, double sigma, int l1_iters,
+                                int irls_iters, double change_th, double *weights, int *l1_out,
+                                int *irls_out, int kernel) {
     if (!I || !QQ || !Q || m <= 0 || n_total <= 0 || ldqq < m || ldq < n_total) return IROTAVG_ERR_BAD_ARG;
+    if (kernel < 0 || kernel > 2) return IROTAVG_ERR_BAD_ARG;
     if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
     if (!irh::window_fits((int)n_total, f, (int)m)) return IROTAVG_ERR_BAD_ARG;
+    if (kernel == 2 && !irh::window_fits_wave((int)n_total, f, (int)m)) return IROTAVG_ERR_BAD_ARG;
     if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
     try {
         std::vector<double> qa((size_t)4 * m), Qa((size_t)4 * n_total);
@@ -342,7 +347,8 @@ int irotavg_window_solve(int64_t m, int64_t n_total, int f, const int32_t *I, co
             for (int c = 0; c < 4; c++) Qa[(size_t)4 * r + c] = Q[(size_t)c * ldq + r];
         irh::WindowSolver *ws = irh::window_solver_new();
         const int rc = irh::window_solve(*ws, (int)n_total, f, (int)m, I, qa.data(), Qa.data(), weights,
-                                         l1_iters, irls_iters, cost, sigma, change_th, l1_out, irls_out);
+                                         l1_iters, irls_iters, cost, sigma, change_th, l1_out, irls_out,
+                                         kernel);
         irh::window_solver_delete(ws);
         for (int64_t r = 0; r < n_total; r++)
             for (int c = 0; c < 4; c++) Q[(size_t)c * ldq + r] = Qa[(size_t)4 * r + c];
@@ -350,6 +356,13 @@ int irotavg_window_solve(int64_t m, int64_t n_total, int f, const int32_t *I, co
     } catch (...) {
         return IROTAVG_ERR_HIP;
     }
+}
+
+int irotavg_window_solve(int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                         int64_t ldqq, double *Q, int64_t ldq, int cost, double sigma, int l1_iters,
+                         int irls_iters, double change_th, double *weights, int *l1_out, int *irls_out) {
+    return irotavg_window_solve_kernel(m, n_total, f, I, QQ, ldqq, Q, ldq, cost, sigma, l1_iters, irls_iters,
+                                       change_th, weights, l1_out, irls_out, 0);
 }
 
 }  // extern "C"

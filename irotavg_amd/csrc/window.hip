@@ -530,11 +530,498 @@ __device__ __forceinline__ double win_weight(int cost, double sigma, double e2, 
     }
 }
 
+// =================================================================================================
+// The wave-resident variant for the usual rotAvg(10) sub-problem (<= 64 edges, <= 16 free views,
+// src/IRotAvg.cpp:158-161,371-378: each view is linked to its 4 predecessors). The general kernel
+// above spends its time in LDS round trips and workgroup barriers; here every edge vector of the
+// primal-dual LP lives in the registers of ONE lane of a wave (lane k = edge k, lane v = free view
+// v), the dense normal matrix is a 16-register row per lane (Gauss-Jordan by v_readlane
+// broadcasts), reductions are wave butterflies, and the three coordinate LPs of l1ra / the three
+// right-hand sides of irls run on three waves at once. Two workgroup barriers per outer iteration.
+// Statement order inside the sums follows the general kernel (k ascending), so both give the same
+// normal matrices bit for bit; only the order of the wave reductions differs.
+// =================================================================================================
+constexpr int SM_MAX_NE = 64;
+constexpr int SM_MAX_NU = 16;
+constexpr int SM_THREADS = 192;
+constexpr unsigned ADJ_NEG = 1u << 16;   // the edge enters the view's row with coefficient -1
+constexpr unsigned ADJ_SELF = 1u << 17;  // make_AtA self-loop entry
+
+__device__ __forceinline__ double rl_d(double x, int k) {  // k wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int rl_i(int x, int k) { return __builtin_amdgcn_readlane(x, k); }
+
+// wave64 reductions on the DPP network (no LDS traffic): four steps inside each row of 16 lanes,
+// two row broadcasts, the total is read from lane 63 -> identical bits in every lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double ident, double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+struct OpSum {
+    static __device__ __forceinline__ double id() { return 0.0; }
+    static __device__ __forceinline__ double f(double a, double b) { return a + b; }
+};
+struct OpMin {
+    static __device__ __forceinline__ double id() { return HUGE_VAL; }
+    static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); }
+};
+struct OpMax {
+    static __device__ __forceinline__ double id() { return -HUGE_VAL; }
+    static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); }
+};
+template <class Op>
+__device__ __forceinline__ double wv_reduce(double v) {
+    v = Op::f(v, dpp_d<0xb1, 0xf>(Op::id(), v));   // quad_perm [1,0,3,2]
+    v = Op::f(v, dpp_d<0x4e, 0xf>(Op::id(), v));   // quad_perm [2,3,0,1]
+    v = Op::f(v, dpp_d<0x124, 0xf>(Op::id(), v));  // row_ror 4
+    v = Op::f(v, dpp_d<0x128, 0xf>(Op::id(), v));  // row_ror 8
+    v = Op::f(v, dpp_d<0x142, 0xa>(Op::id(), v));  // row_bcast 15 -> rows 1, 3
+    v = Op::f(v, dpp_d<0x143, 0xc>(Op::id(), v));  // row_bcast 31 -> rows 2, 3
+    return rl_d(v, 63);
+}
+__device__ __forceinline__ double wv_sum(double v) { return wv_reduce<OpSum>(v); }
+__device__ __forceinline__ double wv_min(double v) { return wv_reduce<OpMin>(v); }
+__device__ __forceinline__ double wv_max(double v) { return wv_reduce<OpMax>(v); }
+
+// what a lane knows about "its" edge (lane k < m) -- and, as lane v < nu, about its free view
+struct SmLane {
+    int m, nu, lane;
+    int cj, ci;  // make_A columns of the edge (+1 at cj, -1 at ci), -1 = absent (ral/l1_irls.cpp:764-777)
+    // incidence lists of view `lane`, ascending edge id; entry = k | (other column + 1) << 8 | flags
+    const unsigned *adjA;  // make_A's A: rows that touch the view (A' products, the IRLS normal matrix)
+    const unsigned *adjH;  // make_AtA's endpoint rule (:825-843): the primal-dual normal matrix
+    int degA, degH, maxA, maxH;  // own list lengths, wave-wide maxima
+    double *Hrow;                // this wave's LDS row of the view (16 entries)
+};
+
+// (A' t)_v on lane v: k ascending, +t_k through cj then -t_k through ci (same order as at_dot)
+__device__ __forceinline__ double sm_at(const SmLane &E, double t) {
+    double s = 0.0;
+    for (int d = 0; d < E.maxA; d++) {
+        const bool on = d < E.degA;
+        const unsigned e = on ? E.adjA[d] : 0u;
+        const double tk = __shfl(t, (int)(e & 63u), 64);
+        if (on) s += (e & ADJ_NEG) ? -tk : tk;
+    }
+    return s;
+}
+// (A x)_k on lane k
+__device__ __forceinline__ double sm_ax(const SmLane &E, double x) {
+    const double xj = __shfl(x, E.cj < 0 ? 0 : E.cj, 64), xi = __shfl(x, E.ci < 0 ? 0 : E.ci, 64);
+    double s = 0.0;
+    if (E.cj >= 0) s += xj;
+    if (E.ci >= 0) s -= xi;
+    return s;
+}
+
+// Gauss-Jordan on rows held in registers: lane i owns row i (h[c], c < 16) and its right-hand
+// side. Pivot rows stay unscaled (row i -= (h_ik / h_kk) * row k, x_i = b_i / h_ii at the end): one
+// broadcast + one fma per column. A non-positive pivot marks a dead variable (never eliminates,
+// solution 0), like dense_solve above / the oracle's Cholesky. False if a non-finite value appears.
+__device__ __forceinline__ bool sm_solve(double (&h)[SM_MAX_NU], double &b, int nu, int lane) {
+    double myip = 0.0;
+#pragma unroll
+    for (int k = 0; k < SM_MAX_NU; k++) {
+        if (k < nu) {
+            const double piv = rl_d(h[k], k);
+            const double ip = (piv > 0.0) ? 1.0 / piv : 0.0;
+            const bool me = lane == k;
+            if (me) myip = ip;
+            const double mult = me ? 0.0 : -(h[k] * ip);
+#pragma unroll
+            for (int c = k + 1; c < SM_MAX_NU; c++) {
+                if (c < nu) h[c] = fma(mult, rl_d(h[c], k), h[c]);
+            }
+            b = fma(mult, rl_d(b, k), b);
+        }
+    }
+    b *= myip;
+    return __ballot(lane < nu && !isfinite(b)) == 0ull;
+}
+
+// one coordinate of the primal-dual LP on one wave, x0 = 0 (ral/l1_irls.cpp:228-468); y on edge
+// lanes, result on view lanes. Returns 0 ok, 1 solver error.
+__device__ int sm_l1decode(const SmLane &E, const double y, const int pdmaxiter, double &xout) {
+    const double PDTOL = 1e-3, alpha = 0.01, beta = 0.5, mu = 10;
+    const int m = E.m, lane = E.lane;
+    const bool ek = lane < m, vk = lane < E.nu;
+    double x = 0.0, Ax = 0.0;
+    const double maxabs = wv_max(ek ? fabs(y) : -HUGE_VAL);
+    double u = 0, f1 = 0, f2 = 0, l1 = 0, l2 = 0, t1 = 0;
+    double a0 = 0, a1 = 0, a2 = 0;
+    if (ek) {  // :252-276
+        u = fabs(y - Ax) * 0.95 + maxabs * 0.10;
+        f1 = Ax - y - u;
+        f2 = -Ax + y - u;
+        l1 = -(1.0 / f1);
+        l2 = -(1.0 / f2);
+        t1 = l1 - l2;
+        a0 = f1 * l1;
+        a1 = f2 * l2;
+        const double rd = 1.0 - l1 - l2;
+        a2 = rd * rd;
+    }
+    const double sa = wv_sum(a0), sb = wv_sum(a1), rd_tail2 = wv_sum(a2);
+    double sdg = -(sa + sb);
+    double tau = mu * 2 * (double)m / sdg;
+    double Atv = sm_at(E, t1);
+    const double atv2 = wv_sum(Atv * Atv);
+    double acc = 0.0;
+    if (ek) {
+        const double c1 = -l1 * f1 - 1.0 / tau, c2 = -l2 * f2 - 1.0 / tau;
+        acc = c1 * c1 + c2 * c2;
+    }
+    double resnorm = sqrt(atv2 + rd_tail2 + wv_sum(acc));
+    int pditer = 0;
+    bool done = (sdg < PDTOL) || (pditer >= pdmaxiter);
+    while (!done) {
+        pditer++;
+        const double itau = 1.0 / tau;
+        double sigx = 0.0, t2 = 0.0, if1 = 0, if2 = 0, w2 = 0, s1 = 1, s2 = 0, qa = 0, qb = 0;
+        t1 = 0.0;
+        if (ek) {  // :292-305
+            if1 = 1.0 / f1;
+            if2 = 1.0 / f2;
+            w2 = -1 - itau * (if1 + if2);
+            qa = l1 / f1;
+            qb = l2 / f2;
+            s1 = -qa - qb;
+            s2 = qa - qb;
+            sigx = s1 - (s2 * s2) / s1;
+            t1 = -if1 + if2;
+            t2 = (s2 / s1) * w2;
+        }
+        // H11p = A' diag(sigx) A with make_AtA's endpoint rule: lane v accumulates row v in LDS
+        // (k ascending), then holds it in registers for the elimination
+        double h[SM_MAX_NU];
+        {
+            double hd = 0.0;
+            if (vk) {
+#pragma unroll
+                for (int c = 0; c < SM_MAX_NU; c++) E.Hrow[c] = 0.0;
+            }
+            for (int d = 0; d < E.maxH; d++) {
+                const bool on = d < E.degH;
+                const unsigned e = on ? E.adjH[d] : 0u;
+                const double s = __shfl(sigx, (int)(e & 63u), 64);
+                if (on) {
+                    if (e & ADJ_SELF) {
+                        hd -= s;
+                    } else {
+                        hd += s;
+                        const int o = (int)((e >> 8) & 255u);
+                        if (o) E.Hrow[o - 1] -= s;
+                    }
+                }
+            }
+            if (vk) E.Hrow[lane] = hd;
+#pragma unroll
+            for (int c = 0; c < SM_MAX_NU; c++) h[c] = vk ? E.Hrow[c] : 0.0;
+        }
+        const double w1 = -itau * sm_at(E, t1);
+        double dx = w1 - sm_at(E, t2);
+        if (!sm_solve(h, dx, E.nu, lane)) return 1;
+        if (!vk) dx = 0.0;
+        const double adx = sm_ax(E, dx);
+        double du = 0, dl1 = 0, dl2 = 0, Adx = 0, smin = HUGE_VAL;
+        t1 = 0.0;
+        if (ek) {  // :324-381
+            const double d_u = (w2 - s2 * adx) / s1;
+            double d1 = -qa;
+            d1 *= (adx - d_u);
+            d1 -= l1;
+            d1 -= itau * if1;
+            double d2 = qb;
+            d2 *= (adx + d_u);
+            d2 -= l2;
+            d2 -= itau * if2;
+            Adx = adx;
+            du = d_u;
+            dl1 = d1;
+            dl2 = d2;
+            t1 = d1 - d2;
+            if (d1 < 0) smin = fmin(smin, -l1 / d1);
+            if (d2 < 0) smin = fmin(smin, -l2 / d2);
+            const double p = adx - d_u;
+            if (p > 0) smin = fmin(smin, -f1 / p);
+            const double q = -adx - d_u;
+            if (q > 0) smin = fmin(smin, -f2 / q);
+        }
+        double s = fmin(1.0, wv_min(smin));
+        if (!(s == s)) return 1;
+        s *= 0.99;
+        const double Atdv = sm_at(E, t1);
+        bool suffdec = false;
+        int backiter = 0;
+        double s_acc = s, rdp2 = 0.0;
+        while (!suffdec) {  // :384-429
+            double b0 = 0, b1 = 0;
+            if (vk) {
+                const double q = Atv + s * Atdv;
+                b0 = q * q;
+            }
+            if (ek) {
+                const double up = u + s * du;
+                const double axp = Ax + s * Adx;
+                const double m1 = l1 + s * dl1, m2 = l2 + s * dl2;
+                const double g1 = axp - y - up, g2 = -axp + y - up;
+                const double r = 1.0 + (-m1 - m2);
+                b0 += r * r;
+                const double c1 = -m1 * g1 - itau, c2 = -m2 * g2 - itau;
+                b1 = c1 * c1 + c2 * c2;
+            }
+            rdp2 = wv_sum(b0);
+            const double rcp2 = wv_sum(b1);
+            suffdec = sqrt(rdp2 + rcp2) <= (1 - alpha * s) * resnorm;
+            s_acc = s;
+            s *= beta;
+            backiter++;
+            if (backiter > 32) {  // "Stuck backtracking": the previous iterate is returned
+                xout = x;
+                return 0;
+            }
+        }
+        x += s_acc * dx;
+        Atv += s_acc * Atdv;
+        a0 = a1 = 0;
+        if (ek) {
+            u = u + s_acc * du;
+            Ax = Ax + s_acc * Adx;
+            l1 = l1 + s_acc * dl1;
+            l2 = l2 + s_acc * dl2;
+            f1 = Ax - y - u;
+            f2 = -Ax + y - u;
+            a0 = f1 * l1;
+            a1 = f2 * l2;
+        }
+        sdg = -(wv_sum(a0) + wv_sum(a1));
+        tau = mu * 2 * (double)m / sdg;
+        acc = 0.0;
+        if (ek) {
+            const double c1 = -l1 * f1 - 1.0 / tau, c2 = -l2 * f2 - 1.0 / tau;
+            acc = c1 * c1 + c2 * c2;
+        }
+        resnorm = sqrt(rdp2 + wv_sum(acc));
+        done = (sdg < PDTOL) || (pditer >= pdmaxiter);
+    }
+    xout = x;
+    return 0;
+}
+
+__global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams P, const int2 *__restrict__ Ig,
+                                                           const double4 *__restrict__ QQ,
+                                                           double4 *__restrict__ Qg,
+                                                           double *__restrict__ weights,
+                                                           WinResult *__restrict__ out) {
+    __shared__ double4 sQ[WIN_MAX_NV];
+    __shared__ double sW[3][SM_MAX_NU];
+    __shared__ double sH[3][SM_MAX_NU][SM_MAX_NU + 1];
+    __shared__ unsigned sAdjA[SM_MAX_NU][SM_MAX_NE], sAdjH[SM_MAX_NU][SM_MAX_NE];
+    __shared__ int sDeg[2][SM_MAX_NU];
+    __shared__ int sStatus[3];
+    const int nv = P.nv, ne = P.ne, f = P.f, nu = nv - f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < nv; i += SM_THREADS) sQ[i] = Qg[i];
+    SmLane E;
+    E.m = ne;
+    E.nu = nu;
+    E.lane = lane;
+    E.cj = E.ci = -1;
+    int ai = -1, aj = -2;  // make_AtA endpoints i - f, j - f (negative = fixed)
+    int ex = 0, ey = 0;
+    double4 qq = make_double4(0, 0, 0, 1);
+    if (lane < ne) {
+        const int2 e = Ig[lane];
+        qq = QQ[lane];
+        ex = e.x;
+        ey = e.y;
+        ai = e.x - f;
+        aj = e.y - f;
+        if (e.y >= f) {  // make_A coefficients (ral/l1_irls.cpp:764-777)
+            if (e.x >= f && e.x == e.y) {
+                E.ci = e.x - f;
+            } else {
+                E.cj = e.y - f;
+                if (e.x >= f) E.ci = e.x - f;
+            }
+        }
+    }
+    const bool ek = lane < ne, vk = lane < nu;
+    if (wave == 0) {  // incidence lists of the free views, ascending edge id
+        int da = 0, dh = 0;
+        const int row = vk ? lane : 0;
+        for (int k = 0; k < ne; k++) {
+            const int kj = rl_i(E.cj, k), ki = rl_i(E.ci, k), i = rl_i(ai, k), j = rl_i(aj, k);
+            if (vk) {
+                if (kj == lane) sAdjA[row][da++] = (unsigned)k | ((unsigned)(ki + 1) << 8);
+                if (ki == lane) sAdjA[row][da++] = (unsigned)k | ((unsigned)(kj + 1) << 8) | ADJ_NEG;
+                if (i >= 0 && i == j) {
+                    if (i == lane) sAdjH[row][dh++] = (unsigned)k | ADJ_SELF;
+                } else {
+                    if (i == lane) sAdjH[row][dh++] = (unsigned)k | ((unsigned)(j >= 0 ? j + 1 : 0) << 8);
+                    if (j == lane) sAdjH[row][dh++] = (unsigned)k | ((unsigned)(i >= 0 ? i + 1 : 0) << 8);
+                }
+            }
+        }
+        if (vk) {
+            sDeg[0][lane] = da;
+            sDeg[1][lane] = dh;
+        }
+    }
+    if (tid < 3) sStatus[tid] = 0;
+    __syncthreads();
+    E.adjA = sAdjA[vk ? lane : 0];
+    E.adjH = sAdjH[vk ? lane : 0];
+    E.degA = vk ? sDeg[0][lane] : 0;
+    E.degH = vk ? sDeg[1][lane] : 0;
+    E.maxA = (int)wv_max((double)E.degA);
+    E.maxH = (int)wv_max((double)E.degH);
+    E.Hrow = sH[wave][vk ? lane : 0];
+    double r[3] = {0, 0, 0};
+    auto residual = [&]() {  // K1 on lane k (ral/l1_irls.cpp:109-127,498-532)
+        if (ek) {
+            double4 qj = sQ[ey];
+            qj.w = -qj.w;
+            const double4 d = qmul(qj, qmul(qq, sQ[ex]));
+            const double s2 = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+            double th = 2.0 * atan2(s2, d.w);
+            if (th < -W_PI)
+                th += 2.0 * W_PI;
+            else if (th >= W_PI)
+                th -= 2.0 * W_PI;
+            const double aux = th / s2;
+            r[0] = d.x * aux;
+            r[1] = d.y * aux;
+            r[2] = d.z * aux;
+            if (s2 < W_EPS) r[0] = r[1] = r[2] = 0.0;
+        }
+    };
+    // score = mean ||W row|| before the exp map; wave 0 updates Q (:729-737 / :894-902, :471-492)
+    auto apply_step = [&]() -> double {
+        double acc = 0.0;
+        if (vk) {
+            const double x = sW[0][lane], y = sW[1][lane], z = sW[2][lane];
+            const double th = sqrt(x * x + y * y + z * z);
+            acc = th;
+            if (wave == 0) {
+                const double sn = sin(th / 2.0), cs = cos(th / 2.0);
+                const double coef = sn / th;
+                double4 w = make_double4(x * coef, y * coef, z * coef, cs);
+                if (!isfinite(w.x)) w.x = 0.0;
+                if (!isfinite(w.y)) w.y = 0.0;
+                if (!isfinite(w.z)) w.z = 0.0;
+                if (!isfinite(w.w)) w.w = 0.0;
+                sQ[lane + f] = qmul(sQ[lane + f], w);
+            }
+        }
+        const double s = wv_sum(acc) / (double)nu;
+        __syncthreads();
+        return s;
+    };
+    int status = 0;
+    // ---------------- l1ra (ral/l1_irls.cpp:851-912): wave c solves coordinate c ----------------
+    double score = HUGE_VAL, change_th = P.change_th;
+    int iter = 0, l1_step = 2;
+    while (((score >= change_th) || (l1_step < 2)) && (iter < P.l1_max) && status == 0) {
+        if (score < change_th) {  // unreachable under the guard above; kept literal (:879-883)
+            l1_step *= 4;
+            change_th /= 100.0;
+        }
+        residual();
+        double xo = 0.0;
+        const int st = sm_l1decode(E, wave == 0 ? r[0] : (wave == 1 ? r[1] : r[2]), l1_step, xo);
+        if (lane == 0) sStatus[wave] = st;
+        if (vk) sW[wave][lane] = xo;
+        __syncthreads();
+        status = sStatus[0] | sStatus[1] | sStatus[2];
+        if (status) break;
+        score = apply_step();
+        iter++;
+    }
+    const int l1_iters = iter;
+    const double l1_score = score;
+    // ---------------- irls (ral/l1_irls.cpp:559-752): wave c solves right-hand side c ------------
+    double d = 1.0;
+    score = HUGE_VAL;
+    iter = 0;
+    while (score > P.change_th && iter < P.irls_max && status == 0) {
+        residual();
+        const double rc = wave == 0 ? r[0] : (wave == 1 ? r[1] : r[2]);
+        // A'D^2A and A'D^2 r with make_A's A: row v on lane v (k ascending)
+        double h[SM_MAX_NU];
+        double hd = 0.0, b = 0.0;
+        if (vk) {
+#pragma unroll
+            for (int c = 0; c < SM_MAX_NU; c++) E.Hrow[c] = 0.0;
+        }
+        for (int q = 0; q < E.maxA; q++) {
+            const bool on = q < E.degA;
+            const unsigned e = on ? E.adjA[q] : 0u;
+            const double dk = __shfl(d, (int)(e & 63u), 64), rk = __shfl(rc, (int)(e & 63u), 64);
+            if (on) {
+                const double s = dk * dk;
+                hd += s;
+                const int o = (int)((e >> 8) & 255u);
+                if (o) E.Hrow[o - 1] -= s;
+                if (e & ADJ_NEG)
+                    b -= s * rk;
+                else
+                    b += s * rk;
+            }
+        }
+        if (vk) E.Hrow[lane] = hd;
+#pragma unroll
+        for (int c = 0; c < SM_MAX_NU; c++) h[c] = vk ? E.Hrow[c] : 0.0;
+        const bool ok = sm_solve(h, b, nu, lane);
+        if (lane == 0) sStatus[wave] = ok ? 0 : 1;
+        if (vk) sW[wave][lane] = b;
+        __syncthreads();
+        status = sStatus[0] | sStatus[1] | sStatus[2];
+        if (status) break;
+        if (ek) {  // E = A W3 - w, weights (:614-727)
+            double e0 = 0, e1 = 0, e2c = 0;
+            if (E.cj >= 0) {
+                e0 += sW[0][E.cj];
+                e1 += sW[1][E.cj];
+                e2c += sW[2][E.cj];
+            }
+            if (E.ci >= 0) {
+                e0 -= sW[0][E.ci];
+                e1 -= sW[1][E.ci];
+                e2c -= sW[2][E.ci];
+            }
+            e0 -= r[0];
+            e1 -= r[1];
+            e2c -= r[2];
+            d = win_weight(P.cost, P.sigma, e0 * e0 + e1 * e1 + e2c * e2c, d);
+        }
+        score = apply_step();
+        iter++;
+    }
+    if (status) status = IROTAVG_ERR_SOLVER;
+    __syncthreads();
+    for (int i = tid; i < nv; i += SM_THREADS) Qg[i] = sQ[i];
+    if (wave == 0 && ek) weights[lane] = d;
+    if (tid == 0) {
+        out->l1_iters = l1_iters;
+        out->irls_iters = iter;
+        out->status = status;
+        out->l1_score = l1_score;
+        out->irls_score = score;
+    }
+}
+
 // ---- host side: persistent staging, one H2D / launch / D2H per solve ---------------------------
 struct WindowSolver {
     hipStream_t stream = nullptr;
     DevBuf<unsigned char> dev;   // [I | QQ | Q | weights | result]
-    unsigned char *host = nullptr;
+    unsigned char *host = nullptr;   // pinned, device-visible
+    unsigned char *hdev = nullptr;   // the same block as the device sees it
     size_t cap = 0;
     bool attr_set = false;
     ~WindowSolver() {
@@ -550,6 +1037,11 @@ static size_t win_lds_bytes(int nv, int ne, int nu) {
            sizeof(int2) * (size_t)ne + (size_t)ne + 64;
 }
 
+bool window_fits_wave(int nv, int f, int ne) {
+    const int nu = nv - f;
+    return nu >= 1 && nu <= SM_MAX_NU && nv <= WIN_MAX_NV && ne >= 1 && ne <= SM_MAX_NE;
+}
+
 bool window_fits(int nv, int f, int ne) {
     const int nu = nv - f;
     return nu >= 1 && nu <= WIN_MAX_NU && nv <= WIN_MAX_NV && ne >= 1 && ne <= WIN_MAX_NE &&
@@ -558,8 +1050,10 @@ bool window_fits(int nv, int f, int ne) {
 
 int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, const double *QQ_aos,
                  double *Q_aos, double *weights, int l1_max, int irls_max, int cost, double sigma,
-                 double change_th, int *l1_iters, int *irls_iters) {
+                 double change_th, int *l1_iters, int *irls_iters, int kernel) {
     if (!window_fits(nv, f, ne)) return IROTAVG_ERR_BAD_ARG;
+    if (kernel == 2 && !window_fits_wave(nv, f, ne)) return IROTAVG_ERR_BAD_ARG;
+    const bool wave = kernel == 2 || (kernel == 0 && window_fits_wave(nv, f, ne));
     if (!ws.stream) IRH_CHECK(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
     const size_t oI = 0, oQQ = oI + sizeof(int2) * (size_t)WIN_MAX_NE;
     const size_t oQ = oQQ + sizeof(double4) * (size_t)WIN_MAX_NE;
@@ -569,26 +1063,38 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
     if (ws.cap < total) {
         ws.dev.alloc(total);
         if (ws.host) (void)hipHostFree(ws.host);
-        IRH_CHECK(hipHostMalloc((void **)&ws.host, total, hipHostMallocDefault));
+        IRH_CHECK(hipHostMalloc((void **)&ws.host, total, hipHostMallocMapped));
+        IRH_CHECK(hipHostGetDevicePointer((void **)&ws.hdev, ws.host, 0));
         ws.cap = total;
     }
     std::memcpy(ws.host + oI, I, sizeof(int32_t) * 2 * (size_t)ne);
     std::memcpy(ws.host + oQQ, QQ_aos, sizeof(double) * 4 * (size_t)ne);
     std::memcpy(ws.host + oQ, Q_aos, sizeof(double) * 4 * (size_t)nv);
-    IRH_CHECK(hipMemcpyAsync(ws.dev.p, ws.host, oW, hipMemcpyHostToDevice, ws.stream));
     WinParams P{nv, f, ne, l1_max, irls_max, cost, change_th, sigma};
-    const size_t shm = win_lds_bytes(nv, ne, nv - f);
-    if (!ws.attr_set) {
-        IRH_CHECK(hipFuncSetAttribute((const void *)k_window_solve,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ws.attr_set = true;
+    if (wave) {
+        // the wave kernel touches its inputs once and its outputs once: it works directly on the
+        // pinned (device-visible) staging block -- launch + synchronise, no copy commands
+        hipLaunchKernelGGL(k_window_wave, dim3(1), dim3(SM_THREADS), 0, ws.stream, P,
+                           (const int2 *)(ws.hdev + oI), (const double4 *)(ws.hdev + oQQ),
+                           (double4 *)(ws.hdev + oQ), (double *)(ws.hdev + oW),
+                           (WinResult *)(ws.hdev + oR));
+        IRH_CHECK(hipGetLastError());
+        IRH_CHECK(hipStreamSynchronize(ws.stream));
+    } else {
+        IRH_CHECK(hipMemcpyAsync(ws.dev.p, ws.host, oW, hipMemcpyHostToDevice, ws.stream));
+        const size_t shm = win_lds_bytes(nv, ne, nv - f);
+        if (!ws.attr_set) {
+            IRH_CHECK(hipFuncSetAttribute((const void *)k_window_solve,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ws.attr_set = true;
+        }
+        hipLaunchKernelGGL(k_window_solve, dim3(1), dim3(WIN_THREADS), shm, ws.stream, P,
+                           (const int2 *)(ws.dev.p + oI), (const double4 *)(ws.dev.p + oQQ),
+                           (double4 *)(ws.dev.p + oQ), (double *)(ws.dev.p + oW),
+                           (WinResult *)(ws.dev.p + oR));
+        IRH_CHECK(hipMemcpyAsync(ws.host + oQ, ws.dev.p + oQ, total - oQ, hipMemcpyDeviceToHost, ws.stream));
+        IRH_CHECK(hipStreamSynchronize(ws.stream));
     }
-    hipLaunchKernelGGL(k_window_solve, dim3(1), dim3(WIN_THREADS), shm, ws.stream, P,
-                       (const int2 *)(ws.dev.p + oI), (const double4 *)(ws.dev.p + oQQ),
-                       (double4 *)(ws.dev.p + oQ), (double *)(ws.dev.p + oW),
-                       (WinResult *)(ws.dev.p + oR));
-    IRH_CHECK(hipMemcpyAsync(ws.host + oQ, ws.dev.p + oQ, total - oQ, hipMemcpyDeviceToHost, ws.stream));
-    IRH_CHECK(hipStreamSynchronize(ws.stream));
     WinResult R;
     std::memcpy(&R, ws.host + oR, sizeof(R));
     std::memcpy(Q_aos, ws.host + oQ, sizeof(double) * 4 * (size_t)nv);

@@ -32,6 +32,52 @@ def test_window_pipeline_matches_oracle(n, m, f):
     np.testing.assert_array_equal(r["Q"][:f], Q0[:f])
 
 
+@pytest.mark.parametrize("n,m,f", [(14, 40, 4), (12, 30, 2), (17, 64, 1), (40, 60, 30), (3, 3, 1)])
+def test_wave_kernel_matches_general_kernel_and_oracle(n, m, f):
+    """<= 16 free views / <= 64 edges: the wave-resident kernel (kernel=2) vs the LDS kernel (1)."""
+    S, Q0 = small(n, m, f, seed=7 * n + m)
+    w = capi.window_solve(S["I"], S["QQ"], Q0, f, 4, SIG, 100, 100, 1e-3, kernel=2)
+    g = capi.window_solve(S["I"], S["QQ"], Q0, f, 4, SIG, 100, 100, 1e-3, kernel=1)
+    auto = capi.window_solve(S["I"], S["QQ"], Q0, f, 4, SIG, 100, 100, 1e-3)
+    a = O.l1ra(S["QQ"], S["I"], Q0, f, 100, 1e-3)
+    b = O.irls(S["QQ"], S["I"], a["Q"], f, 4, SIG, 100, 1e-3)
+    assert (w["l1_iters"], w["irls_iters"]) == (g["l1_iters"], g["irls_iters"]) == (a["iters"], b["iters"])
+    assert synth.angular_distance(w["Q"], b["Q"]).max() < 1e-9
+    assert synth.angular_distance(w["Q"], g["Q"]).max() < 1e-11
+    np.testing.assert_allclose(w["weights"], b["weights"], rtol=1e-7)
+    np.testing.assert_array_equal(auto["Q"], w["Q"])           # automatic choice = wave kernel here
+    np.testing.assert_array_equal(w["Q"][:f], Q0[:f])
+
+
+@pytest.mark.parametrize("cost", range(14))
+def test_wave_kernel_every_cost(cost):
+    S, Q0 = small(16, 60, 2, seed=300 + cost)
+    r = capi.window_solve(S["I"], S["QQ"], Q0, 2, cost, SIG, 3, 12, 1e-3, kernel=2)
+    a = O.l1ra(S["QQ"], S["I"], Q0, 2, 3, 1e-3)
+    b = O.irls(S["QQ"], S["I"], a["Q"], 2, cost, SIG, 12, 1e-3)
+    assert (r["l1_iters"], r["irls_iters"]) == (a["iters"], b["iters"])
+    assert synth.angular_distance(r["Q"], b["Q"]).max() < 1e-8
+    np.testing.assert_allclose(r["weights"], b["weights"], rtol=1e-6, atol=1e-12)
+
+
+def test_wave_kernel_quirk_edges_and_limits():
+    S, Q0 = small(20, 60, 5, seed=19)
+    I, QQ = S["I"].copy(), S["QQ"].copy()
+    flip = np.random.default_rng(1).random(len(I)) < 0.3      # edges whose 2nd endpoint is fixed
+    I[flip] = I[flip][:, ::-1]
+    QQ[flip] = synth.qconj(QQ[flip])
+    r = capi.window_solve(I, QQ, Q0, 5, 4, SIG, 100, 100, 1e-3, kernel=2)
+    a = O.l1ra(QQ, I, Q0, 5, 100, 1e-3)
+    b = O.irls(QQ, I, a["Q"], 5, 4, SIG, 100, 1e-3)
+    assert (r["l1_iters"], r["irls_iters"]) == (a["iters"], b["iters"])
+    assert synth.angular_distance(r["Q"], b["Q"]).max() < 1e-9
+    big, Qb = small(30, 100, 1, seed=2)                       # fits the LDS kernel, not the wave kernel
+    with pytest.raises(capi.IrotavgError) as e:
+        capi.window_solve(big["I"], big["QQ"], Qb, 1, kernel=2)
+    assert e.value.code == capi.ERR_BAD_ARG
+    capi.window_solve(big["I"], big["QQ"], Qb, 1, kernel=0)
+
+
 @pytest.mark.parametrize("cost", range(14))
 def test_window_every_cost(cost):
     S, Q0 = small(40, 200, 2, seed=100 + cost)

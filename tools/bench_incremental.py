@@ -64,18 +64,26 @@ def main():
     t_build = time.perf_counter() - t_build
     lat_local, lat_global = [], []
     edges_solved = 0
+    # the front-end's measurements of the streamed part, generated up front (vectorised): the timed
+    # region below is view-graph maintenance + rotation averaging, not synthetic data generation
+    sv = np.arange(a.warm, n)
+    Rrel = {}
+    for d in range(1, 5):
+        e = synth.qexp(rng.normal(scale=a.noise, size=(len(sv), 3)))
+        Rrel[d] = quat2rmat(synth.qmul(e, synth.qmul(Qgt[sv], synth.qconj(Qgt[sv - d]))))
+    loop_from = {v: int(rng.integers(0, v - 1000)) for v in loop_at}
+    loop_R = {v: rel(u, v) for v, u in loop_from.items()}
     t0 = time.perf_counter()
     for v in range(a.warm, n):
         Rprev = vg.R(v - 1)
-        Rij = rel(v - 1, v)
+        Rij = Rrel[1][v - a.warm]
         vg.addView(Rij @ Rprev)                    # the front-end's initial pose
         vg.connect(v - 1, v, Rij)
         for d in range(2, 5):
-            vg.connect(v - d, v, rel(v - d, v))
+            vg.connect(v - d, v, Rrel[d][v - a.warm])
         loop = v in loop_at
         if loop:
-            u = int(rng.integers(0, v - 1000))
-            vg.connect(u, v, rel(u, v))
+            vg.connect(loop_from[v], v, loop_R[v])
         if v % a.fix_every == 0:
             vg.fixPose(v, Rgt[v])
         t = time.perf_counter()
