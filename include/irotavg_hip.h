@@ -260,6 +260,11 @@ int irotavg_dist_plan_host(int world, int rank, int64_t m, int64_t n_total, int 
 /* library / device info */
 const char *irotavg_version(void);
 int irotavg_device_count(void);
+/* Handles draw their device buffers from a per-device cache so that create/destroy cycles (the
+ * one-shot calls, rot_avg's global re-solves) do not pay hipMalloc/hipFree each time. This returns
+ * the cached blocks to the driver; result = bytes released. IROTAVG_POOL_LIMIT_MB (environment)
+ * bounds the cache (default 16384; 0 = no caching). */
+int64_t irotavg_trim_memory(void);
 const char *irotavg_error_string(int code);
 
 #ifdef __cplusplus

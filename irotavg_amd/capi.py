@@ -32,7 +32,7 @@ SYMBOLS = [
     "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
     "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_plan", "irotavg_dist_plan_host",
-    "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
+    "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_trim_memory", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
 ]
 
 
@@ -138,6 +138,8 @@ def lib():
     L.irotavg_window_solve_kernel.argtypes = [C.c_int64, C.c_int64, C.c_int, _ip, _dp, C.c_int64, _dp, C.c_int64,
                                        C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, _dp,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.irotavg_trim_memory.argtypes = []
+    L.irotavg_trim_memory.restype = C.c_int64
     L.irotavg_rmat2quat.argtypes = [_dp, _dp]
     L.irotavg_rmat2quat.restype = None
     L.irotavg_quat2rmat.argtypes = [_dp, _dp]
@@ -334,6 +336,11 @@ class Graph:
         ms = C.c_double(0)
         check(lib().irotavg_graph_time_kernel(self._h, which, reps, C.byref(ms)), "time_kernel")
         return ms.value
+
+
+def trim_memory():
+    """irotavg_trim_memory: release the cached device buffers of destroyed handles; bytes freed."""
+    return int(lib().irotavg_trim_memory())
 
 
 def window_solve(I, QQ, Q, f, cost=4, sigma=5 * np.pi / 180, l1_iters=100, irls_iters=100,

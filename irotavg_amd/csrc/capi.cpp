@@ -199,7 +199,7 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
     if (g.opt.pcg_check_every <= 0) g.opt.pcg_check_every = 8;
     if (g.opt.device >= 0) IRH_CHECK(hipSetDevice(g.opt.device));
     IRH_CHECK(hipGetDevice(&g.device));
-    IRH_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.stream = StreamPool::get().take();
     g.m = m;
     g.n_total = n_total;
     g.f = f;
@@ -228,14 +228,37 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
     }
 }
 
+// Device buffers of destroyed handles are cached for reuse (common.hpp, DevPool): hand them back.
+int64_t irotavg_trim_memory(void) {
+    try {
+        StreamPool::get().trim();
+        return (int64_t)DevPool::get().trim();
+    } catch (...) {
+        return 0;
+    }
+}
+
 void irotavg_graph_destroy(irotavg_graph *h) {
     if (!h) return;
+    const bool timing = std::getenv("IROTAVG_BUILD_TIMING") != nullptr;
+    double t0 = now_seconds();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t = now_seconds();
+        std::fprintf(stderr, "[irotavg_hip destroy] %-24s %8.3f ms\n", what, 1e3 * (t - t0));
+        t0 = t;
+    };
     hipStream_t s = h->g.stream;
+    const int dev = h->g.device;
     if (s) (void)hipStreamSynchronize(s);
+    lap("sync");
     release_l1_clones(h->g);
+    lap("clones");
     h->g.stream = nullptr;
     delete h;
-    if (s) (void)hipStreamDestroy(s);
+    lap("delete");
+    if (s) StreamPool::get().give(s, dev);
+    lap("stream destroy");
 }
 
 int irotavg_graph_set_rotations(irotavg_graph *h, const double *Q, int64_t ldq) {

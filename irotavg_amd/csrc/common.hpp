@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/irotavg_hip.h"
@@ -26,18 +28,144 @@ struct HipError {
         }                                                                                      \
     } while (0)
 
-// Device buffer (plain hipMalloc; sized once per graph, HBM-resident for the handle's life).
+// Device memory pool. A solve handle owns a few hundred buffers; hipMalloc / hipFree cost ~0.1 ms
+// each and hipFree synchronises the device, which made handle churn (one-shot calls, the global
+// re-solve of rot_avg on every loop closure) cost tens of milliseconds. Released blocks are cached
+// per device and size and handed out again; a block released since the last device-wide
+// synchronisation is "dirty" (work of its previous owner may still be in flight) and the first
+// reuse of a dirty block synchronises the device once. irotavg_trim_memory() returns the cache to
+// the driver; IROTAVG_POOL_LIMIT_MB bounds it (default 16384, 0 disables pooling).
+struct DevPool {
+    struct Block {
+        void *p;
+        size_t bytes;
+        bool dirty;
+    };
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, Block> cache;
+    size_t cached = 0, limit = (size_t)16384 << 20;
+    size_t n_dirty = 0;
+    DevPool() {
+        if (const char *e = std::getenv("IROTAVG_POOL_LIMIT_MB")) limit = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    }
+    static DevPool &get() {
+        static DevPool *pool = new DevPool();  // never destroyed: no hipFree after runtime teardown
+        return *pool;
+    }
+    static size_t round_up(size_t bytes) { return (bytes + 511) & ~(size_t)511; }
+    // returns nullptr if nothing suitable is cached; *got = size of the block handed out
+    void *take(int dev, size_t bytes, size_t *got) {
+        bool sync = false;
+        void *p = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = cache.lower_bound({dev, bytes});
+            if (it == cache.end() || it->first.first != dev || it->first.second > bytes + bytes / 8 + 4096)
+                return nullptr;
+            p = it->second.p;
+            *got = it->second.bytes;
+            sync = it->second.dirty;
+            cached -= it->second.bytes;
+            cache.erase(it);
+            if (sync) {
+                for (auto &kv : cache)
+                    if (kv.first.first == dev) kv.second.dirty = false;
+            }
+        }
+        if (sync) (void)hipDeviceSynchronize();
+        return p;
+    }
+    void give(int dev, void *p, size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (cached + bytes <= limit) {
+                cache.insert({{dev, bytes}, Block{p, bytes, true}});
+                cached += bytes;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+    size_t trim() {
+        std::multimap<std::pair<int, size_t>, Block> drop;
+        size_t freed = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            drop.swap(cache);
+            freed = cached;
+            cached = 0;
+        }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto &kv : drop) {
+            (void)hipSetDevice(kv.first.first);
+            (void)hipFree(kv.second.p);
+        }
+        (void)hipSetDevice(cur);
+        return freed;
+    }
+};
+
+// Streams are recycled the same way (hipStreamCreate / hipStreamDestroy cost 1-2 ms each): a
+// stream handed back must be idle (synchronised by its owner).
+struct StreamPool {
+    std::mutex mu;
+    std::multimap<int, hipStream_t> idle;
+    static StreamPool &get() {
+        static StreamPool *pool = new StreamPool();
+        return *pool;
+    }
+    hipStream_t take() {
+        int dev = 0;
+        IRH_CHECK(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = idle.find(dev);
+            if (it != idle.end()) {
+                hipStream_t s = it->second;
+                idle.erase(it);
+                return s;
+            }
+        }
+        hipStream_t s = nullptr;
+        IRH_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        return s;
+    }
+    void give(hipStream_t s, int dev = -1) {
+        if (!s) return;
+        if (dev < 0) (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle.size() < 64) {
+            idle.insert({dev, s});
+            return;
+        }
+        (void)hipStreamDestroy(s);
+    }
+    void trim() {
+        std::multimap<int, hipStream_t> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            drop.swap(idle);
+        }
+        for (auto &kv : drop) (void)hipStreamDestroy(kv.second);
+    }
+};
+
+// Device buffer (pooled hipMalloc; sized once per graph, HBM-resident for the handle's life).
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     bool own = true;  // false: a non-owning alias of another handle's buffer (read-only data)
+    size_t cap_bytes = 0;
+    int dev = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), own(o.own) {
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), own(o.own), cap_bytes(o.cap_bytes), dev(o.dev) {
         o.p = nullptr;
         o.n = 0;
+        o.cap_bytes = 0;
     }
     DevBuf &operator=(DevBuf &&o) noexcept {
         if (this != &o) {
@@ -45,16 +173,20 @@ struct DevBuf {
             p = o.p;
             n = o.n;
             own = o.own;
+            cap_bytes = o.cap_bytes;
+            dev = o.dev;
             o.p = nullptr;
             o.n = 0;
+            o.cap_bytes = 0;
         }
         return *this;
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p && own) (void)hipFree(p);
+        if (p && own) DevPool::get().give(dev, p, cap_bytes);
         p = nullptr;
         n = 0;
+        cap_bytes = 0;
         own = true;
     }
     void alias(const DevBuf &o) {
@@ -71,7 +203,25 @@ struct DevBuf {
         release();
         n = count;
         if (count == 0) count = 1;
-        IRH_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+        const size_t bytes = DevPool::round_up(count * sizeof(T));
+        IRH_CHECK(hipGetDevice(&dev));
+        size_t got = 0;
+        if (void *q = DevPool::get().take(dev, bytes, &got)) {
+            p = (T *)q;
+            cap_bytes = got;
+            return;
+        }
+        hipError_t e = hipMalloc((void **)&p, bytes);
+        if (e != hipSuccess && DevPool::get().trim() > 0) {  // out of memory: give the cache back first
+            (void)hipGetLastError();
+            e = hipMalloc((void **)&p, bytes);
+        }
+        if (e != hipSuccess) {
+            p = nullptr;
+            n = 0;
+            IRH_CHECK(e);
+        }
+        cap_bytes = bytes;
     }
     void upload(const T *h, size_t count, hipStream_t s) {
         if (count > n) alloc(count);

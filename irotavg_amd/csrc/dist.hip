@@ -488,7 +488,7 @@ int irotavg_dist_create(irotavg_dist **out, int world, int rank, const void *uni
         if (D.opt.pcg_max_iters <= 0) D.opt.pcg_max_iters = 2000;
         if (D.opt.pcg_check_every <= 0) D.opt.pcg_check_every = 8;
         if (D.opt.device >= 0) IRH_CHECK(hipSetDevice(D.opt.device));
-        IRH_CHECK(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
+        D.stream = StreamPool::get().take();
         D.world = world;
         D.m = m;
         D.n_total = n_total;
@@ -533,7 +533,7 @@ void irotavg_dist_destroy(irotavg_dist *h) {
     for (auto &sp : D.shards) sp->g.stream = nullptr;  // shards share D.stream
     D.shards.clear();
     if (D.comm) (void)ncclCommDestroy(D.comm);
-    if (D.stream) (void)hipStreamDestroy(D.stream);
+    if (D.stream) StreamPool::get().give(D.stream);
     delete h;
 }
 

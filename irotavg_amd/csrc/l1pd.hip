@@ -487,7 +487,7 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
     q.f = g.f; q.nu = g.nu; q.ng = g.ng; q.no = g.no;
     q.opt = g.opt;
     q.device = g.device;
-    IRH_CHECK(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+    q.stream = StreamPool::get().take();
     hipStream_t s = q.stream;
     q.ei.alias(g.ei); q.ej.alias(g.ej); q.eflag.alias(g.eflag);
     q.qq.alias(g.qq); q.er.alias(g.er); q.dw.alias(g.dw); q.Q.alias(g.Q);
@@ -525,7 +525,7 @@ static void destroy_clone_streams(Graph &g) {
     for (auto &c : g.l1_clones)
         if (c && c->stream) {
             (void)hipStreamSynchronize(c->stream);
-            (void)hipStreamDestroy(c->stream);
+            StreamPool::get().give(c->stream, g.device);
             c->stream = nullptr;
         }
 }

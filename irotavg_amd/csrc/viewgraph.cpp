@@ -11,8 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
-#include <map>
-#include <set>
+#include <cstdlib>
 #include <vector>
 
 #include "graph.hpp"
@@ -77,7 +76,15 @@ void quat2rmat(const double qin[4], double *R) {
 struct irotavg_viewgraph {
     std::vector<Mat3> pose;                      // absolute rotation per view (Pose::R)
     std::vector<char> fixed;                     // m_fixed_mask
-    std::vector<std::map<int, Mat3>> conn;       // per view: neighbour id -> R_ij of the pair (min,max)
+    std::vector<int> mark;                       // rot_avg scratch: view id -> row, -1 outside a call
+    // per view j: its connections to LOWER ids i < j (the only direction rot_avg walks, :1290-1300),
+    // ascending i, with R_ij and its quaternion (converted once, at connect time)
+    struct Conn {
+        int i;
+        Mat3 R;
+        double q[4];
+    };
+    std::vector<std::vector<Conn>> conn;
     irotavg_options opt;
     irotavg_rotavg_info last{};
     irh::WindowSolver *win = nullptr;  // persistent staging of the single-kernel window solve
@@ -115,6 +122,7 @@ int irotavg_viewgraph_add_view(irotavg_viewgraph *vg, const double R[9]) {
     }
     vg->pose.push_back(M);
     vg->fixed.push_back(0);
+    vg->mark.push_back(-1);
     vg->conn.emplace_back();
     return (int)vg->pose.size() - 1;
 }
@@ -126,11 +134,16 @@ int irotavg_viewgraph_num_views(const irotavg_viewgraph *vg) { return vg ? (int)
 int irotavg_viewgraph_connect(irotavg_viewgraph *vg, int a, int b, const double Rij[9]) {
     if (!vg || !Rij || a == b || a < 0 || b < 0 || a >= (int)vg->pose.size() || b >= (int)vg->pose.size())
         return IROTAVG_ERR_BAD_ARG;
-    if (vg->conn[a].count(b)) return 0;
-    Mat3 M;
-    std::copy(Rij, Rij + 9, M.m);
-    vg->conn[a][b] = M;
-    vg->conn[b][a] = M;
+    const int lo = std::min(a, b), hi = std::max(a, b);
+    auto &list = vg->conn[hi];
+    auto it = std::lower_bound(list.begin(), list.end(), lo,
+                               [](const irotavg_viewgraph::Conn &c, int key) { return c.i < key; });
+    if (it != list.end() && it->i == lo) return 0;
+    irotavg_viewgraph::Conn c;
+    c.i = lo;
+    std::copy(Rij, Rij + 9, c.R.m);
+    rmat2quat(c.R.m, c.q);
+    list.insert(it, c);
     return 1;
 }
 
@@ -167,6 +180,14 @@ int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]
 int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotavg_info *info) {
     if (!vg || win_size <= 2) return IROTAVG_ERR_BAD_ARG;  // assert(winSize > 2) :1265
     irotavg_rotavg_info loc{};
+    const bool timing = std::getenv("IROTAVG_ROTAVG_TIMING") != nullptr;
+    double tl = irh::now_seconds();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t = irh::now_seconds();
+        std::fprintf(stderr, "[rot_avg] %-28s %8.3f ms\n", what, 1e3 * (t - tl));
+        tl = t;
+    };
     const long m = (long)vg->pose.size();
     int win = (int)std::min<long>(m, win_size);  // :1269
     if (win < 2) {
@@ -174,25 +195,36 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
         if (info) *info = loc;
         return IROTAVG_OK;  // :1270-1273
     }
-    // ---- local connections (:1282-1307): for the last `win` views, edges with i < j
+    // ---- local connections (:1282-1307): for the last `win` views, edges with i < j.
+    // `vertices` of the reference is a std::set<int> (ascending ids); here: a mark array + sort.
     std::vector<int32_t> I;
     std::vector<double> qq;  // per edge [x y z w]
-    std::set<int> vertices;
+    std::vector<int> vertices;
+    std::vector<int> &v2i = vg->mark;  // -1 unseen, -2 seen, >= 0 row in Q after relabelling
+    struct Unmark {  // the scratch map is persistent (O(window) work per call): restore on exit
+        std::vector<int> &map;
+        std::vector<int> &touched;
+        ~Unmark() {
+            for (int x : touched) map[x] = -1;
+        }
+    } unmark{v2i, vertices};
+    auto touch = [&](int x) {
+        if (v2i[x] == -1) {
+            v2i[x] = -2;
+            vertices.push_back(x);
+        }
+    };
     for (long t = m - win; t < m; t++) {
         const int j = (int)t;  // frame id == view index (src/IRotAvg.cpp:280-284)
-        for (const auto &kv : vg->conn[j]) {
-            const int i = kv.first;
-            if (i < j) {
-                I.push_back(i);
-                I.push_back(j);
-                vertices.insert(i);
-                vertices.insert(j);
-                double q[4];
-                rmat2quat(kv.second.m, q);
-                qq.insert(qq.end(), q, q + 4);
-            }
+        for (const auto &c : vg->conn[j]) {
+            I.push_back(c.i);
+            I.push_back(j);
+            touch(c.i);
+            touch(j);
+            qq.insert(qq.end(), c.q, c.q + 4);
         }
     }
+    std::sort(vertices.begin(), vertices.end());
     const long ne = (long)qq.size() / 4, nv = (long)vertices.size();
     if (ne < win) {  // :1313-1316
         loc.skipped = 2;
@@ -208,7 +240,6 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     int f = (int)nv - win;
     for (int x : vertices)
         if (x >= m - win && vg->fixed[x]) f++;
-    std::map<int, int> v2i;
     std::vector<int> i2v((size_t)nv);
     int t = 0, k = f;
     for (int x : vertices) {
@@ -245,6 +276,7 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     std::vector<double> QQ((size_t)4 * ne);
     for (long e = 0; e < ne; e++)
         for (int c = 0; c < 4; c++) QQ[(size_t)c * ne + e] = qq[(size_t)4 * e + c];
+    lap("window extraction + packing");
     // ---- solve (:1396-1417): no init_mst (refine from the current poses); l1ra 100 iterations,
     // then irls Geman-McClure, sigma 5 deg, 100 iterations, change_th 1e-3
     const double change_th = .001;
@@ -272,13 +304,18 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
         rc = irotavg_graph_create(&g, ne, nv, f, I.data(), QQ.data(), ne, &vg->opt);
         if (rc != IROTAVG_OK) return rc;
         rc = irotavg_graph_set_rotations(g, Q.data(), nv);
+        lap("graph create + upload");
         if (rc == IROTAVG_OK)
             rc = irotavg_graph_l1ra(g, 100, change_th, &loc.l1_iters, &loc.l1_runtime, nullptr);
+        lap("l1ra");
         if (rc == IROTAVG_OK)
             rc = irotavg_graph_irls(g, IROTAVG_GEMAN_MCCLURE, 5 * M_PI / 180.0, 100, change_th,
                                     &loc.irls_iters, &loc.irls_runtime, nullptr);
+        lap("irls");
         if (rc == IROTAVG_OK) rc = irotavg_graph_get_rotations(g, Q.data(), nv);
+        lap("download");
         irotavg_graph_destroy(g);
+        lap("destroy");
     }
     loc.n_views = (int)nv;
     loc.n_edges = (int)ne;
@@ -292,6 +329,7 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
         const double q[4] = {Q[r], Q[nv + r], Q[2 * nv + r], Q[3 * nv + r]};
         quat2rmat(q, vg->pose[i2v[r]].m);
     }
+    lap("write-back");
     vg->last = loc;
     if (info) *info = loc;
     return IROTAVG_OK;

@@ -1026,7 +1026,7 @@ struct WindowSolver {
     bool attr_set = false;
     ~WindowSolver() {
         if (host) (void)hipHostFree(host);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) StreamPool::get().give(stream);
     }
 };
 
@@ -1054,7 +1054,7 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
     if (!window_fits(nv, f, ne)) return IROTAVG_ERR_BAD_ARG;
     if (kernel == 2 && !window_fits_wave(nv, f, ne)) return IROTAVG_ERR_BAD_ARG;
     const bool wave = kernel == 2 || (kernel == 0 && window_fits_wave(nv, f, ne));
-    if (!ws.stream) IRH_CHECK(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
+    if (!ws.stream) ws.stream = StreamPool::get().take();
     const size_t oI = 0, oQQ = oI + sizeof(int2) * (size_t)WIN_MAX_NE;
     const size_t oQ = oQQ + sizeof(double4) * (size_t)WIN_MAX_NE;
     const size_t oW = oQ + sizeof(double4) * (size_t)WIN_MAX_NV;

@@ -311,3 +311,29 @@ def test_bad_inputs_are_rejected():
     with pytest.raises(capi.IrotavgError) as e:
         capi.Graph(np.array([[0, 1]], dtype=np.int32), QQ[:1], 2, 2)          # no free view
     assert e.value.code == capi.ERR_BAD_ARG
+
+
+def test_handle_churn_reuses_device_memory_without_changing_results(syn):
+    """Buffers of destroyed handles are cached and handed to the next handle (DevPool): a solve on
+    recycled (dirty) memory gives bitwise the result of the first one; irotavg_trim_memory returns
+    the cache to the driver."""
+    G0, Qm = syn
+    m = len(G0["I"])
+
+    def one_shot(cost):
+        Q, w = Qm.copy(order="F"), np.ones(m)
+        it, _ = ral.irls(G0["QQ"], G0["I"], None, cost, SIG, Q, 1, 100, 1e-3, w)
+        return it, Q, w
+
+    capi.trim_memory()
+    first = one_shot(4)
+    outs = [one_shot(c) for c in (1, 4)]               # the L1 solve dirties the recycled blocks
+    assert outs[1][0] == first[0]
+    np.testing.assert_array_equal(outs[1][1], first[1])
+    np.testing.assert_array_equal(outs[1][2], first[2])
+    Qa, Qb = Qm.copy(order="F"), Qm.copy(order="F")
+    ral.l1ra(G0["QQ"], G0["I"], None, Qa, 1, 100, 1e-3)
+    ral.l1ra(G0["QQ"], G0["I"], None, Qb, 1, 100, 1e-3)
+    np.testing.assert_array_equal(Qa, Qb)
+    assert capi.trim_memory() > 0                      # the one-shot calls left their buffers cached
+    assert capi.trim_memory() == 0
