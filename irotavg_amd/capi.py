@@ -48,7 +48,7 @@ class Stats(C.Structure):
                 ("outer_iters", C.c_int64), ("edge_updates", C.c_int64),
                 ("seconds_irls", C.c_double), ("seconds_l1ra", C.c_double), ("levels", C.c_int),
                 ("level_rows", C.c_int64 * 16), ("level_nnz", C.c_int64 * 16),
-                ("last_relres", C.c_double * 3)]
+                ("last_relres", C.c_double * 3), ("pcg_stagnated", C.c_int64)]
 
 
 class RotAvgInfo(C.Structure):

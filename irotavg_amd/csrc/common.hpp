@@ -237,6 +237,11 @@ constexpr int kBlock = 1024;   // threads of the single-workgroup coarse-cycle k
 constexpr int kRowBlock = 256;  // threads per workgroup of the row / edge / vector kernels (4 waves)
 constexpr int kMaxParts = 512;  // dot-product partials (= max grid of a reducing kernel)
 constexpr int kMaxLevels = 16;
+// A pivot of a dense elimination that is not above kDeadTol x the largest diagonal entry of the
+// matrix (the scale of the rounding errors in every Schur complement) is "dead": the unknown
+// solves to 0. That is an isolated view, or the last view of a component that no weighted edge
+// ties to a fixed view -- what SPQR's rank detection / the oracle's Cholesky decide, too.
+constexpr double kDeadTol = 1e-13;
 constexpr int kSellUnroll = 8;  // slice widths are multiples of this (batch size of the row loops)
 
 // per-edge flag bits (host-built; see build.cpp)

@@ -30,8 +30,15 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 // E (npad x npad, row-major, zeroed beforehand) from the SELL level: E = diag + offdiag;
 // identity on the padding rows. One lane per row: a row's entries are written by its owner only.
 __global__ __launch_bounds__(kRowBlock) void k_dense_build(LevelView C, int npad,
-                                                           double *__restrict__ E) {
+                                                           double *__restrict__ E,
+                                                           double *__restrict__ maxdiag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    {   // largest diagonal entry (zeroed beforehand; non-negative doubles order like their bits)
+        double dm = (i < C.n) ? fmax(C.diag[i], 0.0) : 0.0;
+        for (int o = 32; o > 0; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+        if ((threadIdx.x & 63) == 0 && dm > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long *>(maxdiag), (unsigned long long)__double_as_longlong(dm));
+    }
     if (i >= npad) return;
     double *row = E + (size_t)i * npad;
     if (i >= C.n) {
@@ -51,11 +58,12 @@ __global__ __launch_bounds__(kRowBlock) void k_dense_build(LevelView C, int npad
 // panel kernel of block step k: every workgroup inverts D = A_kk (32 x 32) by itself -- ONE wave,
 // one lane per row, the row in registers, 32 fully unrolled scalar Gauss-Jordan steps with the
 // pivot row broadcast by lane reads: no barriers, ~3 us (a barrier-per-step LDS version costs
-// ten times that, and this sits on the critical path of all npad/32 steps). A non-positive pivot
-// zeroes its row/column: that unknown solves to 0. Then the workgroup builds a 32 x 64 chunk of
+// ten times that, and this sits on the critical path of all npad/32 steps). A pivot not above
+// kDeadTol x the largest diagonal entry zeroes its row/column: that unknown solves to 0. Then the workgroup builds a 32 x 64 chunk of
 // Rt, or copies a 64 x 32 chunk of the column panel C.
 __global__ __launch_bounds__(256) void k_gj_panel(int npad, int k0, const double *__restrict__ A,
-                                                  double *__restrict__ Wr, double *__restrict__ Wc) {
+                                                  double *__restrict__ Wr, double *__restrict__ Wc,
+                                                  const double *__restrict__ maxdiag) {
     const int nchunk = npad / GJT;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nchunk) {  // column panel copy
@@ -75,10 +83,12 @@ __global__ __launch_bounds__(256) void k_gj_panel(int npad, int k0, const double
         double d[GJB];
 #pragma unroll
         for (int j = 0; j < GJB; j++) d[j] = A[(size_t)(k0 + l) * npad + k0 + j];
+        // dead-pivot threshold: kDeadTol (common.hpp) x the largest diagonal entry of E
+        const double thr = kDeadTol * maxdiag[0];
 #pragma unroll
         for (int k = 0; k < GJB; k++) {
             const double piv = readlane_d(d[k], k);
-            const double ip = piv > 0.0 ? 1.0 / piv : 0.0;
+            const double ip = (piv > thr && piv > 0.0) ? 1.0 / piv : 0.0;
             const double ck = (l == k) ? 0.0 : d[k];
 #pragma unroll
             for (int j = 0; j < GJB; j++) {
@@ -247,12 +257,14 @@ void dense_refresh(Graph &g) {
     const int npad = g.ndense_pad;
     LevelView V{C.n, C.nsl, C.agg, C.sl_off.p, C.sl_near.p, C.col.p, C.val.p, C.diag.p, C.idg.p};
     IRH_CHECK(hipMemsetAsync(g.dense_inv.p, 0, sizeof(double) * (size_t)npad * npad, g.stream));
+    if (g.dense_maxdiag.n < 1) g.dense_maxdiag.alloc(1);
+    IRH_CHECK(hipMemsetAsync(g.dense_maxdiag.p, 0, sizeof(double), g.stream));
     hipLaunchKernelGGL(k_dense_build, dim3((npad + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,
-                       g.stream, V, npad, g.dense_inv.p);
+                       g.stream, V, npad, g.dense_inv.p, g.dense_maxdiag.p);
     const int nchunk = npad / GJT;
     for (int k0 = 0; k0 < npad; k0 += GJB) {
         hipLaunchKernelGGL(k_gj_panel, dim3(2 * nchunk), dim3(256), 0, g.stream, npad, k0,
-                           g.dense_inv.p, g.dense_wr.p, g.dense_wc.p);
+                           g.dense_inv.p, g.dense_wr.p, g.dense_wc.p, g.dense_maxdiag.p);
         hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
                            g.dense_inv.p, g.dense_wr.p, g.dense_wc.p);
     }

@@ -44,6 +44,7 @@ struct Graph {
     bool dense_valid = false, dense_fresh = false;
     double dense_scale = 1.0, stale_spread = 1.1;
     DevBuf<double> dense_ref_diag, dense_ref_val;  // coarse operator the current inverse was computed from
+    DevBuf<double> dense_maxdiag;                  // largest diagonal entry of that operator (dead-pivot scale)
     int64_t iters_after_refresh = 0;
     int additive_top = 1;  // level 0 enters the preconditioner additively (no fine matrix pass)
 

@@ -576,8 +576,10 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
             g.stats.pcg_solves += q.stats.pcg_solves;
             g.stats.pcg_iters += q.stats.pcg_iters;
             g.stats.pcg_iters_last = q.stats.pcg_iters_last;
+            g.stats.pcg_stagnated += q.stats.pcg_stagnated;
             q.stats.pcg_solves = 0;
             q.stats.pcg_iters = 0;
+            q.stats.pcg_stagnated = 0;
         }
         if (rc != IROTAVG_OK) break;
         hipLaunchKernelGGL(k_pack3, dim3(grid_elems(n)), dim3(kRowBlock), 0, g.stream, n,

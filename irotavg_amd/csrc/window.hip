@@ -76,9 +76,14 @@ __device__ __forceinline__ double wg_max(double v, double *red) {
 // solution 0), like the oracle's sparse Cholesky. Returns false if a non-finite value appears.
 __device__ bool dense_solve(double *H, int n, double *B, int nrhs, double *red) {
     const int ld = n + 1;
+    // dead-pivot threshold: kDeadTol (common.hpp) x the largest original diagonal entry
+    __syncthreads();
+    double dm = 0.0;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) dm = fmax(dm, H[k * ld + k]);
+    const double thr0 = kDeadTol * wg_max(dm, red);
     for (int k = 0; k < n; k++) {
         const double piv = H[k * ld + k];
-        const bool dead = !(piv > 0.0);
+        const bool dead = !(piv > thr0) || !(piv > 0.0);
         const double ip = dead ? 0.0 : 1.0 / piv;
         __syncthreads();
         // scale row k (entries j > k and the right-hand sides)
@@ -625,11 +630,16 @@ __device__ __forceinline__ double sm_ax(const SmLane &E, double x) {
 // solution 0), like dense_solve above / the oracle's Cholesky. False if a non-finite value appears.
 __device__ __forceinline__ bool sm_solve(double (&h)[SM_MAX_NU], double &b, int nu, int lane) {
     double myip = 0.0;
+    double dg = 0.0;  // own original diagonal entry
+#pragma unroll
+    for (int c = 0; c < SM_MAX_NU; c++)
+        if (c == lane) dg = h[c];
+    const double thr = kDeadTol * wv_max(lane < nu ? dg : 0.0);  // relative to the largest one
 #pragma unroll
     for (int k = 0; k < SM_MAX_NU; k++) {
         if (k < nu) {
             const double piv = rl_d(h[k], k);
-            const double ip = (piv > 0.0) ? 1.0 / piv : 0.0;
+            const double ip = (piv > thr && piv > 0.0) ? 1.0 / piv : 0.0;
             const bool me = lane == k;
             if (me) myip = ip;
             const double mult = me ? 0.0 : -(h[k] * ip);

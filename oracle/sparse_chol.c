@@ -15,11 +15,15 @@
  * (George & Liu; Davis, "Direct Methods for Sparse Linear Systems", ch. 4), written from
  * scratch.
  *
- * A zero (or negative/NaN) pivot marks the variable "dead": its row/column is dropped and the
- * variable solves to 0, mimicking the basic solution SPQR returns for a structurally dead
- * column. The number of dead pivots is reported so callers can treat it as a breakdown.
+ * A pivot that is not above ORA_DEAD_TOL times the LARGEST diagonal entry of the matrix (or is
+ * NaN) marks the variable "dead": its row/column is dropped and the variable solves to 0, mimicking the basic
+ * solution SPQR returns for a column it finds dependent (rank detection with a relative
+ * tolerance): an isolated view, or one view of a component that no surviving edge ties to a
+ * fixed view. The number of dead pivots is reported so callers can treat it as a breakdown.
  */
 #include "sparse_chol.h"
+
+#define ORA_DEAD_TOL 1e-13
 
 #include <math.h>
 #include <stdlib.h>
@@ -238,10 +242,15 @@ long ora_chol_factor(ora_chol *c, const long *Ap, const long *Ai, const double *
     long ndead = 0;
     permute_upper(n, Ap, Ai, Ax, c->iperm, c->Cp, c->Ci, c->Cx);
     /* permute_upper may list duplicate (i,j) entries; they are summed by the scatter below */
+    double dmax = 0.0; /* largest diagonal entry: the scale of the rounding in every pivot */
     for (long k = 0; k < n; k++) {
         flag[k] = -1;
         fillpos[k] = c->Lp[k];
         c->dead[k] = 0;
+        double d = 0.0;
+        for (long p = c->Cp[k]; p < c->Cp[k + 1]; p++)
+            if (c->Ci[p] == k) d += c->Cx[p];
+        if (d > dmax) dmax = d;
     }
     for (long k = 0; k < n; k++) {
         long top = row_reach(k, c->Cp, c->Ci, c->parent, n, stack, path, flag);
@@ -270,7 +279,7 @@ long ora_chol_factor(ora_chol *c, const long *Ap, const long *Ai, const double *
         }
         long p = fillpos[k]++;
         c->Li[p] = k;
-        if (!(d > 0.0) || !isfinite(d)) { /* dead pivot */
+        if (!(d > ORA_DEAD_TOL * dmax) || !(d > 0.0) || !isfinite(d)) { /* dead pivot */
             c->dead[k] = 1;
             c->Lx[p] = 1.0;
             ndead++;

@@ -337,3 +337,33 @@ def test_handle_churn_reuses_device_memory_without_changing_results(syn):
     np.testing.assert_array_equal(Qa, Qb)
     assert capi.trim_memory() > 0                      # the one-shot calls left their buffers cached
     assert capi.trim_memory() == 0
+
+
+def test_floating_component_is_gauge_fixed_not_an_error():
+    """Edge (2,0) has its SECOND endpoint fixed, so make_A drops its row (ral/l1_irls.cpp:770-771)
+    and nothing ties the free views to the fixed one: A'D^2A is singular. SPQR returns a basic
+    solution for that (rank detection with a relative tolerance); here the eliminations declare the
+    pivot that cancels to rounding level dead (kDeadTol x the largest diagonal entry) -- on the
+    handle path, in both window kernels and in the oracle -- so the solve runs instead of dying in
+    IROTAVG_ERR_NOT_CONVERGED. Which view gets pinned is solver-defined: only sanity is checked."""
+    I = np.array([[1, 5], [2, 0], [4, 1], [1, 5], [1, 3], [4, 3], [3, 2]], dtype=np.int32)
+    rng = np.random.default_rng(3)
+    Qgt = rng.normal(size=(6, 4)); Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+    QQ = synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(7, 3))), synth.qmul(Qgt[I[:, 1]], synth.qconj(Qgt[I[:, 0]])))
+    Q0 = synth.qmul(synth.qexp(rng.normal(scale=0.05, size=(6, 3))), Qgt); Q0[0] = Qgt[0]
+    for cost in (0, 3, 4):
+        with capi.Graph(I, QQ, 6, 1) as G:
+            G.set_rotations(Q0)
+            r = G.irls(cost, SIG, 20, 1e-3)
+            Q = G.get_rotations()
+        assert r["iters"] >= 1 and np.isfinite(Q).all()
+        np.testing.assert_array_equal(Q[0], Q0[0])
+        ro = O.irls(QQ, I, Q0, 1, cost, SIG, 20, 1e-3)
+        assert ro["rc"] == 0 and np.isfinite(ro["Q"]).all()
+        # the residuals of the surviving edges are gauge independent: both solvers fit them equally well
+        res_g = O.log_map(O.delta_rel(I, QQ, Q))[np.arange(7) != 1, :3]
+        res_o = O.log_map(O.delta_rel(I, QQ, ro["Q"]))[np.arange(7) != 1, :3]
+        assert abs(np.linalg.norm(res_g) - np.linalg.norm(res_o)) < 1e-3
+        for kern in (1, 2):
+            w = capi.window_solve(I, QQ, Q0, 1, cost, SIG, 0, 20, 1e-3, kernel=kern)
+            assert np.isfinite(w["Q"]).all()
