@@ -57,13 +57,14 @@ typedef struct irotavg_options {
     double mg_omega;     /* damped-Jacobi factor; default 0.7 */
     double mg_kc;        /* coarse-correction scale; default 1.0 */
     int device;          /* HIP device ordinal; -1 = current device */
-    int reserved[7];     /* reserved[0] = 1: multiplicative V-cycle on level 0 (default: additive top level);
-                            reserved[1] = 1: re-invert the dense coarse level at every solve (default: adaptive);
-                            reserved[2] = 1: irotavg_viewgraph_rot_avg never uses the single-kernel window path;
-                            reserved[3]: a solve whose residual has stalled (not halved in 64 iterations:
-                            the attainable accuracy of an ill-conditioned system) is accepted if
-                            ||r||/||b|| <= 1e-6 (0, default) or <= 10^-k (k > 0); -1 = never, such a
-                            solve ends in IROTAVG_ERR_NOT_CONVERGED at pcg_max_iters */
+    int mg_multiplicative_top; /* 1: multiplicative V-cycle on level 0 (default 0: additive top level) */
+    int dense_always_refresh;  /* 1: re-invert the dense coarse level at every solve (default 0: adaptive) */
+    int no_window_kernel;      /* 1: irotavg_viewgraph_rot_avg never uses the single-kernel window path */
+    int pcg_stall_accept;      /* a solve whose residual has stalled (not halved in 64 iterations: the
+                                  attainable accuracy of an ill-conditioned system) is accepted if
+                                  ||r||/||b|| <= 1e-6 (0, default) or <= 10^-k (k > 0); -1 = never: such
+                                  a solve ends in IROTAVG_ERR_NOT_CONVERGED at pcg_max_iters */
+    int reserved[3];           /* must be 0 */
 } irotavg_options;
 
 void irotavg_default_options(irotavg_options *opt);
@@ -81,7 +82,7 @@ typedef struct irotavg_stats {
     int64_t level_rows[16];
     int64_t level_nnz[16];
     double last_relres[3];   /* ||r||/||b|| per column at the end of the last solve */
-    int64_t pcg_stagnated;   /* solves accepted at a stalled residual above pcg_rtol (see reserved[3]) */
+    int64_t pcg_stagnated;   /* solves accepted at a stalled residual above pcg_rtol (see pcg_stall_accept) */
 } irotavg_stats;
 
 /* ---------------------------------------------------------------------------------------------

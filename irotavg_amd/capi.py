@@ -40,7 +40,8 @@ class Options(C.Structure):
     _fields_ = [("pcg_rtol", C.c_double), ("pcg_max_iters", C.c_int), ("pcg_check_every", C.c_int),
                 ("mg_levels_max", C.c_int), ("mg_agg0", C.c_int), ("mg_agg", C.c_int),
                 ("mg_dense_max", C.c_int), ("mg_omega", C.c_double), ("mg_kc", C.c_double),
-                ("device", C.c_int), ("reserved", C.c_int * 7)]
+                ("device", C.c_int), ("mg_multiplicative_top", C.c_int), ("dense_always_refresh", C.c_int),
+                ("no_window_kernel", C.c_int), ("pcg_stall_accept", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class Stats(C.Structure):

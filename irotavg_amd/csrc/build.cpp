@@ -337,7 +337,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         g.dense_wc.alloc((size_t)32 * g.ndense_pad);
         g.dense_ref_diag.alloc((size_t)g.ndense_pad);
     }
-    g.additive_top = g.opt.reserved[0] == 1 ? 0 : 1;
+    g.additive_top = g.opt.mg_multiplicative_top == 1 ? 0 : 1;
     // ---- PCG state ----------------------------------------------------------------------
     const size_t nv0 = (size_t)g.levels[0].nsl * 64 + 64;
     g.X.alloc(nv0 + (size_t)g.ng);

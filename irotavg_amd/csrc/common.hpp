@@ -233,7 +233,6 @@ struct DevBuf {
     }
 };
 
-constexpr int kBlock = 1024;   // threads of the single-workgroup coarse-cycle kernel
 constexpr int kRowBlock = 256;  // threads per workgroup of the row / edge / vector kernels (4 waves)
 constexpr int kMaxParts = 512;  // dot-product partials (= max grid of a reducing kernel)
 constexpr int kMaxLevels = 16;

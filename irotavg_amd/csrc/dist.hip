@@ -397,7 +397,7 @@ static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double chan
     while (score > change_th && it < max_iters) {
         for (auto &sp : D.shards) {
             launch_edge_residual(sp->g);
-            assemble(sp->g, 0, sp->g.dw.p, D.opt.reserved[1] == 1);
+            assemble(sp->g, 0, sp->g.dw.p, D.opt.dense_always_refresh == 1);
         }
         rc = pcg_dist(D);
         if (rc != IROTAVG_OK) break;

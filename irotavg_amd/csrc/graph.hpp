@@ -45,7 +45,6 @@ struct Graph {
     double dense_scale = 1.0, stale_spread = 1.1;
     DevBuf<double> dense_ref_diag, dense_ref_val;  // coarse operator the current inverse was computed from
     DevBuf<double> dense_maxdiag;                  // largest diagonal entry of that operator (dead-pivot scale)
-    int64_t iters_after_refresh = 0;
     int additive_top = 1;  // level 0 enters the preconditioner additively (no fine matrix pass)
 
     // PCG (level-0 sized). levels[0].b is the residual r, levels[0].x the pre-smoothed
@@ -82,7 +81,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
 
 // solver entry points (solver.hip)
 void launch_edge_residual(Graph &g);
-int ls_solve(Graph &g, int seq_index = 0);  // assemble (IRLS weights) + PCG; result in g.X
+int ls_solve(Graph &g);  // assemble (IRLS weights) + PCG; result in g.X
 void launch_update_weights(Graph &g, int cost, double sigma);
 double apply_step(Graph &g);
 int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, int *iters,

@@ -1062,7 +1062,6 @@ int pcg_solve(Graph &g) {
     Level &L0 = g.levels[0];
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     const int gr = grid_for_rows(L0);
-    LevelView V0 = view_of(L0);
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
     launch_update(g, true, 0, gr);
     int h_flags[FL_COUNT] = {0, 0, 0, 0};
@@ -1087,7 +1086,7 @@ int pcg_solve(Graph &g) {
     // the solution (counted in stats.pcg_stagnated) instead of running into the iteration cap --
     // the reference's direct factorisations return whatever accuracy they reach, too.
     constexpr int kStallIters = 64;
-    const int ax = g.opt.reserved[3];
+    const int ax = g.opt.pcg_stall_accept;
     const double accept = ax < 0 ? -1.0 : (ax == 0 ? 1e-6 : std::pow(10.0, -(double)ax));
     double best = HUGE_VAL;
     int best_it = 0;
@@ -1136,11 +1135,9 @@ int pcg_solve(Graph &g) {
 // much as ~25 PCG iterations. After the coarse values are refreshed, dense_is_stale() compares the
 // coarse diagonal with the one the inverse was computed from; the inverse is re-used (rescaled)
 // when the change is a nearly uniform factor. Depends on data only (deterministic).
-int ls_solve(Graph &g, int seq_index) {
-    (void)seq_index;
-    assemble(g, 0, g.dw.p, g.opt.reserved[1] == 1);
+int ls_solve(Graph &g) {
+    assemble(g, 0, g.dw.p, g.opt.dense_always_refresh == 1);
     const int rc = pcg_solve(g);
-    if (g.dense_fresh) g.iters_after_refresh = g.stats.pcg_iters_last;
     return rc;
 }
 
@@ -1168,7 +1165,7 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     fill(g, g.dw.p, (long long)g.mpad, 1.0);  // weights.setOnes() (:577)
     while (score > change_th && it < max_iters) {  // :590, strict >
         launch_edge_residual(g);
-        rc = ls_solve(g, it);
+        rc = ls_solve(g);
         if (rc != IROTAVG_OK) break;
         launch_update_weights(g, cost, sigma);
         score = apply_step(g);
@@ -1192,9 +1189,6 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
     hipEvent_t e0, e1;
     IRH_CHECK(hipEventCreate(&e0));
     IRH_CHECK(hipEventCreate(&e1));
-    Level &L0 = g.levels[0];
-    const int gr = grid_for_rows(L0);
-    LevelView V0 = view_of(L0);
     auto once = [&]() {
         switch (which) {
         case 1: launch_edge_residual(g); break;

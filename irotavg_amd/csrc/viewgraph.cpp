@@ -281,7 +281,7 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     // then irls Geman-McClure, sigma 5 deg, 100 iterations, change_th 1e-3
     const double change_th = .001;
     int rc = IROTAVG_OK;
-    if (vg->opt.reserved[2] != 1 && irh::window_fits((int)nv, f, (int)ne)) {
+    if (vg->opt.no_window_kernel != 1 && irh::window_fits((int)nv, f, (int)ne)) {
         // small (sliding-window) problem: the whole l1ra + irls pipeline in ONE kernel launch
         if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
         try {

@@ -107,7 +107,7 @@ def test_window_quirk_edges_and_limits():
 
 
 def test_rotavg_window_path_equals_general_path_and_is_fast():
-    """rotAvg(10) through the window kernel vs the graph-handle path (reserved[2] = 1)."""
+    """rotAvg(10) through the window kernel vs the graph-handle path (no_window_kernel = 1)."""
     import sys, os
     sys.path.insert(0, os.path.dirname(__file__))
     from test_viewgraph import build_sequence, rot
@@ -117,8 +117,7 @@ def test_rotavg_window_path_equals_general_path_and_is_fast():
     by_new = {}
     for (i, j), R in rel.items():
         by_new.setdefault(j, []).append((i, R))
-    res = (capi.C.c_int * 7)(0, 0, 1, 0, 0, 0, 0)
-    fast, slow = ViewGraph(), ViewGraph(reserved=res)
+    fast, slow = ViewGraph(), ViewGraph(no_window_kernel=1)
     tf = ts = 0.0
     for v in range(n):
         R0 = rot(Qgt[0]) if v == 0 else sorted(by_new[v], key=lambda t: -t[0])[0][1] @ fast.R(v - 1)
