@@ -333,8 +333,8 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         g.ndense_pad = (g.ndense + 63) / 64 * 64;
         g.dense_inv.alloc((size_t)g.ndense_pad * g.ndense_pad);
         g.dense_inv.zero(s);
-        g.dense_wr.alloc((size_t)32 * g.ndense_pad);
-        g.dense_wc.alloc((size_t)32 * g.ndense_pad);
+        g.dense_wr.alloc((size_t)64 * g.ndense_pad);  // two 32 x npad panels (look-ahead ping-pong)
+        g.dense_wc.alloc((size_t)64 * g.ndense_pad);
         g.dense_ref_diag.alloc((size_t)g.ndense_pad);
     }
     g.additive_top = g.opt.mg_multiplicative_top == 1 ? 0 : 1;

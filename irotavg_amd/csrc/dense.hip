@@ -10,7 +10,9 @@
 //   A'_kk = D^-1,  A'_kj = D^-1 A_kj,  A'_ik = -A_ik D^-1,  A'_ij = A_ij - A_ik D^-1 A_kj.
 // With Rt = [D^-1 A_k,: with its block k replaced by D^-1] and C = A_:,k this is
 //   rows of block k:  A' = Rt;     other rows:  A'_ij = (j in block k ? 0 : A_ij) - C_i Rt_j,
-// i.e. one panel kernel (builds Rt and copies C) + one rank-32 update kernel per step.
+// i.e. a panel (Rt and a copy of C) and a rank-32 update per step. The update kernel of step k also
+// produces the panel of step k+1 (look-ahead, k_gj_update_la): the serial 32 x 32 inversion then
+// overlaps the bandwidth-bound bulk of the update -- one launch per step instead of two.
 #include "graph.hpp"
 #include "kernels.hpp"
 
@@ -172,6 +174,178 @@ __global__ __launch_bounds__(256) void k_gj_update(int npad, int k0, double *__r
     }
 }
 
+// Update of step k WITH LOOK-AHEAD: the same rank-32 tile update, and in the same launch the panel
+// of step k+1 (what k_gj_panel would compute next) -- the serial D^-1 (~12 us) then overlaps the
+// bandwidth-bound bulk of the update instead of waiting for it:
+//   * workgroup 0 owns the tile that holds D' = A'_{k+1,k+1}; it is dispatched first, updates its
+//     tile, inverts D' and publishes D'^-1 (global `Dg`, then `flag` = step + 1; agent-scope atomics);
+//   * the workgroups of block row k+1 (dispatched next) update their tiles, wait for the flag
+//     (bounded spin) and write their chunk of Rt' = D'^-1 A'_{k+1,cols} into WrN;
+//   * the workgroups of block column k+1 copy their updated 64 x 32 strip into WcN.
+// The producer does not depend on any other workgroup of the launch and is resident before any
+// consumer exists (workgroups are dispatched in blockIdx order): no deadlock.
+__global__ __launch_bounds__(256) void k_gj_update_la(int npad, int k0, double *__restrict__ A,
+                                                      const double *__restrict__ Wr,
+                                                      const double *__restrict__ Wc,
+                                                      double *__restrict__ WrN, double *__restrict__ WcN,
+                                                      double *__restrict__ Dg, int *__restrict__ flag,
+                                                      const double *__restrict__ maxdiag) {
+    __shared__ double Cs[GJT][GJB + 1];
+    __shared__ double Rs[GJB][GJT + 4];
+    const int nt = npad / GJT;
+    const int k1 = k0 + GJB;          // first row/column of block k+1
+    const int tn = k1 / GJT;          // its tile index (rows and columns)
+    int ti, tj;
+    {
+        const int bid = blockIdx.x;
+        if (bid == 0) {
+            ti = tn;
+            tj = tn;
+        } else if (bid < nt) {
+            ti = tn;
+            tj = bid - 1;
+            if (tj >= tn) tj++;
+        } else if (bid < 2 * nt - 1) {
+            tj = tn;
+            ti = bid - nt;
+            if (ti >= tn) ti++;
+        } else {
+            const int r = bid - (2 * nt - 1);
+            ti = r / (nt - 1);
+            tj = r % (nt - 1);
+            if (ti >= tn) ti++;
+            if (tj >= tn) tj++;
+        }
+    }
+    const int r0 = ti * GJT, c0 = tj * GJT;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < GJT * GJB; e += 256) Cs[e / GJB][e % GJB] = Wc[(size_t)(r0 + e / GJB) * GJB + e % GJB];
+    for (int e = tid; e < GJB * GJT; e += 256) Rs[e / GJT][e % GJT] = Wr[(size_t)(e / GJT) * npad + c0 + e % GJT];
+    __syncthreads();
+    const int ty = tid / 16, tx = tid % 16;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < GJB; q++) {
+        double cv[4], rv[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) cv[a] = Cs[ty * 4 + a][q];
+#pragma unroll
+        for (int b = 0; b < 4; b++) rv[b] = Rs[q][tx * 4 + b];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] += cv[a] * rv[b];
+    }
+    double out[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int r = r0 + ty * 4 + a;
+        const bool in_k_row = r >= k0 && r < k0 + GJB;
+        double *arow = A + (size_t)r * npad + c0 + tx * 4;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int c = c0 + tx * 4 + b;
+            if (in_k_row) {
+                out[a][b] = Rs[r - k0][tx * 4 + b];
+            } else {
+                const double old = (c >= k0 && c < k0 + GJB) ? 0.0 : arow[b];
+                out[a][b] = old - acc[a][b];
+            }
+        }
+        *reinterpret_cast<double2 *>(arow) = make_double2(out[a][0], out[a][1]);
+        *reinterpret_cast<double2 *>(arow + 2) = make_double2(out[a][2], out[a][3]);
+    }
+    if (ti != tn && tj != tn) return;
+    // ---- look-ahead part (tiles of block row / block column k+1 only) ----
+    if (tj == tn) {  // column panel of step k+1: the updated 64 x 32 strip, straight from registers
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = c0 + tx * 4 + b;
+                if (c >= k1 && c < k1 + GJB) WcN[(size_t)(r0 + ty * 4 + a) * GJB + (c - k1)] = out[a][b];
+            }
+    }
+    if (ti != tn) return;
+    __syncthreads();  // everyone is done with Cs / Rs of step k
+    // stage the updated rows of block k+1 (32 x 64) in Rs
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int r = r0 + ty * 4 + a;
+        if (r >= k1 && r < k1 + GJB) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) Rs[r - k1][tx * 4 + b] = out[a][b];
+        }
+    }
+    __syncthreads();
+    double(*Dv)[GJB + 1] = Cs;  // D'^-1, 32 x 32 in the first rows of Cs
+    const int want = k0 / GJB + 1;
+    if (blockIdx.x == 0) {  // producer: invert D' (one wave, one lane per row, rows in registers)
+        if (tid < 64) {
+            const int l = tid & 31;
+            double d[GJB];
+#pragma unroll
+            for (int j = 0; j < GJB; j++) d[j] = Rs[l][k1 - c0 + j];
+            const double thr = kDeadTol * maxdiag[0];
+#pragma unroll
+            for (int k = 0; k < GJB; k++) {
+                const double piv = readlane_d(d[k], k);
+                const double ip = (piv > thr && piv > 0.0) ? 1.0 / piv : 0.0;
+                const double ck = (l == k) ? 0.0 : d[k];
+#pragma unroll
+                for (int j = 0; j < GJB; j++) {
+                    const double pr = readlane_d(d[j], k);
+                    const double rk = (j == k) ? ip : pr * ip;
+                    const double od = (j == k) ? 0.0 : d[j];
+                    d[j] = (l == k) ? rk : od - ck * rk;
+                }
+            }
+            if (tid < GJB) {
+#pragma unroll
+                for (int j = 0; j < GJB; j++) {
+                    Dv[l][j] = d[j];
+                    // agent-scope atomic store: coherent across the XCDs' L2s line by line (a
+                    // release fence would write back this XCD's whole L2, an acquire invalidate
+                    // the consumers' -- measured: that eats the whole gain)
+                    __hip_atomic_store(&Dg[l * GJB + j], d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // the same wave publishes the flag once its data stores have completed
+            __builtin_amdgcn_s_waitcnt(0);
+            if (tid == 0) __hip_atomic_store(flag, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    } else {  // consumer: wait for D'^-1 (bounded spin: a lost producer must not hang the GPU)
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < (1 << 24))
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        for (int e = tid; e < GJB * GJB; e += 256)
+            Dv[e / GJB][e % GJB] = __hip_atomic_load(&Dg[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    // Rt' chunk = D'^-1 * A'_{k+1, chunk}; the columns of block k+1 receive D'^-1 itself
+    for (int e = tid; e < GJB * GJT; e += 256) {
+        const int q = e / GJT, c = e % GJT;
+        const int gc = c0 + c;
+        double v;
+        if (gc >= k1 && gc < k1 + GJB) {
+            v = Dv[q][gc - k1];
+        } else {
+            v = 0.0;
+#pragma unroll 8
+            for (int t = 0; t < GJB; t++) v += Dv[q][t] * Rs[t][c];
+        }
+        WrN[(size_t)q * npad + gc] = v;
+    }
+}
+
 // min / max of now[i] / ref[i] over an array (entries that are zero in both are skipped; an entry
 // that is zero in only one of them forces a refresh). One workgroup, fixed-order reduction.
 __global__ __launch_bounds__(1024) void k_value_ratio(long long n, const double *__restrict__ now,
@@ -262,11 +436,35 @@ void dense_refresh(Graph &g) {
     hipLaunchKernelGGL(k_dense_build, dim3((npad + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,
                        g.stream, V, npad, g.dense_inv.p, g.dense_maxdiag.p);
     const int nchunk = npad / GJT;
+    if (nchunk < 2 || std::getenv("IROTAVG_GJ_NO_LOOKAHEAD")) {
+        for (int k0 = 0; k0 < npad; k0 += GJB) {
+            hipLaunchKernelGGL(k_gj_panel, dim3(2 * nchunk), dim3(256), 0, g.stream, npad, k0,
+                               g.dense_inv.p, g.dense_wr.p, g.dense_wc.p, g.dense_maxdiag.p);
+            hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
+                               g.dense_inv.p, g.dense_wr.p, g.dense_wc.p);
+        }
+        return;
+    }
+    // look-ahead sweep: the update of step k also produces the panel of step k+1 (ping-pong panels)
+    const size_t pan = (size_t)32 * npad;
+    if (g.dense_wr.n < 2 * pan) g.dense_wr.alloc(2 * pan);
+    if (g.dense_wc.n < 2 * pan) g.dense_wc.alloc(2 * pan);
+    if (g.dense_la.n < (size_t)GJB * GJB + 8) g.dense_la.alloc((size_t)GJB * GJB + 8);
+    int *flag = reinterpret_cast<int *>(g.dense_la.p + GJB * GJB);
+    IRH_CHECK(hipMemsetAsync(flag, 0, sizeof(int) * 2, g.stream));
+    hipLaunchKernelGGL(k_gj_panel, dim3(2 * nchunk), dim3(256), 0, g.stream, npad, 0, g.dense_inv.p,
+                       g.dense_wr.p, g.dense_wc.p, g.dense_maxdiag.p);
+    int cur = 0;
     for (int k0 = 0; k0 < npad; k0 += GJB) {
-        hipLaunchKernelGGL(k_gj_panel, dim3(2 * nchunk), dim3(256), 0, g.stream, npad, k0,
-                           g.dense_inv.p, g.dense_wr.p, g.dense_wc.p, g.dense_maxdiag.p);
-        hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
-                           g.dense_inv.p, g.dense_wr.p, g.dense_wc.p);
+        double *wr = g.dense_wr.p + cur * pan, *wc = g.dense_wc.p + cur * pan;
+        double *wrn = g.dense_wr.p + (cur ^ 1) * pan, *wcn = g.dense_wc.p + (cur ^ 1) * pan;
+        if (k0 + GJB < npad)
+            hipLaunchKernelGGL(k_gj_update_la, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
+                               g.dense_inv.p, wr, wc, wrn, wcn, g.dense_la.p, flag, g.dense_maxdiag.p);
+        else
+            hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
+                               g.dense_inv.p, wr, wc);
+        cur ^= 1;
     }
 }
 
