@@ -414,6 +414,32 @@ bool dense_is_stale(Graph &g) {
     return false;
 }
 
+// Make `slot` the live inverse (dense_inv, dense_ref_*, dense_scale, dense_valid): the live one is
+// parked under its own number, the requested one (empty = never computed) is brought in.
+void dense_select_slot(Graph &g, int slot) {
+    if (g.ndense <= 0 || slot == g.dense_slot) return;
+    const size_t need = (size_t)std::max(slot, g.dense_slot) + 1;
+    if (g.dense_parked.size() < need) g.dense_parked.resize(need);
+    auto exchange = [&](Graph::DenseSlot &S) {
+        std::swap(S.inv, g.dense_inv);
+        std::swap(S.ref_diag, g.dense_ref_diag);
+        std::swap(S.ref_val, g.dense_ref_val);
+        std::swap(S.scale, g.dense_scale);
+        std::swap(S.valid, g.dense_valid);
+    };
+    exchange(g.dense_parked[g.dense_slot]);  // park the live one
+    Graph::DenseSlot &T = g.dense_parked[slot];
+    if (T.inv.n == 0) {  // first use: same sizes as the parked original
+        const Graph::DenseSlot &O = g.dense_parked[g.dense_slot];
+        T.inv.alloc(O.inv.n);
+        T.ref_diag.alloc(O.ref_diag.n);
+        T.valid = false;
+        T.scale = 1.0;
+    }
+    exchange(T);
+    g.dense_slot = slot;
+}
+
 void dense_refresh(Graph &g) {
     if (g.ndense <= 0) return;
     g.dense_scale = 1.0;

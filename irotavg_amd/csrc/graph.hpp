@@ -45,6 +45,15 @@ struct Graph {
     bool dense_valid = false, dense_fresh = false;
     double dense_scale = 1.0, stale_spread = 1.1;
     DevBuf<double> dense_ref_diag, dense_ref_val;  // coarse operator the current inverse was computed from
+    // parked inverses: l1decode keeps one per primal-dual iteration index, because the Hessian of
+    // PD iteration p of outer iteration t+1 resembles that of (p, t), not that of (p-1, t+1)
+    struct DenseSlot {
+        DevBuf<double> inv, ref_diag, ref_val;
+        double scale = 1.0;
+        bool valid = false;
+    };
+    std::vector<DenseSlot> dense_parked;
+    int dense_slot = 0;  // which slot the live dense_inv / dense_ref_* belong to
     DevBuf<double> dense_maxdiag;                  // largest diagonal entry of that operator (dead-pivot scale)
     int additive_top = 1;  // level 0 enters the preconditioner additively (no fine matrix pass)
 
@@ -115,6 +124,7 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
 bool window_fits_wave(int nv, int f, int ne);
 // dense.hip
 void dense_refresh(Graph &g);
+void dense_select_slot(Graph &g, int slot);
 bool dense_is_stale(Graph &g);
 int dense_apply_grid(const Graph &g);
 void dense_apply(Graph &g, const double4 *b, double4 *y, bool check, bool dot, double *part_dot,

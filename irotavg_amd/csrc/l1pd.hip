@@ -15,6 +15,10 @@
 
 namespace irh {
 
+constexpr int kPdSlots = 2;  // parked dense inverses per solver (pdmaxiter of l1ra is 2)
+constexpr double kPdSpread = 8.0;  // staleness band of a parked primal-dual inverse (IRLS: 1.1)
+
+
 enum PdPlane : int {
     P_Y = 0, P_U, P_AX, P_F1, P_F2, P_L1, P_L2, P_SIGX, P_T1, P_T2, P_ADX, P_DU, P_DL1, P_DL2,
     P_COUNT
@@ -360,6 +364,10 @@ static double fetch_ext(Graph &g, int nparts, bool is_max) {
 
 // One coordinate. y: device pointer (plane of er, or P_Y). Result in pdn plane `xplane`.
 static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, int *stuck) {
+    struct SlotGuard {  // whatever PD slot was last live, the IRLS inverse (slot 0) is live on return
+        Graph &g;
+        ~SlotGuard() { dense_select_slot(g, 0); }
+    } slot_guard{g};
     const double PDTOL = 1e-3, alpha = 0.01, beta = 0.5, mu = 10;  // :231-238
     const long long m = g.m;
     const int n = g.no;
@@ -399,7 +407,17 @@ static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, i
         const double itau = 1.0 / tau;
         hipLaunchKernelGGL(k_pd_sig, dim3(ge), dim3(kRowBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
                            pl(P_L2), itau, pl(P_SIGX), pl(P_T1), pl(P_T2));
-        assemble(g, 1, pl(P_SIGX));
+        // inverse of the same PD iteration of the previous outer iteration, if still close enough
+        // (measured at 100k/2M: the entry ratios against (p, t-1) span 2-20x in the first outer
+        // iterations and <1.5x from the ~7th on; accepting up to kPdSpread costs ~1 PCG iteration
+        // per solve and saves most inversions of a long l1ra run)
+        dense_select_slot(g, std::min(pditer - 1, kPdSlots - 1));
+        {
+            const double keep = g.stale_spread;
+            g.stale_spread = kPdSpread;
+            assemble(g, 1, pl(P_SIGX), g.opt.dense_always_refresh == 1);
+            g.stale_spread = keep;
+        }
         hipLaunchKernelGGL(k_pd_rhs, dim3(gr), dim3(kRowBlock), 0, st, n, L0.nsl, L0.sl_off.p,
                            g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(P_T1), pl(P_T2), itau,
                            L0.b.p);
