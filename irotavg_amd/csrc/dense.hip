@@ -175,26 +175,30 @@ __global__ __launch_bounds__(256) void k_gj_update(int npad, int k0, double *__r
 }
 
 // Update of step k WITH LOOK-AHEAD: the same rank-32 tile update, and in the same launch the panel
-// of step k+1 (what k_gj_panel would compute next) -- the serial D^-1 (~12 us) then overlaps the
-// bandwidth-bound bulk of the update instead of waiting for it:
-//   * workgroup 0 owns the tile that holds D' = A'_{k+1,k+1}; it is dispatched first, updates its
-//     tile, inverts D' and publishes D'^-1 (global `Dg`, then `flag` = step + 1; agent-scope atomics);
-//   * the workgroups of block row k+1 (dispatched next) update their tiles, wait for the flag
-//     (bounded spin) and write their chunk of Rt' = D'^-1 A'_{k+1,cols} into WrN;
-//   * the workgroups of block column k+1 copy their updated 64 x 32 strip into WcN.
-// The producer does not depend on any other workgroup of the launch and is resident before any
-// consumer exists (workgroups are dispatched in blockIdx order): no deadlock.
+// of step k+1 (what k_gj_panel would compute next), so that the serial 32 x 32 inversion overlaps
+// the bandwidth-bound bulk of the update instead of preceding it. No workgroup waits for another:
+//   * every workgroup of block row k+1 (dispatched first) rebuilds D' = A'_{k+1,k+1} itself --
+//     D' = S - C_k[rows k+1] Rt_k[cols k+1], where S is the snapshot of that block taken by the
+//     previous launch (the live block is being overwritten by its owner in this launch) --
+//     inverts it (wave 0) and writes its 32 x 64 chunk of Rt' = D'^-1 A'_{k+1,cols} (block k+1's
+//     own columns receive D'^-1) into WrN;
+//   * the workgroups of block column k+1 copy their updated 64 x 32 strip into WcN;
+//   * the owner of block (k+2, k+2) stores its updated block as the snapshot for the next launch.
+// 42.7 KB of LDS and <= 168 VGPRs: three workgroups per CU, i.e. all tiles of a 2048^2 matrix
+// resident at once (with two per CU the bulk tiles ran in two rounds and cost more than the
+// look-ahead saved).
 __global__ __launch_bounds__(256) void k_gj_update_la(int npad, int k0, double *__restrict__ A,
                                                       const double *__restrict__ Wr,
                                                       const double *__restrict__ Wc,
                                                       double *__restrict__ WrN, double *__restrict__ WcN,
-                                                      double *__restrict__ Dg, int *__restrict__ flag,
+                                                      const double *__restrict__ Sr, double *__restrict__ Sw,
                                                       const double *__restrict__ maxdiag) {
     __shared__ double Cs[GJT][GJB + 1];
-    __shared__ double Rs[GJB][GJT + 4];
+    __shared__ double Rs[GJB][GJT + 4];   // Rt_k chunk; later the updated rows of block k+1
+    __shared__ double Dv[GJB][GJB + 1];   // Rt_k[:, cols k+1], then D', then D'^-1
     const int nt = npad / GJT;
-    const int k1 = k0 + GJB;          // first row/column of block k+1
-    const int tn = k1 / GJT;          // its tile index (rows and columns)
+    const int k1 = k0 + GJB, k2 = k0 + 2 * GJB;  // first row/column of blocks k+1, k+2
+    const int tn = k1 / GJT;                     // tile index of block k+1 (rows and columns)
     int ti, tj;
     {
         const int bid = blockIdx.x;
@@ -219,60 +223,96 @@ __global__ __launch_bounds__(256) void k_gj_update_la(int npad, int k0, double *
     }
     const int r0 = ti * GJT, c0 = tj * GJT;
     const int tid = threadIdx.x;
-    for (int e = tid; e < GJT * GJB; e += 256) Cs[e / GJB][e % GJB] = Wc[(size_t)(r0 + e / GJB) * GJB + e % GJB];
-    for (int e = tid; e < GJB * GJT; e += 256) Rs[e / GJT][e % GJT] = Wr[(size_t)(e / GJT) * npad + c0 + e % GJT];
-    __syncthreads();
+    const bool brow = ti == tn;
     const int ty = tid / 16, tx = tid % 16;
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
-#pragma unroll 4
-    for (int q = 0; q < GJB; q++) {
-        double cv[4], rv[4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) cv[a] = Cs[ty * 4 + a][q];
-#pragma unroll
-        for (int b = 0; b < 4; b++) rv[b] = Rs[q][tx * 4 + b];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) acc[a][b] += cv[a] * rv[b];
-    }
+    // own 4 x 4 old values: issued first, consumed after the rank-32 product
     double out[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-        const int r = r0 + ty * 4 + a;
-        const bool in_k_row = r >= k0 && r < k0 + GJB;
-        double *arow = A + (size_t)r * npad + c0 + tx * 4;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int c = c0 + tx * 4 + b;
-            if (in_k_row) {
-                out[a][b] = Rs[r - k0][tx * 4 + b];
-            } else {
-                const double old = (c >= k0 && c < k0 + GJB) ? 0.0 : arow[b];
-                out[a][b] = old - acc[a][b];
-            }
-        }
-        *reinterpret_cast<double2 *>(arow) = make_double2(out[a][0], out[a][1]);
-        *reinterpret_cast<double2 *>(arow + 2) = make_double2(out[a][2], out[a][3]);
+        const double *arow = A + (size_t)(r0 + ty * 4 + a) * npad + c0 + tx * 4;
+        const double2 v0 = *reinterpret_cast<const double2 *>(arow);
+        const double2 v1 = *reinterpret_cast<const double2 *>(arow + 2);
+        out[a][0] = v0.x;
+        out[a][1] = v0.y;
+        out[a][2] = v1.x;
+        out[a][3] = v1.y;
     }
-    if (ti != tn && tj != tn) return;
-    // ---- look-ahead part (tiles of block row / block column k+1 only) ----
-    if (tj == tn) {  // column panel of step k+1: the updated 64 x 32 strip, straight from registers
+    for (int e = tid; e < GJT * GJB; e += 256) Cs[e / GJB][e % GJB] = Wc[(size_t)(r0 + e / GJB) * GJB + e % GJB];
+    for (int e = tid; e < GJB * GJT; e += 256) Rs[e / GJT][e % GJT] = Wr[(size_t)(e / GJT) * npad + c0 + e % GJT];
+    double snap[4] = {0, 0, 0, 0};  // this thread's 4 entries of the snapshot S (block row k+1 only)
+    if (brow) {
+        for (int e = tid; e < GJB * GJB; e += 256) Dv[e / GJB][e % GJB] = Wr[(size_t)(e / GJB) * npad + k1 + e % GJB];
+#pragma unroll
+        for (int u = 0; u < 4; u++) snap[u] = Sr[tid * 4 + u];
+    }
+    __syncthreads();
+    {
+        double acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+#pragma unroll 4
+        for (int q = 0; q < GJB; q++) {
+            double cv[4], rv[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) cv[a] = Cs[ty * 4 + a][q];
+#pragma unroll
+            for (int b = 0; b < 4; b++) rv[b] = Rs[q][tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] += cv[a] * rv[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int r = r0 + ty * 4 + a;
+            const bool in_k_row = r >= k0 && r < k0 + GJB;
+            double *arow = A + (size_t)r * npad + c0 + tx * 4;
+#pragma unroll
             for (int b = 0; b < 4; b++) {
                 const int c = c0 + tx * 4 + b;
-                if (c >= k1 && c < k1 + GJB) WcN[(size_t)(r0 + ty * 4 + a) * GJB + (c - k1)] = out[a][b];
+                if (in_k_row) {
+                    out[a][b] = Rs[r - k0][tx * 4 + b];
+                } else {
+                    const double old = (c >= k0 && c < k0 + GJB) ? 0.0 : out[a][b];
+                    out[a][b] = old - acc[a][b];
+                }
             }
+            *reinterpret_cast<double2 *>(arow) = make_double2(out[a][0], out[a][1]);
+            *reinterpret_cast<double2 *>(arow + 2) = make_double2(out[a][2], out[a][3]);
+            // hand-overs to the next launch: column panel of block k+1, snapshot of block (k+2, k+2)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = c0 + tx * 4 + b;
+                if (c >= k1 && c < k1 + GJB) WcN[(size_t)r * GJB + (c - k1)] = out[a][b];
+                if (r >= k2 && r < k2 + GJB && c >= k2 && c < k2 + GJB) Sw[(r - k2) * GJB + (c - k2)] = out[a][b];
+            }
+        }
     }
-    if (ti != tn) return;
-    __syncthreads();  // everyone is done with Cs / Rs of step k
-    // stage the updated rows of block k+1 (32 x 64) in Rs
+    if (!brow) return;
+    // ---- look-ahead (block row k+1): D' = S - C_k[rows k+1] * Rt_k[cols k+1], 4 entries per
+    // thread, same summation order as the tile update
+    double dn[4];
+    {
+        const int l = tid / 8, j0 = (tid % 8) * 4;  // entry (l, j0..j0+3); snap[] = S[tid*4..] matches
+        double accd[4] = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int t = 0; t < GJB; t++) {
+            const double cv = Cs[k1 - r0 + l][t];
+#pragma unroll
+            for (int u = 0; u < 4; u++) accd[u] += cv * Dv[t][j0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) dn[u] = snap[u] - accd[u];
+    }
+    __syncthreads();  // all tile updates done (Rs free), all reads of Rt_k[cols k+1] in Dv done
+    {
+        const int l = tid / 8, j0 = (tid % 8) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) Dv[l][j0 + u] = dn[u];
+    }
+    // the updated rows of block k+1 go where the Rt_k chunk was
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int r = r0 + ty * 4 + a;
@@ -282,54 +322,31 @@ __global__ __launch_bounds__(256) void k_gj_update_la(int npad, int k0, double *
         }
     }
     __syncthreads();
-    double(*Dv)[GJB + 1] = Cs;  // D'^-1, 32 x 32 in the first rows of Cs
-    const int want = k0 / GJB + 1;
-    if (blockIdx.x == 0) {  // producer: invert D' (one wave, one lane per row, rows in registers)
-        if (tid < 64) {
-            const int l = tid & 31;
-            double d[GJB];
+    if (tid < 64) {  // invert D': one lane per row, the row in registers, pivot row by lane reads
+        const int l = tid & 31;  // lanes 32..63 mirror lanes 0..31 (keeps the wave uniform)
+        double d[GJB];
 #pragma unroll
-            for (int j = 0; j < GJB; j++) d[j] = Rs[l][k1 - c0 + j];
-            const double thr = kDeadTol * maxdiag[0];
+        for (int j = 0; j < GJB; j++) d[j] = Dv[l][j];
+        const double thr = kDeadTol * maxdiag[0];
 #pragma unroll
-            for (int k = 0; k < GJB; k++) {
-                const double piv = readlane_d(d[k], k);
-                const double ip = (piv > thr && piv > 0.0) ? 1.0 / piv : 0.0;
-                const double ck = (l == k) ? 0.0 : d[k];
+        for (int k = 0; k < GJB; k++) {
+            const double piv = readlane_d(d[k], k);
+            const double ip = (piv > thr && piv > 0.0) ? 1.0 / piv : 0.0;
+            const double ck = (l == k) ? 0.0 : d[k];
 #pragma unroll
-                for (int j = 0; j < GJB; j++) {
-                    const double pr = readlane_d(d[j], k);
-                    const double rk = (j == k) ? ip : pr * ip;
-                    const double od = (j == k) ? 0.0 : d[j];
-                    d[j] = (l == k) ? rk : od - ck * rk;
-                }
+            for (int j = 0; j < GJB; j++) {
+                const double pr = readlane_d(d[j], k);
+                const double rk = (j == k) ? ip : pr * ip;
+                const double od = (j == k) ? 0.0 : d[j];
+                d[j] = (l == k) ? rk : od - ck * rk;
             }
-            if (tid < GJB) {
+        }
+        if (tid < GJB) {
 #pragma unroll
-                for (int j = 0; j < GJB; j++) {
-                    Dv[l][j] = d[j];
-                    // agent-scope atomic store: coherent across the XCDs' L2s line by line (a
-                    // release fence would write back this XCD's whole L2, an acquire invalidate
-                    // the consumers' -- measured: that eats the whole gain)
-                    __hip_atomic_store(&Dg[l * GJB + j], d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            // the same wave publishes the flag once its data stores have completed
-            __builtin_amdgcn_s_waitcnt(0);
-            if (tid == 0) __hip_atomic_store(flag, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < GJB; j++) Dv[l][j] = d[j];
         }
-        __syncthreads();
-    } else {  // consumer: wait for D'^-1 (bounded spin: a lost producer must not hang the GPU)
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < (1 << 24))
-                __builtin_amdgcn_s_sleep(4);
-        }
-        __syncthreads();
-        for (int e = tid; e < GJB * GJB; e += 256)
-            Dv[e / GJB][e % GJB] = __hip_atomic_load(&Dg[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
     }
+    __syncthreads();
     // Rt' chunk = D'^-1 * A'_{k+1, chunk}; the columns of block k+1 receive D'^-1 itself
     for (int e = tid; e < GJB * GJT; e += 256) {
         const int q = e / GJT, c = e % GJT;
@@ -344,6 +361,12 @@ __global__ __launch_bounds__(256) void k_gj_update_la(int npad, int k0, double *
         }
         WrN[(size_t)q * npad + gc] = v;
     }
+}
+
+// snapshot of a 32 x 32 diagonal block (the look-ahead's stable copy of A_{b,b})
+__global__ void k_gj_snapshot(int npad, int b0, const double *__restrict__ A, double *__restrict__ S) {
+    for (int e = threadIdx.x; e < GJB * GJB; e += blockDim.x)
+        S[e] = A[(size_t)(b0 + e / GJB) * npad + b0 + e % GJB];
 }
 
 // min / max of now[i] / ref[i] over an array (entries that are zero in both are skipped; an entry
@@ -472,21 +495,25 @@ void dense_refresh(Graph &g) {
         return;
     }
     // look-ahead sweep: the update of step k also produces the panel of step k+1 (ping-pong panels)
+    // and the snapshot of block (k+2, k+2) for the launch after it (ping-pong snapshots)
     const size_t pan = (size_t)32 * npad;
     if (g.dense_wr.n < 2 * pan) g.dense_wr.alloc(2 * pan);
     if (g.dense_wc.n < 2 * pan) g.dense_wc.alloc(2 * pan);
-    if (g.dense_la.n < (size_t)GJB * GJB + 8) g.dense_la.alloc((size_t)GJB * GJB + 8);
-    int *flag = reinterpret_cast<int *>(g.dense_la.p + GJB * GJB);
-    IRH_CHECK(hipMemsetAsync(flag, 0, sizeof(int) * 2, g.stream));
+    if (g.dense_la.n < (size_t)2 * GJB * GJB) g.dense_la.alloc((size_t)2 * GJB * GJB);
     hipLaunchKernelGGL(k_gj_panel, dim3(2 * nchunk), dim3(256), 0, g.stream, npad, 0, g.dense_inv.p,
                        g.dense_wr.p, g.dense_wc.p, g.dense_maxdiag.p);
+    // step 0 reads the snapshot of block 1 (slot 1) and writes that of block 2 (slot 0)
+    hipLaunchKernelGGL(k_gj_snapshot, dim3(1), dim3(256), 0, g.stream, npad, GJB, g.dense_inv.p,
+                       g.dense_la.p + GJB * GJB);
     int cur = 0;
     for (int k0 = 0; k0 < npad; k0 += GJB) {
         double *wr = g.dense_wr.p + cur * pan, *wc = g.dense_wc.p + cur * pan;
         double *wrn = g.dense_wr.p + (cur ^ 1) * pan, *wcn = g.dense_wc.p + (cur ^ 1) * pan;
+        const int step = k0 / GJB;
+        double *sr = g.dense_la.p + ((step + 1) & 1) * GJB * GJB, *sw = g.dense_la.p + (step & 1) * GJB * GJB;
         if (k0 + GJB < npad)
             hipLaunchKernelGGL(k_gj_update_la, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
-                               g.dense_inv.p, wr, wc, wrn, wcn, g.dense_la.p, flag, g.dense_maxdiag.p);
+                               g.dense_inv.p, wr, wc, wrn, wcn, sr, sw, g.dense_maxdiag.p);
         else
             hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
                                g.dense_inv.p, wr, wc);

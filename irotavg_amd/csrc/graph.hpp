@@ -40,7 +40,7 @@ struct Graph {
     std::vector<Level> levels;
     DevBuf<double> dense_inv;  // explicit inverse of the coarsest level, ndense_pad^2 row-major
     DevBuf<double> dense_wr, dense_wc;  // Gauss-Jordan panels (32 x npad, npad x 32), two of each
-    DevBuf<double> dense_la;            // look-ahead hand-over: next D^-1 (32 x 32) + ready flag
+    DevBuf<double> dense_la;            // look-ahead: two snapshots of upcoming 32 x 32 diagonal blocks
     int ndense = 0, ndense_pad = 0;
     bool dense_valid = false, dense_fresh = false;
     double dense_scale = 1.0, stale_spread = 1.1;
