@@ -29,6 +29,39 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// In-register Gauss-Jordan inversion of a 32 x 32 SPD block: lane l (and its mirror l + 32) holds
+// row l in d[0..31]; pivot rows are broadcast by lane reads. Per pivot and column: two v_readlane
+// and ONE fma (the pivot scaling is folded into the lane's multiplier; the pivot row itself is
+// scaled afterwards under its own exec mask); the reciprocal is v_rcp_f64 + two Newton steps
+// instead of an IEEE division. (Splitting a row over lanes l and l + 32 halves the instruction
+// count but needs ds_bpermute broadcasts: measured 10 % slower -- the LDS round trip sits on the
+// dependent chain.) A pivot not above `thr` is dead: its row and column become zero.
+__device__ __forceinline__ double rcp_newton(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ void gj_invert32(double (&d)[GJB], int l, double thr) {
+#pragma unroll
+    for (int k = 0; k < GJB; k++) {
+        const double piv = readlane_d(d[k], k);
+        const double ip = (piv > thr && piv > 0.0) ? rcp_newton(piv) : 0.0;
+        const bool me = l == k;
+        const double m = me ? 0.0 : d[k] * ip;  // multiple of the pivot row this lane subtracts
+#pragma unroll
+        for (int j = 0; j < GJB; j++) {
+            if (j != k) d[j] = fma(-m, readlane_d(d[j], k), d[j]);
+        }
+        d[k] = me ? ip : -m;
+        if (me) {
+#pragma unroll
+            for (int j = 0; j < GJB; j++)
+                if (j != k) d[j] *= ip;
+        }
+    }
+}
+
 // E (npad x npad, row-major, zeroed beforehand) from the SELL level: E = diag + offdiag;
 // identity on the padding rows. One lane per row: a row's entries are written by its owner only.
 __global__ __launch_bounds__(kRowBlock) void k_dense_build(LevelView C, int npad,
@@ -87,19 +120,7 @@ __global__ __launch_bounds__(256) void k_gj_panel(int npad, int k0, const double
         for (int j = 0; j < GJB; j++) d[j] = A[(size_t)(k0 + l) * npad + k0 + j];
         // dead-pivot threshold: kDeadTol (common.hpp) x the largest diagonal entry of E
         const double thr = kDeadTol * maxdiag[0];
-#pragma unroll
-        for (int k = 0; k < GJB; k++) {
-            const double piv = readlane_d(d[k], k);
-            const double ip = (piv > thr && piv > 0.0) ? 1.0 / piv : 0.0;
-            const double ck = (l == k) ? 0.0 : d[k];
-#pragma unroll
-            for (int j = 0; j < GJB; j++) {
-                const double pr = readlane_d(d[j], k);              // pivot row entry j (pre-update)
-                const double rk = (j == k) ? ip : pr * ip;          // scaled pivot row
-                const double old = (j == k) ? 0.0 : d[j];
-                d[j] = (l == k) ? rk : old - ck * rk;
-            }
-        }
+        gj_invert32(d, l, thr);
         if (tid < GJB) {
 #pragma unroll
             for (int j = 0; j < GJB; j++) D[l][j] = d[j];
@@ -176,23 +197,23 @@ __global__ __launch_bounds__(256) void k_gj_update(int npad, int k0, double *__r
 
 // Update of step k WITH LOOK-AHEAD: the same rank-32 tile update, and in the same launch the panel
 // of step k+1 (what k_gj_panel would compute next), so that the serial 32 x 32 inversion overlaps
-// the bandwidth-bound bulk of the update instead of preceding it. No workgroup waits for another:
+// the update instead of preceding it. No workgroup waits for another:
 //   * every workgroup of block row k+1 (dispatched first) rebuilds D' = A'_{k+1,k+1} itself --
 //     D' = S - C_k[rows k+1] Rt_k[cols k+1], where S is the snapshot of that block taken by the
-//     previous launch (the live block is being overwritten by its owner in this launch) --
-//     inverts it (wave 0) and writes its 32 x 64 chunk of Rt' = D'^-1 A'_{k+1,cols} (block k+1's
-//     own columns receive D'^-1) into WrN;
+//     previous launch (the live block is being overwritten by its owner in this launch) -- and
+//     inverts it on a FIFTH wave while waves 0-3 update the tile (measured: the tile update of
+//     these workgroups competes with 600 others for memory and takes as long as the inversion;
+//     done one after the other the look-ahead gained nothing). Then the workgroup writes its
+//     32 x 64 chunk of Rt' = D'^-1 A'_{k+1,cols} (block k+1's own columns receive D'^-1) to WrN;
 //   * the workgroups of block column k+1 copy their updated 64 x 32 strip into WcN;
 //   * the owner of block (k+2, k+2) stores its updated block as the snapshot for the next launch.
-// 42.7 KB of LDS and <= 168 VGPRs: three workgroups per CU, i.e. all tiles of a 2048^2 matrix
-// resident at once (with two per CU the bulk tiles ran in two rounds and cost more than the
-// look-ahead saved).
-__global__ __launch_bounds__(256) void k_gj_update_la(int npad, int k0, double *__restrict__ A,
-                                                      const double *__restrict__ Wr,
-                                                      const double *__restrict__ Wc,
-                                                      double *__restrict__ WrN, double *__restrict__ WcN,
-                                                      const double *__restrict__ Sr, double *__restrict__ Sw,
-                                                      const double *__restrict__ maxdiag) {
+// 42.7 KB of LDS and <= 128 VGPRs: three 5-wave workgroups per CU, all tiles of a 2048^2 matrix
+// resident at once. In the other workgroups the fifth wave exits at once.
+constexpr int GJ_LA_THREADS = 320;
+__global__ __launch_bounds__(GJ_LA_THREADS, 4) void k_gj_update_la(
+    int npad, int k0, double *__restrict__ A, const double *__restrict__ Wr,
+    const double *__restrict__ Wc, double *__restrict__ WrN, double *__restrict__ WcN,
+    const double *__restrict__ Sr, double *__restrict__ Sw, const double *__restrict__ maxdiag) {
     __shared__ double Cs[GJT][GJB + 1];
     __shared__ double Rs[GJB][GJT + 4];   // Rt_k chunk; later the updated rows of block k+1
     __shared__ double Dv[GJB][GJB + 1];   // Rt_k[:, cols k+1], then D', then D'^-1
@@ -224,29 +245,70 @@ __global__ __launch_bounds__(256) void k_gj_update_la(int npad, int k0, double *
     const int r0 = ti * GJT, c0 = tj * GJT;
     const int tid = threadIdx.x;
     const bool brow = ti == tn;
-    const int ty = tid / 16, tx = tid % 16;
+    const bool inverter = tid >= 256;  // the fifth wave
+    if (inverter && !brow) return;
+    const int nthr = brow ? GJ_LA_THREADS : 256;
+    const int ty = (tid & 255) / 16, tx = tid % 16;
     // own 4 x 4 old values: issued first, consumed after the rank-32 product
     double out[4][4];
+    if (!inverter) {
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const double *arow = A + (size_t)(r0 + ty * 4 + a) * npad + c0 + tx * 4;
-        const double2 v0 = *reinterpret_cast<const double2 *>(arow);
-        const double2 v1 = *reinterpret_cast<const double2 *>(arow + 2);
-        out[a][0] = v0.x;
-        out[a][1] = v0.y;
-        out[a][2] = v1.x;
-        out[a][3] = v1.y;
+        for (int a = 0; a < 4; a++) {
+            const double *arow = A + (size_t)(r0 + ty * 4 + a) * npad + c0 + tx * 4;
+            const double2 v0 = *reinterpret_cast<const double2 *>(arow);
+            const double2 v1 = *reinterpret_cast<const double2 *>(arow + 2);
+            out[a][0] = v0.x;
+            out[a][1] = v0.y;
+            out[a][2] = v1.x;
+            out[a][3] = v1.y;
+        }
     }
-    for (int e = tid; e < GJT * GJB; e += 256) Cs[e / GJB][e % GJB] = Wc[(size_t)(r0 + e / GJB) * GJB + e % GJB];
-    for (int e = tid; e < GJB * GJT; e += 256) Rs[e / GJT][e % GJT] = Wr[(size_t)(e / GJT) * npad + c0 + e % GJT];
+    for (int e = tid; e < GJT * GJB; e += nthr) Cs[e / GJB][e % GJB] = Wc[(size_t)(r0 + e / GJB) * GJB + e % GJB];
+    for (int e = tid; e < GJB * GJT; e += nthr) Rs[e / GJT][e % GJT] = Wr[(size_t)(e / GJT) * npad + c0 + e % GJT];
     double snap[4] = {0, 0, 0, 0};  // this thread's 4 entries of the snapshot S (block row k+1 only)
     if (brow) {
-        for (int e = tid; e < GJB * GJB; e += 256) Dv[e / GJB][e % GJB] = Wr[(size_t)(e / GJB) * npad + k1 + e % GJB];
+        for (int e = tid; e < GJB * GJB; e += nthr) Dv[e / GJB][e % GJB] = Wr[(size_t)(e / GJB) * npad + k1 + e % GJB];
+        if (!inverter) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) snap[u] = Sr[tid * 4 + u];
+            for (int u = 0; u < 4; u++) snap[u] = Sr[tid * 4 + u];
+        }
     }
     __syncthreads();
-    {
+    if (brow) {
+        // D' = S - C_k[rows k+1] * Rt_k[cols k+1]: 4 entries per thread of waves 0-3, same
+        // summation order as the tile update
+        double dn[4] = {0, 0, 0, 0};
+        const int l = (tid & 255) / 8, j0 = (tid % 8) * 4;  // entry (l, j0..j0+3); snap[] matches
+        if (!inverter) {
+            double accd[4] = {0, 0, 0, 0};
+#pragma unroll 4
+            for (int t = 0; t < GJB; t++) {
+                const double cv = Cs[k1 - r0 + l][t];
+#pragma unroll
+                for (int u = 0; u < 4; u++) accd[u] += cv * Dv[t][j0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) dn[u] = snap[u] - accd[u];
+        }
+        __syncthreads();  // all reads of Rt_k[cols k+1] in Dv done
+        if (!inverter) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) Dv[l][j0 + u] = dn[u];
+        }
+        __syncthreads();
+    }
+    if (inverter) {  // invert D' in registers (gj_invert32)
+        const int l = tid & 31;  // lanes 32..63 mirror lanes 0..31 (keeps the wave uniform)
+        double d[GJB];
+#pragma unroll
+        for (int j = 0; j < GJB; j++) d[j] = Dv[l][j];
+        gj_invert32(d, l, kDeadTol * maxdiag[0]);
+        __syncthreads();  // (1) the update waves are done with the Rt_k chunk in Rs
+        if ((tid & 63) < GJB) {
+#pragma unroll
+            for (int j = 0; j < GJB; j++) Dv[l][j] = d[j];
+        }
+    } else {
         double acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -289,66 +351,21 @@ __global__ __launch_bounds__(256) void k_gj_update_la(int npad, int k0, double *
                 if (r >= k2 && r < k2 + GJB && c >= k2 && c < k2 + GJB) Sw[(r - k2) * GJB + (c - k2)] = out[a][b];
             }
         }
-    }
-    if (!brow) return;
-    // ---- look-ahead (block row k+1): D' = S - C_k[rows k+1] * Rt_k[cols k+1], 4 entries per
-    // thread, same summation order as the tile update
-    double dn[4];
-    {
-        const int l = tid / 8, j0 = (tid % 8) * 4;  // entry (l, j0..j0+3); snap[] = S[tid*4..] matches
-        double accd[4] = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int t = 0; t < GJB; t++) {
-            const double cv = Cs[k1 - r0 + l][t];
+        if (!brow) return;
+        __syncthreads();  // (1)
+        // the updated rows of block k+1 go where the Rt_k chunk was
 #pragma unroll
-            for (int u = 0; u < 4; u++) accd[u] += cv * Dv[t][j0 + u];
-        }
+        for (int a = 0; a < 4; a++) {
+            const int r = r0 + ty * 4 + a;
+            if (r >= k1 && r < k1 + GJB) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) dn[u] = snap[u] - accd[u];
-    }
-    __syncthreads();  // all tile updates done (Rs free), all reads of Rt_k[cols k+1] in Dv done
-    {
-        const int l = tid / 8, j0 = (tid % 8) * 4;
-#pragma unroll
-        for (int u = 0; u < 4; u++) Dv[l][j0 + u] = dn[u];
-    }
-    // the updated rows of block k+1 go where the Rt_k chunk was
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int r = r0 + ty * 4 + a;
-        if (r >= k1 && r < k1 + GJB) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) Rs[r - k1][tx * 4 + b] = out[a][b];
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {  // invert D': one lane per row, the row in registers, pivot row by lane reads
-        const int l = tid & 31;  // lanes 32..63 mirror lanes 0..31 (keeps the wave uniform)
-        double d[GJB];
-#pragma unroll
-        for (int j = 0; j < GJB; j++) d[j] = Dv[l][j];
-        const double thr = kDeadTol * maxdiag[0];
-#pragma unroll
-        for (int k = 0; k < GJB; k++) {
-            const double piv = readlane_d(d[k], k);
-            const double ip = (piv > thr && piv > 0.0) ? 1.0 / piv : 0.0;
-            const double ck = (l == k) ? 0.0 : d[k];
-#pragma unroll
-            for (int j = 0; j < GJB; j++) {
-                const double pr = readlane_d(d[j], k);
-                const double rk = (j == k) ? ip : pr * ip;
-                const double od = (j == k) ? 0.0 : d[j];
-                d[j] = (l == k) ? rk : od - ck * rk;
+                for (int b = 0; b < 4; b++) Rs[r - k1][tx * 4 + b] = out[a][b];
             }
         }
-        if (tid < GJB) {
-#pragma unroll
-            for (int j = 0; j < GJB; j++) Dv[l][j] = d[j];
-        }
     }
-    __syncthreads();
+    __syncthreads();  // (2) D'^-1 in Dv, rows of block k+1 in Rs
     // Rt' chunk = D'^-1 * A'_{k+1, chunk}; the columns of block k+1 receive D'^-1 itself
-    for (int e = tid; e < GJB * GJT; e += 256) {
+    for (int e = tid; e < GJB * GJT; e += GJ_LA_THREADS) {
         const int q = e / GJT, c = e % GJT;
         const int gc = c0 + c;
         double v;
@@ -512,7 +529,7 @@ void dense_refresh(Graph &g) {
         const int step = k0 / GJB;
         double *sr = g.dense_la.p + ((step + 1) & 1) * GJB * GJB, *sw = g.dense_la.p + (step & 1) * GJB * GJB;
         if (k0 + GJB < npad)
-            hipLaunchKernelGGL(k_gj_update_la, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
+            hipLaunchKernelGGL(k_gj_update_la, dim3(nchunk * nchunk), dim3(GJ_LA_THREADS), 0, g.stream, npad, k0,
                                g.dense_inv.p, wr, wc, wrn, wcn, sr, sw, g.dense_maxdiag.p);
         else
             hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0,
