@@ -34,8 +34,9 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 // and ONE fma (the pivot scaling is folded into the lane's multiplier; the pivot row itself is
 // scaled afterwards under its own exec mask); the reciprocal is v_rcp_f64 + two Newton steps
 // instead of an IEEE division. (Splitting a row over lanes l and l + 32 halves the instruction
-// count but needs ds_bpermute broadcasts: measured 10 % slower -- the LDS round trip sits on the
-// dependent chain.) A pivot not above `thr` is dead: its row and column become zero.
+// count but needs ds_bpermute broadcasts: measured 10 % slower; publishing the scaled pivot row in
+// LDS and reading it back as broadcast loads: 75 % slower -- the LDS round trip sits on the
+// dependent chain. 13 us for the 32 pivots, measured with s_memtime.) A pivot not above `thr` is dead: its row and column become zero.
 __device__ __forceinline__ double rcp_newton(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(r, fma(-x, r, 1.0), r);
@@ -247,11 +248,31 @@ __global__ __launch_bounds__(GJ_LA_THREADS, 4) void k_gj_update_la(
     const bool brow = ti == tn;
     const bool inverter = tid >= 256;  // the fifth wave
     if (inverter && !brow) return;
-    const int nthr = brow ? GJ_LA_THREADS : 256;
     const int ty = (tid & 255) / 16, tx = tid % 16;
-    // own 4 x 4 old values: issued first, consumed after the rank-32 product
+    // Loads, in the order their consumers sit on the critical path (a wave's loads return in issue
+    // order): what D' needs -- Rt_k[cols k+1], the snapshot, the column panel -- then the row panel
+    // chunk and the tile's own old values, both of which are only waited for after D' is formed.
+    double dvr[4] = {0, 0, 0, 0}, snap[4] = {0, 0, 0, 0}, csr[8], rsr[8];
     double out[4][4];
     if (!inverter) {
+        if (brow) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = tid * 4 + u;
+                dvr[u] = Wr[(size_t)(e / GJB) * npad + k1 + e % GJB];
+                snap[u] = Sr[e];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = tid + 256 * u;
+            csr[u] = Wc[(size_t)(r0 + e / GJB) * GJB + e % GJB];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = tid + 256 * u;
+            rsr[u] = Wr[(size_t)(e / GJT) * npad + c0 + e % GJT];
+        }
 #pragma unroll
         for (int a = 0; a < 4; a++) {
             const double *arow = A + (size_t)(r0 + ty * 4 + a) * npad + c0 + tx * 4;
@@ -262,15 +283,15 @@ __global__ __launch_bounds__(GJ_LA_THREADS, 4) void k_gj_update_la(
             out[a][2] = v1.x;
             out[a][3] = v1.y;
         }
-    }
-    for (int e = tid; e < GJT * GJB; e += nthr) Cs[e / GJB][e % GJB] = Wc[(size_t)(r0 + e / GJB) * GJB + e % GJB];
-    for (int e = tid; e < GJB * GJT; e += nthr) Rs[e / GJT][e % GJT] = Wr[(size_t)(e / GJT) * npad + c0 + e % GJT];
-    double snap[4] = {0, 0, 0, 0};  // this thread's 4 entries of the snapshot S (block row k+1 only)
-    if (brow) {
-        for (int e = tid; e < GJB * GJB; e += nthr) Dv[e / GJB][e % GJB] = Wr[(size_t)(e / GJB) * npad + k1 + e % GJB];
-        if (!inverter) {
+        if (brow) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) snap[u] = Sr[tid * 4 + u];
+            for (int u = 0; u < 4; u++) Dv[(tid * 4 + u) / GJB][(tid * 4 + u) % GJB] = dvr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) Cs[(tid + 256 * u) / GJB][(tid + 256 * u) % GJB] = csr[u];
+        if (!brow) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) Rs[(tid + 256 * u) / GJT][(tid + 256 * u) % GJT] = rsr[u];
         }
     }
     __syncthreads();
@@ -294,6 +315,8 @@ __global__ __launch_bounds__(GJ_LA_THREADS, 4) void k_gj_update_la(
         if (!inverter) {
 #pragma unroll
             for (int u = 0; u < 4; u++) Dv[l][j0 + u] = dn[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) Rs[(tid + 256 * u) / GJT][(tid + 256 * u) % GJT] = rsr[u];
         }
         __syncthreads();
     }
@@ -364,19 +387,25 @@ __global__ __launch_bounds__(GJ_LA_THREADS, 4) void k_gj_update_la(
         }
     }
     __syncthreads();  // (2) D'^-1 in Dv, rows of block k+1 in Rs
-    // Rt' chunk = D'^-1 * A'_{k+1, chunk}; the columns of block k+1 receive D'^-1 itself
-    for (int e = tid; e < GJB * GJT; e += GJ_LA_THREADS) {
-        const int q = e / GJT, c = e % GJT;
-        const int gc = c0 + c;
-        double v;
-        if (gc >= k1 && gc < k1 + GJB) {
-            v = Dv[q][gc - k1];
-        } else {
-            v = 0.0;
+    // Rt' chunk = D'^-1 * A'_{k+1, chunk}; the columns of block k+1 receive D'^-1 itself.
+    // Thread -> row q, columns c8, c8 + 8, ... (conflict-free LDS reads, D'^-1 entry read once per 8)
+    if (!inverter) {
+        const int q = tid / 8, c8 = tid % 8;
+        double rt[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) rt[b] = 0.0;
 #pragma unroll 8
-            for (int t = 0; t < GJB; t++) v += Dv[q][t] * Rs[t][c];
+        for (int t = 0; t < GJB; t++) {
+            const double dq = Dv[q][t];
+#pragma unroll
+            for (int b = 0; b < 8; b++) rt[b] += dq * Rs[t][c8 + 8 * b];
         }
-        WrN[(size_t)q * npad + gc] = v;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int gc = c0 + c8 + 8 * b;
+            if (gc >= k1 && gc < k1 + GJB) rt[b] = Dv[q][gc - k1];
+            WrN[(size_t)q * npad + gc] = rt[b];
+        }
     }
 }
 
