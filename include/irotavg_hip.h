@@ -64,7 +64,8 @@ typedef struct irotavg_options {
                                   attainable accuracy of an ill-conditioned system) is accepted if
                                   ||r||/||b|| <= 1e-6 (0, default) or <= 10^-k (k > 0); -1 = never: such
                                   a solve ends in IROTAVG_ERR_NOT_CONVERGED at pcg_max_iters */
-    int reserved[3];           /* must be 0 */
+    int no_fused_pspmv;        /* 1: keep the PCG p-update and the SpMV as two launches (default 0: fused on one GPU) */
+    int reserved[2];           /* must be 0 */
 } irotavg_options;
 
 void irotavg_default_options(irotavg_options *opt);
@@ -172,7 +173,9 @@ int irotavg_graph_l1decode_pd(irotavg_graph *g, const double *y, int pdmaxiter, 
  * returns the mean milliseconds per launch. which: 1 = K1 edge_residual, 2 = K2 weight update
  * (Geman-McClure), 3 = matrix assembly (all levels, without the dense inversion), 4 = level-0 SpMV
  * (q = L p), 5 = one preconditioner application, 6 = so(3) step kernel (non-destructive variant),
- * 7 = dense coarse-level inversion (blocked Gauss-Jordan). */
+ * 7 = dense coarse-level inversion (blocked Gauss-Jordan), 8 = the PCG p-update fused into the
+ * level-0 SpMV (what a single-GPU solve of a graph without far entries runs instead of 4;
+ * IROTAVG_ERR_BAD_ARG if this graph's PCG does not use it). */
 int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_per_launch);
 
 /* ---------------------------------------------------------------------------------------------

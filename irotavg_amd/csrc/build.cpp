@@ -288,6 +288,8 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         L.val.alloc((size_t)M.len);
         L.val.zero(s);
         if (lev == 0) {
+            g.l0_far_entries = 0;
+            for (int sl = 0; sl < M.nsl; sl++) g.l0_far_entries += (M.sl_off[sl + 1] - M.sl_off[sl]) - M.sl_near[sl];
             std::vector<uint32_t> seid((size_t)M.len, 0xffffffffu);
             for (size_t t = 0; t < slot_eid.size(); t++) seid[M.pos[t]] = slot_eid[t];
             g.slot_eid.upload(seid, s);
@@ -342,6 +344,8 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     const size_t nv0 = (size_t)g.levels[0].nsl * 64 + 64;
     g.X.alloc(nv0 + (size_t)g.ng);
     g.P.alloc(nv0);
+    g.P2.alloc(nv0);
+    g.P2.zero(s);
     g.AP.alloc(nv0);
     g.X.zero(s);
     g.P.zero(s);

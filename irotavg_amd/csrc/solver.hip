@@ -452,6 +452,168 @@ __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const doubl
     block_sum3_store(a0, a1, a2, part_pq + 4 * blockIdx.x);
 }
 
+// The p-update fused into the SpMV (single GPU, additive top level): an empty kernel costs 4.7 us
+// on this machine (dispatch + completion of a dependent launch), the p-update itself 1.6 us. The
+// SpMV loads the window of p its tile needs into LDS anyway; here it FORMS those entries instead,
+// p_new = omega D^-1 r + kc P y1 + beta p_old (same statements as k_pcg_pupdate_add), stores its own
+// 256 rows to Pnew (ping-pong with Pold: other workgroups still read p_old of these rows for their
+// halos). Only for matrices WITHOUT far entries (every neighbour inside the tile window, i.e. no
+// loop closures on level 0): a far entry would need four gathers instead of one.
+template <bool FIRST>
+__global__ __launch_bounds__(kRowBlock) void k_pspmv_dot(
+    LevelView L, int sh, double *__restrict__ scal, int par, const double *__restrict__ part_rz, int np0,
+    const double *__restrict__ part_rz2, int np1, const double4 *__restrict__ R,
+    const double4 *__restrict__ yc, double omega, double kc, const double4 *__restrict__ Pold,
+    double4 *__restrict__ Pnew, double4 *__restrict__ q, double *__restrict__ part_pq,
+    int *__restrict__ flags) {
+    const int done = flags[FL_DONE];
+    __shared__ double wx[kWinLen], wy[kWinLen], wz[kWinLen];
+    double a0 = 0, a1 = 0, a2 = 0;
+    const int ntiles = (L.nsl + 3) / 4;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    const int lane = threadIdx.x & 63;
+    // window inputs of the first tile: requested before beta is reduced
+    double4 r_pre[2], y_pre[2], p_pre[2];
+    double w_pre[2];
+    auto win_load = [&](int t, double4 (&r)[2], double4 (&y)[2], double4 (&po)[2], double (&w)[2]) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo), whi = min(L.n, r0 + 256 + kWinHalo);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = wlo + (int)threadIdx.x + u * kRowBlock;
+            r[u] = y[u] = po[u] = make_double4(0, 0, 0, 0);
+            w[u] = 0.0;
+            if (i < whi && (int)threadIdx.x + u * kRowBlock < kWinLen) {
+                r[u] = R[i];
+                y[u] = yc[i >> sh];
+                w[u] = L.idg[i];
+                if (!FIRST) po[u] = Pold[i];
+            }
+        }
+    };
+    if (t0 < t1) win_load(t0, r_pre, y_pre, p_pre, w_pre);
+    if (done) return;
+    double be[3];
+    {
+        double ra[3], rb[3], rzn[3];
+        load_reduced3(part_rz, np0, ra);
+        load_reduced3(part_rz2, np1, rb);
+        bool finite = true;
+        for (int c = 0; c < 3; c++) {
+            rzn[c] = ra[c] + kc * rb[c];
+            const double rzo = scal[(par ? SC_RZ1 : SC_RZ0) + c];
+            be[c] = (FIRST || !(rzo > 0.0)) ? 0.0 : rzn[c] / rzo;
+            finite = finite && isfinite(rzn[c]);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int c = 0; c < 3; c++) scal[(par ? SC_RZ0 : SC_RZ1) + c] = rzn[c];
+            if (!finite) flags[FL_DONE] = 2;
+        }
+    }
+    auto pnew = [&](const double4 &r, const double4 &y, const double4 &po, double wi) {
+        const double w = omega * wi;
+        double4 p = make_double4(w * r.x + kc * y.x, w * r.y + kc * y.y, w * r.z + kc * y.z, 0.0);
+        if (!FIRST) {
+            p.x += be[0] * po.x;
+            p.y += be[1] * po.y;
+            p.z += be[2] * po.z;
+        }
+        return p;
+    };
+    for (int t = t0; t < t1; t++) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo), whi = min(L.n, r0 + 256 + kWinHalo);
+        const int sl = min(t * 4 + (int)(threadIdx.x >> 6), L.nsl - 1);
+        const bool live = t * 4 + (int)(threadIdx.x >> 6) < L.nsl;
+        const int row = sl * 64 + lane;
+        const int o0 = L.sl_off[sl], wn = L.sl_near[sl];
+        const double d = L.diag[row];
+        double4 rr[2], yy[2], pp[2];
+        double ww[2];
+        if (t == t0) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                rr[u] = r_pre[u];
+                yy[u] = y_pre[u];
+                pp[u] = p_pre[u];
+                ww[u] = w_pre[u];
+            }
+        } else {
+            win_load(t, rr, yy, pp, ww);
+        }
+        __syncthreads();  // the previous tile's readers are done with the window
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int iw = (int)threadIdx.x + u * kRowBlock;
+            if (iw < kWinLen) {
+                const int i = wlo + iw;
+                double4 pv = make_double4(0, 0, 0, 0);
+                if (i < whi) {
+                    pv = pnew(rr[u], yy[u], pp[u], ww[u]);
+                    if (i >= r0 && i < r0 + 256) Pnew[i] = pv;  // own rows of this tile
+                }
+                wx[iw] = pv.x;
+                wy[iw] = pv.y;
+                wz[iw] = pv.z;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            const int2 *__restrict__ c = reinterpret_cast<const int2 *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+            const double2 *__restrict__ v = reinterpret_cast<const double2 *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
+            double s0 = 0, s1 = 0, s2 = 0;
+            constexpr int HB = kSellUnroll / 2;
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2i *__restrict__ cs = reinterpret_cast<const v2i *>(c);
+            const v2d *__restrict__ vs = reinterpret_cast<const v2d *>(v);
+            v2i cc[HB], cn[HB];
+            v2d vv[HB], vn[HB];
+            if (wn > 0) {
+#pragma unroll
+                for (int u = 0; u < HB; u++) {
+                    cc[u] = __builtin_nontemporal_load(&cs[(size_t)u * 64]);
+                    vv[u] = __builtin_nontemporal_load(&vs[(size_t)u * 64]);
+                }
+            }
+            for (int q0 = 0; q0 < wn / 2; q0 += HB) {
+                if (q0 + HB < wn / 2) {
+#pragma unroll
+                    for (int u = 0; u < HB; u++) {
+                        cn[u] = __builtin_nontemporal_load(&cs[(size_t)(q0 + HB + u) * 64]);
+                        vn[u] = __builtin_nontemporal_load(&vs[(size_t)(q0 + HB + u) * 64]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < HB; u++) {
+                    const int i0 = cc[u].x - wlo, i1 = cc[u].y - wlo;
+                    s0 += vv[u].x * wx[i0] + vv[u].y * wx[i1];
+                    s1 += vv[u].x * wy[i0] + vv[u].y * wy[i1];
+                    s2 += vv[u].x * wz[i0] + vv[u].y * wz[i1];
+                }
+#pragma unroll
+                for (int u = 0; u < HB; u++) {
+                    cc[u] = cn[u];
+                    vv[u] = vn[u];
+                }
+            }
+            if (row < L.n) {
+                const int ir = row - wlo;
+                const double px = wx[ir], py = wy[ir], pz = wz[ir];
+                s0 += d * px;
+                s1 += d * py;
+                s2 += d * pz;
+                q[row] = make_double4(s0, s1, s2, 0.0);
+                a0 += px * s0;
+                a1 += py * s1;
+                a2 += pz * s2;
+            }
+        }
+    }
+    block_sum3_store(a0, a1, a2, part_pq + 4 * blockIdx.x);
+}
+
 // r = b - L x for the lane's row, summed over each aggregate of `agg` consecutive lanes:
 // bc = P' r, and the coarse pre-smoothed iterate xc = omega Dc^-1 bc
 __device__ __forceinline__ void down_row(const LevelView &L, int row, const double4 *b,
@@ -1009,8 +1171,9 @@ void launch_spmv(Graph &g) {
                        g.bghost.p, g.bval.p);
 }
 
-void launch_update(Graph &g, bool init, int par, int np_pq) {
+void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *pvec) {
     Level &L0 = g.levels[0];
+    const double4 *P = pvec ? pvec : g.P.p;
     const int nl = (int)g.levels.size();
     if (g.additive_top && nl > 1) {
         Level &L1 = g.levels[1];
@@ -1018,22 +1181,22 @@ void launch_update(Graph &g, bool init, int par, int np_pq) {
         if (init)
             hipLaunchKernelGGL((k_pcg_update_restrict<true>), dim3(grid), dim3(kRowBlock), 0, g.stream,
                                L0.n, L0.nsl, L0.agg, g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, L0.b.p,
-                               g.P.p, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p, g.opt.mg_omega,
+                               P, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p, g.opt.mg_omega,
                                g.part_rr.p, g.part_rz.p, g.flags.p);
         else
             hipLaunchKernelGGL((k_pcg_update_restrict<false>), dim3(grid), dim3(kRowBlock), 0,
                                g.stream, L0.n, L0.nsl, L0.agg, g.scal.p, par, g.part_pq.p, np_pq,
-                               g.X.p + g.ng, L0.b.p, g.P.p, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p,
+                               g.X.p + g.ng, L0.b.p, P, g.AP.p, L0.idg.p, L1.b.p, L1.x.p, L1.idg.p,
                                g.opt.mg_omega, g.part_rr.p, g.part_rz.p, g.flags.p);
     } else {
         const int ge = grid_for_elems(L0.n);
         if (init)
             hipLaunchKernelGGL((k_pcg_update<true>), dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n,
-                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, L0.b.p, g.P.p, g.AP.p,
+                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, L0.b.p, P, g.AP.p,
                                L0.idg.p, L0.x.p, g.opt.mg_omega, g.part_rr.p, g.flags.p);
         else
             hipLaunchKernelGGL((k_pcg_update<false>), dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n,
-                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, L0.b.p, g.P.p, g.AP.p,
+                               g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, L0.b.p, P, g.AP.p,
                                L0.idg.p, L0.x.p, g.opt.mg_omega, g.part_rr.p, g.flags.p);
     }
 }
@@ -1068,12 +1231,32 @@ int pcg_solve(Graph &g) {
     int it = 0;
     const int check = std::max(1, g.opt.pcg_check_every);
     const int maxit = std::max(1, g.opt.pcg_max_iters);
+    // single GPU + additive top level: p-update and SpMV are one launch (k_pspmv_dot), the search
+    // direction ping-pongs between P and P2
+    const bool fused = g.additive_top && g.levels.size() > 1 && g.ng == 0 && g.l0_far_entries == 0 &&
+                       g.opt.no_fused_pspmv != 1;
+    double4 *PP[2] = {g.P.p, g.P2.p};
     auto iteration_tail = [&](const PrecInfo &pi) {
         const int first = (it == 0);
         const int par = it & 1;
-        launch_pupdate(g, par, first, pi);
-        launch_spmv(g);
-        launch_update(g, false, par ^ 1, gr);
+        if (fused) {
+            const int sh = __builtin_ctz((unsigned)L0.agg);
+            if (first)
+                hipLaunchKernelGGL((k_pspmv_dot<true>), dim3(gr), dim3(kRowBlock), 0, g.stream, view_of(L0), sh,
+                                   g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, L0.b.p,
+                                   g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, PP[par], PP[par ^ 1],
+                                   g.AP.p, g.part_pq.p, g.flags.p);
+            else
+                hipLaunchKernelGGL((k_pspmv_dot<false>), dim3(gr), dim3(kRowBlock), 0, g.stream, view_of(L0), sh,
+                                   g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, L0.b.p,
+                                   g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, PP[par], PP[par ^ 1],
+                                   g.AP.p, g.part_pq.p, g.flags.p);
+            launch_update(g, false, par ^ 1, gr, PP[par ^ 1]);
+        } else {
+            launch_pupdate(g, par, first, pi);
+            launch_spmv(g);
+            launch_update(g, false, par ^ 1, gr);
+        }
         it++;
     };
     // Poll schedule: consecutive solves of an IRLS run need almost the same number of iterations,
@@ -1199,6 +1382,14 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
             launch_spmv(g);
             break;
         case 5: (void)precondition(g, 0, -1.0); break;
+        case 8: {  // the fused p-update + SpMV of the single-GPU PCG (k_pspmv_dot)
+            Level &L0 = g.levels[0];
+            hipLaunchKernelGGL((k_pspmv_dot<false>), dim3(grid_for_rows(L0)), dim3(kRowBlock), 0, g.stream,
+                               view_of(L0), __builtin_ctz((unsigned)L0.agg), g.scal.p, 0, g.part_rz.p, 1,
+                               g.part_rz2.p, 1, L0.b.p, g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, g.P.p,
+                               g.P2.p, g.AP.p, g.part_pq.p, g.flags.p);
+            break;
+        }
         case 6:
             hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kRowBlock), 0, g.stream,
                                g.nu, g.f, g.ng, g.X.p, g.Q.p, g.part_score.p, 0);
@@ -1206,7 +1397,10 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         default: break;
         }
     };
-    if (which < 1 || which > 7) return IROTAVG_ERR_BAD_ARG;
+    if (which < 1 || which > 8) return IROTAVG_ERR_BAD_ARG;
+    if (which == 8 && !(g.additive_top && g.levels.size() > 1 && g.ng == 0 && g.l0_far_entries == 0 &&
+                        g.opt.no_fused_pspmv != 1))
+        return IROTAVG_ERR_BAD_ARG;  // this graph's PCG does not use the fused kernel
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
     once();  // warm-up
     IRH_CHECK(hipEventRecord(e0, g.stream));
