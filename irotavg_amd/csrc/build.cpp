@@ -340,12 +340,32 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         g.dense_ref_diag.alloc((size_t)g.ndense_pad);
     }
     g.additive_top = g.opt.mg_multiplicative_top == 1 ? 0 : 1;
+    // Can the PCG update also do the down-sweep of level 1 (k_pcg_update_restrict2)? Aggregates of 8
+    // on levels 0 and 1, one GPU, and every level-1 neighbour of a tile's 32 level-1 rows inside
+    // the 48-row window the update kernel holds in LDS.
+    g.l1_fused = 0;
+    if (g.additive_top && H.size() >= 3 && H[0].agg == 8 && H[1].agg == 8 && g.ng == 0 &&
+        g.l0_far_entries == 0 && g.opt.no_fused_pspmv != 1) {
+        bool ok = true;
+        const HostLevel &h1 = H[1];
+        for (int r = 0; r < h1.n && ok; r++) {
+            const int lo = (r / 32) * 32 - 8, hi = (r / 32) * 32 + 40;
+            for (int t = h1.rowptr[r]; t < h1.rowptr[r + 1]; t++)
+                if (h1.col[t] < lo || h1.col[t] >= hi) {
+                    ok = false;
+                    break;
+                }
+        }
+        g.l1_fused = ok ? 1 : 0;
+    }
     // ---- PCG state ----------------------------------------------------------------------
     const size_t nv0 = (size_t)g.levels[0].nsl * 64 + 64;
     g.X.alloc(nv0 + (size_t)g.ng);
     g.P.alloc(nv0);
     g.P2.alloc(nv0);
     g.P2.zero(s);
+    g.R2.alloc(nv0);
+    g.R2.zero(s);
     g.AP.alloc(nv0);
     g.X.zero(s);
     g.P.zero(s);

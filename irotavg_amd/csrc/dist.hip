@@ -278,6 +278,7 @@ static int build_shard(Dist &D, Shard &S, const int32_t *I, const double *QQ, in
     S.gedge = P.ledge;
     Graph &g = S.g;
     g.opt = D.opt;
+    g.opt.no_fused_pspmv = 1;  // the sharded PCG exchanges p between its p-update and its SpMV
     g.stream = D.stream;
     g.m = ml;
     g.n_total = ft + ng + no;

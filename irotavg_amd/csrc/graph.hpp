@@ -60,7 +60,9 @@ struct Graph {
     // PCG (level-0 sized). levels[0].b is the residual r, levels[0].x the pre-smoothed
     // iterate, levels[0].y the preconditioned residual z.
     DevBuf<double4> X, P, AP;
+    int l1_fused = 0;  // the PCG update kernel also does the level-1 down-sweep (build.cpp)
     long long l0_far_entries = 0;  // level-0 SELL entry-columns outside the tile windows (loop closures)
+    DevBuf<double4> R2;  // second residual buffer (l1_fused: the update kernel writes r out of place)
     DevBuf<double4> P2;  // second search-direction buffer: the fused p-update + SpMV ping-pongs P / P2
     DevBuf<double> part_pq, part_rr, part_rz, part_rz2, part_score;  // kMaxParts x 4
     DevBuf<double> scal;
@@ -109,7 +111,8 @@ void fill(Graph &g, double *p, long long n, double v);
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true);
 int pcg_solve(Graph &g);
 void launch_spmv(Graph &g);
-void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = nullptr);
+void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = nullptr,
+                   const double4 *rin = nullptr, double4 *rout = nullptr);
 void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi);
 PrecInfo precondition(Graph &g, int first, double rtol2);
 int grid_for_rows(const Level &L);

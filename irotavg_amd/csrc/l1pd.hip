@@ -527,9 +527,10 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
     q.ndense = g.ndense; q.ndense_pad = g.ndense_pad; q.additive_top = g.additive_top;
     q.stale_spread = g.stale_spread;
     q.l0_far_entries = g.l0_far_entries;
+    q.l1_fused = g.l1_fused;
     q.dense_inv.alloc_like(g.dense_inv, s); q.dense_wr.alloc_like(g.dense_wr, s);
     q.dense_wc.alloc_like(g.dense_wc, s); q.dense_ref_diag.alloc_like(g.dense_ref_diag, s);
-    q.X.alloc_like(g.X, s); q.P.alloc_like(g.P, s); q.P2.alloc_like(g.P2, s); q.AP.alloc_like(g.AP, s);
+    q.X.alloc_like(g.X, s); q.P.alloc_like(g.P, s); q.P2.alloc_like(g.P2, s); q.R2.alloc_like(g.R2, s); q.AP.alloc_like(g.AP, s);
     q.part_pq.alloc_like(g.part_pq, s); q.part_rr.alloc_like(g.part_rr, s);
     q.part_rz.alloc_like(g.part_rz, s); q.part_rz2.alloc_like(g.part_rz2, s);
     q.part_score.alloc_like(g.part_score, s);

@@ -906,6 +906,166 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict(
     if (!INIT && blockIdx.x == 0 && threadIdx.x == 0) flags[FL_ITERS] += 1;
 }
 
+// The PCG update AND the down-sweep of level 1 in one launch (one dependent launch = 4.7 us): the
+// workgroup forms r_new not only for its 256 rows but for the window [tile - 64, tile + 320) (two
+// more loads of r and q per halo row), restricts it to b1 / x1 = omega D1^-1 b1 for the 48 level-1
+// rows of the window (LDS), and lanes 0..31 then evaluate the level-1 residual b1 - L1 x1 of the
+// tile's own 32 level-1 rows from that window and restrict it to level 2 -- what
+// k_residual_restrict did in a launch of its own. Requires agg = 8 on levels 0 and 1 and every
+// level-1 neighbour within 8 rows of the tile's level-1 range (Graph::l1_fused, checked at build
+// time: band graphs). Thread tid holds window slots tid and tid + 256; exactly one of them is an
+// own row of the tile. The residual ping-pongs between two buffers (Rin -> Rout).
+constexpr int kL1Win = kWinLen / 8;  // 48 level-1 rows per window
+template <bool INIT>
+__global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict2(
+    int n, int nsl, const double *__restrict__ scal, int par, const double *__restrict__ part_pq,
+    int nparts, double4 *__restrict__ X, const double4 *__restrict__ Rin, double4 *__restrict__ Rout,
+    const double4 *__restrict__ P, const double4 *__restrict__ AP, const double *__restrict__ idg,
+    LevelView L1, double4 *__restrict__ b1, double4 *__restrict__ x1, double4 *__restrict__ b2,
+    double4 *__restrict__ x2, const double *__restrict__ idg2, double omega,
+    double *__restrict__ part_rr, double *__restrict__ part_rz, int *__restrict__ flags) {
+    const int done = flags[FL_DONE];
+    __shared__ double wb[3][kL1Win], wxv[3][kL1Win];
+    const int ntiles = (nsl + 3) / 4;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    const int tid = threadIdx.x;
+    struct Win {
+        double4 r[2], q[2], p, x;  // r, q of both slots; p, x and idg of the own row
+        double w;
+    };
+    auto win_load = [&](int t, Win &W) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int iw = tid + u * kRowBlock, i = wlo + iw;
+            W.r[u] = W.q[u] = make_double4(0, 0, 0, 0);
+            if (iw < kWinLen && i < n) {
+                W.r[u] = Rin[i];
+                if (!INIT) W.q[u] = AP[i];
+            }
+        }
+        const int io = wlo + tid + (tid >= r0 - wlo ? 0 : kRowBlock);  // the own row among the two slots
+        W.p = W.x = make_double4(0, 0, 0, 0);
+        W.w = 0.0;
+        if (io < n) {
+            W.w = idg[io];
+            if (!INIT) {
+                W.p = P[io];
+                W.x = X[io];
+            }
+        }
+    };
+    // the first tile's vectors are requested BEFORE alpha is reduced from the partials
+    Win W0;
+    if (t0 < t1) win_load(t0, W0);
+    if (done) return;
+    double al[3] = {0, 0, 0};
+    if (!INIT) {
+        double pq[3];
+        load_reduced3(part_pq, nparts, pq);
+        for (int c = 0; c < 3; c++) {
+            const double rz = scal[(par ? SC_RZ1 : SC_RZ0) + c];
+            al[c] = pq[c] > 0.0 ? rz / pq[c] : 0.0;
+        }
+    }
+    double a0 = 0, a1 = 0, a2 = 0, z0 = 0, z1 = 0, z2 = 0;
+    for (int t = t0; t < t1; t++) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo);
+        Win W;
+        if (t == t0)
+            W = W0;
+        else
+            win_load(t, W);
+        const int uo = tid >= r0 - wlo ? 0 : 1;  // which slot is the own row
+        __syncthreads();  // the previous tile's level-1 rows are done with the window
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int iw = tid + u * kRowBlock, i = wlo + iw;
+            double4 r = W.r[u];
+            if (!INIT) {
+                r.x -= al[0] * W.q[u].x;
+                r.y -= al[1] * W.q[u].y;
+                r.z -= al[2] * W.q[u].z;
+            }
+            if (u == uo && i < n) {  // own row: x, r, ||r||^2 and the Jacobi part of r.z
+                if (INIT) {
+                    X[i] = make_double4(0, 0, 0, 0);
+                } else {
+                    double4 x = W.x;
+                    x.x += al[0] * W.p.x;
+                    x.y += al[1] * W.p.y;
+                    x.z += al[2] * W.p.z;
+                    X[i] = x;
+                }
+                Rout[i] = r;  // never in place: neighbouring workgroups read Rin of these rows as halo
+                const double w = omega * W.w;
+                a0 += r.x * r.x;
+                a1 += r.y * r.y;
+                a2 += r.z * r.z;
+                z0 += w * r.x * r.x;
+                z1 += w * r.y * r.y;
+                z2 += w * r.z * r.z;
+            }
+            // restriction to level 1 (aggregates of 8 consecutive rows = 8 consecutive lanes)
+            const double c0 = seg_sum(r.x, 8), c1 = seg_sum(r.y, 8), c2 = seg_sum(r.z, 8);
+            if ((i & 7) == 0 && iw < kWinLen) {
+                const int I = i >> 3, Iw = iw >> 3;
+                const bool live = i < n;
+                const double w = live ? omega * L1.idg[I] : 0.0;
+                wb[0][Iw] = c0;
+                wb[1][Iw] = c1;
+                wb[2][Iw] = c2;
+                wxv[0][Iw] = w * c0;
+                wxv[1][Iw] = w * c1;
+                wxv[2][Iw] = w * c2;
+                if (live && i >= r0 && i < r0 + 256) {
+                    b1[I] = make_double4(c0, c1, c2, 0.0);
+                    x1[I] = make_double4(w * c0, w * c1, w * c2, 0.0);
+                }
+            }
+        }
+        __syncthreads();
+        // level-1 residual of the tile's own 32 level-1 rows, restricted to level 2
+        if (tid < 32) {
+            const int W1lo = wlo >> 3;
+            const int row = (r0 >> 3) + tid;
+            double s0 = 0, s1 = 0, s2 = 0, e0 = 0, e1 = 0, e2 = 0;
+            if (row < L1.n) {
+                const int sl = row >> 6, ln = row & 63;
+                const int o0 = L1.sl_off[sl], w = L1.sl_off[sl + 1] - o0;
+                for (int k = 0; k < w; k++) {
+                    const size_t pos = sell_pos(o0, k, ln);
+                    const double v = L1.val[pos];
+                    const int ci = min(max(L1.col[pos] - W1lo, 0), kL1Win - 1);  // padding: v = 0
+                    s0 += v * wxv[0][ci];
+                    s1 += v * wxv[1][ci];
+                    s2 += v * wxv[2][ci];
+                }
+                const int me = row - W1lo;
+                const double d = L1.diag[row];
+                e0 = wb[0][me] - (s0 + d * wxv[0][me]);
+                e1 = wb[1][me] - (s1 + d * wxv[1][me]);
+                e2 = wb[2][me] - (s2 + d * wxv[2][me]);
+            }
+            e0 = seg_sum(e0, 8);
+            e1 = seg_sum(e1, 8);
+            e2 = seg_sum(e2, 8);
+            if ((row & 7) == 0 && row < L1.n) {
+                const int J = row >> 3;
+                b2[J] = make_double4(e0, e1, e2, 0.0);
+                const double w = omega * idg2[J];
+                x2[J] = make_double4(w * e0, w * e1, w * e2, 0.0);
+            }
+        }
+    }
+    block_sum3_store(a0, a1, a2, part_rr + 4 * blockIdx.x);
+    block_sum3_store(z0, z1, z2, part_rz + 4 * blockIdx.x);
+    if (!INIT && blockIdx.x == 0 && threadIdx.x == 0) flags[FL_ITERS] += 1;
+}
+
 // beta from r.z = (r.z0 partials) + kc * (b1.y1 partials); p = omega D^-1 r + kc * P y1 + beta p
 __global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate_add(
     int n, int sh, double *__restrict__ scal, int par, int first, const double *__restrict__ part_rz,
@@ -1089,11 +1249,12 @@ void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
 // launched carries the PCG convergence prologue. `dot_from`: the kernel producing
 // levels[from].y also emits partial sums of b.y into `part_dot`.
 static void cycle_from(Graph &g, int from, bool check_first, bool dot_from, double *part_dot,
-                       int np_rr, int first, double rtol2, int *np_dot) {
+                       int np_rr, int first, double rtol2, int *np_dot, bool first_down_done = false) {
     const int nl = (int)g.levels.size();
     const double omega = g.opt.mg_omega, kc = g.opt.mg_kc;
     bool check = check_first;
-    for (int l = from; l < nl - 1; l++) {
+    // first_down_done: levels[from + 1].b / .x were already produced (k_pcg_update_restrict2)
+    for (int l = first_down_done ? from + 1 : from; l < nl - 1; l++) {
         Level &F = g.levels[l];
         Level &C = g.levels[l + 1];
         const int grid = grid_for_rows(F);
@@ -1156,7 +1317,7 @@ PrecInfo precondition(Graph &g, int first, double rtol2) {
     }
     if (g.additive_top) {
         pi.np_rz = g.additive_top && nl > 1 ? grid_for_rows(L0) : np_rr;  // r.z0 partials of the update kernel
-        cycle_from(g, 1, true, true, g.part_rz2.p, np_rr, first, rtol2, &pi.np_rz2);
+        cycle_from(g, 1, true, true, g.part_rz2.p, np_rr, first, rtol2, &pi.np_rz2, g.l1_fused && nl > 2);
     } else {
         cycle_from(g, 0, true, true, g.part_rz.p, np_rr, first, rtol2, &pi.np_rz);
     }
@@ -1171,11 +1332,26 @@ void launch_spmv(Graph &g) {
                        g.bghost.p, g.bval.p);
 }
 
-void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *pvec) {
+void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *pvec, const double4 *rin,
+                   double4 *rout) {
     Level &L0 = g.levels[0];
     const double4 *P = pvec ? pvec : g.P.p;
     const int nl = (int)g.levels.size();
-    if (g.additive_top && nl > 1) {
+    if (g.additive_top && nl > 2 && g.l1_fused && rin && rout) {
+        Level &L1 = g.levels[1];
+        Level &L2 = g.levels[2];
+        const int grid = grid_for_rows(L0);
+        if (init)
+            hipLaunchKernelGGL((k_pcg_update_restrict2<true>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n,
+                               L0.nsl, g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, rin, rout, P, g.AP.p,
+                               L0.idg.p, view_of(L1), L1.b.p, L1.x.p, L2.b.p, L2.x.p, L2.idg.p, g.opt.mg_omega,
+                               g.part_rr.p, g.part_rz.p, g.flags.p);
+        else
+            hipLaunchKernelGGL((k_pcg_update_restrict2<false>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n,
+                               L0.nsl, g.scal.p, par, g.part_pq.p, np_pq, g.X.p + g.ng, rin, rout, P, g.AP.p,
+                               L0.idg.p, view_of(L1), L1.b.p, L1.x.p, L2.b.p, L2.x.p, L2.idg.p, g.opt.mg_omega,
+                               g.part_rr.p, g.part_rz.p, g.flags.p);
+    } else if (g.additive_top && nl > 1) {
         Level &L1 = g.levels[1];
         const int grid = grid_for_rows(L0);
         if (init)
@@ -1226,7 +1402,19 @@ int pcg_solve(Graph &g) {
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     const int gr = grid_for_rows(L0);
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
-    launch_update(g, true, 0, gr);
+    // with the level-1 down-sweep fused into the update (l1_fused) the residual ping-pongs between
+    // levels[0].b and R2: rcur is the buffer holding the current r
+    double4 *RR[2] = {L0.b.p, g.R2.p};
+    int rcur = 0;
+    auto update = [&](bool init, int par, const double4 *pvec) {
+        if (g.l1_fused) {
+            launch_update(g, init, par, gr, pvec, RR[rcur], RR[rcur ^ 1]);
+            rcur ^= 1;
+        } else {
+            launch_update(g, init, par, gr, pvec);
+        }
+    };
+    update(true, 0, nullptr);
     int h_flags[FL_COUNT] = {0, 0, 0, 0};
     int it = 0;
     const int check = std::max(1, g.opt.pcg_check_every);
@@ -1243,19 +1431,19 @@ int pcg_solve(Graph &g) {
             const int sh = __builtin_ctz((unsigned)L0.agg);
             if (first)
                 hipLaunchKernelGGL((k_pspmv_dot<true>), dim3(gr), dim3(kRowBlock), 0, g.stream, view_of(L0), sh,
-                                   g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, L0.b.p,
+                                   g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, RR[rcur],
                                    g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, PP[par], PP[par ^ 1],
                                    g.AP.p, g.part_pq.p, g.flags.p);
             else
                 hipLaunchKernelGGL((k_pspmv_dot<false>), dim3(gr), dim3(kRowBlock), 0, g.stream, view_of(L0), sh,
-                                   g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, L0.b.p,
+                                   g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, RR[rcur],
                                    g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, PP[par], PP[par ^ 1],
                                    g.AP.p, g.part_pq.p, g.flags.p);
-            launch_update(g, false, par ^ 1, gr, PP[par ^ 1]);
+            update(false, par ^ 1, PP[par ^ 1]);
         } else {
             launch_pupdate(g, par, first, pi);
             launch_spmv(g);
-            launch_update(g, false, par ^ 1, gr);
+            update(false, par ^ 1, nullptr);
         }
         it++;
     };
