@@ -41,7 +41,7 @@ def build_problem(n, m, p_loop, seed):
     return S, Q0
 
 
-def kernel_rooflines(G, S, st):
+def kernel_rooflines(G, S, st, sharded=False):
     """HIP-event timed kernels -> algorithmic GB/s (formulas: SURVEY.md 8(d))."""
     from irotavg_amd import capi
     m, n_t = S["m"], S["n"]
@@ -59,6 +59,8 @@ def kernel_rooflines(G, S, st):
         ms = G.time_kernel(w, 50)
         out[name] = dict(ms=ms, bytes=alg[name], gbs=alg[name] / (ms * 1e-3) / 1e9)
     try:  # band-only graphs on one GPU run the p-update fused into the SpMV (k_pspmv_dot)
+        if sharded:   # the sharded PCG exchanges p between its p-update and its SpMV: unfused kernels
+            raise capi.IrotavgError(capi.ERR_BAD_ARG, "sharded")
         ms = G.time_kernel(8, 50)
         by = nnz0 * (8 + 4) + 4 * (nu + 1) + nu * (24 + 24 + 8 + 3 + 24 + 24)
         out["pspmv"] = dict(ms=ms, bytes=by, gbs=by / (ms * 1e-3) / 1e9)
@@ -222,7 +224,7 @@ def main():
                        "views sharded in %d contiguous ranges, 1 shard/GPU, RCCL halo + all-reduce" % world},
             "final_scores": [float(x) for x in res["scores"]],
         }
-        kr = kernel_rooflines(G, S, st)
+        kr = kernel_rooflines(G, S, st, sharded=dstats is not None)
         dom = "pspmv" if "pspmv" in kr else "spmv"
         dname = {"spmv": "k_spmv_dot (level-0 SELL-64 SpMV + fused dot, dominant PCG kernel)",
                  "pspmv": "k_pspmv_dot (PCG p-update fused into the level-0 SELL-64 SpMV + dot, dominant PCG kernel)"}[dom]
