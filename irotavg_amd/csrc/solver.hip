@@ -330,6 +330,51 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_diag(LevelView C, int nf, 
     for (int t_ = t0_; t_ < t1_; t_++)                         \
         if (const int sl_ = t_ * 4 + (threadIdx.x >> 6); sl_ < (L).nsl)
 
+// Near part of one SELL row (the first `wn` entry-columns of its slice: columns inside the tile
+// window): a pure 16 B/lane matrix stream -- the gathered vector comes from the LDS copy of the
+// window (wx, wy, wz; index = column - wlo). wn is a multiple of 8: batches of 4 pairs, all 8 loads
+// of a batch issued before use and the next batch's loads issued before the current one is consumed.
+__device__ __forceinline__ void near_window_row(const LevelView &L, int o0, int wn, int lane, int wlo,
+                                                const double *wx, const double *wy, const double *wz,
+                                                double &s0, double &s1, double &s2) {
+    constexpr int HB = kSellUnroll / 2;
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2i *__restrict__ cs = reinterpret_cast<const v2i *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+    const v2d *__restrict__ vs = reinterpret_cast<const v2d *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
+    s0 = s1 = s2 = 0.0;
+    v2i cc[HB], cn[HB];
+    v2d vv[HB], vn[HB];
+    if (wn > 0) {
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+            cc[u] = __builtin_nontemporal_load(&cs[(size_t)u * 64]);
+            vv[u] = __builtin_nontemporal_load(&vs[(size_t)u * 64]);
+        }
+    }
+    for (int q0 = 0; q0 < wn / 2; q0 += HB) {
+        if (q0 + HB < wn / 2) {
+#pragma unroll
+            for (int u = 0; u < HB; u++) {
+                cn[u] = __builtin_nontemporal_load(&cs[(size_t)(q0 + HB + u) * 64]);
+                vn[u] = __builtin_nontemporal_load(&vs[(size_t)(q0 + HB + u) * 64]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+            const int i0 = cc[u].x - wlo, i1 = cc[u].y - wlo;
+            s0 += vv[u].x * wx[i0] + vv[u].y * wx[i1];
+            s1 += vv[u].x * wy[i0] + vv[u].y * wy[i1];
+            s2 += vv[u].x * wz[i0] + vv[u].y * wz[i1];
+        }
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+            cc[u] = cn[u];
+            vv[u] = vn[u];
+        }
+    }
+}
+
 // q = L p, partial dot products p.q -- the dominant kernel of the PCG.
 // The 256-row tile's window of p (rows [tile - 64, tile + 320)) is copied into LDS once (12 KB,
 // coalesced); the near part of every row (all of it on a band graph) then reads p from LDS, so
@@ -381,46 +426,8 @@ __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const doubl
         }
         __syncthreads();
         if (live) {
-            const int2 *__restrict__ c = reinterpret_cast<const int2 *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
-            const double2 *__restrict__ v = reinterpret_cast<const double2 *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
-            double s0 = 0, s1 = 0, s2 = 0;
-            // wn is a multiple of 8: batches of 4 pairs, all 8 loads of a batch issued before use
-            // and the next batch's loads issued before the current batch is consumed
-            constexpr int HB = kSellUnroll / 2;
-            typedef int v2i __attribute__((ext_vector_type(2)));
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            const v2i *__restrict__ cs = reinterpret_cast<const v2i *>(c);
-            const v2d *__restrict__ vs = reinterpret_cast<const v2d *>(v);
-            v2i cc[HB], cn[HB];
-            v2d vv[HB], vn[HB];
-            if (wn > 0) {
-#pragma unroll
-                for (int u = 0; u < HB; u++) {
-                    cc[u] = __builtin_nontemporal_load(&cs[(size_t)u * 64]);
-                    vv[u] = __builtin_nontemporal_load(&vs[(size_t)u * 64]);
-                }
-            }
-            for (int q0 = 0; q0 < wn / 2; q0 += HB) {
-                if (q0 + HB < wn / 2) {
-#pragma unroll
-                    for (int u = 0; u < HB; u++) {
-                        cn[u] = __builtin_nontemporal_load(&cs[(size_t)(q0 + HB + u) * 64]);
-                        vn[u] = __builtin_nontemporal_load(&vs[(size_t)(q0 + HB + u) * 64]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < HB; u++) {
-                    const int i0 = cc[u].x - wlo, i1 = cc[u].y - wlo;
-                    s0 += vv[u].x * wx[i0] + vv[u].y * wx[i1];
-                    s1 += vv[u].x * wy[i0] + vv[u].y * wy[i1];
-                    s2 += vv[u].x * wz[i0] + vv[u].y * wz[i1];
-                }
-#pragma unroll
-                for (int u = 0; u < HB; u++) {
-                    cc[u] = cn[u];
-                    vv[u] = vn[u];
-                }
-            }
+            double s0, s1, s2;
+            near_window_row(L, o0, wn, lane, wlo, wx, wy, wz, s0, s1, s2);
             double f0, f1, f2;
             row_offdiag_t<false>(L, row, p, nullptr, 0, 0.0, f0, f1, f2, wn);  // far entries
             s0 += f0;
@@ -560,44 +567,8 @@ __global__ __launch_bounds__(kRowBlock) void k_pspmv_dot(
         }
         __syncthreads();
         if (live) {
-            const int2 *__restrict__ c = reinterpret_cast<const int2 *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
-            const double2 *__restrict__ v = reinterpret_cast<const double2 *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
-            double s0 = 0, s1 = 0, s2 = 0;
-            constexpr int HB = kSellUnroll / 2;
-            typedef int v2i __attribute__((ext_vector_type(2)));
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            const v2i *__restrict__ cs = reinterpret_cast<const v2i *>(c);
-            const v2d *__restrict__ vs = reinterpret_cast<const v2d *>(v);
-            v2i cc[HB], cn[HB];
-            v2d vv[HB], vn[HB];
-            if (wn > 0) {
-#pragma unroll
-                for (int u = 0; u < HB; u++) {
-                    cc[u] = __builtin_nontemporal_load(&cs[(size_t)u * 64]);
-                    vv[u] = __builtin_nontemporal_load(&vs[(size_t)u * 64]);
-                }
-            }
-            for (int q0 = 0; q0 < wn / 2; q0 += HB) {
-                if (q0 + HB < wn / 2) {
-#pragma unroll
-                    for (int u = 0; u < HB; u++) {
-                        cn[u] = __builtin_nontemporal_load(&cs[(size_t)(q0 + HB + u) * 64]);
-                        vn[u] = __builtin_nontemporal_load(&vs[(size_t)(q0 + HB + u) * 64]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < HB; u++) {
-                    const int i0 = cc[u].x - wlo, i1 = cc[u].y - wlo;
-                    s0 += vv[u].x * wx[i0] + vv[u].y * wx[i1];
-                    s1 += vv[u].x * wy[i0] + vv[u].y * wy[i1];
-                    s2 += vv[u].x * wz[i0] + vv[u].y * wz[i1];
-                }
-#pragma unroll
-                for (int u = 0; u < HB; u++) {
-                    cc[u] = cn[u];
-                    vv[u] = vn[u];
-                }
-            }
+            double s0, s1, s2;
+            near_window_row(L, o0, wn, lane, wlo, wx, wy, wz, s0, s1, s2);
             if (row < L.n) {
                 const int ir = row - wlo;
                 const double px = wx[ir], py = wy[ir], pz = wz[ir];
