@@ -9,11 +9,35 @@
 //    endpoints independently (:825-843), so an edge with i free, j fixed still adds to (i,i).
 // The CSR pattern is static for the life of the handle; only values are refreshed per solve.
 #include <algorithm>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 #include "graph.hpp"
 
 namespace irh {
+
+// The host phases below are loops over edges, rows or slices with independent iterations: they run
+// on up to 16 host threads (contiguous chunks; every result is independent of the thread count --
+// where a serial loop defined an order, the order is restored by sorting on the edge id).
+template <class F>
+static void parallel_for(int64_t n, int64_t min_chunk, F &&fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, n / std::max<int64_t>(1, min_chunk)));
+    if (const char *e = getenv("IROTAVG_BUILD_THREADS")) T = std::min(16, std::max(1, atoi(e)));
+    if (T <= 1) {
+        fn((int64_t)0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t step = (n + T - 1) / T;
+    for (int t = 1; t < T; t++) {
+        const int64_t b = std::min(n, t * step), e = std::min(n, b + step);
+        if (b < e) th.emplace_back([&fn, b, e, t]() { fn(b, e, t); });
+    }
+    fn((int64_t)0, std::min(n, step), 0);
+    for (auto &x : th) x.join();
+}
 
 static int pow2floor(int v) {
     int p = 1;
@@ -39,31 +63,35 @@ static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector
         return c >= t0 - kWinHalo && c < t0 + 256 + kWinHalo;
     };
     auto roundup = [](int w) { return (w + kSellUnroll - 1) / kSellUnroll * kSellUnroll; };
-    std::vector<int> nnear((size_t)n, 0);
-    for (int sl = 0; sl < M.nsl; sl++) {
-        int wn = 0, wf = 0;
-        for (int r = sl * 64; r < std::min(n, sl * 64 + 64); r++) {
-            int nn = 0;
-            for (int t = rowptr[r]; t < rowptr[r + 1]; t++) nn += is_near(r, col[t]) ? 1 : 0;
-            nnear[r] = nn;
-            wn = std::max(wn, nn);
-            wf = std::max(wf, rowptr[r + 1] - rowptr[r] - nn);
+    std::vector<int> width((size_t)M.nsl, 0);
+    parallel_for(M.nsl, 256, [&](int64_t s0, int64_t s1, int) {
+        for (int sl = (int)s0; sl < (int)s1; sl++) {
+            int wn = 0, wf = 0;
+            for (int r = sl * 64; r < std::min(n, sl * 64 + 64); r++) {
+                int nn = 0;
+                for (int t = rowptr[r]; t < rowptr[r + 1]; t++) nn += is_near(r, col[t]) ? 1 : 0;
+                wn = std::max(wn, nn);
+                wf = std::max(wf, rowptr[r + 1] - rowptr[r] - nn);
+            }
+            wn = roundup(wn);
+            wf = roundup(wf);
+            M.sl_near[sl] = wn;
+            width[sl] = wn + wf;
         }
-        wn = roundup(wn);
-        wf = roundup(wf);
-        M.sl_near[sl] = wn;
-        M.sl_off[sl + 1] = M.sl_off[sl] + wn + wf;
-    }
+    });
+    for (int sl = 0; sl < M.nsl; sl++) M.sl_off[sl + 1] = M.sl_off[sl] + width[sl];
     M.len = 64ll * M.sl_off[M.nsl];
     M.pos.resize((size_t)rowptr[n]);
-    for (int r = 0; r < n; r++) {
-        const int sl = r >> 6, lane = r & 63;
-        int kn = 0, kf = M.sl_near[sl];
-        for (int t = rowptr[r]; t < rowptr[r + 1]; t++) {
-            const int k = is_near(r, col[t]) ? kn++ : kf++;
-            M.pos[t] = (int)sell_pos(M.sl_off[sl], k, lane);
+    parallel_for(n, 4096, [&](int64_t r0, int64_t r1, int) {
+        for (int r = (int)r0; r < (int)r1; r++) {
+            const int sl = r >> 6, lane = r & 63;
+            int kn = 0, kf = M.sl_near[sl];
+            for (int t = rowptr[r]; t < rowptr[r + 1]; t++) {
+                const int k = is_near(r, col[t]) ? kn++ : kf++;
+                M.pos[t] = (int)sell_pos(M.sl_off[sl], k, lane);
+            }
         }
-    }
+    });
     return M;
 }
 
@@ -86,22 +114,29 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.mpad = (m + 63) / 64 * 64;  // streams are padded so kernels may read whole 16-B pairs
     std::vector<int> ei((size_t)g.mpad, 0), ej((size_t)g.mpad, 0);
     std::vector<uint8_t> eflag((size_t)g.mpad, 0);
-    for (int64_t k = 0; k < m; k++) {
-        const int i = I[2 * k], j = I[2 * k + 1];
-        if (i < 0 || j < 0 || i >= g.n_total || j >= g.n_total) return IROTAVG_ERR_BAD_ARG;
-        ei[k] = i;
-        ej[k] = j;
-        uint8_t fl = 0;
-        if (j >= f) {
-            if (i >= f && i == j) {
-                fl = EF_CI;  // self loop: the -1 overwrites the +1
-            } else {
-                fl |= EF_CJ;
-                if (i >= f) fl |= EF_CI;
+    std::atomic<bool> bad(false);
+    parallel_for(m, 65536, [&](int64_t k0, int64_t k1, int) {
+        for (int64_t k = k0; k < k1; k++) {
+            const int i = I[2 * k], j = I[2 * k + 1];
+            if (i < 0 || j < 0 || i >= g.n_total || j >= g.n_total) {
+                bad = true;
+                return;
             }
+            ei[k] = i;
+            ej[k] = j;
+            uint8_t fl = 0;
+            if (j >= f) {
+                if (i >= f && i == j) {
+                    fl = EF_CI;  // self loop: the -1 overwrites the +1
+                } else {
+                    fl |= EF_CJ;
+                    if (i >= f) fl |= EF_CI;
+                }
+            }
+            eflag[k] = fl;
         }
-        eflag[k] = fl;
-    }
+    });
+    if (bad) return IROTAVG_ERR_BAD_ARG;
     g.ei.upload(ei, s);
     g.ej.upload(ej, s);
     g.eflag.upload(eflag, s);
@@ -113,11 +148,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.er.alloc((size_t)3 * g.mpad);
     g.er.zero(s);
     g.dw.alloc((size_t)g.mpad);
-    {
-        std::vector<double> ones((size_t)g.mpad, 1.0);
-        g.dw.upload(ones, s);
-        IRH_CHECK(hipStreamSynchronize(s));
-    }
+    fill(g, g.dw.p, (long long)g.mpad, 1.0);  // default weights (irls resets them anyway, :577)
     g.Q.alloc((size_t)g.n_total);
     g.Q.zero(s);
 
@@ -128,20 +159,23 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     // to a fixed or ghost view is a "boundary slot" of the owned row.
     auto cls = [&](int v) { return v < f ? 0 : (v < fo ? 1 : 2); };
     std::vector<int> rowptr((size_t)nu + 1, 0), bptr((size_t)nu + 1, 0);
-    for (int64_t k = 0; k < m; k++) {
-        const int ci = cls(ei[k]), cj = cls(ej[k]);
-        const int i = ei[k] - fo, j = ej[k] - fo;
-        if (ci == 2 && cj == 2 && i != j) {
-            rowptr[i + 1]++;
-            rowptr[j + 1]++;
-        } else if (ci == 2 && cj == 2) {
-            bptr[i + 1]++;  // self loop
-        } else if (cj == 2) {
-            bptr[j + 1]++;  // i fixed or ghost
-        } else if (ci == 2) {
-            bptr[i + 1]++;  // j fixed (dropped by make_A, kept by make_AtA) or ghost
+    auto bump = [](int &x) { return __atomic_fetch_add(&x, 1, __ATOMIC_RELAXED); };
+    parallel_for(m, 65536, [&](int64_t k0, int64_t k1, int) {
+        for (int64_t k = k0; k < k1; k++) {
+            const int ci = cls(ei[k]), cj = cls(ej[k]);
+            const int i = ei[k] - fo, j = ej[k] - fo;
+            if (ci == 2 && cj == 2 && i != j) {
+                bump(rowptr[i + 1]);
+                bump(rowptr[j + 1]);
+            } else if (ci == 2 && cj == 2) {
+                bump(bptr[i + 1]);  // self loop
+            } else if (cj == 2) {
+                bump(bptr[j + 1]);  // i fixed or ghost
+            } else if (ci == 2) {
+                bump(bptr[i + 1]);  // j fixed (dropped by make_A, kept by make_AtA) or ghost
+            }
         }
-    }
+    });
     for (int v = 0; v < nu; v++) {
         rowptr[v + 1] += rowptr[v];
         bptr[v + 1] += bptr[v];
@@ -154,43 +188,61 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         uint32_t eid;
     };
     std::vector<Ent> ents((size_t)nnz0);
+    struct BEnt {
+        uint32_t eid;
+        int ghost;
+        uint8_t flag;
+    };
+    std::vector<BEnt> bents((size_t)nb);
+    {
+        // slots are claimed with atomic counters (arbitrary order inside a row); the sorts below
+        // restore the order a serial pass over the edges would give
+        std::vector<int> pos(rowptr.begin(), rowptr.end() - 1), bpos(bptr.begin(), bptr.end() - 1);
+        parallel_for(m, 65536, [&](int64_t k0, int64_t k1, int) {
+            for (int64_t k = k0; k < k1; k++) {
+                const int ci = cls(ei[k]), cj = cls(ej[k]);
+                const int i = ei[k] - fo, j = ej[k] - fo;
+                if (ci == 2 && cj == 2 && i != j) {
+                    ents[bump(pos[j])] = Ent{i, (uint32_t)(k << 1) | 1u};  // row j: +1 coefficient
+                    ents[bump(pos[i])] = Ent{j, (uint32_t)(k << 1)};       // row i: -1 coefficient
+                } else if (ci == 2 && cj == 2) {
+                    bents[bump(bpos[i])] = BEnt{(uint32_t)(k << 1), -1, (uint8_t)(BF_IRLS | BF_L1H | BF_NEG)};
+                } else if (cj == 2) {  // row j, other endpoint i fixed or ghost
+                    bents[bump(bpos[j])] = BEnt{(uint32_t)(k << 1) | 1u, ci == 1 ? ei[k] - f : -1,
+                                                (uint8_t)(BF_IRLS | BF_L1H)};
+                } else if (ci == 2) {  // row i, other endpoint j fixed (make_A drops it) or ghost
+                    bents[bump(bpos[i])] = BEnt{(uint32_t)(k << 1), cj == 1 ? ej[k] - f : -1,
+                                                (uint8_t)(cj == 1 ? (BF_IRLS | BF_L1H) : BF_L1H)};
+                }
+            }
+        });
+    }
+    lap("adjacency count/fill");
+    // sort each row by column, edge order breaking ties (locality for the gathers, a canonical
+    // order for the coarse-level maps); boundary slots of a row by edge order
+    std::vector<int> col((size_t)nnz0);
+    std::vector<uint32_t> slot_eid((size_t)nnz0);
     std::vector<uint32_t> beid((size_t)nb);
     std::vector<uint8_t> bflag((size_t)nb);
     std::vector<int> bghost((size_t)nb, -1);
-    {
-        std::vector<int> pos(rowptr.begin(), rowptr.end() - 1), bpos(bptr.begin(), bptr.end() - 1);
-        for (int64_t k = 0; k < m; k++) {
-            const int ci = cls(ei[k]), cj = cls(ej[k]);
-            const int i = ei[k] - fo, j = ej[k] - fo;
-            if (ci == 2 && cj == 2 && i != j) {
-                ents[pos[j]++] = Ent{i, (uint32_t)(k << 1) | 1u};  // row j: +1 coefficient
-                ents[pos[i]++] = Ent{j, (uint32_t)(k << 1)};       // row i: -1 coefficient
-            } else if (ci == 2 && cj == 2) {
-                beid[bpos[i]] = (uint32_t)(k << 1);
-                bflag[bpos[i]++] = BF_IRLS | BF_L1H | BF_NEG;
-            } else if (cj == 2) {  // row j, other endpoint i fixed or ghost
-                beid[bpos[j]] = (uint32_t)(k << 1) | 1u;
-                bghost[bpos[j]] = ci == 1 ? ei[k] - f : -1;
-                bflag[bpos[j]++] = BF_IRLS | BF_L1H;
-            } else if (ci == 2) {  // row i, other endpoint j fixed (make_A drops it) or ghost
-                beid[bpos[i]] = (uint32_t)(k << 1);
-                bghost[bpos[i]] = cj == 1 ? ej[k] - f : -1;
-                bflag[bpos[i]++] = cj == 1 ? (BF_IRLS | BF_L1H) : BF_L1H;
+    parallel_for(nu, 2048, [&](int64_t v0, int64_t v1, int) {
+        for (int v = (int)v0; v < (int)v1; v++) {
+            std::sort(ents.begin() + rowptr[v], ents.begin() + rowptr[v + 1], [](const Ent &a, const Ent &b) {
+                return a.col != b.col ? a.col < b.col : a.eid < b.eid;
+            });
+            for (int t = rowptr[v]; t < rowptr[v + 1]; t++) {
+                col[t] = ents[t].col;
+                slot_eid[t] = ents[t].eid;
+            }
+            std::sort(bents.begin() + bptr[v], bents.begin() + bptr[v + 1],
+                      [](const BEnt &a, const BEnt &b) { return a.eid < b.eid; });
+            for (int t = bptr[v]; t < bptr[v + 1]; t++) {
+                beid[t] = bents[t].eid;
+                bflag[t] = bents[t].flag;
+                bghost[t] = bents[t].ghost;
             }
         }
-    }
-    lap("adjacency count/fill");
-    // sort each row by column (edge order breaks ties): locality for the gathers and a
-    // canonical order for the coarse-level maps
-    for (int v = 0; v < nu; v++)
-        std::stable_sort(ents.begin() + rowptr[v], ents.begin() + rowptr[v + 1],
-                         [](const Ent &a, const Ent &b) { return a.col < b.col; });
-    std::vector<int> col((size_t)nnz0);
-    std::vector<uint32_t> slot_eid((size_t)nnz0);
-    for (int64_t t = 0; t < nnz0; t++) {
-        col[t] = ents[t].col;
-        slot_eid[t] = ents[t].eid;
-    }
+    });
     ents.clear();
     ents.shrink_to_fit();
 
@@ -237,29 +289,61 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         HostLevel C;
         C.n = (F.n + agg - 1) / agg;
         C.rowptr.assign((size_t)C.n + 1, 0);
-        C.col.reserve((size_t)fnnz / 4 + 16);
-        C.cidx.reserve((size_t)fnnz);
-        C.cptr.push_back(0);
-        std::vector<std::pair<int, int>> tmp;  // (coarse col, fine slot)
-        for (int Ic = 0; Ic < C.n; Ic++) {
-            tmp.clear();
-            const int v0 = Ic * agg, v1 = std::min(F.n, v0 + agg);
-            for (int v = v0; v < v1; v++)
-                for (int t = F.rowptr[v]; t < F.rowptr[v + 1]; t++) {
-                    const int Jc = F.col[t] / agg;
-                    if (Jc != Ic) tmp.emplace_back(Jc, t);
+        // every thread builds the rows of a contiguous range of coarse rows into its own vectors;
+        // they are concatenated in range order afterwards
+        struct Part {
+            int64_t c0 = 0, c1 = 0;
+            std::vector<int> col, cidx, cptr_local, rowlen;  // cptr_local: offsets into this part's cidx
+        };
+        std::vector<Part> parts(16);
+        parallel_for(C.n, 512, [&](int64_t c0, int64_t c1, int tid) {
+            Part &P = parts[(size_t)tid];
+            P.c0 = c0;
+            P.c1 = c1;
+            P.rowlen.assign((size_t)(c1 - c0), 0);
+            std::vector<std::pair<int, int>> tmp;  // (coarse col, fine slot)
+            for (int Ic = (int)c0; Ic < (int)c1; Ic++) {
+                tmp.clear();
+                const int v0 = Ic * agg, v1 = std::min(F.n, v0 + agg);
+                for (int v = v0; v < v1; v++)
+                    for (int t = F.rowptr[v]; t < F.rowptr[v + 1]; t++) {
+                        const int Jc = F.col[t] / agg;
+                        if (Jc != Ic) tmp.emplace_back(Jc, t);
+                    }
+                std::sort(tmp.begin(), tmp.end());
+                int nrow = 0;
+                for (size_t q = 0; q < tmp.size(); q++) {
+                    if (q == 0 || tmp[q].first != tmp[q - 1].first) {
+                        P.cptr_local.push_back((int)P.cidx.size());
+                        P.col.push_back(tmp[q].first);
+                        nrow++;
+                    }
+                    P.cidx.push_back(tmp[q].second);
                 }
-            std::sort(tmp.begin(), tmp.end());
-            for (size_t q = 0; q < tmp.size(); q++) {
-                if (q == 0 || tmp[q].first != tmp[q - 1].first) {
-                    if (q != 0) C.cptr.push_back((int)C.cidx.size());
-                    C.col.push_back(tmp[q].first);
-                }
-                C.cidx.push_back(tmp[q].second);
+                P.rowlen[(size_t)(Ic - c0)] = nrow;
             }
-            if (!tmp.empty()) C.cptr.push_back((int)C.cidx.size());
-            C.rowptr[Ic + 1] = (int)C.col.size();
+        });
+        std::sort(parts.begin(), parts.end(), [](const Part &a, const Part &b) {
+            return (a.c1 > a.c0) != (b.c1 > b.c0) ? (a.c1 > a.c0) : a.c0 < b.c0;
+        });
+        size_t ncol = 0, nidx = 0;
+        for (const Part &P : parts) {
+            ncol += P.col.size();
+            nidx += P.cidx.size();
         }
+        C.col.reserve(ncol);
+        C.cidx.reserve(nidx);
+        C.cptr.reserve(ncol + 1);
+        for (const Part &P : parts) {
+            if (P.c1 <= P.c0) continue;
+            const int base = (int)C.cidx.size();
+            for (int o : P.cptr_local) C.cptr.push_back(base + o);
+            C.col.insert(C.col.end(), P.col.begin(), P.col.end());
+            C.cidx.insert(C.cidx.end(), P.cidx.begin(), P.cidx.end());
+            for (int64_t Ic = P.c0; Ic < P.c1; Ic++)
+                C.rowptr[(size_t)Ic + 1] = C.rowptr[(size_t)Ic] + P.rowlen[(size_t)(Ic - P.c0)];
+        }
+        C.cptr.push_back((int)C.cidx.size());
         H.push_back(std::move(C));
     }
 
@@ -278,10 +362,14 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         L.nsl = M.nsl;
         L.sell_len = M.len;
         std::vector<int> scol((size_t)M.len);
-        for (int sl = 0; sl < M.nsl; sl++)  // padding: a valid near column (row 0 of the slice), value 0
-            for (int k = M.sl_off[sl]; k < M.sl_off[sl + 1]; k++)
-                for (int lane = 0; lane < 64; lane++) scol[(size_t)k * 64 + lane] = sl * 64;
-        for (size_t t = 0; t < h.col.size(); t++) scol[M.pos[t]] = h.col[t];
+        parallel_for(M.nsl, 128, [&](int64_t s0, int64_t s1, int) {
+            for (int sl = (int)s0; sl < (int)s1; sl++)  // padding: a valid near column (row 0 of the slice), value 0
+                for (int k = M.sl_off[sl]; k < M.sl_off[sl + 1]; k++)
+                    for (int lane = 0; lane < 64; lane++) scol[(size_t)k * 64 + lane] = sl * 64;
+        });
+        parallel_for((int64_t)h.col.size(), 65536, [&](int64_t a, int64_t b, int) {
+            for (int64_t t = a; t < b; t++) scol[M.pos[t]] = h.col[t];
+        });
         L.sl_off.upload(M.sl_off, s);
         L.sl_near.upload(M.sl_near, s);
         L.col.upload(scol, s);
@@ -291,7 +379,9 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
             g.l0_far_entries = 0;
             for (int sl = 0; sl < M.nsl; sl++) g.l0_far_entries += (M.sl_off[sl + 1] - M.sl_off[sl]) - M.sl_near[sl];
             std::vector<uint32_t> seid((size_t)M.len, 0xffffffffu);
-            for (size_t t = 0; t < slot_eid.size(); t++) seid[M.pos[t]] = slot_eid[t];
+            parallel_for((int64_t)slot_eid.size(), 65536, [&](int64_t a, int64_t b, int) {
+                for (int64_t t = a; t < b; t++) seid[M.pos[t]] = slot_eid[t];
+            });
             g.slot_eid.upload(seid, s);
             IRH_CHECK(hipStreamSynchronize(s));
         }
@@ -303,7 +393,9 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         L.idg.zero(s);
         if (lev > 0) {
             std::vector<int> cidx2(h.cidx.size());
-            for (size_t q = 0; q < h.cidx.size(); q++) cidx2[q] = prev.pos[h.cidx[q]];
+            parallel_for((int64_t)h.cidx.size(), 65536, [&](int64_t a, int64_t b, int) {
+                for (int64_t q = a; q < b; q++) cidx2[q] = prev.pos[h.cidx[q]];
+            });
             L.cptr.upload(h.cptr, s);
             L.cidx.upload(cidx2, s);
             L.cpos.upload(M.pos, s);
