@@ -334,23 +334,46 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_diag(LevelView C, int nf, 
 // window): a pure 16 B/lane matrix stream -- the gathered vector comes from the LDS copy of the
 // window (wx, wy, wz; index = column - wlo). wn is a multiple of 8: batches of 4 pairs, all 8 loads
 // of a batch issued before use and the next batch's loads issued before the current one is consumed.
-__device__ __forceinline__ void near_window_row(const LevelView &L, int o0, int wn, int lane, int wlo,
-                                                const double *wx, const double *wy, const double *wz,
-                                                double &s0, double &s1, double &s2) {
-    constexpr int HB = kSellUnroll / 2;
+struct NearBatch {  // the first batch of a row's near entries (4 column pairs, 4 value pairs)
     typedef int v2i __attribute__((ext_vector_type(2)));
     typedef double v2d __attribute__((ext_vector_type(2)));
+    v2i c[kSellUnroll / 2];
+    v2d v[kSellUnroll / 2];
+};
+// issue the loads of a row's first near batch (so that they fly during the reductions / the LDS
+// window fill that precede the row loop)
+__device__ __forceinline__ void near_prefetch(const LevelView &L, int o0, int wn, int lane, NearBatch &B) {
+    constexpr int HB = kSellUnroll / 2;
+    const NearBatch::v2i *__restrict__ cs = reinterpret_cast<const NearBatch::v2i *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+    const NearBatch::v2d *__restrict__ vs = reinterpret_cast<const NearBatch::v2d *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < HB; u++) {
+        B.c[u] = NearBatch::v2i{0, 0};
+        B.v[u] = NearBatch::v2d{0.0, 0.0};
+    }
+    if (wn > 0) {
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+            B.c[u] = __builtin_nontemporal_load(&cs[(size_t)u * 64]);
+            B.v[u] = __builtin_nontemporal_load(&vs[(size_t)u * 64]);
+        }
+    }
+}
+__device__ __forceinline__ void near_window_row(const LevelView &L, int o0, int wn, int lane, int wlo,
+                                                const double *wx, const double *wy, const double *wz,
+                                                const NearBatch &first, double &s0, double &s1, double &s2) {
+    constexpr int HB = kSellUnroll / 2;
+    typedef NearBatch::v2i v2i;
+    typedef NearBatch::v2d v2d;
     const v2i *__restrict__ cs = reinterpret_cast<const v2i *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
     const v2d *__restrict__ vs = reinterpret_cast<const v2d *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
     s0 = s1 = s2 = 0.0;
     v2i cc[HB], cn[HB];
     v2d vv[HB], vn[HB];
-    if (wn > 0) {
 #pragma unroll
-        for (int u = 0; u < HB; u++) {
-            cc[u] = __builtin_nontemporal_load(&cs[(size_t)u * 64]);
-            vv[u] = __builtin_nontemporal_load(&vs[(size_t)u * 64]);
-        }
+    for (int u = 0; u < HB; u++) {
+        cc[u] = first.c[u];
+        vv[u] = first.v[u];
     }
     for (int q0 = 0; q0 < wn / 2; q0 += HB) {
         if (q0 + HB < wn / 2) {
@@ -408,6 +431,8 @@ __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const doubl
         const int o0 = L.sl_off[sl], wn = L.sl_near[sl];
         const double4 pr = p[min(row, L.n - 1)];
         const double d = L.diag[row];
+        NearBatch nb;
+        near_prefetch(L, o0, live ? wn : 0, lane, nb);
         double4 wv0 = make_double4(0, 0, 0, 0), wv1 = wv0;
         const int i0w = threadIdx.x, i1w = threadIdx.x + kRowBlock;
         if (i0w < whi - wlo) wv0 = p[wlo + i0w];
@@ -427,7 +452,7 @@ __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const doubl
         __syncthreads();
         if (live) {
             double s0, s1, s2;
-            near_window_row(L, o0, wn, lane, wlo, wx, wy, wz, s0, s1, s2);
+            near_window_row(L, o0, wn, lane, wlo, wx, wy, wz, nb, s0, s1, s2);
             double f0, f1, f2;
             row_offdiag_t<false>(L, row, p, nullptr, 0, 0.0, f0, f1, f2, wn);  // far entries
             s0 += f0;
@@ -536,6 +561,8 @@ __global__ __launch_bounds__(kRowBlock) void k_pspmv_dot(
         const int row = sl * 64 + lane;
         const int o0 = L.sl_off[sl], wn = L.sl_near[sl];
         const double d = L.diag[row];
+        NearBatch nb;
+        near_prefetch(L, o0, live ? wn : 0, lane, nb);
         double4 rr[2], yy[2], pp[2];
         double ww[2];
         if (t == t0) {
@@ -568,7 +595,7 @@ __global__ __launch_bounds__(kRowBlock) void k_pspmv_dot(
         __syncthreads();
         if (live) {
             double s0, s1, s2;
-            near_window_row(L, o0, wn, lane, wlo, wx, wy, wz, s0, s1, s2);
+            near_window_row(L, o0, wn, lane, wlo, wx, wy, wz, nb, s0, s1, s2);
             if (row < L.n) {
                 const int ir = row - wlo;
                 const double px = wx[ir], py = wy[ir], pz = wz[ir];
