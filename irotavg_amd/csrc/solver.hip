@@ -489,9 +489,9 @@ __global__ __launch_bounds__(kRowBlock) void k_spmv_dot(LevelView L, const doubl
 // SpMV loads the window of p its tile needs into LDS anyway; here it FORMS those entries instead,
 // p_new = omega D^-1 r + kc P y1 + beta p_old (same statements as k_pcg_pupdate_add), stores its own
 // 256 rows to Pnew (ping-pong with Pold: other workgroups still read p_old of these rows for their
-// halos). Only for matrices WITHOUT far entries (every neighbour inside the tile window, i.e. no
-// loop closures on level 0): a far entry would need four gathers instead of one.
-template <bool FIRST>
+// halos). A far entry (loop closure) needs four gathers instead of one: FAR = true handles the
+// case of a FEW of them (<= 1/32 of the entry-columns); with more, the two kernels stay separate.
+template <bool FIRST, bool FAR>
 __global__ __launch_bounds__(kRowBlock) void k_pspmv_dot(
     LevelView L, int sh, double *__restrict__ scal, int par, const double *__restrict__ part_rz, int np0,
     const double *__restrict__ part_rz2, int np1, const double4 *__restrict__ R,
@@ -596,6 +596,23 @@ __global__ __launch_bounds__(kRowBlock) void k_pspmv_dot(
         if (live) {
             double s0, s1, s2;
             near_window_row(L, o0, wn, lane, wlo, wx, wy, wz, nb, s0, s1, s2);
+            if (FAR) {
+                // the few far entries (a handful of loop closures): p_new of the far column is formed
+                // from its four inputs, one entry pair at a time. Only used when far entry-columns
+                // are rare (pcg_solve); with many of them the separate p-update is cheaper.
+                const int wtot = L.sl_off[sl + 1] - o0;
+                const int2 *__restrict__ fc = reinterpret_cast<const int2 *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+                const double2 *__restrict__ fv = reinterpret_cast<const double2 *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
+                for (int k0 = wn; k0 < wtot; k0 += 2) {
+                    const int2 cp = fc[(size_t)(k0 / 2) * 64];
+                    const double2 vp = fv[(size_t)(k0 / 2) * 64];
+                    const double4 pa = pnew(R[cp.x], yc[cp.x >> sh], FIRST ? R[cp.x] : Pold[cp.x], L.idg[cp.x]);
+                    const double4 pb = pnew(R[cp.y], yc[cp.y >> sh], FIRST ? R[cp.y] : Pold[cp.y], L.idg[cp.y]);
+                    s0 += vp.x * pa.x + vp.y * pb.x;
+                    s1 += vp.x * pa.y + vp.y * pb.y;
+                    s2 += vp.x * pa.z + vp.y * pb.z;
+                }
+            }
             if (row < L.n) {
                 const int ir = row - wlo;
                 const double px = wx[ir], py = wy[ir], pz = wz[ir];
@@ -1419,24 +1436,29 @@ int pcg_solve(Graph &g) {
     const int maxit = std::max(1, g.opt.pcg_max_iters);
     // single GPU + additive top level: p-update and SpMV are one launch (k_pspmv_dot), the search
     // direction ping-pongs between P and P2
-    const bool fused = g.additive_top && g.levels.size() > 1 && g.ng == 0 && g.l0_far_entries == 0 &&
-                       g.opt.no_fused_pspmv != 1;
+    const bool fused = g.additive_top && g.levels.size() > 1 && g.ng == 0 &&
+                       g.l0_far_entries * 32 <= g.levels[0].sell_len / 64 && g.opt.no_fused_pspmv != 1;
+    const bool far = g.l0_far_entries > 0;
     double4 *PP[2] = {g.P.p, g.P2.p};
     auto iteration_tail = [&](const PrecInfo &pi) {
         const int first = (it == 0);
         const int par = it & 1;
         if (fused) {
             const int sh = __builtin_ctz((unsigned)L0.agg);
-            if (first)
-                hipLaunchKernelGGL((k_pspmv_dot<true>), dim3(gr), dim3(kRowBlock), 0, g.stream, view_of(L0), sh,
-                                   g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, RR[rcur],
-                                   g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, PP[par], PP[par ^ 1],
-                                   g.AP.p, g.part_pq.p, g.flags.p);
+#define PSPMV_LAUNCH(F1, FR)                                                                           \
+    hipLaunchKernelGGL((k_pspmv_dot<F1, FR>), dim3(gr), dim3(kRowBlock), 0, g.stream, view_of(L0), sh,   \
+                       g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, RR[rcur],            \
+                       g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, PP[par], PP[par ^ 1], g.AP.p,        \
+                       g.part_pq.p, g.flags.p)
+            if (first && far)
+                PSPMV_LAUNCH(true, true);
+            else if (first)
+                PSPMV_LAUNCH(true, false);
+            else if (far)
+                PSPMV_LAUNCH(false, true);
             else
-                hipLaunchKernelGGL((k_pspmv_dot<false>), dim3(gr), dim3(kRowBlock), 0, g.stream, view_of(L0), sh,
-                                   g.scal.p, par, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2, RR[rcur],
-                                   g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, PP[par], PP[par ^ 1],
-                                   g.AP.p, g.part_pq.p, g.flags.p);
+                PSPMV_LAUNCH(false, false);
+#undef PSPMV_LAUNCH
             update(false, par ^ 1, PP[par ^ 1]);
         } else {
             launch_pupdate(g, par, first, pi);
@@ -1570,7 +1592,7 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         case 5: (void)precondition(g, 0, -1.0); break;
         case 8: {  // the fused p-update + SpMV of the single-GPU PCG (k_pspmv_dot)
             Level &L0 = g.levels[0];
-            hipLaunchKernelGGL((k_pspmv_dot<false>), dim3(grid_for_rows(L0)), dim3(kRowBlock), 0, g.stream,
+            hipLaunchKernelGGL((k_pspmv_dot<false, false>), dim3(grid_for_rows(L0)), dim3(kRowBlock), 0, g.stream,
                                view_of(L0), __builtin_ctz((unsigned)L0.agg), g.scal.p, 0, g.part_rz.p, 1,
                                g.part_rz2.p, 1, L0.b.p, g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, g.P.p,
                                g.P2.p, g.AP.p, g.part_pq.p, g.flags.p);
