@@ -31,8 +31,8 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 
 // In-register Gauss-Jordan inversion of a 32 x 32 SPD block: lane l (and its mirror l + 32) holds
 // row l in d[0..31]; pivot rows are broadcast by lane reads. Per pivot and column: two v_readlane
-// and ONE fma (the pivot scaling is folded into the lane's multiplier; the pivot row itself is
-// scaled afterwards under its own exec mask); the reciprocal is v_rcp_f64 + two Newton steps
+// and ONE fma (the pivot scaling is folded into the lane's multiplier and into a per-lane row
+// scale); the reciprocal is v_rcp_f64 + two Newton steps
 // instead of an IEEE division. (Splitting a row over lanes l and l + 32 halves the instruction
 // count but needs ds_bpermute broadcasts: measured 10 % slower; publishing the scaled pivot row in
 // LDS and reading it back as broadcast loads: 75 % slower -- the LDS round trip sits on the
@@ -44,23 +44,28 @@ __device__ __forceinline__ double rcp_newton(double x) {
     return r;
 }
 __device__ __forceinline__ void gj_invert32(double (&d)[GJB], int l, double thr) {
+    // Row l is held as sc * d[] (sc = this lane's scale): scaling the pivot row by 1/pivot is then
+    // two scalar operations on lane k instead of 31 multiplies executed for one active lane, and
+    // the rows are scaled once, in parallel, at the end.
+    double sc = 1.0;
 #pragma unroll
     for (int k = 0; k < GJB; k++) {
-        const double piv = readlane_d(d[k], k);
+        const double sk = readlane_d(sc, k);
+        const double piv = sk * readlane_d(d[k], k);  // true pivot
         const double ip = (piv > thr && piv > 0.0) ? rcp_newton(piv) : 0.0;
+        const double skn = sk * ip;                   // scale of the pivot row after the step
         const bool me = l == k;
-        const double m = me ? 0.0 : d[k] * ip;  // multiple of the pivot row this lane subtracts
+        const double m = me ? 0.0 : d[k] * skn;       // multiple of the (unscaled) pivot row to subtract
 #pragma unroll
         for (int j = 0; j < GJB; j++) {
             if (j != k) d[j] = fma(-m, readlane_d(d[j], k), d[j]);
         }
-        d[k] = me ? ip : -m;
-        if (me) {
-#pragma unroll
-            for (int j = 0; j < GJB; j++)
-                if (j != k) d[j] *= ip;
-        }
+        // column k: true value ip on the pivot row (= skn * (1 / sk)), -a_lk * ip elsewhere
+        d[k] = me ? (sk != 0.0 ? 1.0 / sk : 0.0) : -(d[k] * ip);
+        if (me) sc = skn;
     }
+#pragma unroll
+    for (int j = 0; j < GJB; j++) d[j] *= sc;
 }
 
 // E (npad x npad, row-major, zeroed beforehand) from the SELL level: E = diag + offdiag;
