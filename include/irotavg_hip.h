@@ -65,7 +65,9 @@ typedef struct irotavg_options {
                                   ||r||/||b|| <= 1e-6 (0, default) or <= 10^-k (k > 0); -1 = never: such
                                   a solve ends in IROTAVG_ERR_NOT_CONVERGED at pcg_max_iters */
     int no_fused_pspmv;        /* 1: keep the PCG p-update and the SpMV as two launches (default 0: fused on one GPU) */
-    int reserved[2];           /* must be 0 */
+    int no_lowrank_repair;     /* 1: a non-uniformly changed coarse operator is always re-inverted (default 0:
+                                  <= 64 deviating long-range entries are repaired by a low-rank update) */
+    int reserved[1];           /* must be 0 */
 } irotavg_options;
 
 void irotavg_default_options(irotavg_options *opt);
@@ -84,6 +86,8 @@ typedef struct irotavg_stats {
     int64_t level_nnz[16];
     double last_relres[3];   /* ||r||/||b|| per column at the end of the last solve */
     int64_t pcg_stagnated;   /* solves accepted at a stalled residual above pcg_rtol (see pcg_stall_accept) */
+    int64_t dense_inversions; /* full inversions of the dense coarse level */
+    int64_t dense_repairs;    /* low-rank (Woodbury) repairs of that inverse instead of an inversion */
 } irotavg_stats;
 
 /* ---------------------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ class Options(C.Structure):
                 ("mg_levels_max", C.c_int), ("mg_agg0", C.c_int), ("mg_agg", C.c_int),
                 ("mg_dense_max", C.c_int), ("mg_omega", C.c_double), ("mg_kc", C.c_double),
                 ("device", C.c_int), ("mg_multiplicative_top", C.c_int), ("dense_always_refresh", C.c_int),
-                ("no_window_kernel", C.c_int), ("pcg_stall_accept", C.c_int), ("no_fused_pspmv", C.c_int), ("reserved", C.c_int * 2)]
+                ("no_window_kernel", C.c_int), ("pcg_stall_accept", C.c_int), ("no_fused_pspmv", C.c_int), ("no_lowrank_repair", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class Stats(C.Structure):
@@ -49,7 +49,8 @@ class Stats(C.Structure):
                 ("outer_iters", C.c_int64), ("edge_updates", C.c_int64),
                 ("seconds_irls", C.c_double), ("seconds_l1ra", C.c_double), ("levels", C.c_int),
                 ("level_rows", C.c_int64 * 16), ("level_nnz", C.c_int64 * 16),
-                ("last_relres", C.c_double * 3), ("pcg_stagnated", C.c_int64)]
+                ("last_relres", C.c_double * 3), ("pcg_stagnated", C.c_int64),
+                ("dense_inversions", C.c_int64), ("dense_repairs", C.c_int64)]
 
 
 class RotAvgInfo(C.Structure):

@@ -40,6 +40,8 @@ struct Graph {
     std::vector<Level> levels;
     DevBuf<double> dense_inv;  // explicit inverse of the coarsest level, ndense_pad^2 row-major
     DevBuf<double> dense_wr, dense_wc;  // Gauss-Jordan panels (32 x npad, npad x 32), two of each
+    DevBuf<double> dense_wb;            // scratch of the low-rank repair (Z, W, S, S^-1, entry list)
+    int dense_repairs_in_a_row = 0;     // since the last full inversion
     DevBuf<double> dense_la;            // look-ahead: two snapshots of upcoming 32 x 32 diagonal blocks
     int ndense = 0, ndense_pad = 0;
     bool dense_valid = false, dense_fresh = false;
@@ -130,7 +132,7 @@ bool window_fits_wave(int nv, int f, int ne);
 // dense.hip
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);
-bool dense_is_stale(Graph &g);
+bool dense_is_stale(Graph &g, bool allow_repair = false);
 int dense_apply_grid(const Graph &g);
 void dense_apply(Graph &g, const double4 *b, double4 *y, bool check, bool dot, double *part_dot,
                  int np_rr, int first, double rtol2);

@@ -597,6 +597,8 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
             g.stats.pcg_iters += q.stats.pcg_iters;
             g.stats.pcg_iters_last = q.stats.pcg_iters_last;
             g.stats.pcg_stagnated += q.stats.pcg_stagnated;
+            g.stats.dense_inversions += q.stats.dense_inversions;
+            q.stats.dense_inversions = 0;
             q.stats.pcg_solves = 0;
             q.stats.pcg_iters = 0;
             q.stats.pcg_stagnated = 0;

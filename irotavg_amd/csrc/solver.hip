@@ -1249,7 +1249,7 @@ void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
                            dim3(kRowBlock), 0, g.stream, view_of(C), F.n, F.agg, F.excess.p,
                            C.excess.p, C.diag.p, C.idg.p);
     }
-    if (refresh_dense || dense_is_stale(g)) {
+    if (refresh_dense || dense_is_stale(g, mode == 0)) {
         dense_refresh(g);
         g.dense_valid = true;
         g.dense_fresh = true;

@@ -148,3 +148,29 @@ def test_fused_pcg_launches_match_the_separate_kernels(n, m, levels, f, p):
         assert synth.angular_distance(out[0][1], ro["Q"]).max() < 1e-8
     else:
         assert int(S["is_loop"].sum()) > 0
+
+
+@pytest.mark.parametrize("closures", [3, 40])
+def test_lowrank_repair_of_the_dense_inverse(closures):
+    """A sequence with a few loop closures: between IRLS iterations only the closures' long-range
+    coarse entries move non-uniformly, and the dense inverse is repaired by a Woodbury update
+    instead of being recomputed. Same IRLS iterations, same PCG effort, same rotations as with
+    no_lowrank_repair = 1; the counters show that repairs replaced inversions."""
+    n, m = 40000, 596000
+    S = synth.make_graph(n, m, closures / m, seed=8)
+    assert int(S["is_loop"].sum()) == closures
+    Q0 = mst(S, n)
+    out = {}
+    for nr in (0, 1):
+        with capi.Graph(S["I"], S["QQ"], n, 1, no_lowrank_repair=nr) as G:
+            G.set_rotations(Q0)
+            r = G.irls(4, SIG, 100, 1e-3)
+            st = G.stats()
+            out[nr] = (r["iters"], G.get_rotations(), G.get_weights(), st)
+    assert out[0][0] == out[1][0] and out[0][0] >= 3
+    assert synth.angular_distance(out[0][1], out[1][1]).max() < 1e-10
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-8)
+    a, b = out[0][3], out[1][3]
+    assert b["dense_repairs"] == 0 and b["dense_inversions"] >= out[1][0] - 1
+    assert a["dense_repairs"] >= 1 and a["dense_inversions"] < b["dense_inversions"]
+    assert a["pcg_iters"] <= b["pcg_iters"] + 3 * out[0][0]
