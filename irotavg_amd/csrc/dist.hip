@@ -76,17 +76,21 @@ __global__ __launch_bounds__(256) void k_pack(int cnt, const int *__restrict__ i
 // overwritten); the all-reduce then runs directly on row 0 and the consumers read it with
 // nparts = 1 -- no staging copies.
 __global__ __launch_bounds__(256) void k_reduce_parts(double *__restrict__ pa, int na,
-                                                      double *__restrict__ pb, int nb) {
-    double a[3], b[3] = {0, 0, 0};
+                                                      double *__restrict__ pb, int nb,
+                                                      double *__restrict__ pc, int nc) {
+    double a[3], b[3] = {0, 0, 0}, c3[3] = {0, 0, 0};
     load_reduced3(pa, na, a);
     if (pb) load_reduced3(pb, nb, b);
+    if (pc) load_reduced3(pc, nc, c3);
     if (threadIdx.x == 0) {
         for (int c = 0; c < 3; c++) {
             pa[c] = a[c];
             if (pb) pb[c] = b[c];
+            if (pc) pc[c] = c3[c];
         }
         pa[3] = 0.0;
         if (pb) pb[3] = 0.0;
+        if (pc) pc[3] = 0.0;
     }
 }
 
@@ -97,6 +101,27 @@ __global__ void k_add_small(int n, double *__restrict__ dst, const double *__res
 
 // ---- collectives ------------------------------------------------------------------------------
 // sum over all shards of the 4-double rows `pa(shard)` (and `pb(shard)` when given), in place
+typedef double *(*RowOf)(Shard &);
+static void allreduce_rows(Dist &D, const RowOf *rows, int nrows) {
+    if (D.use_rccl) {  // one group = one fused launch for the nrows x 4 doubles
+        Shard &S = *D.shards[0];
+        NCCL_CHECK(ncclGroupStart());
+        for (int w = 0; w < nrows; w++)
+            NCCL_CHECK(ncclAllReduce(rows[w](S), rows[w](S), 4, ncclDouble, ncclSum, D.comm, D.stream));
+        NCCL_CHECK(ncclGroupEnd());
+        return;
+    }
+    if (D.shards.size() == 1) return;
+    Shard &S0 = *D.shards[0];
+    for (int w = 0; w < nrows; w++) {
+        double *d0 = rows[w](S0);
+        for (size_t s = 1; s < D.shards.size(); s++)  // fixed shard order
+            hipLaunchKernelGGL(k_add_small, dim3(1), dim3(64), 0, D.stream, 4, d0, rows[w](*D.shards[s]));
+        for (size_t s = 1; s < D.shards.size(); s++)
+            IRH_CHECK(hipMemcpyAsync(rows[w](*D.shards[s]), d0, sizeof(double) * 4, hipMemcpyDeviceToDevice,
+                                     D.stream));
+    }
+}
 template <typename FA, typename FB>
 static void allreduce_rows(Dist &D, FA pa, FB pb, bool two) {
     if (D.use_rccl) {
@@ -304,8 +329,8 @@ static int build_shard(Dist &D, Shard &S, const int32_t *I, const double *QQ, in
 }
 
 // ---- sharded PCG ----------------------------------------------------------------------------------
-static void reduce_pair(Dist &D, double *pa, int na, double *pb, int nb) {
-    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, D.stream, pa, na, pb, nb);
+static void reduce_pair(Dist &D, double *pa, int na, double *pb, int nb, double *pc = nullptr, int nc = 0) {
+    hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(256), 0, D.stream, pa, na, pb, nb, pc, nc);
 }
 
 static int pcg_dist(Dist &D) {
@@ -325,31 +350,48 @@ static int pcg_dist(Dist &D) {
         Graph &g = sp->g;
         IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, D.stream));
         launch_update(g, true, 0, 1);
-        reduce_pair(D, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
+        if (!(g.additive_top && g.levels.size() > 1))
+            reduce_pair(D, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
     }
-    allreduce_rows(D, p_rr, p_rz, true);
+    if (!additive(D.shards[0]->g)) allreduce_rows(D, p_rr, p_rz, true);
     int it = 0;
     int h_flags[FL_COUNT] = {0, 0, 0, 0};
     const int check = std::max(1, D.opt.pcg_check_every);
     const int maxit = std::max(1, D.opt.pcg_max_iters);
+    // Additive top level (the default): ||r||^2 and the Jacobi part of r.z come out of the update
+    // kernel, the coarse part of r.z out of the (shard-local) preconditioner -- all three travel in
+    // ONE all-reduce after the preconditioner, and convergence is tested in the p-update that
+    // consumes them. Two all-reduces per iteration (this one and p.Lp). Multiplicative top level:
+    // the older three-stage flow (||r||^2 is needed by the preconditioner's first kernel).
+    const bool merged = additive(D.shards[0]->g);
+    const RowOf rows3[3] = {+[](Shard &S) { return S.g.part_rr.p; }, +[](Shard &S) { return S.g.part_rz.p; },
+                            +[](Shard &S) { return S.g.part_rz2.p; }};
     auto prec_all = [&]() {
         for (auto &sp : D.shards) {
             Graph &g = sp->g;
-            PrecInfo pi = precondition(g, it == 0, rtol2);
-            // the coarse (additive) or full (multiplicative) r.z partials of this shard
-            if (additive(g))
+            PrecInfo pi = precondition(g, it == 0, rtol2, !merged);
+            if (merged)
+                reduce_pair(D, g.part_rr.p, it == 0 ? upd_parts(g) : upd_parts(g), g.part_rz.p, upd_parts(g),
+                            g.part_rz2.p, pi.np_rz2);
+            else if (additive(g))
                 reduce_pair(D, g.part_rz2.p, pi.np_rz2, nullptr, 0);
             else
                 reduce_pair(D, g.part_rz.p, pi.np_rz, nullptr, 0);
         }
-        allreduce_rows(D, p_prec, p_prec, false);
+        if (merged)
+            allreduce_rows(D, rows3, 3);
+        else
+            allreduce_rows(D, p_prec, p_prec, false);
     };
-    auto tail_all = [&]() {
+    auto pupdate_all = [&]() {  // merged flow: carries the convergence test
         const int first = (it == 0), par = it & 1;
         PrecInfo one;
         one.np_rz = 1;
         one.np_rz2 = 1;
-        for (auto &sp : D.shards) launch_pupdate(sp->g, par, first, one);
+        for (auto &sp : D.shards) launch_pupdate(sp->g, par, first, one, merged, 1, rtol2);
+    };
+    auto tail_all = [&]() {
+        const int par = it & 1;
         halo_exchange(D, HALO_P);
         for (auto &sp : D.shards) {
             Graph &g = sp->g;
@@ -360,24 +402,27 @@ static int pcg_dist(Dist &D) {
         for (auto &sp : D.shards) {
             Graph &g = sp->g;
             launch_update(g, false, par ^ 1, 1);
-            reduce_pair(D, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
+            if (!merged) reduce_pair(D, g.part_rr.p, upd_parts(g), g.part_rz.p, upd_parts(g));
         }
-        allreduce_rows(D, p_rr, p_rz, true);
+        if (!merged) allreduce_rows(D, p_rr, p_rz, true);
         it++;
     };
     int chunk = D.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(D.stats.pcg_iters_last, maxit) : check;
     while (true) {
         for (int c = 0; c < chunk; c++) {
             prec_all();
+            pupdate_all();
             tail_all();
         }
         chunk = std::max(2, check / 2);
         prec_all();
+        if (merged) pupdate_all();  // the convergence test of the merged flow lives in the p-update
         IRH_CHECK(hipMemcpyAsync(h_flags, D.shards[0]->g.flags.p, sizeof(int) * FL_COUNT,
                                  hipMemcpyDeviceToHost, D.stream));
         IRH_CHECK(hipStreamSynchronize(D.stream));
         if (h_flags[FL_DONE] != 0) break;
         if (it >= maxit) break;
+        if (!merged) pupdate_all();
         tail_all();
     }
     D.stats.pcg_solves += 1;

@@ -115,8 +115,9 @@ int pcg_solve(Graph &g);
 void launch_spmv(Graph &g);
 void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = nullptr,
                    const double4 *rin = nullptr, double4 *rout = nullptr);
-void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi);
-PrecInfo precondition(Graph &g, int first, double rtol2);
+void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi, bool check = false, int np_rr = 1,
+                    double rtol2 = 0.0);
+PrecInfo precondition(Graph &g, int first, double rtol2, bool check = true);
 int grid_for_rows(const Level &L);
 int grid_for_elems(long long n);
 int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f);

@@ -1082,11 +1082,13 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict2(
 }
 
 // beta from r.z = (r.z0 partials) + kc * (b1.y1 partials); p = omega D^-1 r + kc * P y1 + beta p
+template <bool CHECK>
 __global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate_add(
     int n, int sh, double *__restrict__ scal, int par, int first, const double *__restrict__ part_rz,
     int np0, const double *__restrict__ part_rz2, int np1, const double4 *__restrict__ R,
     const double *__restrict__ idg, const double4 *__restrict__ yc, double omega, double kc,
-    double4 *__restrict__ P, int *__restrict__ flags) {
+    double4 *__restrict__ P, int *__restrict__ flags, const double *__restrict__ part_rr, int np_rr,
+    double rtol2) {
     const int done = flags[FL_DONE];
     const int i_pre = blockIdx.x * blockDim.x + threadIdx.x;
     double4 r_pre = make_double4(0, 0, 0, 0), y_pre = r_pre, p_pre = r_pre;
@@ -1098,6 +1100,9 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate_add(
         if (!first) p_pre = P[i_pre];
     }
     if (done) return;
+    // sharded runs test convergence here (||r||^2 arrives with r.z in ONE all-reduce after the
+    // preconditioner) instead of in the preconditioner's first kernel
+    if (CHECK && pcg_check(part_rr, np_rr, first, rtol2, scal, flags)) return;
     double ra[3], rb[3], rzn[3], be[3];
     load_reduced3(part_rz, np0, ra);
     load_reduced3(part_rz2, np1, rb);
@@ -1312,7 +1317,7 @@ static void cycle_from(Graph &g, int from, bool check_first, bool dot_from, doub
 // Preconditioner application. Multiplicative mode: z = levels[0].y, r.z partials in part_rz
 // (np_rz of them). Additive-top mode: levels[1].y = M1^-1 P0' r and b1.y1 partials in part_rz2
 // (np_rz2); z itself is formed inside the p-update.
-PrecInfo precondition(Graph &g, int first, double rtol2) {
+PrecInfo precondition(Graph &g, int first, double rtol2, bool check) {
     PrecInfo pi;
     const int nl = (int)g.levels.size();
     Level &L0 = g.levels[0];
@@ -1332,7 +1337,7 @@ PrecInfo precondition(Graph &g, int first, double rtol2) {
     }
     if (g.additive_top) {
         pi.np_rz = g.additive_top && nl > 1 ? grid_for_rows(L0) : np_rr;  // r.z0 partials of the update kernel
-        cycle_from(g, 1, true, true, g.part_rz2.p, np_rr, first, rtol2, &pi.np_rz2, g.l1_fused && nl > 2);
+        cycle_from(g, 1, check, true, g.part_rz2.p, np_rr, first, rtol2, &pi.np_rz2, g.l1_fused && nl > 2);
     } else {
         cycle_from(g, 0, true, true, g.part_rz.p, np_rr, first, rtol2, &pi.np_rz);
     }
@@ -1392,16 +1397,22 @@ void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *pvec,
     }
 }
 
-void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi) {
+void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi, bool check, int np_rr, double rtol2) {
     Level &L0 = g.levels[0];
     const int nl = (int)g.levels.size();
     const int ge = grid_for_elems(L0.n);
     if (g.additive_top && nl > 1) {
         const int sh = __builtin_ctz((unsigned)L0.agg);
-        hipLaunchKernelGGL(k_pcg_pupdate_add, dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n, sh,
-                           g.scal.p, par, first, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2,
-                           L0.b.p, L0.idg.p, g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, g.P.p,
-                           g.flags.p);
+        if (check)
+            hipLaunchKernelGGL((k_pcg_pupdate_add<true>), dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n, sh,
+                               g.scal.p, par, first, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2,
+                               L0.b.p, L0.idg.p, g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, g.P.p,
+                               g.flags.p, g.part_rr.p, np_rr, rtol2);
+        else
+            hipLaunchKernelGGL((k_pcg_pupdate_add<false>), dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n, sh,
+                               g.scal.p, par, first, g.part_rz.p, pi.np_rz, g.part_rz2.p, pi.np_rz2,
+                               L0.b.p, L0.idg.p, g.levels[1].y.p, g.opt.mg_omega, g.opt.mg_kc, g.P.p,
+                               g.flags.p, g.part_rr.p, np_rr, rtol2);
     } else {
         hipLaunchKernelGGL(k_pcg_pupdate, dim3(ge), dim3(kRowBlock), 0, g.stream, L0.n, g.scal.p, par,
                            first, g.part_rz.p, pi.np_rz, L0.y.p, g.P.p, g.flags.p);
