@@ -55,7 +55,8 @@ typedef struct irotavg_options {
     int mg_dense_max;    /* coarsening stops at <= this many rows; that level is inverted densely
                             (blocked Gauss-Jordan on the GPU) and applied exactly; default and cap 2048 */
     double mg_omega;     /* damped-Jacobi factor; default 0.7 */
-    double mg_kc;        /* coarse-correction scale; default 1.0 */
+    double mg_kc;        /* coarse-correction scale (over-correction of the piecewise-constant aggregates);
+                            0 (default) = choose: 2.0 for a graph without loop closures, 1.6 otherwise */
     int device;          /* HIP device ordinal; -1 = current device */
     int mg_multiplicative_top; /* 1: multiplicative V-cycle on level 0 (default 0: additive top level) */
     int dense_always_refresh;  /* 1: re-invert the dense coarse level at every solve (default 0: adaptive) */

@@ -528,7 +528,6 @@ int irotavg_dist_create(irotavg_dist **out, int world, int rank, const void *uni
             irotavg_default_options(&D.opt);
         if (D.opt.pcg_rtol <= 0) D.opt.pcg_rtol = 1e-10;
         if (D.opt.mg_omega <= 0) D.opt.mg_omega = 0.7;
-        if (D.opt.mg_kc <= 0) D.opt.mg_kc = 1.0;
         if (D.opt.mg_dense_max <= 0) D.opt.mg_dense_max = 2048;
         if (D.opt.mg_levels_max <= 0) D.opt.mg_levels_max = 16;
         if (D.opt.pcg_max_iters <= 0) D.opt.pcg_max_iters = 2000;
