@@ -50,7 +50,8 @@ typedef struct irotavg_options {
     int pcg_max_iters;   /* default 2000 */
     int pcg_check_every; /* PCG iterations enqueued between host polls of the done flag; default 8 */
     int mg_levels_max;   /* cap on multigrid levels (1 = plain Jacobi-PCG); default 16 */
-    int mg_agg0;         /* aggregate size of the finest level (0 = choose from the mean degree) */
+    int mg_agg0;         /* aggregate size of the finest level (0 = choose: 8, or the smallest power of two
+                            that reaches the dense level) */
     int mg_agg;          /* aggregate size of the other levels (0 = choose; default) */
     int mg_dense_max;    /* coarsening stops at <= this many rows; that level is inverted densely
                             (blocked Gauss-Jordan on the GPU) and applied exactly; default and cap 2048 */
@@ -65,7 +66,9 @@ typedef struct irotavg_options {
                                   attainable accuracy of an ill-conditioned system) is accepted if
                                   ||r||/||b|| <= 1e-6 (0, default) or <= 10^-k (k > 0); -1 = never: such
                                   a solve ends in IROTAVG_ERR_NOT_CONVERGED at pcg_max_iters */
-    int no_fused_pspmv;        /* 1: keep the PCG p-update and the SpMV as two launches (default 0: fused on one GPU) */
+    int no_fused_pspmv;        /* 1: no kernel fusion inside the PCG iteration (default 0: on one GPU the
+                                  p-update runs inside the SpMV and, on graphs without loop closures, the
+                                  level-1 down-sweep inside the update kernel) */
     int no_lowrank_repair;     /* 1: a non-uniformly changed coarse operator is always re-inverted (default 0:
                                   <= 64 deviating long-range entries are repaired by a low-rank update) */
     int reserved[1];           /* must be 0 */
