@@ -367,3 +367,25 @@ def test_floating_component_is_gauge_fixed_not_an_error():
         for kern in (1, 2):
             w = capi.window_solve(I, QQ, Q0, 1, cost, SIG, 0, 20, 1e-3, kernel=kern)
             assert np.isfinite(w["Q"]).all()
+
+
+def test_graph_build_is_independent_of_the_host_thread_count(syn, monkeypatch):
+    """irotavg_graph_create builds adjacency, coarse patterns and SELL layout on several host threads
+    (slots claimed with atomic counters, then sorted on the edge id): a solve on a handle built by
+    1 thread and one built by the default thread count must agree bit for bit."""
+    G0, Qm = syn
+    outs = []
+    for threads in ("1", "7", None):
+        if threads is None:
+            monkeypatch.delenv("IROTAVG_BUILD_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("IROTAVG_BUILD_THREADS", threads)
+        with capi.Graph(G0["I"], G0["QQ"], 3000, 1) as G:
+            G.set_rotations(Qm)
+            G.l1ra(2, 1e-3)
+            G.irls(4, SIG, 20, 1e-3)
+            outs.append((G.get_rotations(), G.get_weights(), G.stats()["pcg_iters"]))
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o[0], outs[0][0])
+        np.testing.assert_array_equal(o[1], outs[0][1])
+        assert o[2] == outs[0][2]
