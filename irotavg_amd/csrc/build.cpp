@@ -384,7 +384,8 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
             // 100k views (PCG iterations per solve, kc = 1.0 / 1.6 / 2.0): band graphs of degree
             // 4..30: 75..27 / 61..20 / 57..19; with 0.2-10 % loop closures: 34..32 / 26..27 / 28..32.
             // The preconditioner stays SPD for every kc > 0 (omega < 1).
-            if (g.opt.mg_kc <= 0) g.opt.mg_kc = g.l0_far_entries == 0 ? 2.0 : 1.6;
+            g.kc_auto = g.opt.mg_kc <= 0;
+            if (g.kc_auto) g.opt.mg_kc = g.l0_far_entries == 0 ? 2.0 : 1.6;
             std::vector<uint32_t> seid((size_t)M.len, 0xffffffffu);
             parallel_for((int64_t)slot_eid.size(), 65536, [&](int64_t a, int64_t b, int) {
                 for (int64_t t = a; t < b; t++) seid[M.pos[t]] = slot_eid[t];

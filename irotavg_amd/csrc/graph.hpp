@@ -62,6 +62,7 @@ struct Graph {
     // PCG (level-0 sized). levels[0].b is the residual r, levels[0].x the pre-smoothed
     // iterate, levels[0].y the preconditioned residual z.
     DevBuf<double4> X, P, AP;
+    bool kc_auto = false;  // opt.mg_kc was chosen from the structure (build.cpp), not given
     int l1_fused = 0;  // the PCG update kernel also does the level-1 down-sweep (build.cpp)
     long long l0_far_entries = 0;  // level-0 SELL entry-columns outside the tile windows (loop closures)
     DevBuf<double4> R2;  // second residual buffer (l1_fused: the update kernel writes r out of place)
