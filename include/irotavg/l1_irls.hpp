@@ -112,6 +112,15 @@ inline void fail(int rc, const char *where) {
     std::exit(-1);
 #endif
 }
+/* IROTAVG_ERR_NOT_CONVERGED: the inner PCG stopped at its iteration cap. The reference's direct
+ * solvers always return a result, so the shim reports it the way the reference reports
+ * " Max Iteration" (ral/l1_irls.cpp:746-749): a message, and the rotations / weights the C call has
+ * already written back are kept. Everything else is the reference's std::cerr + exit(-1). */
+inline bool soft(int rc, const char *where) {
+    if (rc != IROTAVG_ERR_NOT_CONVERGED) return false;
+    std::fprintf(stderr, "%s: warning: %s (result kept)\n", where, irotavg_error_string(rc));
+    return true;
+}
 inline std::vector<int32_t> flat(const I_t &I) {
     std::vector<int32_t> e(2 * I.size());
     for (size_t k = 0; k < I.size(); k++) {
@@ -164,7 +173,7 @@ inline void l1ra(const Mat &QQ, const I_t &I, const SpMat & /*A*/, Mat &Q, const
     std::vector<int32_t> e = detail::flat(I);
     int rc = irotavg_l1ra((int64_t)I.size(), Q.rows(), f, e.data(), QQ.data(), shim_ld(QQ), Q.data(),
                           shim_ld(Q), max_iters, change_th, &iter, &runtime);
-    if (rc != IROTAVG_OK) detail::fail(rc, "l1ra");
+    if (rc != IROTAVG_OK && !detail::soft(rc, "l1ra")) detail::fail(rc, "l1ra");
 }
 
 /* ral/l1_irls.hpp:104-107. weights must be pre-sized to m (ral/test.cpp:299). */
@@ -176,7 +185,7 @@ inline void irls(const Mat &QQ, const I_t &I, const SpMat & /*A*/, Cost cost, do
     int rc = irotavg_irls((int64_t)I.size(), Q.rows(), f, e.data(), QQ.data(), shim_ld(QQ), (int)cost,
                           sigma, Q.data(), shim_ld(Q), max_iters, change_th, weights.data(),
                           &iteration, &runtime);
-    if (rc != IROTAVG_OK) detail::fail(rc, "irls");
+    if (rc != IROTAVG_OK && !detail::soft(rc, "irls")) detail::fail(rc, "irls");
 }
 
 /* ral/l1_irls.hpp:112 */

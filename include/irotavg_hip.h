@@ -209,7 +209,8 @@ void irotavg_viewgraph_destroy(irotavg_viewgraph *vg);
 int irotavg_viewgraph_add_view(irotavg_viewgraph *vg, const double R[9]);
 int irotavg_viewgraph_num_views(const irotavg_viewgraph *vg);
 /* replaces View::connect (src/View.hpp:92, src/ViewGraph.cpp:1438-1455): returns 1 if the
- * connection was added, 0 if the pair was already connected */
+ * connection was added, 0 if the pair was already connected. Rij is the rotation from view i to
+ * view j (R_j = R_ij R_i); the pair is kept under (min, max), so a call with i > j stores Rij^T */
 int irotavg_viewgraph_connect(irotavg_viewgraph *vg, int i, int j, const double Rij[9]);
 /* replace ViewGraph::fixPose / isPoseFixed / countFixedPoses (src/ViewGraph.hpp:69-73) */
 int irotavg_viewgraph_fix_pose(irotavg_viewgraph *vg, int idx, const double R[9]);

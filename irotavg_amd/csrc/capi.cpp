@@ -485,7 +485,7 @@ int irotavg_l1ra(int64_t m, int64_t n_total, int f, const int32_t *I, const doub
     if (rc != IROTAVG_OK) return rc;
     rc = irotavg_graph_set_rotations(h, Q, ldq);
     if (rc == IROTAVG_OK) rc = irotavg_graph_l1ra(h, max_iters, change_th, iter, runtime, nullptr);
-    if (rc == IROTAVG_OK) (void)irotavg_graph_get_rotations(h, Q, ldq);
+    if (rc == IROTAVG_OK || rc == IROTAVG_ERR_NOT_CONVERGED) (void)irotavg_graph_get_rotations(h, Q, ldq);
     irotavg_graph_destroy(h);
     return rc;
 }

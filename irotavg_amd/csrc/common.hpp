@@ -40,11 +40,12 @@ struct DevPool {
         void *p;
         size_t bytes;
         bool dirty;
+        uint64_t epoch;  // value of DevPool::epoch when the block was released
     };
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, Block> cache;
     size_t cached = 0, limit = (size_t)16384 << 20;
-    size_t n_dirty = 0;
+    uint64_t epoch = 0;  // advances with every release
     DevPool() {
         if (const char *e = std::getenv("IROTAVG_POOL_LIMIT_MB")) limit = (size_t)std::strtoull(e, nullptr, 10) << 20;
     }
@@ -57,6 +58,7 @@ struct DevPool {
     void *take(int dev, size_t bytes, size_t *got) {
         bool sync = false;
         void *p = nullptr;
+        uint64_t epoch_seen = 0;
         {
             std::lock_guard<std::mutex> lk(mu);
             auto it = cache.lower_bound({dev, bytes});
@@ -67,19 +69,26 @@ struct DevPool {
             sync = it->second.dirty;
             cached -= it->second.bytes;
             cache.erase(it);
-            if (sync) {
-                for (auto &kv : cache)
-                    if (kv.first.first == dev) kv.second.dirty = false;
-            }
+            epoch_seen = epoch;
         }
-        if (sync) (void)hipDeviceSynchronize();
+        if (sync) {
+            // The block (and every block released before this point) may still be in use by its
+            // previous owner's queued work: synchronise FIRST, and only then mark as clean the
+            // blocks that were already cached when the synchronisation began (a block released
+            // while it ran carries a newer epoch and stays dirty). Another thread that takes a
+            // dirty block meanwhile synchronises itself -- never hands it out early.
+            (void)hipDeviceSynchronize();
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &kv : cache)
+                if (kv.first.first == dev && kv.second.epoch <= epoch_seen) kv.second.dirty = false;
+        }
         return p;
     }
     void give(int dev, void *p, size_t bytes) {
         {
             std::lock_guard<std::mutex> lk(mu);
             if (cached + bytes <= limit) {
-                cache.insert({{dev, bytes}, Block{p, bytes, true}});
+                cache.insert({{dev, bytes}, Block{p, bytes, true, ++epoch}});
                 cached += bytes;
                 return;
             }

@@ -130,7 +130,9 @@ int irotavg_viewgraph_add_view(irotavg_viewgraph *vg, const double R[9]) {
 int irotavg_viewgraph_num_views(const irotavg_viewgraph *vg) { return vg ? (int)vg->pose.size() : 0; }
 
 // View::connect (src/ViewGraph.cpp:1438-1455): undirected, one ViewConnection per pair, a second
-// connect of the same pair is refused. Rij relates the lower to the higher id: R_j = R_ij R_i.
+// connect of the same pair is refused. Rij relates a to b: R_b = R_ab R_a. The pair is stored under
+// (lo, hi) with R_hi = R R_lo, so a call with a > b stores the transpose (the reference only ever
+// calls connect(prev, curr) with prev < curr).
 int irotavg_viewgraph_connect(irotavg_viewgraph *vg, int a, int b, const double Rij[9]) {
     if (!vg || !Rij || a == b || a < 0 || b < 0 || a >= (int)vg->pose.size() || b >= (int)vg->pose.size())
         return IROTAVG_ERR_BAD_ARG;
@@ -141,7 +143,12 @@ int irotavg_viewgraph_connect(irotavg_viewgraph *vg, int a, int b, const double 
     if (it != list.end() && it->i == lo) return 0;
     irotavg_viewgraph::Conn c;
     c.i = lo;
-    std::copy(Rij, Rij + 9, c.R.m);
+    if (a < b) {
+        std::copy(Rij, Rij + 9, c.R.m);
+    } else {  // R_ab given with a > b: R_lo->hi = R_ab^T
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) c.R.m[3 * r + q] = Rij[3 * q + r];
+    }
     rmat2quat(c.R.m, c.q);
     list.insert(it, c);
     return 1;
@@ -374,7 +381,11 @@ int irotavg_window_solve_kernel(int64_t m, int64_t n_total, int f, const int32_t
     if (!I || !QQ || !Q || m <= 0 || n_total <= 0 || ldqq < m || ldq < n_total) return IROTAVG_ERR_BAD_ARG;
     if (kernel < 0 || kernel > 2) return IROTAVG_ERR_BAD_ARG;
     if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
+    // the single-workgroup kernels index LDS / global arrays with f and the edge endpoints unguarded
+    if (f < 0 || f >= n_total) return IROTAVG_ERR_BAD_ARG;
     if (!irh::window_fits((int)n_total, f, (int)m)) return IROTAVG_ERR_BAD_ARG;
+    for (int64_t k = 0; k < 2 * m; k++)
+        if (I[k] < 0 || I[k] >= n_total) return IROTAVG_ERR_BAD_ARG;
     if (kernel == 2 && !irh::window_fits_wave((int)n_total, f, (int)m)) return IROTAVG_ERR_BAD_ARG;
     if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
     try {

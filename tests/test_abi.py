@@ -109,6 +109,20 @@ def test_bad_arguments():
     h = C.c_void_p()
     assert L.irotavg_graph_create(C.byref(h), 0, 2, 1, None, None, 0, None) == capi.ERR_BAD_ARG
     assert L.irotavg_graph_irls(None, 4, 0.1, 1, 1e-3, None, None, None) == capi.ERR_BAD_ARG
+    # irotavg_window_solve: f and the edge endpoints index LDS unguarded inside the kernel, so they
+    # are validated at the ABI (before any device is touched)
+    I = np.array([[0, 1], [1, 2]], dtype=np.int32)
+    QQ = np.tile([0, 0, 0, 1.0], (2, 1))
+    Q = np.tile([0, 0, 0, 1.0], (3, 1))
+    for bad_f in (-5, 3):
+        with pytest.raises(capi.IrotavgError) as e:
+            capi.window_solve(I, QQ, Q.copy(), bad_f)
+        assert e.value.code == capi.ERR_BAD_ARG
+    for bad in (-1, 3):
+        Ib = I.copy(); Ib[1, 1] = bad
+        with pytest.raises(capi.IrotavgError) as e:
+            capi.window_solve(Ib, QQ, Q.copy(), 1)
+        assert e.value.code == capi.ERR_BAD_ARG
     assert ral.parse_cost("geman-mcclure") == 4 and ral.parse_cost("L1.5") == 2
     with pytest.raises(ValueError):
         ral.parse_cost("nope")

@@ -138,3 +138,27 @@ def test_incremental_stream_matches_oracle():
                    (b["n_views"], b["n_fixed"], b["l1_iters"], b["irls_iters"]), (v, a, b)
     for v in range(n):
         np.testing.assert_allclose(vg.R(v), vo.R[v], atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_connect_with_swapped_arguments_stores_the_transpose():
+    """irotavg_viewgraph_connect(j, i, R_ji) with j > i is the same constraint as connect(i, j, R_ji^T)
+    (the reference only ever calls connect(prev, curr), src/ViewGraph.cpp:1438-1455)."""
+    n = 30
+    Qgt, rel = build_sequence(n, seed=3)
+    a, b = ViewGraph(), ViewGraph()
+    rng = np.random.default_rng(5)
+    for v in range(n):
+        R0 = rot(synth.qmul(synth.qexp(rng.normal(scale=0.05, size=(1, 3)))[0], Qgt[v]))
+        a.addView(R0); b.addView(R0)
+    for k, ((i, j), R) in enumerate(rel.items()):
+        a.connect(i, j, R)
+        if k % 2:
+            b.connect(j, i, R.T)
+        else:
+            b.connect(i, j, R)
+    a.fixPose(0, rot(Qgt[0])); b.fixPose(0, rot(Qgt[0]))
+    ra, rb = a.rotAvg(5000000), b.rotAvg(5000000)
+    assert (ra["l1_iters"], ra["irls_iters"]) == (rb["l1_iters"], rb["irls_iters"])
+    for v in range(n):
+        np.testing.assert_allclose(a.R(v), b.R(v), atol=1e-12)
