@@ -66,6 +66,21 @@ def kernel_rooflines(G, S, st, sharded=False):
         out["pspmv"] = dict(ms=ms, bytes=by, gbs=by / (ms * 1e-3) / 1e9)
     except capi.IrotavgError:
         pass
+    try:  # the two-launch Chronopoulos-Gear iteration (cgcg.hip): band-only graphs with >= 3 levels on one GPU
+        if sharded:
+            raise capi.IrotavgError(capi.ERR_BAD_ARG, "sharded")
+        n1, nd = st["level_rows"][1], st["level_rows"][2]
+        nnz1 = st["level_nnz"][1]
+        coarse = 2 * 24 * n1 + 12 * nnz1 + 24 * nd + (8 * nd * nd if st["levels"] == 3 else 0)
+        ms = G.time_kernel(9, 50)
+        # matrix once, r / idg / diag in, u / w out, plus the coarse data every tile slice comes from
+        by = nnz0 * (8 + 4) + 4 * (nu + 1) + nu * (24 + 8 + 8 + 24 + 24) + coarse
+        out["cg_apply"] = dict(ms=ms, bytes=by, gbs=by / (ms * 1e-3) / 1e9)
+        ms = G.time_kernel(10, 50)
+        by = nu * 24 * 10 + 2 * 24 * n1 + 12 * nnz1 + 2 * 24 * nd   # r w s u p x in, p s x r out, b1 x1 b2 x2 out
+        out["cg_update"] = dict(ms=ms, bytes=by, gbs=by / (ms * 1e-3) / 1e9)
+    except capi.IrotavgError:
+        pass
     out["precondition"] = dict(ms=G.time_kernel(5, 50))
     out["dense_inversion"] = dict(ms=G.time_kernel(7, 5))
     return out
@@ -134,6 +149,8 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--classic", action="store_true",
+                    help="A/B: the classic PCG recurrences (separate launches) instead of the two-launch iteration")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the sharded (RCCL) path even with one rank (exercises it on a 1-GPU box)")
     args = ap.parse_args()
@@ -162,7 +179,8 @@ def main():
     # all-reduced dot products; see DESIGN.md "Multi-GPU") -- strong scaling.
     G = D = None
     if dist is None:
-        G = capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=args.rtol, device=dev)
+        G = capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=args.rtol, device=dev,
+                       pcg_classic=1 if args.classic else 0)
         G.set_rotations(Q0)
         G.snapshot_rotations()
 
@@ -225,13 +243,16 @@ def main():
             "final_scores": [float(x) for x in res["scores"]],
         }
         kr = kernel_rooflines(G, S, st, sharded=dstats is not None)
-        dom = "pspmv" if "pspmv" in kr else "spmv"
+        dom = "cg_apply" if "cg_apply" in kr else ("pspmv" if "pspmv" in kr else "spmv")
         dname = {"spmv": "k_spmv_dot (level-0 SELL-64 SpMV + fused dot, dominant PCG kernel)",
-                 "pspmv": "k_pspmv_dot (PCG p-update fused into the level-0 SELL-64 SpMV + dot, dominant PCG kernel)"}[dom]
+                 "pspmv": "k_pspmv_dot (PCG p-update fused into the level-0 SELL-64 SpMV + dot, dominant PCG kernel)",
+                 "cg_apply": "k_cg_apply (u = M^-1 r incl. the tile's slice of the dense coarse solve and the level-1 "
+                             "up-sweep, then the level-0 SELL-64 SpMV w = L u + dots; dominant PCG kernel)"}[dom]
         line["roofline"] = {"kernel": dname,
                             "bound": "hbm", "achieved": kr[dom]["gbs"], "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": kr[dom]["gbs"] / HBM_PEAK_GBS,
-                            "traffic": pmc_traffic("k_pspmv_dot" if dom == "pspmv" else "k_spmv_dot"),
+                            "traffic": pmc_traffic({"pspmv": "k_pspmv_dot", "spmv": "k_spmv_dot",
+                                                    "cg_apply": "k_cg_apply"}[dom]),
                             "ms_per_launch": kr[dom]["ms"], "algorithmic_bytes": kr[dom]["bytes"]}
         line["roofline_edge_residual"] = {
             "kernel": "k_edge_residual (K1, the kernel north_star names)", "bound": "hbm",

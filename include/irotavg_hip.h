@@ -71,7 +71,8 @@ typedef struct irotavg_options {
                                   level-1 down-sweep inside the update kernel) */
     int no_lowrank_repair;     /* 1: a non-uniformly changed coarse operator is always re-inverted (default 0:
                                   <= 64 deviating long-range entries are repaired by a low-rank update) */
-    int reserved[1];           /* must be 0 */
+    int pcg_classic;           /* 1: the PCG iteration always runs as separate launches (default 0: on one
+                                  GPU a graph without loop closures runs it as two launches, cgcg.hip) */
 } irotavg_options;
 
 void irotavg_default_options(irotavg_options *opt);

@@ -361,6 +361,12 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         L.agg = h.agg;
         L.nsl = M.nsl;
         L.sell_len = M.len;
+        L.max_near = 0;
+        L.uni_w = M.nsl > 0 ? M.sl_off[1] - M.sl_off[0] : 0;
+        for (int sl = 0; sl < M.nsl; sl++) {
+            L.max_near = std::max(L.max_near, M.sl_near[sl]);
+            if (M.sl_off[sl + 1] - M.sl_off[sl] != L.uni_w || M.sl_near[sl] != L.uni_w) L.uni_w = 0;
+        }
         std::vector<int> scol((size_t)M.len);
         parallel_for(M.nsl, 128, [&](int64_t s0, int64_t s1, int) {
             for (int sl = (int)s0; sl < (int)s1; sl++)  // padding: a valid near column (row 0 of the slice), value 0
@@ -444,6 +450,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     // on levels 0 and 1, one GPU, and every level-1 neighbour of a tile's 32 level-1 rows inside
     // the 48-row window the update kernel holds in LDS.
     g.l1_fused = 0;
+    g.cg2 = 0;
     if (g.additive_top && H.size() >= 3 && H[0].agg == 8 && H[1].agg == 8 && g.ng == 0 &&
         g.l0_far_entries == 0 && g.opt.no_fused_pspmv != 1) {
         bool ok = true;
@@ -457,6 +464,23 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
                 }
         }
         g.l1_fused = ok ? 1 : 0;
+        // the two-launch iteration (cgcg.hip) also runs the level-1 UP-sweep inside a level-0 kernel:
+        // the 48 level-1 rows under a tile window need all their neighbours within the 64 extended
+        // rows, i.e. within 8 rows
+        bool band8 = ok;
+        for (int r = 0; r < h1.n && band8; r++)
+            for (int t = h1.rowptr[r]; t < h1.rowptr[r + 1]; t++)
+                if (h1.col[t] < r - 8 || h1.col[t] > r + 8) {
+                    band8 = false;
+                    break;
+                }
+        g.cg2 = (band8 && g.ndense > 0 && g.opt.pcg_classic != 1) ? 1 : 0;
+        g.dense32 = 0;  // tile slices of the coarse solve read the fp64 inverse; IROTAVG_CG2_FP32_DENSE=1: an fp32 copy
+        if (const char *e = getenv("IROTAVG_CG2_FP32_DENSE")) g.dense32 = atoi(e) == 1 ? 1 : 0;
+        if (g.cg2) {
+            g.b2p.alloc((size_t)3 * g.ndense_pad);
+            g.b2p.zero(s);
+        }
     }
     // ---- PCG state ----------------------------------------------------------------------
     const size_t nv0 = (size_t)g.levels[0].nsl * 64 + 64;

@@ -1,0 +1,813 @@
+// cgcg.hip -- the PCG iteration as TWO launches (one GPU, band-dominated view-graphs).
+//
+// What SuiteSparseQR does at ral/l1_irls.cpp:550 and UMFPACK at :147-169 is a multigrid-
+// preconditioned CG here (solver.hip). Its iteration was four dependent launches (p-update + SpMV |
+// x/r update + restriction + level-1 down-sweep | dense coarse solve | level-1 up-sweep), and every
+// one of them is latency-bound at 100k views: ~3 us of launch + a chain of ~2 us memory round trips
+// before the first useful byte. This file cuts the iteration to the minimum number of global
+// synchronisation points a preconditioned CG with a global coarse solve can have -- two:
+//
+//   k_cg_update : alpha, beta from the partial dots; p = u + beta p, s = w + beta s, x += alpha p,
+//                 r -= alpha s; restriction of r to level 1, level-1 down-sweep, restriction to
+//                 level 2 (all tile-local: r_new is formed for the tile's window)
+//   k_cg_apply  : u = M^-1 r and w = L u.  The workgroup of a 256-row tile computes ITS OWN slice of
+//                 the coarse solve (8 rows of the dense inverse x the level-2 right-hand side, or 8
+//                 loads when level 2 is not the dense level), the level-1 up-sweep of the 64 level-1
+//                 rows under and around its window, forms u on the window in LDS and runs the SELL
+//                 SpMV from it; partial dots r.u and u.w.
+//
+// The recurrences are Chronopoulos & Gear's (s = L p is carried by recurrence, so the only reduction
+// of an iteration -- gamma = r.u, delta = u.w -- is consumed by the NEXT launch and nothing has to
+// wait inside a kernel):
+//   beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old).
+// Same preconditioner, same arithmetic per row and the same fixed-order reductions as the classic
+// path; results are bitwise reproducible run to run.
+//
+// Eligibility (build.cpp, Graph::cg2): one GPU, additive top level, aggregates of 8 on levels 0 and
+// 1, no far (loop-closure) entries on level 0, every level-1 neighbour within 8 rows (band graphs),
+// at least three levels.
+#include <algorithm>
+#include <cmath>
+
+#include "graph.hpp"
+#include "kernels.hpp"
+
+namespace irh {
+
+constexpr int kL1Pre = 8;   // entries of a level-1 row requested up front (a band graph's row has <= 8)
+
+// ---------------------------------------------------------------------------------------------
+// k_cg_update. MODE 0: start of a solve (x = 0, r = b: restriction only). MODE 1: first iteration
+// (beta = 0). MODE 2: general. Thread tid holds window slots tid and tid + 256; exactly one of them
+// is an own row of the tile. r and s ping-pong between two buffers (neighbouring workgroups read the
+// old values of these rows as their halo).
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
+    int n, int nsl, double *__restrict__ scal, int par, const double *__restrict__ part_g,
+    const double *__restrict__ part_d, int nparts, double4 *__restrict__ X,
+    const double4 *__restrict__ Rin, double4 *__restrict__ Rout, const double4 *__restrict__ Sin,
+    double4 *__restrict__ Sout, double4 *__restrict__ P, const double4 *__restrict__ U,
+    const double4 *__restrict__ W, LevelView L1, double4 *__restrict__ b1, double4 *__restrict__ x1,
+    double4 *__restrict__ b2, double4 *__restrict__ x2, const double *__restrict__ idg2, double omega,
+    double *__restrict__ part_rr, int *__restrict__ flags, double *__restrict__ b2p, int ndpad) {
+    const int done = flags[FL_DONE];
+    __shared__ double wb[3][kL1Win], wxv[3][kL1Win];
+    const int ntiles = (nsl + 3) / 4;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    const int tid = threadIdx.x;
+    struct Win {
+        double4 r[2], w[2], s[2];  // both window slots
+        double4 u, p, x;           // own row
+    };
+    auto win_load = [&](int t, Win &V) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int iw = tid + u * kRowBlock, i = wlo + iw;
+            V.r[u] = V.w[u] = V.s[u] = make_double4(0, 0, 0, 0);
+            if (iw < kWinLen && i < n) {
+                V.r[u] = Rin[i];
+                if (MODE != 0) V.w[u] = W[i];
+                if (MODE == 2) V.s[u] = Sin[i];
+            }
+        }
+        const int io = wlo + tid + (tid >= r0 - wlo ? 0 : kRowBlock);  // the own row among the two slots
+        V.u = V.p = V.x = make_double4(0, 0, 0, 0);
+        if (io < n && MODE != 0) {
+            V.u = U[io];
+            V.x = X[io];
+            if (MODE == 2) V.p = P[io];
+        }
+    };
+    // level-1 row (SELL entries, diagonal) of one of the tile's own 32 level-1 rows: lanes 0..31
+    struct Row1 {
+        double v[kL1Pre], d;
+        int c[kL1Pre], o0, w;
+    };
+    auto row1_load = [&](int t, Row1 &Rw) {
+        const int row = t * 32 + tid;
+        Rw.w = 0;
+        Rw.o0 = 0;
+        Rw.d = 0.0;
+#pragma unroll
+        for (int k = 0; k < kL1Pre; k++) {
+            Rw.v[k] = 0.0;
+            Rw.c[k] = 0;
+        }
+        if (tid < 32 && row < L1.n) {
+            const int sl = row >> 6, ln = row & 63;
+            Rw.o0 = L1.sl_off[sl];
+            Rw.w = L1.sl_off[sl + 1] - Rw.o0;
+            Rw.d = L1.diag[row];
+#pragma unroll
+            for (int k = 0; k < kL1Pre; k++)
+                if (k < Rw.w) {
+                    const size_t pos = sell_pos(Rw.o0, k, ln);
+                    Rw.v[k] = L1.val[pos];
+                    Rw.c[k] = L1.col[pos];
+                }
+        }
+    };
+    // the first tile's vectors are requested BEFORE the scalars are reduced from the partials
+    Win V0;
+    Row1 Q0;
+    if (t0 < t1) {
+        win_load(t0, V0);
+        row1_load(t0, Q0);
+    }
+    if (done) return;
+    double al[3] = {0, 0, 0}, be[3] = {0, 0, 0};
+    if (MODE != 0) {
+        double g3[3], d3[3];
+        load_reduced3(part_g, nparts, g3);
+        load_reduced3(part_d, nparts, d3);
+        bool finite = true;
+        for (int c = 0; c < 3; c++) {
+            const double go = scal[(par ? SC_GAM1 : SC_GAM0) + c], ao = scal[(par ? SC_ALF1 : SC_ALF0) + c];
+            const bool chain = MODE == 2 && go > 0.0 && ao > 0.0;
+            be[c] = chain ? g3[c] / go : 0.0;
+            const double den = d3[c] - (chain ? be[c] * g3[c] / ao : 0.0);
+            al[c] = den > 0.0 ? g3[c] / den : 0.0;  // gamma = 0: the column is solved exactly
+            finite = finite && isfinite(g3[c]) && isfinite(d3[c]);
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            for (int c = 0; c < 3; c++) {
+                scal[(par ? SC_GAM0 : SC_GAM1) + c] = g3[c];
+                scal[(par ? SC_ALF0 : SC_ALF1) + c] = al[c];
+            }
+            if (!finite) flags[FL_DONE] = 2;
+        }
+    }
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int t = t0; t < t1; t++) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo);
+        Win V;
+        Row1 Rw;
+        if (t == t0) {
+            V = V0;
+            Rw = Q0;
+        } else {
+            win_load(t, V);
+            row1_load(t, Rw);
+        }
+        const int uo = tid >= r0 - wlo ? 0 : 1;  // which slot is the own row
+        __syncthreads();  // the previous tile's level-1 rows are done with the window
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int iw = tid + u * kRowBlock, i = wlo + iw;
+            double4 r = V.r[u];
+            double4 s = V.w[u];
+            if (MODE != 0) {
+                if (MODE == 2) {
+                    s.x += be[0] * V.s[u].x;
+                    s.y += be[1] * V.s[u].y;
+                    s.z += be[2] * V.s[u].z;
+                }
+                r.x -= al[0] * s.x;
+                r.y -= al[1] * s.y;
+                r.z -= al[2] * s.z;
+            }
+            if (u == uo && i < n) {  // own row: p, s, x, r and ||r||^2
+                if (MODE == 0) {
+                    X[i] = make_double4(0, 0, 0, 0);
+                } else {
+                    double4 p = V.u;
+                    if (MODE == 2) {
+                        p.x += be[0] * V.p.x;
+                        p.y += be[1] * V.p.y;
+                        p.z += be[2] * V.p.z;
+                    }
+                    P[i] = p;
+                    Sout[i] = s;  // never in place: neighbouring workgroups read Sin of these rows
+                    double4 x = V.x;
+                    x.x += al[0] * p.x;
+                    x.y += al[1] * p.y;
+                    x.z += al[2] * p.z;
+                    X[i] = x;
+                }
+                Rout[i] = r;
+                a0 += r.x * r.x;
+                a1 += r.y * r.y;
+                a2 += r.z * r.z;
+            }
+            // restriction to level 1 (aggregates of 8 consecutive rows = 8 consecutive lanes)
+            const double c0 = seg_sum(r.x, 8), c1 = seg_sum(r.y, 8), c2 = seg_sum(r.z, 8);
+            if ((i & 7) == 0 && iw < kWinLen) {
+                const int I = i >> 3, Iw = iw >> 3;
+                const bool live = i < n;
+                const double w = live ? omega * L1.idg[I] : 0.0;
+                wb[0][Iw] = c0;
+                wb[1][Iw] = c1;
+                wb[2][Iw] = c2;
+                wxv[0][Iw] = w * c0;
+                wxv[1][Iw] = w * c1;
+                wxv[2][Iw] = w * c2;
+                if (live && i >= r0 && i < r0 + 256) {
+                    b1[I] = make_double4(c0, c1, c2, 0.0);
+                    x1[I] = make_double4(w * c0, w * c1, w * c2, 0.0);
+                }
+            }
+        }
+        __syncthreads();
+        // level-1 residual of the tile's own 32 level-1 rows, restricted to level 2
+        if (tid < 32) {
+            const int W1lo = wlo >> 3;
+            const int row = (r0 >> 3) + tid;
+            double s0 = 0, s1 = 0, s2 = 0, e0 = 0, e1 = 0, e2 = 0;
+            if (row < L1.n) {
+#pragma unroll
+                for (int k = 0; k < kL1Pre; k++) {  // entries requested at the top of the tile
+                    const int ci = min(max(Rw.c[k] - W1lo, 0), kL1Win - 1);  // padding: v = 0
+                    s0 += Rw.v[k] * wxv[0][ci];
+                    s1 += Rw.v[k] * wxv[1][ci];
+                    s2 += Rw.v[k] * wxv[2][ci];
+                }
+                for (int k = kL1Pre; k < Rw.w; k++) {
+                    const size_t pos = sell_pos(Rw.o0, k, row & 63);
+                    const double v = L1.val[pos];
+                    const int ci = min(max(L1.col[pos] - W1lo, 0), kL1Win - 1);
+                    s0 += v * wxv[0][ci];
+                    s1 += v * wxv[1][ci];
+                    s2 += v * wxv[2][ci];
+                }
+                const int me = row - W1lo;
+                const double d = Rw.d;
+                e0 = wb[0][me] - (s0 + d * wxv[0][me]);
+                e1 = wb[1][me] - (s1 + d * wxv[1][me]);
+                e2 = wb[2][me] - (s2 + d * wxv[2][me]);
+            }
+            e0 = seg_sum(e0, 8);
+            e1 = seg_sum(e1, 8);
+            e2 = seg_sum(e2, 8);
+            if ((row & 7) == 0 && row < L1.n) {
+                const int J = row >> 3;
+                b2[J] = make_double4(e0, e1, e2, 0.0);
+                if (b2p != nullptr) {  // planar copy: k_cg_apply stages it into LDS by LDS-DMA
+                    b2p[J] = e0;
+                    b2p[ndpad + J] = e1;
+                    b2p[2 * ndpad + J] = e2;
+                }
+                const double w = omega * idg2[J];
+                x2[J] = make_double4(w * e0, w * e1, w * e2, 0.0);
+            }
+        }
+    }
+    block_sum3_store(a0, a1, a2, part_rr + 4 * blockIdx.x);
+    if (MODE != 0 && blockIdx.x == 0 && tid == 0) flags[FL_ITERS] += 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_cg_apply. YMODE 2: level 2 is the dense level; the workgroup multiplies the 8 rows of the
+// explicit inverse it needs with the level-2 right-hand side (staged in LDS once). YMODE 1: level 2
+// has levels below it; its correction y2 was computed by the generic cycle and is loaded.
+// Level-1 geometry of the tile at row r0 (a multiple of 256): window rows [r0/8 - 8, r0/8 + 40),
+// extended rows [r0/8 - 16, r0/8 + 48) (the window's rows and every neighbour of theirs), level-2
+// rows [r0/64 - 2, r0/64 + 6).
+// ---------------------------------------------------------------------------------------------
+template <int YMODE, typename ET, int NJ, int NB, bool ONE>
+__global__ __launch_bounds__(kRowBlock, 2) void k_cg_apply(
+    LevelView L, int uw, LevelView L1, int uw1, const double4 *__restrict__ R, double4 *__restrict__ U,
+    double4 *__restrict__ Wv, const double4 *__restrict__ b1, const double4 *__restrict__ x1,
+    const double *__restrict__ b2p, const double4 *__restrict__ y2g, const ET *__restrict__ Einv,
+    int nd, int ndpad, double dscale, double omega, double kc, double *__restrict__ part_g,
+    double *__restrict__ part_d, const double *__restrict__ part_rr, int np_rr, int first, double rtol2,
+    double *__restrict__ scal, int *__restrict__ flags, long long *dbg) {
+#define CG_STAMP(k) \
+    if (dbg != nullptr && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) dbg[k] = wall_clock64()
+    CG_STAMP(0);
+    const int done = flags[FL_DONE];
+    __shared__ double wx[kWinLen], wy[kWinLen], wz[kWinLen];
+    __shared__ double ex[3][kL1Ext], ey[3][kL1Win], y2s[3][8];
+    extern __shared__ double sb[];  // YMODE 2: 3 * ndpad, the level-2 right-hand side
+    const int ntiles = (L.nsl + 3) / 4;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    constexpr int CPL = 16 / (int)sizeof(ET);  // columns of a dense-inverse row per 16-byte lane load (2 or 4)
+    typedef ET vE __attribute__((ext_vector_type(CPL)));
+    // What the coarse slice needs is requested at the top of the tile, before anything waits on
+    // memory; the phases below then only wait for LDS and barriers. (The matrix row and the level-1
+    // row follow once the dense-inverse registers are free: more than ~250 live VGPRs would cost the
+    // second workgroup of a CU its residency -- measured 34 vs 26 us.)
+    struct Pre {
+        double4 r[2];          // window slots: residual
+        double w[2];           //               1 / diagonal
+        vE ea[NJ], eb[NJ];     // YMODE 2: this wave's two rows of the dense inverse, 16 bytes per lane and step
+        double4 x1v, y2v;      // lanes < 64: x1 of an extended row; lanes < 8: y2 (YMODE 1)
+    };
+    auto pre_load = [&](int t, Pre &A) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo), whi = min(L.n, r0 + 256 + kWinHalo);
+        const int base2 = (r0 >> 6) - 2, baseE = (r0 >> 3) - 16;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int iw = tid + u * kRowBlock, i = wlo + iw;
+            const int ic = min(i, whi - 1);  // slots beyond the window re-read its last row (never used)
+            A.r[u] = R[ic];
+            A.w[u] = L.idg[ic];
+        }
+        if (YMODE == 2) {
+            // branch-free: a row outside the level reads row 0 (its result is zeroed when y2 is stored),
+            // a column pair beyond npad re-reads the last pair (skipped by the fma loop)
+            const int J0 = base2 + 2 * wv, J1 = J0 + 1;
+            const ET *__restrict__ e0p = Einv + (size_t)(J0 >= 0 && J0 < nd ? J0 : 0) * ndpad;
+            const ET *__restrict__ e1p = Einv + (size_t)(J1 >= 0 && J1 < nd ? J1 : 0) * ndpad;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int c = min(CPL * (lane + 64 * j), ndpad - CPL);  // ndpad is a multiple of 64
+                A.ea[j] = *reinterpret_cast<const vE *>(e0p + c);
+                A.eb[j] = *reinterpret_cast<const vE *>(e1p + c);
+            }
+        }
+        A.x1v = A.y2v = make_double4(0, 0, 0, 0);
+        if (tid < kL1Ext) {
+            const int I = baseE + tid;
+            if (I >= 0 && I < L1.n) A.x1v = x1[I];
+        }
+        if (YMODE == 1 && tid < 8) {
+            const int J = base2 + tid;
+            if (J >= 0 && J < nd) A.y2v = y2g[J];
+        }
+    };
+    Pre A;
+    if (YMODE == 2) {
+        // level-2 right-hand side (planar copy written by k_cg_update) -> LDS by LDS-DMA: no staging
+        // registers, no ds_write pass. A wave moves 64 x 16 B per instruction to a wave-uniform LDS base.
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int it = 0; it < 4; it++) {  // 4 x 512 doubles >= npad (<= 2048)
+                const int base = it * 512 + wv * 128;
+                if (base + 2 * lane < ndpad)
+                    __builtin_amdgcn_global_load_lds(
+                        (const void __attribute__((address_space(1))) *)(b2p + (size_t)pl * ndpad + base + 2 * lane),
+                        (void __attribute__((address_space(3))) *)(sb + pl * ndpad + base), 16, 0, 0);
+            }
+    }
+    if (t0 < t1) pre_load(t0, A);
+    if (done) return;
+    CG_STAMP(1);
+    if (pcg_check(part_rr, np_rr, first, rtol2, scal, flags)) return;  // uniform across the grid
+    CG_STAMP(2);
+    double g0 = 0, g1 = 0, g2 = 0, d0 = 0, d1 = 0, d2 = 0;
+    // ONE: the grid has a workgroup per tile (every graph up to 131k views). The tile loop of the
+    // general form makes the register allocator keep the prologue's values across a back edge that is
+    // never taken: 80-280 spilled VGPRs; straight-line code has none.
+    auto tile_body = [&](const int t) {
+        const int r0 = t * 256;
+        const int wlo = max(0, r0 - kWinHalo), whi = min(L.n, r0 + 256 + kWinHalo);
+        const int base2 = (r0 >> 6) - 2, baseE = (r0 >> 3) - 16, base1 = (r0 >> 3) - 8;
+        const int sl = min(t * 4 + wv, L.nsl - 1);
+        const bool live = t * 4 + wv < L.nsl;
+        const int row = sl * 64 + lane;
+        if (t != t0) pre_load(t, A);
+        const int o0 = uw > 0 ? sl * uw : L.sl_off[sl];
+        const int wn = uw > 0 ? uw : L.sl_near[sl];
+        const double dg = L.diag[row];
+        v2i mc[NB > 0 ? NB : 1][kSellUnroll / 2];
+        v2d mv[NB > 0 ? NB : 1][kSellUnroll / 2];
+        NearBatch nb;
+        {
+            const v2i *cs = reinterpret_cast<const v2i *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+            const v2d *vs = reinterpret_cast<const v2d *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
+            if (NB > 0) {
+#pragma unroll
+                for (int bq = 0; bq < (NB > 0 ? NB : 1); bq++)
+#pragma unroll
+                    for (int u = 0; u < kSellUnroll / 2; u++) {
+                        mc[bq][u] = v2i{sl * 64, sl * 64};  // a near column, value 0
+                        mv[bq][u] = v2d{0.0, 0.0};
+                        if (live && bq * kSellUnroll < wn) {
+                            mc[bq][u] = __builtin_nontemporal_load(&cs[(size_t)(bq * (kSellUnroll / 2) + u) * 64]);
+                            mv[bq][u] = __builtin_nontemporal_load(&vs[(size_t)(bq * (kSellUnroll / 2) + u) * 64]);
+                        }
+                    }
+            } else {
+                near_prefetch(L, o0, live ? wn : 0, lane, nb);
+            }
+        }
+        __syncthreads();  // sb staged; the previous tile is done with every LDS array
+        CG_STAMP(3);
+        // ---- the tile's slice of the coarse solve: y2 on 8 level-2 rows
+        if (YMODE == 2) {
+            double p0 = 0, p1 = 0, p2 = 0, q0 = 0, q1 = 0, q2 = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int c = CPL * (lane + 64 * j);
+                // keep the scheduler from hoisting all the LDS reads above the first fma
+                if ((j & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                if (c < ndpad) {
+#pragma unroll
+                    for (int q = 0; q < CPL; q += 2) {
+                        const v2d bx = *reinterpret_cast<const v2d *>(sb + c + q);
+                        const v2d by = *reinterpret_cast<const v2d *>(sb + ndpad + c + q);
+                        const v2d bz = *reinterpret_cast<const v2d *>(sb + 2 * ndpad + c + q);
+                        const double a0 = (double)A.ea[j][q], a1 = (double)A.ea[j][q + 1];
+                        const double c0 = (double)A.eb[j][q], c1 = (double)A.eb[j][q + 1];
+                        p0 += a0 * bx.x + a1 * bx.y;
+                        p1 += a0 * by.x + a1 * by.y;
+                        p2 += a0 * bz.x + a1 * bz.y;
+                        q0 += c0 * bx.x + c1 * bx.y;
+                        q1 += c0 * by.x + c1 * by.y;
+                        q2 += c0 * bz.x + c1 * bz.y;
+                    }
+                }
+            }
+            p0 = wave_sum(p0);
+            p1 = wave_sum(p1);
+            p2 = wave_sum(p2);
+            q0 = wave_sum(q0);
+            q1 = wave_sum(q1);
+            q2 = wave_sum(q2);
+            if (lane == 0) {
+                const int J0 = base2 + 2 * wv, J1 = J0 + 1;
+                const double z0 = J0 >= 0 && J0 < nd ? dscale : 0.0, z1 = J1 >= 0 && J1 < nd ? dscale : 0.0;
+                y2s[0][2 * wv] = p0 * z0;
+                y2s[1][2 * wv] = p1 * z0;
+                y2s[2][2 * wv] = p2 * z0;
+                y2s[0][2 * wv + 1] = q0 * z1;
+                y2s[1][2 * wv + 1] = q1 * z1;
+                y2s[2][2 * wv + 1] = q2 * z1;
+            }
+        } else if (tid < 8) {
+            y2s[0][tid] = A.y2v.x;
+            y2s[1][tid] = A.y2v.y;
+            y2s[2][tid] = A.y2v.z;
+        }
+        CG_STAMP(10);
+        // ---- now that the dense-inverse registers are free: request the lane's WHOLE matrix row (NB
+        // batches of 8 entries; the row loop further down then never waits on memory) and, lanes < 48,
+        // the level-1 row. All of these are read-only and unaliased, so the compiler would hoist them
+        // to the top of the kernel (next to the dense rows: spills); passing the base pointers through
+        // an empty asm pins them here.
+        double l1v[kL1Pre], l1d = 0.0, l1w = 0.0;
+        int l1c[kL1Pre], l1o0 = 0, l1wd = 0;
+        double4 b1v = make_double4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < kL1Pre; k++) {
+            l1v[k] = 0.0;
+            l1c[k] = 0;
+        }
+        if (tid < kL1Win) {
+            const int I = base1 + tid;
+            if (I >= 0 && I < L1.n) {
+                const int s1l = I >> 6, ln = I & 63;
+                const double4 *b1p = b1;
+                const double *v1p = L1.val;
+                const int *c1p = L1.col;
+                asm volatile("" : "+v"(b1p), "+v"(v1p), "+v"(c1p) : : "memory");
+                b1v = b1p[I];
+                l1d = L1.diag[I];
+                l1w = omega * L1.idg[I];
+                l1o0 = uw1 > 0 ? s1l * uw1 : L1.sl_off[s1l];
+                l1wd = uw1 > 0 ? uw1 : L1.sl_off[s1l + 1] - l1o0;
+#pragma unroll
+                for (int k = 0; k < kL1Pre; k++)
+                    if (k < l1wd) {
+                        const size_t pos = sell_pos(l1o0, k, ln);
+                        l1v[k] = v1p[pos];
+                        l1c[k] = c1p[pos];
+                    }
+            }
+        }
+        CG_STAMP(11);
+        __syncthreads();
+        CG_STAMP(4);
+        // ---- level-1 up-sweep, part 1: x1' = x1 + kc P1 y2 on the extended rows
+        if (tid < kL1Ext) {
+            const int I = baseE + tid;
+            double4 v = A.x1v;
+            if (I >= 0 && I < L1.n) {
+                const int J = (I >> 3) - base2;
+                v.x += kc * y2s[0][J];
+                v.y += kc * y2s[1][J];
+                v.z += kc * y2s[2][J];
+            }
+            ex[0][tid] = v.x;
+            ex[1][tid] = v.y;
+            ex[2][tid] = v.z;
+        }
+        __syncthreads();
+        CG_STAMP(5);
+        // ---- part 2: y1 = x1' + omega D1^-1 (b1 - L1 x1') on the window's level-1 rows
+        if (tid < kL1Win) {
+            const int I = base1 + tid;
+            double y0 = 0, y1 = 0, y2 = 0;
+            if (I >= 0 && I < L1.n) {
+                double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+                for (int k = 0; k < kL1Pre; k++) {
+                    const int ci = min(max(l1c[k] - baseE, 0), kL1Ext - 1);  // padding: v = 0
+                    s0 += l1v[k] * ex[0][ci];
+                    s1 += l1v[k] * ex[1][ci];
+                    s2 += l1v[k] * ex[2][ci];
+                }
+                for (int k = kL1Pre; k < l1wd; k++) {
+                    const size_t pos = sell_pos(l1o0, k, I & 63);
+                    const double v = L1.val[pos];
+                    const int ci = min(max(L1.col[pos] - baseE, 0), kL1Ext - 1);
+                    s0 += v * ex[0][ci];
+                    s1 += v * ex[1][ci];
+                    s2 += v * ex[2][ci];
+                }
+                const int me = I - baseE;
+                const double p0 = ex[0][me], p1 = ex[1][me], p2 = ex[2][me];
+                y0 = p0 + l1w * (b1v.x - (s0 + l1d * p0));
+                y1 = p1 + l1w * (b1v.y - (s1 + l1d * p1));
+                y2 = p2 + l1w * (b1v.z - (s2 + l1d * p2));
+            }
+            ey[0][tid] = y0;
+            ey[1][tid] = y1;
+            ey[2][tid] = y2;
+        }
+        __syncthreads();
+        CG_STAMP(6);
+        // ---- u = omega D^-1 r + kc P0 y1 on the window; own rows stored, r.u accumulated
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int iw = tid + u * kRowBlock;
+            if (iw < kWinLen) {
+                const int i = wlo + iw;
+                double4 uv = make_double4(0, 0, 0, 0);
+                if (i < whi) {
+                    const double w = omega * A.w[u];
+                    const int I1 = (i >> 3) - base1;
+                    uv.x = w * A.r[u].x + kc * ey[0][I1];
+                    uv.y = w * A.r[u].y + kc * ey[1][I1];
+                    uv.z = w * A.r[u].z + kc * ey[2][I1];
+                    if (i >= r0 && i < r0 + 256) {  // own rows of this tile
+                        U[i] = uv;
+                        g0 += A.r[u].x * uv.x;
+                        g1 += A.r[u].y * uv.y;
+                        g2 += A.r[u].z * uv.z;
+                    }
+                }
+                wx[iw] = uv.x;
+                wy[iw] = uv.y;
+                wz[iw] = uv.z;
+            }
+        }
+        __syncthreads();
+        CG_STAMP(7);
+        // ---- w = L u for the own rows, u.w accumulated
+        if (live) {
+            double s0 = 0, s1 = 0, s2 = 0;
+            if (NB > 0) {
+#pragma unroll
+                for (int bq = 0; bq < (NB > 0 ? NB : 1); bq++)
+#pragma unroll
+                    for (int u = 0; u < kSellUnroll / 2; u++) {
+                        const int i0 = mc[bq][u].x - wlo, i1 = mc[bq][u].y - wlo;
+                        s0 += mv[bq][u].x * wx[i0] + mv[bq][u].y * wx[i1];
+                        s1 += mv[bq][u].x * wy[i0] + mv[bq][u].y * wy[i1];
+                        s2 += mv[bq][u].x * wz[i0] + mv[bq][u].y * wz[i1];
+                    }
+                if (wn > NB * kSellUnroll) {  // a slice wider than the register-resident part
+                    double f0, f1, f2;
+                    NearBatch nb2;
+                    near_prefetch_at(L, o0, NB * kSellUnroll, wn, lane, nb2);
+                    near_window_row_from(L, o0, NB * kSellUnroll, wn, lane, wlo, wx, wy, wz, nb2, f0, f1, f2);
+                    s0 += f0;
+                    s1 += f1;
+                    s2 += f2;
+                }
+            } else {
+                near_window_row(L, o0, wn, lane, wlo, wx, wy, wz, nb, s0, s1, s2);
+            }
+            if (row < L.n) {
+                const int ir = row - wlo;
+                const double ux = wx[ir], uy = wy[ir], uz = wz[ir];
+                s0 += dg * ux;
+                s1 += dg * uy;
+                s2 += dg * uz;
+                Wv[row] = make_double4(s0, s1, s2, 0.0);
+                d0 += ux * s0;
+                d1 += uy * s1;
+                d2 += uz * s2;
+            }
+        }
+    };
+    if (ONE) {
+        if (t0 < t1) tile_body(t0);
+    } else {
+        for (int t = t0; t < t1; t++) tile_body(t);
+    }
+    CG_STAMP(8);
+    block_sum3_store(g0, g1, g2, part_g + 4 * blockIdx.x);
+    block_sum3_store(d0, d1, d2, part_d + 4 * blockIdx.x);
+    CG_STAMP(9);
+#undef CG_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Cg2Bufs {
+    double4 *R[2], *S[2], *P, *U, *W;
+};
+Cg2Bufs cg2_bufs(Graph &g) {
+    Level &L0 = g.levels[0];
+    // residual: levels[0].b (the right-hand side on entry) <-> R2; s: P2 <-> levels[0].e;
+    // u: levels[0].y; w: AP; p: P
+    return Cg2Bufs{{L0.b.p, g.R2.p}, {g.P2.p, L0.e.p}, g.P.p, L0.y.p, g.AP.p};
+}
+}  // namespace
+
+void cg2_launch_update(Graph &g, int mode, int par, int rcur) {
+    Level &L0 = g.levels[0];
+    Level &L1 = g.levels[1];
+    Level &L2 = g.levels[2];
+    const Cg2Bufs B = cg2_bufs(g);
+    const int grid = grid_for_rows(L0);
+#define CG_UPD(M)                                                                                        \
+    hipLaunchKernelGGL((k_cg_update<M>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl, g.scal.p, \
+                       par, g.part_rz.p, g.part_pq.p, grid, g.X.p, B.R[rcur], B.R[rcur ^ 1], B.S[rcur],   \
+                       B.S[rcur ^ 1], B.P, B.U, B.W, view_of(L1), L1.b.p, L1.x.p, L2.b.p, L2.x.p,         \
+                       L2.idg.p, g.opt.mg_omega, g.part_rr.p, g.flags.p,                                     \
+                       g.levels.size() == 3 ? g.b2p.p : (double *)nullptr, g.ndense_pad)
+    if (mode == 0)
+        CG_UPD(0);
+    else if (mode == 1)
+        CG_UPD(1);
+    else
+        CG_UPD(2);
+#undef CG_UPD
+}
+
+void cg2_launch_apply(Graph &g, int first, int rcur, double rtol2, long long *dbg = nullptr) {
+    Level &L0 = g.levels[0];
+    Level &L1 = g.levels[1];
+    Level &L2 = g.levels[2];
+    const Cg2Bufs B = cg2_bufs(g);
+    const int grid = grid_for_rows(L0);
+    const int nl = (int)g.levels.size();
+    // NB: batches of 8 entries of a level-0 row held in registers (band graph, 19 neighbours each side: 5)
+    const int nb = L0.max_near <= 40 ? 5 : 0;
+    const bool one = (L0.nsl + 3) / 4 <= grid;  // a workgroup per tile
+    if (nl == 3) {
+        const size_t shm = sizeof(double) * 3 * (size_t)g.ndense_pad;
+#define CG_APPLY2(ET, EP, NJ, NB, ONE)                                                                        \
+    hipLaunchKernelGGL((k_cg_apply<2, ET, NJ, NB, ONE>), dim3(grid), dim3(kRowBlock), shm, g.stream,            \
+                       view_of(L0), L0.uni_w, view_of(L1), L1.uni_w, B.R[rcur], B.U, B.W, L1.b.p, L1.x.p,       \
+                       g.b2p.p, (const double4 *)nullptr, EP, g.ndense, g.ndense_pad, g.dense_scale,            \
+                       g.opt.mg_omega, g.opt.mg_kc, g.part_rz.p, g.part_pq.p, g.part_rr.p, grid, first, rtol2,  \
+                       g.scal.p, g.flags.p, dbg)
+        if (g.dense32) {
+            // the fp32 copy of the inverse (cg2_refresh_inv32): NJ = ceil(npad / 256) 16-byte steps per lane
+            const float *E = g.dense_inv32.p;
+            if (nb == 5 && one) {
+                if (g.ndense_pad <= 1024)
+                    CG_APPLY2(float, E, 4, 5, true);
+                else if (g.ndense_pad <= 1792)
+                    CG_APPLY2(float, E, 7, 5, true);
+                else
+                    CG_APPLY2(float, E, 8, 5, true);
+            } else if (one) {
+                CG_APPLY2(float, E, 8, 0, true);
+            } else {
+                CG_APPLY2(float, E, 8, 0, false);
+            }
+        } else {  // fp64 slices (default): NJ = ceil(npad / 128)
+            const double *E = g.dense_inv.p;
+            if (g.ndense_pad <= 1664 && one)
+                CG_APPLY2(double, E, 13, 0, true);
+            else if (one)
+                CG_APPLY2(double, E, 16, 0, true);
+            else
+                CG_APPLY2(double, E, 16, 0, false);
+        }
+#undef CG_APPLY2
+    } else {
+        // level 2 has levels below it: its correction comes from the generic cycle (solver.hip)
+        cycle_levels(g, 2);
+#define CG_APPLY1(NB, ONE)                                                                                    \
+    hipLaunchKernelGGL((k_cg_apply<1, double, 1, NB, ONE>), dim3(grid), dim3(kRowBlock), 0, g.stream,           \
+                       view_of(L0), L0.uni_w, view_of(L1), L1.uni_w, B.R[rcur], B.U, B.W, L1.b.p, L1.x.p,       \
+                       (const double *)nullptr, L2.y.p, (const double *)nullptr, L2.n, 0, 1.0, g.opt.mg_omega,  \
+                       g.opt.mg_kc, g.part_rz.p, g.part_pq.p, g.part_rr.p, grid, first, rtol2, g.scal.p,        \
+                       g.flags.p, dbg)
+        if (nb == 5 && one)
+            CG_APPLY1(5, true);
+        else if (one)
+            CG_APPLY1(0, true);
+        else
+            CG_APPLY1(0, false);
+#undef CG_APPLY1
+    }
+}
+
+// fp32 copy of the explicit inverse of the dense level for k_cg_apply: the coarse correction is a
+// preconditioner component, its rounding (6e-8 relative) does not touch the accuracy of the solve,
+// and half the bytes is half the registers a tile slice occupies while it is in flight.
+__global__ __launch_bounds__(256) void k_inv_to_f32(long long n, const double *__restrict__ a, float *__restrict__ b) {
+    const long long i = 2 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) {
+        const double2 v = *reinterpret_cast<const double2 *>(a + i);
+        *reinterpret_cast<float2 *>(b + i) = make_float2((float)v.x, (float)v.y);
+    }
+}
+static void cg2_refresh_inv32(Graph &g) {
+    if (!g.dense32 || g.inv32_epoch == g.dense_epoch) return;
+    const long long n = (long long)g.ndense_pad * g.ndense_pad;
+    if (g.dense_inv32.n < (size_t)n) g.dense_inv32.alloc((size_t)n);
+    hipLaunchKernelGGL(k_inv_to_f32, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, g.stream, n, g.dense_inv.p,
+                       g.dense_inv32.p);
+    g.inv32_epoch = g.dense_epoch;
+}
+
+// PCG on L X = levels[0].b (three columns), two launches per iteration. Same contract as pcg_solve.
+int pcg_solve_cg2(Graph &g) {
+    const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
+    if (g.levels.size() == 3) cg2_refresh_inv32(g);
+    IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
+    int rcur = 0;  // which of the two r / s buffers is current
+    cg2_launch_update(g, 0, 0, rcur);
+    rcur ^= 1;
+    int h_flags[FL_COUNT] = {0, 0, 0, 0};
+    int it = 0;
+    const int check = std::max(1, g.opt.pcg_check_every);
+    const int maxit = std::max(1, g.opt.pcg_max_iters);
+    auto apply = [&]() { cg2_launch_apply(g, it == 0, rcur, rtol2); };
+    auto update = [&]() {
+        cg2_launch_update(g, it == 0 ? 1 : 2, it & 1, rcur);
+        rcur ^= 1;
+        it++;
+    };
+    // poll schedule, stagnation rule: as in pcg_solve (solver.hip)
+    int chunk = g.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(g.stats.pcg_iters_last, maxit) : check;
+    constexpr int kStallIters = 64;
+    const int ax = g.opt.pcg_stall_accept;
+    const double accept = ax < 0 ? -1.0 : (ax == 0 ? 1e-6 : std::pow(10.0, -(double)ax));
+    double best = HUGE_VAL;
+    int best_it = 0;
+    bool stagnated = false;
+    double h_scal[SC_COUNT];
+    while (true) {
+        for (int c = 0; c < chunk; c++) {
+            apply();
+            update();
+        }
+        chunk = std::max(2, check / 2);
+        apply();  // its prologue tests the convergence of the last update
+        IRH_CHECK(hipMemcpyAsync(h_flags, g.flags.p, sizeof(int) * FL_COUNT, hipMemcpyDeviceToHost, g.stream));
+        IRH_CHECK(hipMemcpyAsync(h_scal, g.scal.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, g.stream));
+        IRH_CHECK(hipStreamSynchronize(g.stream));
+        if (h_flags[FL_DONE] != 0) break;
+        const double cur = std::max(h_scal[SC_RELRES], std::max(h_scal[SC_RELRES + 1], h_scal[SC_RELRES + 2]));
+        if (cur < 0.5 * best) {
+            best = cur;
+            best_it = it;
+        } else if (it - best_it >= kStallIters && cur <= accept) {
+            stagnated = true;
+            break;
+        }
+        if (it >= maxit) break;
+        update();  // not converged: that application is the next iteration's
+    }
+    g.stats.pcg_solves += 1;
+    g.stats.pcg_iters += stagnated ? it : h_flags[FL_ITERS];
+    g.stats.pcg_iters_last = stagnated ? it : h_flags[FL_ITERS];
+    for (int c = 0; c < 3; c++) g.stats.last_relres[c] = h_scal[SC_RELRES + c];
+    if (h_flags[FL_DONE] == 2) return IROTAVG_ERR_SOLVER;
+    if (stagnated) {
+        g.stats.pcg_stagnated += 1;
+        return IROTAVG_OK;
+    }
+    if (h_flags[FL_DONE] == 0) return IROTAVG_ERR_NOT_CONVERGED;
+    return IROTAVG_OK;
+}
+
+// kernel timing for bench.py's roofline leg (time_kernel, solver.hip): one launch of each kernel in
+// its steady-state form on whatever the buffers hold
+void cg2_time_once(Graph &g, int which) {
+    if (g.levels.size() == 3) cg2_refresh_inv32(g);
+    if (which == 0)
+        cg2_launch_apply(g, 0, 0, -1.0);
+    else
+        cg2_launch_update(g, 2, 0, 0);
+}
+
+// development aid: wall-clock stamps (100 MHz) of the phases of k_cg_apply in one mid-grid workgroup;
+// out[k] = microseconds from kernel entry to stamp k (IROTAVG_CG2_STAMPS, tools/)
+int cg2_phase_stamps(Graph &g, double *out, int n) {
+    DevBuf<long long> d;
+    d.alloc(16);
+    IRH_CHECK(hipMemsetAsync(d.p, 0, sizeof(long long) * 16, g.stream));
+    IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
+    if (g.levels.size() == 3) cg2_refresh_inv32(g);
+    for (int r = 0; r < 3; r++) cg2_launch_apply(g, 0, 0, -1.0, d.p);
+    long long h[16];
+    IRH_CHECK(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < n && k < 16; k++) out[k] = (double)(h[k] - h[0]) * 0.01;
+    return IROTAVG_OK;
+}
+
+}  // namespace irh

@@ -270,7 +270,13 @@ enum ScalIdx : int {
     SC_RZ1 = 4,   // rz of parity 1
     SC_BB = 8,    // ||b||^2 per column
     SC_RELRES = 12,  // ||r||/||b|| per column at the last check
-    SC_COUNT = 16
+    // Chronopoulos-Gear recurrences of the two-launch iteration (cgcg.hip): gamma = r.u and alpha of
+    // the previous iteration, two parities each
+    SC_GAM0 = 16,
+    SC_GAM1 = 20,
+    SC_ALF0 = 24,
+    SC_ALF1 = 28,
+    SC_COUNT = 32
 };
 // int flags block
 enum FlagIdx : int {
@@ -294,12 +300,17 @@ __host__ __device__ inline size_t sell_pos(int o0, int k, int lane) {
 }
 constexpr int kWinHalo = 64;   // rows on either side of a 256-row tile held in the LDS window
 constexpr int kWinLen = 256 + 2 * kWinHalo;
+constexpr int kL1Win = kWinLen / 8;  // level-1 rows under a tile window (aggregates of 8)
+constexpr int kL1Ext = 64;           // level-1 rows [tile/8 - 16, tile/8 + 48): the window's rows and their neighbours
 struct Level {
     int n = 0;        // rows
     int nnz = 0;      // real off-diagonal entries
     int agg = 0;      // rows per aggregate towards the next (coarser) level; 0 on the coarsest
     int nsl = 0;      // slices
     long long sell_len = 0;  // 64 * total entry-columns
+    int max_near = 0;        // widest near part of a slice (entry-columns)
+    int uni_w = 0;           // every slice is this wide and all of it is near (band graphs), else 0:
+                             // kernels then derive sl_off / sl_near instead of loading them
     DevBuf<int> sl_off, sl_near, col;
     DevBuf<double> val;     // off-diagonal values (<= 0 for a Laplacian)
     DevBuf<double> excess;  // diag - sum|offdiag| : Dirichlet mass from fixed neighbours

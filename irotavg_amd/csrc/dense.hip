@@ -650,6 +650,7 @@ static bool dense_lowrank_repair(Graph &g, double c) {
     hipLaunchKernelGGL(k_wb_ref_diag, dim3(1), dim3(1024), 0, g.stream, C.n, r, c, list, g.dense_ref_diag.p);
     IRH_CHECK(hipStreamSynchronize(g.stream));  // hSinv / hl leave scope
     g.dense_scale = 1.0;
+    g.dense_epoch++;  // dense_inv changed: copies of it (cgcg.hip) are stale
     g.stats.dense_repairs++;
     return true;
 }
@@ -718,10 +719,12 @@ void dense_select_slot(Graph &g, int slot) {
     }
     exchange(T);
     g.dense_slot = slot;
+    g.dense_epoch++;
 }
 
 void dense_refresh(Graph &g) {
     if (g.ndense <= 0) return;
+    g.dense_epoch++;
     g.dense_scale = 1.0;
     g.dense_repairs_in_a_row = 0;
     g.stats.dense_inversions++;

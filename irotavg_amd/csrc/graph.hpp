@@ -39,6 +39,10 @@ struct Graph {
 
     std::vector<Level> levels;
     DevBuf<double> dense_inv;  // explicit inverse of the coarsest level, ndense_pad^2 row-major
+    DevBuf<float> dense_inv32;  // fp32 copy for the tile slices of k_cg_apply (cgcg.hip), refreshed lazily
+    uint64_t dense_epoch = 1, inv32_epoch = 0;  // dense_epoch advances whenever dense_inv's content changes
+    int dense32 = 0;            // 1: k_cg_apply reads an fp32 copy of the inverse (IROTAVG_CG2_FP32_DENSE=1; measured
+                                // 2-3 % faster, not worth a preconditioner whose definiteness rests on fp32 rounding)
     DevBuf<double> dense_wr, dense_wc;  // Gauss-Jordan panels (32 x npad, npad x 32), two of each
     DevBuf<double> dense_wb;            // scratch of the low-rank repair (Z, W, S, S^-1, entry list)
     int dense_repairs_in_a_row = 0;     // since the last full inversion
@@ -64,7 +68,9 @@ struct Graph {
     DevBuf<double4> X, P, AP;
     bool kc_auto = false;  // opt.mg_kc was chosen from the structure (build.cpp), not given
     int l1_fused = 0;  // the PCG update kernel also does the level-1 down-sweep (build.cpp)
+    int cg2 = 0;       // the PCG iteration runs as two launches (cgcg.hip; build.cpp decides)
     long long l0_far_entries = 0;  // level-0 SELL entry-columns outside the tile windows (loop closures)
+    DevBuf<double> b2p;  // planar copy of the dense level's right-hand side (3 x ndense_pad; cgcg.hip)
     DevBuf<double4> R2;  // second residual buffer (l1_fused: the update kernel writes r out of place)
     DevBuf<double4> P2;  // second search-direction buffer: the fused p-update + SpMV ping-pongs P / P2
     DevBuf<double> part_pq, part_rr, part_rz, part_rz2, part_score;  // kMaxParts x 4
@@ -119,9 +125,15 @@ void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = n
 void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi, bool check = false, int np_rr = 1,
                     double rtol2 = 0.0);
 PrecInfo precondition(Graph &g, int first, double rtol2, bool check = true);
+int round_grid(long long gsz);
 int grid_for_rows(const Level &L);
 int grid_for_elems(long long n);
 int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f);
+// cgcg.hip: the two-launch PCG iteration
+int pcg_solve_cg2(Graph &g);
+void cg2_time_once(Graph &g, int which);
+int cg2_phase_stamps(Graph &g, double *out, int n);
+void cycle_levels(Graph &g, int from);  // solver.hip: levels[from].b/.x -> levels[from].y
 // window.hip: single-kernel solve of small (sliding-window) problems
 struct WindowSolver;
 WindowSolver *window_solver_new();

@@ -20,6 +20,10 @@ struct LevelView {
     const double *val, *diag, *idg;
 };
 
+inline LevelView view_of(const Level &L) {
+    return LevelView{L.n, L.nsl, L.agg, L.sl_off.p, L.sl_near.p, L.col.p, L.val.p, L.diag.p, L.idg.p};
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -207,6 +211,83 @@ __device__ __forceinline__ void row_offdiag_prolong(const LevelView &L, int row,
                                                     const double4 *__restrict__ xc, int sh, double kc,
                                                     double &s0, double &s1, double &s2) {
     row_offdiag_t<true>(L, row, x, xc, sh, kc, s0, s1, s2);
+}
+
+// Near part of one SELL row (the first `wn` entry-columns of its slice: columns inside the tile
+// window): a pure 16 B/lane matrix stream -- the gathered vector comes from the LDS copy of the
+// window (wx, wy, wz; index = column - wlo). wn is a multiple of 8: batches of 4 pairs, all 8 loads
+// of a batch issued before use and the next batch's loads issued before the current one is consumed.
+struct NearBatch {  // the first batch of a row's near entries (4 column pairs, 4 value pairs)
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2i c[kSellUnroll / 2];
+    v2d v[kSellUnroll / 2];
+};
+// issue the loads of a row's first near batch (so that they fly during the reductions / the LDS
+// window fill that precede the row loop)
+// (kbeg: first entry-column of the part of the row to walk, a multiple of 8; 0 = the whole near part)
+__device__ __forceinline__ void near_prefetch_at(const LevelView &L, int o0, int kbeg, int wn, int lane, NearBatch &B) {
+    constexpr int HB = kSellUnroll / 2;
+    const NearBatch::v2i *__restrict__ cs = reinterpret_cast<const NearBatch::v2i *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+    const NearBatch::v2d *__restrict__ vs = reinterpret_cast<const NearBatch::v2d *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < HB; u++) {
+        B.c[u] = NearBatch::v2i{0, 0};
+        B.v[u] = NearBatch::v2d{0.0, 0.0};
+    }
+    if (wn > kbeg) {
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+            B.c[u] = __builtin_nontemporal_load(&cs[(size_t)(kbeg / 2 + u) * 64]);
+            B.v[u] = __builtin_nontemporal_load(&vs[(size_t)(kbeg / 2 + u) * 64]);
+        }
+    }
+}
+__device__ __forceinline__ void near_prefetch(const LevelView &L, int o0, int wn, int lane, NearBatch &B) {
+    near_prefetch_at(L, o0, 0, wn, lane, B);
+}
+__device__ __forceinline__ void near_window_row_from(const LevelView &L, int o0, int kbeg, int wn, int lane, int wlo,
+                                                     const double *wx, const double *wy, const double *wz,
+                                                     const NearBatch &first, double &s0, double &s1, double &s2) {
+    constexpr int HB = kSellUnroll / 2;
+    typedef NearBatch::v2i v2i;
+    typedef NearBatch::v2d v2d;
+    const v2i *__restrict__ cs = reinterpret_cast<const v2i *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
+    const v2d *__restrict__ vs = reinterpret_cast<const v2d *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
+    s0 = s1 = s2 = 0.0;
+    v2i cc[HB], cn[HB];
+    v2d vv[HB], vn[HB];
+#pragma unroll
+    for (int u = 0; u < HB; u++) {
+        cc[u] = first.c[u];
+        vv[u] = first.v[u];
+    }
+    for (int q0 = kbeg / 2; q0 < wn / 2; q0 += HB) {
+        if (q0 + HB < wn / 2) {
+#pragma unroll
+            for (int u = 0; u < HB; u++) {
+                cn[u] = __builtin_nontemporal_load(&cs[(size_t)(q0 + HB + u) * 64]);
+                vn[u] = __builtin_nontemporal_load(&vs[(size_t)(q0 + HB + u) * 64]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+            const int i0 = cc[u].x - wlo, i1 = cc[u].y - wlo;
+            s0 += vv[u].x * wx[i0] + vv[u].y * wx[i1];
+            s1 += vv[u].x * wy[i0] + vv[u].y * wy[i1];
+            s2 += vv[u].x * wz[i0] + vv[u].y * wz[i1];
+        }
+#pragma unroll
+        for (int u = 0; u < HB; u++) {
+            cc[u] = cn[u];
+            vv[u] = vn[u];
+        }
+    }
+}
+__device__ __forceinline__ void near_window_row(const LevelView &L, int o0, int wn, int lane, int wlo,
+                                                const double *wx, const double *wy, const double *wz,
+                                                const NearBatch &first, double &s0, double &s1, double &s2) {
+    near_window_row_from(L, o0, 0, wn, lane, wlo, wx, wy, wz, first, s0, s1, s2);
 }
 
 // Hamilton product, [x y z w] (ral/l1_irls.cpp:99-105)

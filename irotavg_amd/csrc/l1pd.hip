@@ -523,6 +523,7 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
         Level &A = g.levels[l];
         Level &B = q.levels[l];
         B.n = A.n; B.nnz = A.nnz; B.agg = A.agg; B.nsl = A.nsl; B.sell_len = A.sell_len;
+        B.max_near = A.max_near; B.uni_w = A.uni_w;
         B.sl_off.alias(A.sl_off); B.sl_near.alias(A.sl_near); B.col.alias(A.col);
         B.cptr.alias(A.cptr); B.cidx.alias(A.cidx); B.cpos.alias(A.cpos);
         B.val.alloc_like(A.val, s); B.excess.alloc_like(A.excess, s);
@@ -533,6 +534,9 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
     q.stale_spread = g.stale_spread;
     q.l0_far_entries = g.l0_far_entries;
     q.l1_fused = g.l1_fused;
+    q.cg2 = g.cg2;
+    q.dense32 = g.dense32;
+    q.b2p.alloc_like(g.b2p, s);
     q.kc_auto = g.kc_auto;
     q.dense_inv.alloc_like(g.dense_inv, s); q.dense_wr.alloc_like(g.dense_wr, s);
     q.dense_wc.alloc_like(g.dense_wc, s); q.dense_ref_diag.alloc_like(g.dense_ref_diag, s);

@@ -330,74 +330,6 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_diag(LevelView C, int nf, 
     for (int t_ = t0_; t_ < t1_; t_++)                         \
         if (const int sl_ = t_ * 4 + (threadIdx.x >> 6); sl_ < (L).nsl)
 
-// Near part of one SELL row (the first `wn` entry-columns of its slice: columns inside the tile
-// window): a pure 16 B/lane matrix stream -- the gathered vector comes from the LDS copy of the
-// window (wx, wy, wz; index = column - wlo). wn is a multiple of 8: batches of 4 pairs, all 8 loads
-// of a batch issued before use and the next batch's loads issued before the current one is consumed.
-struct NearBatch {  // the first batch of a row's near entries (4 column pairs, 4 value pairs)
-    typedef int v2i __attribute__((ext_vector_type(2)));
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    v2i c[kSellUnroll / 2];
-    v2d v[kSellUnroll / 2];
-};
-// issue the loads of a row's first near batch (so that they fly during the reductions / the LDS
-// window fill that precede the row loop)
-__device__ __forceinline__ void near_prefetch(const LevelView &L, int o0, int wn, int lane, NearBatch &B) {
-    constexpr int HB = kSellUnroll / 2;
-    const NearBatch::v2i *__restrict__ cs = reinterpret_cast<const NearBatch::v2i *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
-    const NearBatch::v2d *__restrict__ vs = reinterpret_cast<const NearBatch::v2d *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
-#pragma unroll
-    for (int u = 0; u < HB; u++) {
-        B.c[u] = NearBatch::v2i{0, 0};
-        B.v[u] = NearBatch::v2d{0.0, 0.0};
-    }
-    if (wn > 0) {
-#pragma unroll
-        for (int u = 0; u < HB; u++) {
-            B.c[u] = __builtin_nontemporal_load(&cs[(size_t)u * 64]);
-            B.v[u] = __builtin_nontemporal_load(&vs[(size_t)u * 64]);
-        }
-    }
-}
-__device__ __forceinline__ void near_window_row(const LevelView &L, int o0, int wn, int lane, int wlo,
-                                                const double *wx, const double *wy, const double *wz,
-                                                const NearBatch &first, double &s0, double &s1, double &s2) {
-    constexpr int HB = kSellUnroll / 2;
-    typedef NearBatch::v2i v2i;
-    typedef NearBatch::v2d v2d;
-    const v2i *__restrict__ cs = reinterpret_cast<const v2i *>(L.col) + (size_t)(o0 / 2) * 64 + lane;
-    const v2d *__restrict__ vs = reinterpret_cast<const v2d *>(L.val) + (size_t)(o0 / 2) * 64 + lane;
-    s0 = s1 = s2 = 0.0;
-    v2i cc[HB], cn[HB];
-    v2d vv[HB], vn[HB];
-#pragma unroll
-    for (int u = 0; u < HB; u++) {
-        cc[u] = first.c[u];
-        vv[u] = first.v[u];
-    }
-    for (int q0 = 0; q0 < wn / 2; q0 += HB) {
-        if (q0 + HB < wn / 2) {
-#pragma unroll
-            for (int u = 0; u < HB; u++) {
-                cn[u] = __builtin_nontemporal_load(&cs[(size_t)(q0 + HB + u) * 64]);
-                vn[u] = __builtin_nontemporal_load(&vs[(size_t)(q0 + HB + u) * 64]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < HB; u++) {
-            const int i0 = cc[u].x - wlo, i1 = cc[u].y - wlo;
-            s0 += vv[u].x * wx[i0] + vv[u].y * wx[i1];
-            s1 += vv[u].x * wy[i0] + vv[u].y * wy[i1];
-            s2 += vv[u].x * wz[i0] + vv[u].y * wz[i1];
-        }
-#pragma unroll
-        for (int u = 0; u < HB; u++) {
-            cc[u] = cn[u];
-            vv[u] = vn[u];
-        }
-    }
-}
-
 // q = L p, partial dot products p.q -- the dominant kernel of the PCG.
 // The 256-row tile's window of p (rows [tile - 64, tile + 320)) is copied into LDS once (12 KB,
 // coalesced); the near part of every row (all of it on a band graph) then reads p from LDS, so
@@ -930,7 +862,6 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict(
 // level-1 neighbour within 8 rows of the tile's level-1 range (Graph::l1_fused, checked at build
 // time: band graphs). Thread tid holds window slots tid and tid + 256; exactly one of them is an
 // own row of the tile. The residual ping-pongs between two buffers (Rin -> Rout).
-constexpr int kL1Win = kWinLen / 8;  // 48 level-1 rows per window
 template <bool INIT>
 __global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict2(
     int n, int nsl, const double *__restrict__ scal, int par, const double *__restrict__ part_pq,
@@ -1213,13 +1144,12 @@ int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f) {
 // =============================================================================================
 // host drivers
 // =============================================================================================
-static LevelView view_of(const Level &L) {
-    return LevelView{L.n, L.nsl, L.agg, L.sl_off.p, L.sl_near.p, L.col.p, L.val.p, L.diag.p, L.idg.p};
-}
-
-static int round_grid(long long gsz) {
+int round_grid(long long gsz) {
+    // a multiple of 8 (tile_range deals adjacent chunks to the workgroups of one XCD), rounded UP: with
+    // fewer workgroups than tiles some workgroup gets two tiles and the whole launch waits for it
+    // (391 tiles on 384 workgroups: every row kernel took two tile times)
+    if (gsz >= 8) gsz = (gsz + 7) & ~7ll;
     gsz = std::min<long long>(gsz, kMaxParts);
-    if (gsz >= 8) gsz &= ~7ll;
     return (int)std::max<long long>(gsz, 1);
 }
 int grid_for_rows(const Level &L) { return round_grid((L.nsl + 3) / 4); }
@@ -1312,6 +1242,10 @@ static void cycle_from(Graph &g, int from, bool check_first, bool dot_from, doub
                                view_of(F), F.b.p, F.x.p, C.y.p, F.y.p, omega, kc, part_dot, g.flags.p);
         }
     }
+}
+
+void cycle_levels(Graph &g, int from) {
+    cycle_from(g, from, false, false, nullptr, 0, 0, 0.0, nullptr, false);
 }
 
 // Preconditioner application. Multiplicative mode: z = levels[0].y, r.z partials in part_rz
@@ -1424,6 +1358,7 @@ void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi, bool check
 // p-update -> q = L p -> x/r update. The host polls the done flag every pcg_check_every
 // iterations; kernels enqueued past convergence return immediately.
 int pcg_solve(Graph &g) {
+    if (g.cg2) return pcg_solve_cg2(g);
     Level &L0 = g.levels[0];
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     const int gr = grid_for_rows(L0);
@@ -1588,6 +1523,13 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
 // kernel timing for the roofline leg of bench.py (HIP events on the handle's stream)
 // ---------------------------------------------------------------------------------------------
 int time_kernel(Graph &g, int which, int reps, double *ms) {
+    if (which >= 100 && which < 116) {  // development aid: phase stamp (us) of k_cg_apply, see cgcg.hip
+        if (!g.cg2) return IROTAVG_ERR_BAD_ARG;
+        double st[16];
+        const int rc = cg2_phase_stamps(g, st, 16);
+        *ms = st[which - 100];
+        return rc;
+    }
     hipEvent_t e0, e1;
     IRH_CHECK(hipEventCreate(&e0));
     IRH_CHECK(hipEventCreate(&e1));
@@ -1609,6 +1551,8 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
                                g.P2.p, g.AP.p, g.part_pq.p, g.flags.p);
             break;
         }
+        case 9: cg2_time_once(g, 0); break;   // k_cg_apply (u = M^-1 r, w = L u) of the two-launch iteration
+        case 10: cg2_time_once(g, 1); break;  // k_cg_update
         case 6:
             hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kRowBlock), 0, g.stream,
                                g.nu, g.f, g.ng, g.X.p, g.Q.p, g.part_score.p, 0);
@@ -1616,7 +1560,8 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         default: break;
         }
     };
-    if (which < 1 || which > 8) return IROTAVG_ERR_BAD_ARG;
+    if (which < 1 || which > 10) return IROTAVG_ERR_BAD_ARG;
+    if ((which == 9 || which == 10) && !g.cg2) return IROTAVG_ERR_BAD_ARG;  // not this graph's PCG
     if (which == 8 && !(g.additive_top && g.levels.size() > 1 && g.ng == 0 && g.l0_far_entries == 0 &&
                         g.opt.no_fused_pspmv != 1))
         return IROTAVG_ERR_BAD_ARG;  // this graph's PCG does not use the fused kernel

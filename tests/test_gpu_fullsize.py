@@ -131,17 +131,20 @@ def test_fused_pcg_launches_match_the_separate_kernels(n, m, levels, f, p):
     Q0 = mst(S, n)
     Q0[:f] = S["Qgt"][:f]
     out = {}
-    for nf in (0, 1):
-        with capi.Graph(S["I"], S["QQ"], n, f, no_fused_pspmv=nf) as G:
+    # 0: default (three-level band graphs: the two-launch Chronopoulos-Gear iteration of cgcg.hip),
+    # 1: every kernel separate, 2: the classic recurrences with the round-1 fusions
+    for key, (nf, pc) in enumerate([(0, 0), (1, 0), (0, 1)]):
+        with capi.Graph(S["I"], S["QQ"], n, f, no_fused_pspmv=nf, pcg_classic=pc) as G:
             G.set_rotations(Q0)
             r = G.irls(4, SIG, 100, 1e-3)
             st = G.stats()
             assert st["levels"] == levels
-            out[nf] = (r["iters"], G.get_rotations(), G.get_weights(), st["pcg_iters"])
-    assert out[0][0] == out[1][0]
-    assert abs(out[0][3] - out[1][3]) <= 2 * out[0][0]
-    assert synth.angular_distance(out[0][1], out[1][1]).max() < 1e-10
-    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-8)
+            out[key] = (r["iters"], G.get_rotations(), G.get_weights(), st["pcg_iters"])
+    for k in (1, 2):
+        assert out[0][0] == out[k][0]
+        assert abs(out[0][3] - out[k][3]) <= 2 * out[0][0]
+        assert synth.angular_distance(out[0][1], out[k][1]).max() < 1e-10
+        np.testing.assert_allclose(out[0][2], out[k][2], rtol=1e-8)
     if p == 0.0:
         ro = O.irls(S["QQ"], S["I"], Q0, f, 4, SIG, 100, 1e-3)
         assert ro["iters"] == out[0][0]
