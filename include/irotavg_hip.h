@@ -257,16 +257,37 @@ int irotavg_window_solve_kernel(int64_t m, int64_t n_total, int f, const int32_t
  * loopback (no RCCL): the sharded algebra can then be checked on a single GPU.
  * ------------------------------------------------------------------------------------------ */
 typedef struct irotavg_dist irotavg_dist;
+/* A host-staged wire for the sharded solve: the library stages device data through host buffers and
+ * calls back into the application, which moves the bytes with whatever it has (e.g.
+ * torch.distributed over gloo). One process = one shard, as with RCCL. Used where RCCL cannot run
+ * (two ranks on ONE GPU in the multi-process test, tests/test_gpu_dist_mp.py) -- the control flow of
+ * the sharded path is the same, only the wire differs. Both callbacks return 0 on success. */
+typedef struct irotavg_transport {
+    void *ctx;
+    /* in-place reduction of n doubles over all ranks; op: 0 sum, 1 min, 2 max */
+    int (*allreduce)(void *ctx, double *buf, int n, int op);
+    /* one point-to-point round: for q < npeers send send_cnt[q] doubles from send + send_off[q] to rank
+     * peers[q] and receive recv_cnt[q] doubles from it into recv + recv_off[q] */
+    int (*exchange)(void *ctx, int npeers, const int *peers, const double *send, const int64_t *send_off,
+                    const int64_t *send_cnt, double *recv, const int64_t *recv_off, const int64_t *recv_cnt);
+} irotavg_transport;
 int irotavg_dist_unique_id(void *out128);
 int irotavg_dist_create(irotavg_dist **d, int world, int rank, const void *unique_id128, int64_t m,
                         int64_t n_total, int f, const int32_t *I, const double *QQ, int64_t ldqq,
                         const irotavg_options *opt);
+int irotavg_dist_create_hosted(irotavg_dist **d, int world, int rank, const irotavg_transport *transport,
+                               int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                               int64_t ldqq, const irotavg_options *opt);
 void irotavg_dist_destroy(irotavg_dist *d);
 int irotavg_dist_set_rotations(irotavg_dist *d, const double *Q, int64_t ldq); /* GLOBAL n_total x 4 */
 int irotavg_dist_get_rotations(irotavg_dist *d, double *Q, int64_t ldq); /* writes the rows this process owns */
 int irotavg_dist_get_weights(irotavg_dist *d, double *weights);          /* writes its local edges */
 int irotavg_dist_irls(irotavg_dist *d, int cost, double sigma, int max_iters, double change_th,
                       int *iters, double *runtime, double *score_trace);
+/* replaces irotavg::l1ra (ral/l1_irls.hpp:100-102) on the sharded graph: the callers run l1ra THEN
+ * irls (src/ViewGraph.cpp:1400-1417, ral/test.cpp:295-301) */
+int irotavg_dist_l1ra(irotavg_dist *d, int max_iters, double change_th, int *iters, double *runtime,
+                      double *score_trace);
 int irotavg_dist_get_stats(irotavg_dist *d, irotavg_stats *out);
 int irotavg_dist_plan(irotavg_dist *d, int local_index, int64_t counts[6], int *peers, int *send_cnt,
                       int *recv_cnt, int cap);

@@ -32,6 +32,7 @@ SYMBOLS = [
     "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
     "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_plan", "irotavg_dist_plan_host",
+    "irotavg_dist_l1ra", "irotavg_dist_create_hosted",
     "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_trim_memory", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
 ]
 
@@ -157,6 +158,9 @@ def lib():
     L.irotavg_dist_get_weights.argtypes = [vp, _dp]
     L.irotavg_dist_irls.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int),
                                     _dp, _dp]
+    L.irotavg_dist_l1ra.argtypes = [vp, C.c_int, C.c_double, C.POINTER(C.c_int), _dp, _dp]
+    L.irotavg_dist_create_hosted.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(Transport), C.c_int64,
+                                             C.c_int64, C.c_int, _ip, _dp, C.c_int64, C.POINTER(Options)]
     L.irotavg_dist_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.irotavg_dist_plan.argtypes = [vp, C.c_int, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.c_int]
@@ -389,11 +393,72 @@ def plan_host(world, rank, I, n_total, f):
     return out
 
 
+_AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+_I64P = C.POINTER(C.c_int64)
+_EX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), _I64P, _I64P,
+                     C.POINTER(C.c_double), _I64P, _I64P)
+
+
+class Transport(C.Structure):
+    """irotavg_transport (include/irotavg_hip.h): the host-staged wire of the sharded solve."""
+    _fields_ = [("ctx", C.c_void_p), ("allreduce", _AR_FN), ("exchange", _EX_FN)]
+
+
+def torch_transport(group=None):
+    """An irotavg_transport over torch.distributed (any backend that moves CPU tensors, e.g. gloo).
+    Returns (Transport, keepalive): keep `keepalive` referenced for the life of the handle."""
+    import torch
+    import torch.distributed as dist
+    ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}
+
+    def allreduce(_ctx, buf, n, op):
+        try:
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            t = torch.from_numpy(a)
+            dist.all_reduce(t, op=ops[op], group=group)
+            return 0
+        except Exception as e:  # never raise through the C frames
+            print("[irotavg transport] allreduce failed:", e, flush=True)
+            return 1
+
+    def exchange(_ctx, npeers, peers, send, so, sc, recv, ro, rc):
+        try:
+            reqs, keep = [], []
+            me = dist.get_rank(group)
+            order = sorted(range(npeers), key=lambda q: peers[q])
+            for q in order:
+                h = peers[q]
+                srt = torch.from_numpy(np.ctypeslib.as_array(send, shape=(so[q] + sc[q],))[so[q]:].copy()) \
+                    if sc[q] > 0 else None
+                rcv = torch.empty(rc[q], dtype=torch.float64) if rc[q] > 0 else None
+                keep.append((q, rcv))
+                # deadlock-free pairing: the lower rank sends first
+                steps = [("s", srt), ("r", rcv)] if me < h else [("r", rcv), ("s", srt)]
+                for kind, t in steps:
+                    if t is None:
+                        continue
+                    if kind == "s":
+                        dist.send(t, dst=h, group=group)
+                    else:
+                        dist.recv(t, src=h, group=group)
+            for q, rcv in keep:
+                if rcv is not None:
+                    np.ctypeslib.as_array(recv, shape=(ro[q] + rc[q],))[ro[q]:] = rcv.numpy()
+            return 0
+        except Exception as e:
+            print("[irotavg transport] exchange failed:", e, flush=True)
+            return 1
+
+    ar, ex = _AR_FN(allreduce), _EX_FN(exchange)
+    return Transport(None, ar, ex), (ar, ex)
+
+
 class DistGraph:
     """Sharded IRLS (irotavg_dist_*). unique_id=None: all `world` shards in this process on one GPU
     (loopback transport); otherwise this process holds shard `rank` and talks RCCL."""
 
-    def __init__(self, I, QQ, n_total, f, world, rank=0, unique_id=None, **opts):
+    def __init__(self, I, QQ, n_total, f, world, rank=0, unique_id=None, transport=None, **opts):
+        """transport: (Transport, keepalive) from torch_transport(): host-staged wire instead of RCCL."""
         I = edges(I)
         QQ = fmat(QQ)
         self.m, self.n_total, self.f, self.world, self.rank = len(I), int(n_total), int(f), world, rank
@@ -402,8 +467,13 @@ class DistGraph:
         uid = None
         if unique_id is not None:
             uid = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
-        rc = lib().irotavg_dist_create(C.byref(self._h), world, rank, uid, self.m, self.n_total, self.f,
-                                       _i(I), _d(QQ), QQ.shape[0], C.byref(o))
+        if transport is not None:
+            self._transport = transport
+            rc = lib().irotavg_dist_create_hosted(C.byref(self._h), world, rank, C.byref(transport[0]), self.m,
+                                                  self.n_total, self.f, _i(I), _d(QQ), QQ.shape[0], C.byref(o))
+        else:
+            rc = lib().irotavg_dist_create(C.byref(self._h), world, rank, uid, self.m, self.n_total, self.f,
+                                           _i(I), _d(QQ), QQ.shape[0], C.byref(o))
         if rc != OK:
             self._h = C.c_void_p()
             raise IrotavgError(rc, "irotavg_dist_create")
@@ -453,6 +523,15 @@ class DistGraph:
                                      C.byref(rt), _d(trace))
         if rc != OK and rc not in allow_rc:
             raise IrotavgError(rc, "irotavg_dist_irls")
+        return dict(rc=rc, iters=iters.value, runtime=rt.value, scores=trace[:iters.value].copy())
+
+    def l1ra(self, max_iters=5, change_th=1e-3, allow_rc=()):
+        iters = C.c_int(0)
+        rt = C.c_double(0)
+        trace = np.full(max(max_iters, 1), np.nan)
+        rc = lib().irotavg_dist_l1ra(self._h, max_iters, change_th, C.byref(iters), C.byref(rt), _d(trace))
+        if rc != OK and rc not in allow_rc:
+            raise IrotavgError(rc, "irotavg_dist_l1ra")
         return dict(rc=rc, iters=iters.value, runtime=rt.value, scores=trace[:iters.value].copy())
 
     def stats(self):

@@ -38,6 +38,7 @@ struct Shard {
     DevBuf<int> send_idx;            // owned-local indices to pack, grouped by peer
     DevBuf<double4> sendbuf;
     DevBuf<double> gsum;             // 16 doubles: staging of the all-reduced scalars
+    DevBuf<uint8_t> eown;            // per local edge: 1 = this shard counts it in sums over edges (L1RA)
     int send_total = 0;
 };
 
@@ -48,6 +49,9 @@ struct Dist {
     std::vector<std::unique_ptr<Shard>> shards;  // local shards (all of them in loopback mode)
     bool use_rccl = false;
     ncclComm_t comm = nullptr;
+    bool hosted = false;  // wire = the caller's host-staged transport (irotavg_dist_create_hosted)
+    irotavg_transport tr{};
+    std::vector<double> hbuf, hbuf2;  // host staging of the hosted transport
     hipStream_t stream = nullptr;
     irotavg_options opt{};
     irotavg_stats stats{};
@@ -102,7 +106,25 @@ __global__ void k_add_small(int n, double *__restrict__ dst, const double *__res
 // ---- collectives ------------------------------------------------------------------------------
 // sum over all shards of the 4-double rows `pa(shard)` (and `pb(shard)` when given), in place
 typedef double *(*RowOf)(Shard &);
+static void hosted_allreduce_rows(Dist &D, double *const *rows, int nrows) {
+    // device rows -> host -> the caller's all-reduce -> device (one process = one shard here)
+    D.hbuf.assign((size_t)4 * nrows, 0.0);
+    for (int w = 0; w < nrows; w++)
+        IRH_CHECK(hipMemcpyAsync(D.hbuf.data() + 4 * w, rows[w], sizeof(double) * 4, hipMemcpyDeviceToHost, D.stream));
+    IRH_CHECK(hipStreamSynchronize(D.stream));
+    if (D.tr.allreduce(D.tr.ctx, D.hbuf.data(), 4 * nrows, 0) != 0) throw HipError{hipErrorUnknown};
+    for (int w = 0; w < nrows; w++)
+        IRH_CHECK(hipMemcpyAsync(rows[w], D.hbuf.data() + 4 * w, sizeof(double) * 4, hipMemcpyHostToDevice, D.stream));
+    IRH_CHECK(hipStreamSynchronize(D.stream));  // hbuf is reused by the next call
+}
+
 static void allreduce_rows(Dist &D, const RowOf *rows, int nrows) {
+    if (D.hosted) {
+        double *r[8];
+        for (int w = 0; w < nrows; w++) r[w] = rows[w](*D.shards[0]);
+        hosted_allreduce_rows(D, r, nrows);
+        return;
+    }
     if (D.use_rccl) {  // one group = one fused launch for the nrows x 4 doubles
         Shard &S = *D.shards[0];
         NCCL_CHECK(ncclGroupStart());
@@ -124,6 +146,11 @@ static void allreduce_rows(Dist &D, const RowOf *rows, int nrows) {
 }
 template <typename FA, typename FB>
 static void allreduce_rows(Dist &D, FA pa, FB pb, bool two) {
+    if (D.hosted) {
+        double *r[2] = {pa(*D.shards[0]), pb(*D.shards[0])};
+        hosted_allreduce_rows(D, r, two ? 2 : 1);
+        return;
+    }
     if (D.use_rccl) {
         Shard &S = *D.shards[0];
         NCCL_CHECK(ncclGroupStart());
@@ -158,6 +185,35 @@ static void halo_exchange(Dist &D, HaloWhat what) {
         if (S.send_total > 0)
             hipLaunchKernelGGL(k_pack, dim3((S.send_total + 255) / 256), dim3(256), 0, D.stream,
                                S.send_total, S.send_idx.p, halo_src(S, what), S.sendbuf.p);
+    }
+    if (D.hosted) {
+        Shard &S = *D.shards[0];
+        const int np = (int)S.peers.size();
+        if (np == 0) return;
+        std::vector<int64_t> so(np), sc(np), ro(np), rc(np);
+        int64_t rtot = 0;
+        for (int q = 0; q < np; q++) {  // counts in doubles (4 per view)
+            so[q] = 4 * (int64_t)S.send_off[q];
+            sc[q] = 4 * (int64_t)S.send_cnt[q];
+            ro[q] = 4 * (int64_t)S.recv_off[q];
+            rc[q] = 4 * (int64_t)S.recv_cnt[q];
+            rtot = std::max(rtot, ro[q] + rc[q]);
+        }
+        D.hbuf.assign((size_t)4 * S.send_total + 4, 0.0);
+        D.hbuf2.assign((size_t)rtot + 4, 0.0);
+        if (S.send_total > 0)
+            IRH_CHECK(hipMemcpyAsync(D.hbuf.data(), S.sendbuf.p, sizeof(double4) * (size_t)S.send_total,
+                                     hipMemcpyDeviceToHost, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+        if (D.tr.exchange(D.tr.ctx, np, S.peers.data(), D.hbuf.data(), so.data(), sc.data(), D.hbuf2.data(),
+                          ro.data(), rc.data()) != 0)
+            throw HipError{hipErrorUnknown};
+        for (int q = 0; q < np; q++)
+            if (rc[q] > 0)
+                IRH_CHECK(hipMemcpyAsync(halo_dst(S, what) + S.recv_off[q], D.hbuf2.data() + ro[q],
+                                         sizeof(double) * (size_t)rc[q], hipMemcpyHostToDevice, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+        return;
     }
     if (D.use_rccl) {
         Shard &S = *D.shards[0];
@@ -301,6 +357,17 @@ static int build_shard(Dist &D, Shard &S, const int32_t *I, const double *QQ, in
         for (int c = 0; c < 4; c++) QQl[(size_t)c * ml + t] = QQ[(size_t)c * ldqq + k];
     }
     S.gedge = P.ledge;
+    {   // who sums a cross-shard edge (L1RA reduces over edges): the shard that owns its j endpoint; a
+        // fixed j: the owner of i; both fixed: rank 0 (the only shard holding such an edge)
+        std::vector<uint8_t> own((size_t)ml, 0);
+        for (int64_t t = 0; t < ml; t++) {
+            const int64_t k = P.ledge[t];
+            const int i = I[2 * k], j = I[2 * k + 1];
+            own[t] = (j >= f ? owned(j) : (i >= f ? owned(i) : true)) ? 1 : 0;
+        }
+        S.eown.upload(own, D.stream);
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+    }
     Graph &g = S.g;
     g.opt = D.opt;
     g.opt.no_fused_pspmv = 1;  // the sharded PCG exchanges p between its p-update and its SpMV
@@ -433,6 +500,22 @@ static int pcg_dist(Dist &D) {
     return IROTAVG_OK;
 }
 
+// n host doubles combined over all processes (op 0 sum, 1 min, 2 max); nothing to do when every
+// shard lives in this process (loopback)
+static void combine_host(Dist &D, double *v, int n, int op) {
+    if (D.hosted) {
+        if (D.tr.allreduce(D.tr.ctx, v, n, op) != 0) throw HipError{hipErrorUnknown};
+    } else if (D.use_rccl) {
+        Shard &S = *D.shards[0];
+        if (n > 16) throw HipError{hipErrorUnknown};
+        IRH_CHECK(hipMemcpyAsync(S.gsum.p, v, sizeof(double) * n, hipMemcpyHostToDevice, D.stream));
+        NCCL_CHECK(ncclAllReduce(S.gsum.p, S.gsum.p, n, ncclDouble, op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax),
+                                 D.comm, D.stream));
+        IRH_CHECK(hipMemcpyAsync(v, S.gsum.p, sizeof(double) * n, hipMemcpyDeviceToHost, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+    }
+}
+
 static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double change_th, int *iters,
                      double *runtime, double *trace) {
     if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
@@ -454,13 +537,7 @@ static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double chan
             (void)apply_step(sp->g);  // updates owned AND ghost rotations; scores owned views only
             local += sp->g.last_score_sum;
         }
-        if (D.use_rccl) {
-            Shard &S = *D.shards[0];
-            IRH_CHECK(hipMemcpyAsync(S.gsum.p, &local, sizeof(double), hipMemcpyHostToDevice, D.stream));
-            NCCL_CHECK(ncclAllReduce(S.gsum.p, S.gsum.p, 1, ncclDouble, ncclSum, D.comm, D.stream));
-            IRH_CHECK(hipMemcpyAsync(&local, S.gsum.p, sizeof(double), hipMemcpyDeviceToHost, D.stream));
-            IRH_CHECK(hipStreamSynchronize(D.stream));
-        }
+        combine_host(D, &local, 1, 0);
         score = local / (double)D.nu;
         if (trace) trace[it] = score;
         it++;
@@ -472,6 +549,57 @@ static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double chan
     D.stats.outer_iters += it;
     D.stats.edge_updates += (int64_t)it * D.m;
     D.stats.seconds_irls += toc - tic;
+    return rc;
+}
+
+// Sharded L1RA (ral/l1_irls.cpp:851-912 with l1decode_pd :228-468 inside). The primal-dual LP of a
+// coordinate runs over all shards at once (l1decode_group, l1pd.hip): every shard advances the edge
+// vectors of its own edges (a cross-shard edge lives on both shards and is advanced identically on
+// both), A'y walks the owned views, sums over edges count an edge once (Shard::eown), the Hessian
+// system is the sharded PCG above, A dx needs one halo exchange of dx, and the scalars that steer
+// the iteration (duality gap, step bound, back-tracking norms) are combined over the processes --
+// every process takes the same decisions. The three coordinates run one after the other.
+static int l1ra_dist(Dist &D, int max_iters, double change_th, int *iters, double *runtime, double *trace) {
+    const double tic = now_seconds();
+    double score = HUGE_VAL;
+    int l1_step = 2;  // :868
+    int it = 0, rc = IROTAVG_OK;
+    for (auto &sp : D.shards) pd_prepare_graph(sp->g);
+    while (((score >= change_th) || (l1_step < 2)) && (it < max_iters)) {  // :877, >=
+        if (score < change_th) {  // :879-883 -- unreachable under the guard above; kept literal
+            l1_step *= 4;
+            change_th /= 100.0;
+        }
+        for (auto &sp : D.shards) launch_edge_residual(sp->g);
+        for (int c = 0; c < 3 && rc == IROTAVG_OK; c++) {  // :889-892
+            PdGroup G;
+            for (auto &sp : D.shards)
+                G.mem.push_back(PdMember{&sp->g, sp->eown.p, sp->g.er.p + (size_t)c * sp->g.mpad});
+            G.m_global = D.m;
+            G.combine = [&D](double *v, int n, int op) { combine_host(D, v, n, op); };
+            G.halo_x = [&D]() { halo_exchange(D, HALO_X); };
+            G.solve = [&D]() { return pcg_dist(D); };
+            rc = l1decode_group(G, l1_step, kPdXPlane0 + c, nullptr);
+        }
+        if (rc != IROTAVG_OK) break;
+        for (auto &sp : D.shards) pd_pack_solution(sp->g);
+        halo_exchange(D, HALO_X);  // ghost views receive their owners' steps
+        double local = 0.0;
+        for (auto &sp : D.shards) {
+            (void)apply_step(sp->g);  // :894-902
+            local += sp->g.last_score_sum;
+        }
+        combine_host(D, &local, 1, 0);
+        score = local / (double)D.nu;
+        if (trace) trace[it] = score;
+        it++;
+    }
+    IRH_CHECK(hipStreamSynchronize(D.stream));
+    const double toc = now_seconds();
+    *iters = it;
+    *runtime = toc - tic;
+    D.stats.outer_iters += it;
+    D.stats.seconds_l1ra += toc - tic;
     return rc;
 }
 
@@ -508,13 +636,13 @@ int irotavg_dist_unique_id(void *out128) {
     return IROTAVG_OK;
 }
 
-int irotavg_dist_create(irotavg_dist **out, int world, int rank, const void *unique_id128, int64_t m,
-                        int64_t n_total, int f, const int32_t *I, const double *QQ, int64_t ldqq,
-                        const irotavg_options *opt) {
+static int dist_create_impl(irotavg_dist **out, int world, int rank, const void *unique_id128,
+                            const irotavg_transport *tr, int64_t m, int64_t n_total, int f, const int32_t *I,
+                            const double *QQ, int64_t ldqq, const irotavg_options *opt) {
     if (!out || !I || !QQ || world < 1 || m <= 0 || n_total <= 0 || f < 0 || n_total - f < 1 ||
         ldqq < m || n_total > 0x7fffffffLL)
         return IROTAVG_ERR_BAD_ARG;
-    const bool loopback = unique_id128 == nullptr;
+    const bool loopback = unique_id128 == nullptr && tr == nullptr;
     if (!loopback && (rank < 0 || rank >= world)) return IROTAVG_ERR_BAD_ARG;
     *out = nullptr;
     if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
@@ -544,7 +672,9 @@ int irotavg_dist_create(irotavg_dist **out, int world, int rank, const void *uni
             irotavg_dist_destroy(h);
             return IROTAVG_ERR_BAD_ARG;
         }
-        D.use_rccl = !loopback;
+        D.hosted = tr != nullptr;
+        if (D.hosted) D.tr = *tr;
+        D.use_rccl = !loopback && !D.hosted;
         if (D.use_rccl) {
             ncclUniqueId id;
             std::memcpy(&id, unique_id128, sizeof(id));
@@ -569,6 +699,19 @@ int irotavg_dist_create(irotavg_dist **out, int world, int rank, const void *uni
         if (h) irotavg_dist_destroy(h);
         return IROTAVG_ERR_HIP;
     }
+}
+
+int irotavg_dist_create(irotavg_dist **out, int world, int rank, const void *unique_id128, int64_t m,
+                        int64_t n_total, int f, const int32_t *I, const double *QQ, int64_t ldqq,
+                        const irotavg_options *opt) {
+    return dist_create_impl(out, world, rank, unique_id128, nullptr, m, n_total, f, I, QQ, ldqq, opt);
+}
+
+int irotavg_dist_create_hosted(irotavg_dist **out, int world, int rank, const irotavg_transport *transport,
+                               int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                               int64_t ldqq, const irotavg_options *opt) {
+    if (!transport || !transport->allreduce || !transport->exchange) return IROTAVG_ERR_BAD_ARG;
+    return dist_create_impl(out, world, rank, nullptr, transport, m, n_total, f, I, QQ, ldqq, opt);
 }
 
 void irotavg_dist_destroy(irotavg_dist *h) {
@@ -646,6 +789,14 @@ int irotavg_dist_irls(irotavg_dist *h, int cost, double sigma, int max_iters, do
     if (!h || !iters || !runtime) return IROTAVG_ERR_BAD_ARG;
     API_TRY
     return irls_dist(h->D, cost, sigma, max_iters, change_th, iters, runtime, trace);
+    API_CATCH
+}
+
+int irotavg_dist_l1ra(irotavg_dist *h, int max_iters, double change_th, int *iters, double *runtime,
+                      double *trace) {
+    if (!h || !iters || !runtime) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    return l1ra_dist(h->D, max_iters, change_th, iters, runtime, trace);
     API_CATCH
 }
 

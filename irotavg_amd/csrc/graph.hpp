@@ -1,6 +1,7 @@
 // graph.hpp -- the device-resident view-graph handle behind the C ABI.
 #pragma once
 #include <chrono>
+#include <functional>
 #include <memory>
 
 #include "common.hpp"
@@ -129,6 +130,24 @@ int round_grid(long long gsz);
 int grid_for_rows(const Level &L);
 int grid_for_elems(long long n);
 int normalise_host_rows(int64_t n, double *Q, int64_t ldq, int f);
+// l1pd.hip: the primal-dual LP over a group of solvers (one on a single GPU; one per local shard in
+// a sharded run, dist.hip)
+struct PdMember {
+    Graph *g;
+    const uint8_t *eown;  // device mask: 1 = this member sums the edge (nullptr: all of them)
+    const double *y;      // device pointer: the member's right-hand side of the LP (edge plane)
+};
+struct PdGroup {
+    std::vector<PdMember> mem;
+    long long m_global = 0;                           // edges of the whole problem
+    std::function<void(double *, int, int)> combine;  // across processes, n host doubles; op 0 sum, 1 min, 2 max
+    std::function<void()> halo_x;                     // ghost entries of every member's X <- their owners
+    std::function<int()> solve;                       // H dx = rhs on the assembled values, dx -> X component 0
+};
+int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck);
+void pd_prepare_graph(Graph &g);
+void pd_pack_solution(Graph &g);  // pdn planes kPdXPlane0.. -> X (owned rows)
+constexpr int kPdXPlane0 = 3;  // pdn planes 3, 4, 5 hold the three coordinates' solutions (PdnPlane N_X0..)
 // cgcg.hip: the two-launch PCG iteration
 int pcg_solve_cg2(Graph &g);
 void cg2_time_once(Graph &g, int which);

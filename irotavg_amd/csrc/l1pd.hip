@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_init(long long m, const double
                                                     double *__restrict__ u, double *__restrict__ f1,
                                                     double *__restrict__ f2, double *__restrict__ l1,
                                                     double *__restrict__ l2, double *__restrict__ t,
-                                                    double *__restrict__ part) {
+                                                    double *__restrict__ part,
+                                                    const uint8_t *__restrict__ own) {
     double a0 = 0, a1 = 0, a2 = 0;
     EDGE_LOOP(k) {
         const double ax = Ax[k], yy = y[k];
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_init(long long m, const double
         l1[k] = m1;
         l2[k] = m2;
         t[k] = m1 - m2;
+        if (own != nullptr && !own[k]) continue;  // sharded: a cross-shard edge is summed by one shard only
         a0 += g1 * m1;
         a1 += g2 * m2;
         const double rd = 1.0 - m1 - m2;
@@ -106,9 +108,11 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_rcent(long long m, const doubl
                                                      const double *__restrict__ f2,
                                                      const double *__restrict__ l1,
                                                      const double *__restrict__ l2, double itau,
-                                                     double *__restrict__ part) {
+                                                     double *__restrict__ part,
+                                                     const uint8_t *__restrict__ own) {
     double a0 = 0;
     EDGE_LOOP(k) {
+        if (own != nullptr && !own[k]) continue;
         const double c1 = -l1[k] * f1[k] - itau, c2 = -l2[k] * f2[k] - itau;
         a0 += c1 * c1 + c2 * c2;
     }
@@ -260,9 +264,10 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_trial_edge(
     long long m, const double *__restrict__ y, double s, double itau, const double *__restrict__ u,
     const double *__restrict__ du, const double *__restrict__ Ax, const double *__restrict__ Adx,
     const double *__restrict__ l1, const double *__restrict__ dl1, const double *__restrict__ l2,
-    const double *__restrict__ dl2, double *__restrict__ part) {
+    const double *__restrict__ dl2, double *__restrict__ part, const uint8_t *__restrict__ own) {
     double a0 = 0, a1 = 0;
     EDGE_LOOP(k) {
+        if (own != nullptr && !own[k]) continue;
         const double up = u[k] + s * du[k];
         const double axp = Ax[k] + s * Adx[k];
         const double m1 = l1[k] + s * dl1[k], m2 = l2[k] + s * dl2[k];
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_commit_edge(
     const double *__restrict__ du, double *__restrict__ Ax, const double *__restrict__ Adx,
     double *__restrict__ l1, const double *__restrict__ dl1, double *__restrict__ l2,
     const double *__restrict__ dl2, double *__restrict__ f1, double *__restrict__ f2,
-    double *__restrict__ part) {
+    double *__restrict__ part, const uint8_t *__restrict__ own) {
     double a0 = 0, a1 = 0;
     EDGE_LOOP(k) {
         const double up = u[k] + s * du[k];
@@ -306,6 +311,7 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_commit_edge(
         l2[k] = m2;
         f1[k] = g1;
         f2[k] = g2;
+        if (own != nullptr && !own[k]) continue;
         a0 += g1 * m1;
         a1 += g2 * m2;
     }
@@ -362,93 +368,159 @@ static double fetch_ext(Graph &g, int nparts, bool is_max) {
     return r;
 }
 
-// One coordinate. y: device pointer (plane of er, or P_Y). Result in pdn plane `xplane`.
-static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, int *stuck) {
+// One coordinate of ral/l1_irls.cpp:228-468 over a GROUP of solvers: one member on a single GPU, one
+// member per local shard in a sharded run (dist.hip). Every member runs the same kernels on its own
+// edges and views; sums over edges count a cross-shard edge once (PdMember::eown), sums over views
+// run over owned views; `combine` adds what other processes hold. y: device pointer per member
+// (plane of er, or P_Y). Result in pdn plane `xplane` of every member (owned views).
+void pd_prepare_graph(Graph &g) { pd_prepare(g); }
+
+int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
     struct SlotGuard {  // whatever PD slot was last live, the IRLS inverse (slot 0) is live on return
-        Graph &g;
-        ~SlotGuard() { dense_select_slot(g, 0); }
-    } slot_guard{g};
+        PdGroup &G;
+        ~SlotGuard() {
+            for (auto &M : G.mem) dense_select_slot(*M.g, 0);
+        }
+    } slot_guard{G};
     const double PDTOL = 1e-3, alpha = 0.01, beta = 0.5, mu = 10;  // :231-238
-    const long long m = g.m;
-    const int n = g.no;
-    Level &L0 = g.levels[0];
-    const int ge = grid_edges(m), gv = grid_elems(n), gr = grid_rows(L0);
-    hipStream_t st = g.stream;
-    double *P = g.pd.p;
-    auto pl = [&](int i) { return P + (size_t)i * g.mpad; };
-    double *x = g.pdn.p + (size_t)xplane * n;
-    double *Atv = g.pdn.p + (size_t)N_ATV * n, *Atdv = g.pdn.p + (size_t)N_ATDV * n;
+    const double mglob = (double)G.m_global;
     double s3[3];
     if (stuck) *stuck = 0;
-
-    IRH_CHECK(hipMemsetAsync(x, 0, sizeof(double) * (size_t)n, st));             // x0 = 0
-    IRH_CHECK(hipMemsetAsync(pl(P_AX), 0, sizeof(double) * (size_t)g.mpad, st));  // Ax = A*0
-    hipLaunchKernelGGL(k_pd_absmax, dim3(ge), dim3(kRowBlock), 0, st, m, y, pl(P_AX), g.pd_part.p);
-    const double maxabs = fetch_ext(g, ge, true);
-    hipLaunchKernelGGL(k_pd_init, dim3(ge), dim3(kRowBlock), 0, st, m, y, pl(P_AX), maxabs, pl(P_U),
-                       pl(P_F1), pl(P_F2), pl(P_L1), pl(P_L2), pl(P_T1), g.pd_part.p);
-    fetch_parts(g, ge, s3);
-    double sdg = -(s3[0] + s3[1]);           // :264
-    double tau = mu * 2 * (double)m / sdg;   // :265
+    auto pl = [](Graph &g, int i) { return g.pd.p + (size_t)i * g.mpad; };
+    auto xv = [&](Graph &g) { return g.pdn.p + (size_t)xplane * g.no; };
+    auto atv = [](Graph &g) { return g.pdn.p + (size_t)N_ATV * g.no; };
+    auto atdv = [](Graph &g) { return g.pdn.p + (size_t)N_ATDV * g.no; };
+    auto ge = [](Graph &g) { return grid_edges(g.m); };
+    auto gv = [](Graph &g) { return grid_elems(g.no); };
+    auto gr = [](Graph &g) { return grid_rows(g.levels[0]); };
+    // fixed-order sum over the members' partial arrays (members in order), then over processes
+    auto sum_all = [&](auto nparts_of, double out[3]) {
+        out[0] = out[1] = out[2] = 0.0;
+        for (auto &M : G.mem) {
+            double t[3];
+            fetch_parts(*M.g, nparts_of(*M.g), t);
+            for (int c = 0; c < 3; c++) out[c] += t[c];
+        }
+        if (G.combine) G.combine(out, 3, 0);
+    };
+    auto ext_all = [&](auto nparts_of, bool is_max) {
+        double r = is_max ? -HUGE_VAL : HUGE_VAL;
+        for (auto &M : G.mem) {
+            const double t = fetch_ext(*M.g, nparts_of(*M.g), is_max);
+            r = is_max ? std::max(r, t) : std::min(r, t);
+            if (t != t) r = t;  // NaN must surface (breakdown)
+        }
+        if (G.combine) G.combine(&r, 1, is_max ? 2 : 1);
+        return r;
+    };
+    for (auto &M : G.mem) {
+        Graph &g = *M.g;
+        hipStream_t st = g.stream;
+        IRH_CHECK(hipMemsetAsync(xv(g), 0, sizeof(double) * (size_t)g.no, st));           // x0 = 0
+        IRH_CHECK(hipMemsetAsync(pl(g, P_AX), 0, sizeof(double) * (size_t)g.mpad, st));    // Ax = A*0
+        hipLaunchKernelGGL(k_pd_absmax, dim3(ge(g)), dim3(kRowBlock), 0, st, (long long)g.m, M.y, pl(g, P_AX),
+                           g.pd_part.p);
+    }
+    const double maxabs = ext_all(ge, true);
+    for (auto &M : G.mem) {
+        Graph &g = *M.g;
+        hipLaunchKernelGGL(k_pd_init, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, pl(g, P_AX),
+                           maxabs, pl(g, P_U), pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), pl(g, P_T1),
+                           g.pd_part.p, M.eown);
+    }
+    sum_all(ge, s3);
+    double sdg = -(s3[0] + s3[1]);     // :264
+    double tau = mu * 2 * mglob / sdg;  // :265
     double rd_tail2 = s3[2];
-    hipLaunchKernelGGL(k_at_mul, dim3(gr), dim3(kRowBlock), 0, st, n, L0.nsl, L0.sl_off.p,
-                       g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(P_T1), Atv, g.pd_part.p);
-    fetch_parts(g, gr, s3);
+    auto at_mul = [&](int tplane, bool into_atdv) {
+        for (auto &M : G.mem) {
+            Graph &g = *M.g;
+            Level &L0 = g.levels[0];
+            hipLaunchKernelGGL(k_at_mul, dim3(gr(g)), dim3(kRowBlock), 0, g.stream, g.no, L0.nsl, L0.sl_off.p,
+                               g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, tplane),
+                               into_atdv ? atdv(g) : atv(g), g.pd_part.p);
+        }
+    };
+    at_mul(P_T1, false);
+    sum_all(gr, s3);
     const double atv2 = s3[0];
-    hipLaunchKernelGGL(k_pd_rcent, dim3(ge), dim3(kRowBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
-                       pl(P_L2), 1.0 / tau, g.pd_part.p);
-    fetch_parts(g, ge, s3);
-    double resnorm = std::sqrt(atv2 + rd_tail2 + s3[0]);  // :278-281
+    auto rcent = [&](double itau) {
+        for (auto &M : G.mem) {
+            Graph &g = *M.g;
+            hipLaunchKernelGGL(k_pd_rcent, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, pl(g, P_F1),
+                               pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau, g.pd_part.p, M.eown);
+        }
+        sum_all(ge, s3);
+        return s3[0];
+    };
+    double resnorm = std::sqrt(atv2 + rd_tail2 + rcent(1.0 / tau));  // :278-281
 
     int pditer = 0;
     bool done = (sdg < PDTOL) || (pditer >= pdmaxiter);  // :284
     while (!done) {
         pditer++;
         const double itau = 1.0 / tau;
-        hipLaunchKernelGGL(k_pd_sig, dim3(ge), dim3(kRowBlock), 0, st, m, pl(P_F1), pl(P_F2), pl(P_L1),
-                           pl(P_L2), itau, pl(P_SIGX), pl(P_T1), pl(P_T2));
-        // inverse of the same PD iteration of the previous outer iteration, if still close enough
-        // (measured at 100k/2M: the entry ratios against (p, t-1) span 2-20x in the first outer
-        // iterations and <1.5x from the ~7th on; accepting up to kPdSpread costs ~1 PCG iteration
-        // per solve and saves most inversions of a long l1ra run)
-        dense_select_slot(g, std::min(pditer - 1, kPdSlots - 1));
-        {
-            const double keep = g.stale_spread;
-            g.stale_spread = kPdSpread;
-            assemble(g, 1, pl(P_SIGX), g.opt.dense_always_refresh == 1);
-            g.stale_spread = keep;
+        for (auto &M : G.mem) {
+            Graph &g = *M.g;
+            Level &L0 = g.levels[0];
+            hipStream_t st = g.stream;
+            hipLaunchKernelGGL(k_pd_sig, dim3(ge(g)), dim3(kRowBlock), 0, st, (long long)g.m, pl(g, P_F1),
+                               pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau, pl(g, P_SIGX), pl(g, P_T1), pl(g, P_T2));
+            // inverse of the same PD iteration of the previous outer iteration, if still close enough
+            // (measured at 100k/2M: the entry ratios against (p, t-1) span 2-20x in the first outer
+            // iterations and <1.5x from the ~7th on; accepting up to kPdSpread costs ~1 PCG iteration
+            // per solve and saves most inversions of a long l1ra run)
+            dense_select_slot(g, std::min(pditer - 1, kPdSlots - 1));
+            {
+                const double keep = g.stale_spread;
+                g.stale_spread = kPdSpread;
+                assemble(g, 1, pl(g, P_SIGX), g.opt.dense_always_refresh == 1);
+                g.stale_spread = keep;
+            }
+            hipLaunchKernelGGL(k_pd_rhs, dim3(gr(g)), dim3(kRowBlock), 0, st, g.no, L0.nsl, L0.sl_off.p,
+                               g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, P_T1), pl(g, P_T2), itau,
+                               L0.b.p);
         }
-        hipLaunchKernelGGL(k_pd_rhs, dim3(gr), dim3(kRowBlock), 0, st, n, L0.nsl, L0.sl_off.p,
-                           g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(P_T1), pl(P_T2), itau,
-                           L0.b.p);
         // the primal-dual Hessians (weights 1/f^2 spread over decades) want less over-correction than
         // the IRLS systems of a band graph: 1.6 measured best on both topologies
-        const double kc_keep = g.opt.mg_kc;
-        if (g.kc_auto) g.opt.mg_kc = std::min(kc_keep, 1.6);
-        int rc = pcg_solve(g);  // dx in g.X component 0
-        g.opt.mg_kc = kc_keep;
+        std::vector<double> kc_keep;
+        for (auto &M : G.mem) {
+            kc_keep.push_back(M.g->opt.mg_kc);
+            if (M.g->kc_auto) M.g->opt.mg_kc = std::min(M.g->opt.mg_kc, 1.6);
+        }
+        int rc = G.solve();  // dx in X component 0 of every member (owned views)
+        for (size_t q = 0; q < G.mem.size(); q++) G.mem[q].g->opt.mg_kc = kc_keep[q];
         if (rc != IROTAVG_OK) return rc == IROTAVG_ERR_NOT_CONVERGED ? rc : IROTAVG_ERR_SOLVER;
-        hipLaunchKernelGGL(k_pd_dir, dim3(ge), dim3(kRowBlock), 0, st, m, g.f, g.ei.p, g.ej.p,
-                           g.eflag.p, g.X.p, pl(P_F1), pl(P_F2), pl(P_L1), pl(P_L2), itau, pl(P_ADX),
-                           pl(P_DU), pl(P_DL1), pl(P_DL2), pl(P_T1), g.pd_part.p);
-        double s = std::fmin(1.0, fetch_ext(g, ge, false));  // :347-380
+        if (G.halo_x) G.halo_x();  // A dx needs dx of the ghost views
+        for (auto &M : G.mem) {
+            Graph &g = *M.g;
+            hipLaunchKernelGGL(k_pd_dir, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, g.f, g.ei.p,
+                               g.ej.p, g.eflag.p, g.X.p, pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau,
+                               pl(g, P_ADX), pl(g, P_DU), pl(g, P_DL1), pl(g, P_DL2), pl(g, P_T1), g.pd_part.p);
+        }
+        double s = std::fmin(1.0, ext_all(ge, false));  // :347-380
         if (!(s == s)) return IROTAVG_ERR_SOLVER;
-        s *= 0.99;                                            // :381
-        hipLaunchKernelGGL(k_at_mul, dim3(gr), dim3(kRowBlock), 0, st, n, L0.nsl, L0.sl_off.p,
-                           g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(P_T1), Atdv, g.pd_part.p);
+        s *= 0.99;  // :381
+        at_mul(P_T1, true);
         // backtracking (:384-429)
         bool suffdec = false;
         int backiter = 0;
         double s_acc = s, rdp2 = 0.0;
         while (!suffdec) {
-            hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv), dim3(kRowBlock), 0, st, n, s, Atv, Atdv,
-                               g.pd_part.p);
-            fetch_parts(g, gv, s3);
+            for (auto &M : G.mem) {
+                Graph &g = *M.g;
+                hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv(g)), dim3(kRowBlock), 0, g.stream, g.no, s, atv(g),
+                                   atdv(g), g.pd_part.p);
+            }
+            sum_all(gv, s3);
             const double rdv = s3[0];
-            hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge), dim3(kRowBlock), 0, st, m, y, s, itau,
-                               pl(P_U), pl(P_DU), pl(P_AX), pl(P_ADX), pl(P_L1), pl(P_DL1), pl(P_L2),
-                               pl(P_DL2), g.pd_part.p);
-            fetch_parts(g, ge, s3);
+            for (auto &M : G.mem) {
+                Graph &g = *M.g;
+                hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, s,
+                                   itau, pl(g, P_U), pl(g, P_DU), pl(g, P_AX), pl(g, P_ADX), pl(g, P_L1),
+                                   pl(g, P_DL1), pl(g, P_L2), pl(g, P_DL2), g.pd_part.p, M.eown);
+            }
+            sum_all(ge, s3);
             rdp2 = rdv + s3[0];
             suffdec = std::sqrt(rdp2 + s3[1]) <= (1 - alpha * s) * resnorm;  // :419
             s_acc = s;
@@ -459,21 +531,30 @@ static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, i
                 return IROTAVG_OK;
             }
         }
-        hipLaunchKernelGGL(k_pd_commit_vert, dim3(gv), dim3(kRowBlock), 0, st, n, s_acc, x, g.X.p, Atv,
-                           Atdv);
-        hipLaunchKernelGGL(k_pd_commit_edge, dim3(ge), dim3(kRowBlock), 0, st, m, y, s_acc, pl(P_U),
-                           pl(P_DU), pl(P_AX), pl(P_ADX), pl(P_L1), pl(P_DL1), pl(P_L2), pl(P_DL2),
-                           pl(P_F1), pl(P_F2), g.pd_part.p);
-        fetch_parts(g, ge, s3);
-        sdg = -(s3[0] + s3[1]);             // :446
-        tau = mu * 2 * (double)m / sdg;     // :448
-        hipLaunchKernelGGL(k_pd_rcent, dim3(ge), dim3(kRowBlock), 0, st, m, pl(P_F1), pl(P_F2),
-                           pl(P_L1), pl(P_L2), 1.0 / tau, g.pd_part.p);
-        fetch_parts(g, ge, s3);
-        resnorm = std::sqrt(rdp2 + s3[0]);  // :455-458
+        for (auto &M : G.mem) {
+            Graph &g = *M.g;
+            hipLaunchKernelGGL(k_pd_commit_vert, dim3(gv(g)), dim3(kRowBlock), 0, g.stream, g.no, s_acc, xv(g),
+                               g.X.p + g.ng, atv(g), atdv(g));
+            hipLaunchKernelGGL(k_pd_commit_edge, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y,
+                               s_acc, pl(g, P_U), pl(g, P_DU), pl(g, P_AX), pl(g, P_ADX), pl(g, P_L1), pl(g, P_DL1),
+                               pl(g, P_L2), pl(g, P_DL2), pl(g, P_F1), pl(g, P_F2), g.pd_part.p, M.eown);
+        }
+        sum_all(ge, s3);
+        sdg = -(s3[0] + s3[1]);            // :446
+        tau = mu * 2 * mglob / sdg;        // :448
+        resnorm = std::sqrt(rdp2 + rcent(1.0 / tau));  // :455-458
         done = (sdg < PDTOL) || (pditer >= pdmaxiter);  // :460
     }
     return IROTAVG_OK;
+}
+
+// single-GPU form: a group of one
+static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, int *stuck) {
+    PdGroup G;
+    G.mem.push_back(PdMember{&g, nullptr, y});
+    G.m_global = g.m;
+    G.solve = [&g]() { return pcg_solve(g); };
+    return l1decode_group(G, pdmaxiter, xplane, stuck);
 }
 
 int l1decode_pd_dev(Graph &g, int er_plane, const double *y_host, int pdmaxiter, double *x_host,
@@ -558,6 +639,14 @@ static void destroy_clone_streams(Graph &g) {
             StreamPool::get().give(c->stream, g.device);
             c->stream = nullptr;
         }
+}
+
+// the three coordinates' solutions (pdn planes N_X0..N_X2, owned views) -> X as double4 rows
+void pd_pack_solution(Graph &g) {
+    const int n = g.no;
+    hipLaunchKernelGGL(k_pack3, dim3(grid_elems(n)), dim3(kRowBlock), 0, g.stream, n,
+                       g.pdn.p + (size_t)N_X0 * n, g.pdn.p + (size_t)N_X1 * n, g.pdn.p + (size_t)N_X2 * n,
+                       g.X.p + g.ng);
 }
 
 void release_l1_clones(Graph &g) {

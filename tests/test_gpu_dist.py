@@ -78,3 +78,29 @@ def test_bad_world_size():
     S, Q0 = problem(200, 1200, 0.0)
     with pytest.raises(capi.IrotavgError):
         capi.DistGraph(S["I"], S["QQ"], 200, 1, 8)     # 199 free views cannot feed 8 shards
+
+
+@pytest.mark.parametrize("world,p_loop", [(2, 0.0), (4, 0.02), (3, 0.01)])
+def test_loopback_sharded_l1ra_then_irls_equals_unsharded(world, p_loop):
+    """The callers' pipeline (l1ra then irls: src/ViewGraph.cpp:1400-1417, ral/test.cpp:295-301) on the
+    sharded graph against the single-GPU handle: same outer iteration counts, scores, rotations."""
+    n, m, f = 6000, 60000, 2
+    S, Q0 = problem(n, m, p_loop, f, seed=2)
+    with capi.Graph(S["I"], S["QQ"], n, f) as G:
+        G.set_rotations(Q0)
+        a1 = G.l1ra(3, 1e-3)
+        Q1 = G.get_rotations()
+        a2 = G.irls(4, SIG, 20, 1e-3)
+        Qa, wa = G.get_rotations(), G.get_weights()
+    Qw = Q0.copy()
+    with capi.DistGraph(S["I"], S["QQ"], n, f, world) as D:
+        D.set_rotations(Q0)
+        b1 = D.l1ra(3, 1e-3)
+        Qb1 = D.get_rotations(into=Qw).copy()
+        b2 = D.irls(4, SIG, 20, 1e-3)
+        Qb, wb = D.get_rotations(into=Qw), D.get_weights()
+    assert a1["iters"] == b1["iters"] and a2["iters"] == b2["iters"]
+    np.testing.assert_allclose(a1["scores"], b1["scores"], rtol=1e-6)
+    assert synth.angular_distance(Q1, Qb1).max() < 1e-8
+    assert synth.angular_distance(Qa, Qb).max() < 1e-8
+    np.testing.assert_allclose(wa, wb, rtol=1e-6)
