@@ -86,19 +86,59 @@ def kernel_rooflines(G, S, st, sharded=False):
     return out
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (tools/profile_counters.sh + tools/summarize_pmc.py -> profiles/r01_pmc_summary.json)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+PMC_SUMMARY = "r02_pmc_summary.json"
+
+
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload
+    (tools/profile_counters.sh + tools/summarize_pmc.py -> profiles/r02_pmc_summary.json). The counters
+    need their own rocprofv3 passes, so they cannot be collected inside a plain bench run; the summary
+    carries the workload string of the bench line it was taken on, and a run on any other workload
+    reports null instead of a number that belongs to another size or topology."""
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     try:
         with open(path) as fh:
             table = json.load(fh)
+        if table.get("_meta", {}).get("workload") != workload:
+            return None
         for name, row in table.items():   # template kernels appear as "name<args>"
             if name == kernel or name.startswith(kernel + "<"):
                 return float(row["traffic_bytes"])
         return None
     except Exception:
         return None
+
+
+def suitesparse_baseline(S, Q0, budget_s=20.0):
+    """if the GPU box has SuiteSparse (it is not in this image), time the reference's
+    own library call -- SuiteSparseQR X = A \\ B per IRLS iteration (ral/l1_irls.cpp:536-556) -- through
+    oracle/spqr_harness.cpp on the same graph. Returns a dict, or a reason string."""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "spqr_harness.cpp")
+    exe = os.path.join(tempfile.gettempdir(), "irotavg_spqr_harness")
+    probe = subprocess.run(["g++", "-O2", "-std=c++11", src, "-o", exe, "-I/usr/include/suitesparse", "-lspqr",
+                            "-lcholmod", "-lsuitesparseconfig"], capture_output=True, text=True)
+    if probe.returncode != 0:
+        return "SuiteSparse (SuiteSparseQR.hpp / libspqr) not found on this box: " + \
+               (probe.stderr.strip().splitlines() or ["compile failed"])[0][:160]
+    from oracle import oracle as O
+    w3 = O.log_map(O.delta_rel(S["I"], S["QQ"], Q0))[:, :3]
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as fh:
+        fh.write("%d %d %d\n" % (S["m"], S["n"], 1))
+        for (i, j), r in zip(S["I"], w3):
+            fh.write("%d %d %.17g %.17g %.17g\n" % (i, j, r[0], r[1], r[2]))
+        path = fh.name
+    try:
+        out = subprocess.run([exe, path, str(budget_s)], capture_output=True, text=True, timeout=10 * budget_s + 60)
+        sec, reps = [float(x) for x in out.stdout.split()[:2]]
+        return dict(value=S["m"] * reps / sec, unit="edge-updates/s", cores=1, kind="reference-library",
+                    sample="%d SuiteSparseQR least-squares solves (one per IRLS iteration, unit weights) of the same "
+                           "%d-view/%d-edge graph, %.1f s" % (int(reps), S["n"], S["m"], sec))
+    except Exception as e:
+        return "SuiteSparse harness failed: %s" % e
+    finally:
+        os.unlink(path)
 
 
 def cpu_baseline(S, Q0, p_loop, budget_s=25.0):
@@ -252,12 +292,13 @@ def main():
                             "bound": "hbm", "achieved": kr[dom]["gbs"], "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": kr[dom]["gbs"] / HBM_PEAK_GBS,
                             "traffic": pmc_traffic({"pspmv": "k_pspmv_dot", "spmv": "k_spmv_dot",
-                                                    "cg_apply": "k_cg_apply"}[dom]),
+                                                    "cg_apply": "k_cg_apply"}[dom], line["config"]["workload"]),
                             "ms_per_launch": kr[dom]["ms"], "algorithmic_bytes": kr[dom]["bytes"]}
         line["roofline_edge_residual"] = {
             "kernel": "k_edge_residual (K1, the kernel north_star names)", "bound": "hbm",
             "achieved": kr["edge_residual"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kr["edge_residual"]["gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic("k_edge_residual"),
+            "frac": kr["edge_residual"]["gbs"] / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("k_edge_residual", line["config"]["workload"]),
             "ms_per_launch": kr["edge_residual"]["ms"], "algorithmic_bytes": kr["edge_residual"]["bytes"]}
         line["kernels"] = {k: {kk: (float(vv) if not isinstance(vv, int) else vv) for kk, vv in v.items()}
                            for k, v in kr.items()}
@@ -297,8 +338,29 @@ def main():
             line["also_pcg_rtol_1e-8"] = {"value": S["m"] * r3["iters"] * reps / d3, "unit": "edge-updates/s",
                                           "iters_to_converge": r3["iters"], "ms_per_step": 1e3 * d3 / reps,
                                           "pcg_iters_per_solve": s3["pcg_iters"] / max(s3["pcg_solves"], 1)}
+        if not args.no_extra and world == 1:
+            # what a caller of the drop-in irotavg_irls pays with HOST buffers: graph build (adjacency,
+            # hierarchy, SELL) + upload + the same solve + download, per call (the resident
+            # figure above is the amortised / incremental case)
+            from irotavg_amd import ral
+            reps = 3
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                Qh = Q0.copy()
+                wh = np.zeros(S["m"])
+                it1, _rt = ral.irls(S["QQ"], S["I"], None, 4, SIG, Qh, 1, 100, 1e-3, wh)
+            d1 = time.perf_counter() - t1
+            line["also_one_shot_host_buffers"] = {
+                "value": S["m"] * it1 * reps / d1, "unit": "edge-updates/s", "ms_per_call": 1e3 * d1 / reps,
+                "iters_to_converge": it1,
+                "note": "irotavg_irls from host pointers: handle creation + PCIe both ways inside the timed region"}
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(S, Q0, args.p_loop)
+            ss = suitesparse_baseline(S, Q0)
+            if isinstance(ss, dict):
+                line["cpu_baseline_suitesparse"] = ss
+            else:
+                line["cpu_baseline"]["suitesparse_probe"] = ss
         G.close()
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -5,7 +5,10 @@ Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): F
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports one half of the bytes of wide coalesced
 streaming reads, so the read side is doubled ("fetch_x2"); WRITE_SIZE is uncalibrated and taken
 as is. traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 bytes per launch.
-Usage: python tools/summarize_pmc.py gpurun_out/prof5 profiles/r01_pmc_summary.json
+The summary is stamped with the workload string of the bench line the trace pass printed
+(`_meta.workload`): bench.py only quotes `roofline.traffic` from a summary whose workload is the one it
+is running (a stale number next to another size's algorithmic bytes is worse than null).
+Usage: python tools/summarize_pmc.py gpurun_out/prof5 profiles/r02_pmc_summary.json
 """
 import csv
 import json
@@ -36,7 +39,18 @@ def main(d, out):
     for k, s in stats.items():
         if "fetch_kib" in s and "write_kib" in s:
             s["traffic_bytes"] = 2 * s["fetch_kib"] * 1024 + s["write_kib"] * 1024
+    meta = {}
+    try:  # the bench line of the trace pass (tools/profile_counters.sh redirects stdout into trace.log)
+        for line in open(d + "/trace.log"):
+            if line.startswith("{") and '"config"' in line:
+                b = json.loads(line)
+                meta = dict(workload=b["config"]["workload"], pcg_rtol=b["config"].get("pcg_rtol"),
+                            ms_per_step=b.get("ms_per_step"), value=b.get("value"))
+    except Exception as e:
+        meta = dict(error=str(e))
+    stats["_meta"] = meta
     json.dump(stats, open(out, "w"), indent=1)
+    stats.pop("_meta")
     for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["pct"])[:16]:
         print("%-34s calls %6d avg %9.1f us %5.1f%%  fetch %10.0f KiB write %10.0f KiB traffic %8.1f MB" % (
             k[:34], s["calls"], s["avg_us"], s["pct"], s.get("fetch_kib", -1), s.get("write_kib", -1),
