@@ -436,6 +436,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     // dense inverse of the coarsest level (only when it is small enough and there is a hierarchy)
     g.ndense = 0;
     g.ndense_pad = 0;
+    g.dense_bw = 0;
     if (g.levels.back().n <= std::min(g.opt.mg_dense_max, 2048) && g.opt.mg_levels_max > 1) {
         g.ndense = g.levels.back().n;
         g.ndense_pad = (g.ndense + 63) / 64 * 64;
@@ -444,6 +445,13 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         g.dense_wr.alloc((size_t)64 * g.ndense_pad);  // two 32 x npad panels (look-ahead ping-pong)
         g.dense_wc.alloc((size_t)64 * g.ndense_pad);
         g.dense_ref_diag.alloc((size_t)g.ndense_pad);
+        // half-bandwidth of the coarsest operator: a banded one (view sequences without loop closures: 1-3)
+        // is inverted by a banded LDL' + one substitution per column instead of the dense sweep (dense.hip)
+        const HostLevel &hd = H.back();
+        int bw = 0;
+        for (int r = 0; r < hd.n; r++)
+            for (int t = hd.rowptr[r]; t < hd.rowptr[r + 1]; t++) bw = std::max(bw, std::abs(hd.col[t] - r));
+        g.dense_bw = bw;
     }
     g.additive_top = g.opt.mg_multiplicative_top == 1 ? 0 : 1;
     // Can the PCG update also do the down-sweep of level 1 (k_pcg_update_restrict2)? Aggregates of 8

@@ -722,6 +722,200 @@ void dense_select_slot(Graph &g, int slot) {
     g.dense_epoch++;
 }
 
+// ---- banded coarsest operator: LDL' + one substitution per column --------------------------------
+// A view sequence without loop closures coarsens to a BANDED operator (half-bandwidth 1-3 at 100k
+// views). The blocked Gauss-Jordan sweep above spends npad / 32 dependent block steps (~20 us each:
+// 1.0 ms at 1563 rows) whatever the structure; for a band of half-width BW the same explicit inverse
+// is n columns of E X = I, each a forward and a backward substitution of BW multiply-adds per row:
+//   * every workgroup factorises E = L D L' itself (one lane, the last BW rows of L and D in
+//     registers: n dependent steps of ~BW^2 fma; redundant across the ~n/256 workgroups, but they run
+//     side by side and nothing has to be published),
+//   * then one thread per column runs the two substitutions from the LDS copy of L (broadcast reads)
+//     with the column's running values in registers, storing rows as it goes (coalesced across the
+//     workgroup's columns).
+// A pivot not above kDeadTol x the largest diagonal entry is dead: that unknown solves to 0 (the
+// same rule as the dense sweep). ~0.1 ms instead of 1.0 ms.
+constexpr int kBandMax = 4;
+template <int BW>
+__global__ __launch_bounds__(256) void k_band_inverse(LevelView C, int npad, double *__restrict__ X) {
+    // LDS: one record per row, W doubles (16-byte aligned): l[0..BW-1] (l[d-1] = L(r, r-d)), then 1 / d(r)
+    constexpr int W = ((BW + 1) + 1) & ~1;
+    extern __shared__ double lds[];
+    const int n = C.n;
+    double *rec = lds;
+    const int tid = threadIdx.x;
+    __shared__ double smax[4];
+    // band of E into LDS: slot BW holds the diagonal for now, slots 0..BW-1 the sub-diagonals
+    for (int e = tid; e < n * W; e += 256) rec[e] = 0.0;
+    __syncthreads();
+    double dm = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const double d = C.diag[i];
+        rec[(size_t)i * W + BW] = d;
+        dm = fmax(dm, d);
+        const int sl = i >> 6, ln = i & 63;
+        const int o0 = C.sl_off[sl], w = C.sl_off[sl + 1] - o0;
+        for (int k = 0; k < w; k++) {
+            const size_t p = sell_pos(o0, k, ln);
+            const double v = C.val[p];
+            const int c = C.col[p];
+            if (v != 0.0 && c < i && i - c <= BW) rec[(size_t)i * W + (i - c - 1)] += v;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+    if ((tid & 63) == 0) smax[tid >> 6] = dm;
+    __syncthreads();
+    const double thr = kDeadTol * fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    if (tid == 0) {
+        // row-wise LDL': u(i, j) = a(i, j) - sum_p u(i, p) l(j, p), l(i, j) = u(i, j) / d(j),
+        // d(i) = a(i, i) - sum_j u(i, j) l(i, j); pl[q][.] = row i-1-q of L, pd[q] = 1 / d(i-1-q)
+        double pl[BW][BW], pd[BW];
+#pragma unroll
+        for (int q = 0; q < BW; q++) {
+            pd[q] = 0.0;
+#pragma unroll
+            for (int d = 0; d < BW; d++) pl[q][d] = 0.0;
+        }
+        constexpr int FB = 8;  // rows per batch: their band entries are read from LDS before the
+                               // dependent chain starts (an LDS round trip per row otherwise)
+        for (int i0 = 0; i0 < n; i0 += FB) {
+            double ab[FB][W];
+#pragma unroll
+            for (int b = 0; b < FB; b++) {
+                const int i = min(i0 + b, n - 1);
+#pragma unroll
+                for (int d = 0; d < W; d++) ab[b][d] = rec[(size_t)i * W + d];  // a(i, i-1-d); [BW] = a(i, i)
+            }
+#pragma unroll
+            for (int b = 0; b < FB; b++) {
+                const int i = i0 + b;
+                if (i >= n) break;
+                double u[BW], l[BW];
+                double dd = ab[b][BW];
+                // columns j = i-BW .. i-1, i.e. d = BW-1 .. 0 (ascending j)
+#pragma unroll
+                for (int d = BW - 1; d >= 0; d--) {
+                    // u(i, j) with j = i-1-d: subtract sum over p = j-1-e (e >= 0) of u(i, p) l(j, p);
+                    // p = i-1-(d+1+e): u index d+1+e, l(j, p) = pl[d][e]
+                    double t = ab[b][d];
+#pragma unroll
+                    for (int e = 0; e + d + 1 < BW; e++) t -= u[d + 1 + e] * pl[d][e];
+                    u[d] = t;
+                    l[d] = t * pd[d];
+                    dd -= t * l[d];
+                }
+                const bool dead = !(dd > thr);
+                // reciprocal: hardware estimate + two Newton steps (an fp64 division is a ~150-cycle
+                // routine, and there is one per row on this serial path)
+                double idd = __builtin_amdgcn_rcp(dd);
+                idd = fma(fma(-dd, idd, 1.0), idd, idd);
+                idd = fma(fma(-dd, idd, 1.0), idd, idd);
+                if (dead) idd = 0.0;
+#pragma unroll
+                for (int d = 0; d < BW; d++) {
+                    if (dead) l[d] = 0.0;  // the unknown solves to 0: no coupling through its row
+                    rec[(size_t)i * W + d] = l[d];
+                }
+                rec[(size_t)i * W + BW] = idd;
+                // shift the register window
+#pragma unroll
+                for (int q = BW - 1; q > 0; q--) {
+                    pd[q] = pd[q - 1];
+#pragma unroll
+                    for (int d = 0; d < BW; d++) pl[q][d] = pl[q - 1][d];
+                }
+                pd[0] = idd;
+#pragma unroll
+                for (int d = 0; d < BW; d++) pl[0][d] = l[d];
+            }
+        }
+    }
+    __syncthreads();
+    // one column per thread
+    const int c = blockIdx.x * 256 + tid;
+    const int c0 = blockIdx.x * 256;
+    if (c0 >= n) return;
+    const bool live = c < n;
+    double yy[BW];  // y(r-1) .. y(r-BW)
+#pragma unroll
+    for (int d = 0; d < BW; d++) yy[d] = 0.0;
+    constexpr int U = 8;  // rows per batch: L / D^-1 (LDS, broadcast) and z (global) are read before the
+                          // dependent chain of the batch starts
+    for (int rb = c0; rb < n; rb += U) {  // forward: L y = e_c, z = D^-1 y stored in place of X(r, c)
+        double lr[U][W];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = min(rb + u, n - 1);
+#pragma unroll
+            for (int d = 0; d < W; d++) lr[u][d] = rec[(size_t)r * W + d];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = rb + u;
+            if (r >= n) break;
+            double y = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int d = 0; d < BW; d++) y -= lr[u][d] * yy[d];
+            if (r < c) y = 0.0;
+#pragma unroll
+            for (int d = BW - 1; d > 0; d--) yy[d] = yy[d - 1];
+            yy[0] = y;
+            if (live) X[(size_t)r * npad + c] = y * lr[u][BW];
+        }
+    }
+    double xx[BW];  // x(r+1) .. x(r+BW)
+#pragma unroll
+    for (int d = 0; d < BW; d++) xx[d] = 0.0;
+    // backward: L' x = z. z comes back from global memory (~2 us per round trip): the NEXT batch's rows
+    // are requested before the current batch's dependent chain runs
+    auto load_z = [&](int rb, double (&z)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = rb - u;
+            z[u] = (live && r >= c0 && r >= 0) ? X[(size_t)r * npad + c] : 0.0;
+        }
+    };
+    double zc[U], zn[U];
+    load_z(n - 1, zc);
+    for (int rb = n - 1; rb >= 0; rb -= U) {
+        double lc[U][BW];
+        load_z(rb - U, zn);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = rb - u;
+#pragma unroll
+            for (int d = 0; d < BW; d++) {
+                const int q = r + d + 1;  // L(r+d+1, r)
+                lc[u][d] = (r >= 0 && q < n) ? rec[(size_t)q * W + d] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int r = rb - u;
+            if (r < 0) break;
+            double x = zc[u];
+#pragma unroll
+            for (int d = 0; d < BW; d++) x -= lc[u][d] * xx[d];
+#pragma unroll
+            for (int d = BW - 1; d > 0; d--) xx[d] = xx[d - 1];
+            xx[0] = x;
+            if (live) X[(size_t)r * npad + c] = x;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) zc[u] = zn[u];
+    }
+}
+
+template <int BW>
+static void band_inverse_launch(Graph &g, const LevelView &V) {
+    const int n = g.ndense, npad = g.ndense_pad;
+    const size_t shm = sizeof(double) * (size_t)n * (((BW + 1) + 1) & ~1);
+    if (shm > 48 * 1024)
+        IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_band_inverse<BW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((k_band_inverse<BW>), dim3((n + 255) / 256), dim3(256), shm, g.stream, V, npad, g.dense_inv.p);
+}
+
 void dense_refresh(Graph &g) {
     if (g.ndense <= 0) return;
     g.dense_epoch++;
@@ -742,6 +936,15 @@ void dense_refresh(Graph &g) {
     const int npad = g.ndense_pad;
     LevelView V{C.n, C.nsl, C.agg, C.sl_off.p, C.sl_near.p, C.col.p, C.val.p, C.diag.p, C.idg.p};
     IRH_CHECK(hipMemsetAsync(g.dense_inv.p, 0, sizeof(double) * (size_t)npad * npad, g.stream));
+    if (g.dense_bw >= 1 && g.dense_bw <= kBandMax && !std::getenv("IROTAVG_NO_BAND_INVERSE")) {
+        switch (g.dense_bw) {
+        case 1: band_inverse_launch<1>(g, V); break;
+        case 2: band_inverse_launch<2>(g, V); break;
+        case 3: band_inverse_launch<3>(g, V); break;
+        default: band_inverse_launch<4>(g, V); break;
+        }
+        return;
+    }
     if (g.dense_maxdiag.n < 1) g.dense_maxdiag.alloc(1);
     IRH_CHECK(hipMemsetAsync(g.dense_maxdiag.p, 0, sizeof(double), g.stream));
     hipLaunchKernelGGL(k_dense_build, dim3((npad + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,

@@ -49,6 +49,7 @@ struct Graph {
     int dense_repairs_in_a_row = 0;     // since the last full inversion
     DevBuf<double> dense_la;            // look-ahead: two snapshots of upcoming 32 x 32 diagonal blocks
     int ndense = 0, ndense_pad = 0;
+    int dense_bw = 0;  // half-bandwidth of the coarsest operator's pattern (build.cpp)
     bool dense_valid = false, dense_fresh = false;
     double dense_scale = 1.0, stale_spread = 1.1;
     DevBuf<double> dense_ref_diag, dense_ref_val;  // coarse operator the current inverse was computed from

@@ -611,7 +611,7 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
         B.diag.alloc_like(A.diag, s); B.idg.alloc_like(A.idg, s);
         B.b.alloc_like(A.b, s); B.x.alloc_like(A.x, s); B.y.alloc_like(A.y, s); B.e.alloc_like(A.e, s);
     }
-    q.ndense = g.ndense; q.ndense_pad = g.ndense_pad; q.additive_top = g.additive_top;
+    q.ndense = g.ndense; q.ndense_pad = g.ndense_pad; q.dense_bw = g.dense_bw; q.additive_top = g.additive_top;
     q.stale_spread = g.stale_spread;
     q.l0_far_entries = g.l0_far_entries;
     q.l1_fused = g.l1_fused;
