@@ -339,6 +339,27 @@ def main():
                                           "iters_to_converge": r3["iters"], "ms_per_step": 1e3 * d3 / reps,
                                           "pcg_iters_per_solve": s3["pcg_iters"] / max(s3["pcg_solves"], 1)}
         if not args.no_extra and world == 1:
+            # the callers' real pipeline: l1ra THEN irls (ral/test.cpp:295-301 with its defaults: 5 L1RA and
+            # 50 IRLS iterations, change_th 1e-3; src/ViewGraph.cpp:1400-1417 allows 100 L1RA iterations)
+            G.restore_rotations()
+            G.l1ra(1, 1e-3)            # allocates the primal-dual planes and the solver clones
+            G.restore_rotations()
+            G.synchronize()
+            t1 = time.perf_counter()
+            ra = G.l1ra(5, 1e-3)
+            G.synchronize()
+            t2 = time.perf_counter()
+            rb = G.irls(4, SIG, 50, 1e-3)
+            G.synchronize()
+            t3 = time.perf_counter()
+            line["also_l1ra_then_irls"] = {
+                "l1ra_iters": ra["iters"], "l1ra_ms": 1e3 * (t2 - t1),
+                "l1ra_ms_per_outer_iteration": 1e3 * (t2 - t1) / max(ra["iters"], 1),
+                "irls_iters": rb["iters"], "irls_ms": 1e3 * (t3 - t2),
+                "edge_updates_per_s_whole_pipeline": S["m"] * (ra["iters"] + rb["iters"]) / (t3 - t1),
+                "note": "l1ra(5) then irls(50): the reference demo's defaults; l1ra = 3 coordinate LPs x 2 primal-dual "
+                        "iterations per outer iteration, each a Hessian solve by the same PCG"}
+            G.restore_rotations()
             # what a caller of the drop-in irotavg_irls pays with HOST buffers: graph build (adjacency,
             # hierarchy, SELL) + upload + the same solve + download, per call (the resident
             # figure above is the amortised / incremental case)

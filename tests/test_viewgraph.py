@@ -1,7 +1,11 @@
 """The ViewGraph / Pose counterpart (irotavg_viewgraph_*): container semantics on the CPU, and
 rotAvg against the oracle's literal restatement of src/ViewGraph.cpp:1263-1435 on the GPU."""
+import os
+
 import numpy as np
 import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 from irotavg_amd import capi, synth
 from irotavg_amd.viewgraph import ViewGraph
@@ -162,3 +166,76 @@ def test_connect_with_swapped_arguments_stores_the_transpose():
     assert (ra["l1_iters"], ra["irls_iters"]) == (rb["l1_iters"], rb["irls_iters"])
     for v in range(n):
         np.testing.assert_allclose(a.R(v), b.R(v), atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_incremental_stream_with_loop_closures_at_scale_matches_oracle():
+    """Config 5's call pattern at a size the oracle still covers: 2000 warm views, 1200 streamed one by
+    one (rotAvg(10) each -- the single-launch window kernel), 3 loop closures (global re-solves through
+    the multi-level handle path), a ground-truth fix every 20 frames. Every call's bookkeeping and
+    iteration counts equal the oracle's, and so do the final poses."""
+    warm, stream, n_loops = 2000, 1200, 3
+    n = warm + stream
+    rng = np.random.default_rng(21)
+    Qgt = rng.normal(size=(n, 4)); Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+
+    def relR(i, j):
+        e = synth.qexp(rng.normal(scale=0.01, size=(1, 3)))[0]
+        return rot(synth.qmul(e, synth.qmul(Qgt[j], synth.qconj(Qgt[i]))))
+    vg, vo = ViewGraph(), ViewGraphOracle()
+    for v in range(warm):        # a converged history: ground truth perturbed at the noise level
+        R0 = rot(synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(1, 3)))[0], Qgt[v]))
+        vg.addView(R0); vo.addView(R0)
+        for d in range(1, min(4, v) + 1):
+            R = relR(v - d, v)
+            vg.connect(v - d, v, R); vo.connect(v - d, v, R)
+        if v % 20 == 0:
+            vg.fixPose(v, rot(Qgt[v])); vo.fixPose(v, rot(Qgt[v]))
+    loop_at = set(rng.choice(np.arange(warm + 50, n), size=n_loops, replace=False).tolist())
+    n_global = 0
+    for v in range(warm, n):
+        R1 = relR(v - 1, v)
+        R0 = R1 @ vo.R[v - 1]
+        vg.addView(R0); vo.addView(R0)
+        vg.connect(v - 1, v, R1); vo.connect(v - 1, v, R1)
+        for d in range(2, 5):
+            R = relR(v - d, v)
+            vg.connect(v - d, v, R); vo.connect(v - d, v, R)
+        loop = v in loop_at
+        if loop:
+            u = int(rng.integers(0, v - 500))
+            R = relR(u, v)
+            vg.connect(u, v, R); vo.connect(u, v, R)
+        if v % 20 == 0:
+            vg.fixPose(v, rot(Qgt[v])); vo.fixPose(v, rot(Qgt[v]))
+        a, b = vg.rotAvg(5000000 if loop else 10), vo.rotAvg(5000000 if loop else 10)
+        n_global += 1 if loop else 0
+        assert a["skipped"] == b["skipped"] == 0
+        assert (a["n_views"], a["n_edges"], a["n_fixed"], a["l1_iters"], a["irls_iters"]) == \
+               (b["n_views"], b["n_edges"], b["n_fixed"], b["l1_iters"], b["irls_iters"]), (v, loop, a, b)
+    assert n_global == n_loops
+    worst = max(np.abs(vg.R(v) - vo.R[v]).max() for v in range(n))
+    assert worst < 1e-6, worst
+    err = [synth.angular_distance(O.rmat2quat(vg.R(v)), Qgt[v]) for v in range(warm, n, 13)]
+    assert max(err) < 0.05
+
+
+@pytest.mark.gpu
+def test_config5_full_size_stream_properties():
+    """BASELINE.json config 5 at FULL size (50k warm + 50k streamed views, 10 loop closures; the oracle
+    cannot follow at this size): the stream completes, every pose stays a rotation, user-fixed poses
+    are untouched, and the streamed poses stay within the drift a sequence with fixes every 20 frames
+    allows (mean angular error vs ground truth < 0.02 rad). Rate and latencies are printed."""
+    import json
+    import subprocess
+    import sys as _sys
+    tool = os.path.join(os.path.dirname(HERE), "tools", "bench_incremental.py")
+    r = subprocess.run([_sys.executable, tool, "--warm", "50000", "--stream", "50000", "--loops", "10"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    print(line)
+    assert d["streamed_views"] == 50000 and d["loop_closures"] == 10
+    assert d["mean_angular_error_rad"] < 0.02 and d["max_angular_error_rad"] < 0.2
+    assert d["views_per_s"] > 1000.0
