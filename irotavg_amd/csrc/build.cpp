@@ -482,7 +482,10 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
                     band8 = false;
                     break;
                 }
-        g.cg2 = (band8 && g.ndense > 0 && g.opt.pcg_classic != 1) ? 1 : 0;
+        // ... and a workgroup per 256-row tile (<= 512 tiles: up to 131k views). Beyond that the kernels are
+        // bandwidth-bound, not latency-bound, and the classic launches measured faster (1M/20M: 1.88 vs 1.70 G)
+        const bool one_tile = (H[0].n + 255) / 256 <= kMaxParts;
+        g.cg2 = (band8 && one_tile && g.ndense > 0 && g.opt.pcg_classic != 1) ? 1 : 0;
         g.dense32 = 0;  // tile slices of the coarse solve read the fp64 inverse; IROTAVG_CG2_FP32_DENSE=1: an fp32 copy
         if (const char *e = getenv("IROTAVG_CG2_FP32_DENSE")) g.dense32 = atoi(e) == 1 ? 1 : 0;
         if (g.cg2) {

@@ -42,13 +42,48 @@ constexpr int kL1Pre = 8;   // entries of a level-1 row requested up front (a ba
 // is an own row of the tile. r and s ping-pong between two buffers (neighbouring workgroups read the
 // old values of these rows as their halo).
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+// every thread obtains the fixed-order sums of TWO partial arrays in one pass (one round trip to memory
+// and one pair of barriers instead of two: this sits at the head of k_cg_update's dependency chain)
+__device__ __forceinline__ void load_reduced3x2(const double *pa, const double *pb, int nparts, double a[3],
+                                                double b[3]) {
+    __shared__ double sm[6][4];
+    const int t = threadIdx.x;
+    if (t < 256) {
+        double v[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int q = t + 256 * h;
+            if (q < nparts) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    v[c] += pa[4 * q + c];
+                    v[3 + c] += pb[4 * q + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) v[c] = wave_sum(v[c]);
+        if ((t & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) sm[c][t >> 6] = v[c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        a[c] = ((sm[c][0] + sm[c][1]) + sm[c][2]) + sm[c][3];
+        b[c] = ((sm[3 + c][0] + sm[3 + c][1]) + sm[3 + c][2]) + sm[3 + c][3];
+    }
+    __syncthreads();
+}
+
+template <int MODE, bool ONE>
 __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
     int n, int nsl, double *__restrict__ scal, int par, const double *__restrict__ part_g,
     const double *__restrict__ part_d, int nparts, double4 *__restrict__ X,
     const double4 *__restrict__ Rin, double4 *__restrict__ Rout, const double4 *__restrict__ Sin,
     double4 *__restrict__ Sout, double4 *__restrict__ P, const double4 *__restrict__ U,
-    const double4 *__restrict__ W, LevelView L1, double4 *__restrict__ b1, double4 *__restrict__ x1,
+    const double4 *__restrict__ W, LevelView L1, int uw1, double4 *__restrict__ b1, double4 *__restrict__ x1,
     double4 *__restrict__ b2, double4 *__restrict__ x2, const double *__restrict__ idg2, double omega,
     double *__restrict__ part_rr, int *__restrict__ flags, double *__restrict__ b2p, int ndpad) {
     const int done = flags[FL_DONE];
@@ -57,73 +92,51 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
     int t0, t1;
     tile_range(ntiles, t0, t1);
     const int tid = threadIdx.x;
-    struct Win {
-        double4 r[2], w[2], s[2];  // both window slots
+    // everything a tile reads is requested at its top, BEFORE the scalars are reduced from the partials
+    struct Pre {
+        double4 r[2], w[2], s[2];  // both window slots (slots beyond the window re-read its last row)
         double4 u, p, x;           // own row
+        double w1[2];              // omega / diagonal of the level-1 rows this thread restricts to
+        double v[kL1Pre], d;       // lanes 0..31: level-1 row (entries, diagonal) of an own level-1 row
+        int c[kL1Pre], o0, wd;
+        double i2;                 // lanes 0..31 with row % 8 == 0: 1 / diagonal of the level-2 row
     };
-    auto win_load = [&](int t, Win &V) {
+    auto pre_load = [&](int t, Pre &V) {
         const int r0 = t * 256;
         const int wlo = max(0, r0 - kWinHalo);
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int iw = tid + u * kRowBlock, i = wlo + iw;
-            V.r[u] = V.w[u] = V.s[u] = make_double4(0, 0, 0, 0);
-            if (iw < kWinLen && i < n) {
-                V.r[u] = Rin[i];
-                if (MODE != 0) V.w[u] = W[i];
-                if (MODE == 2) V.s[u] = Sin[i];
-            }
+            const int iw = tid + u * kRowBlock;
+            const int i = min(wlo + min(iw, kWinLen - 1), n - 1);
+            V.r[u] = Rin[i];
+            V.w[u] = MODE != 0 ? W[i] : make_double4(0, 0, 0, 0);
+            V.s[u] = MODE == 2 ? Sin[i] : make_double4(0, 0, 0, 0);
+            V.w1[u] = L1.idg[i >> 3];
         }
-        const int io = wlo + tid + (tid >= r0 - wlo ? 0 : kRowBlock);  // the own row among the two slots
-        V.u = V.p = V.x = make_double4(0, 0, 0, 0);
-        if (io < n && MODE != 0) {
-            V.u = U[io];
-            V.x = X[io];
-            if (MODE == 2) V.p = P[io];
-        }
-    };
-    // level-1 row (SELL entries, diagonal) of one of the tile's own 32 level-1 rows: lanes 0..31
-    struct Row1 {
-        double v[kL1Pre], d;
-        int c[kL1Pre], o0, w;
-    };
-    auto row1_load = [&](int t, Row1 &Rw) {
-        const int row = t * 32 + tid;
-        Rw.w = 0;
-        Rw.o0 = 0;
-        Rw.d = 0.0;
+        const int io = min(wlo + tid + (tid >= r0 - wlo ? 0 : kRowBlock), n - 1);  // the own row among the two slots
+        V.u = MODE != 0 ? U[io] : make_double4(0, 0, 0, 0);
+        V.x = MODE != 0 ? X[io] : make_double4(0, 0, 0, 0);
+        V.p = MODE == 2 ? P[io] : make_double4(0, 0, 0, 0);
+        const int row = min(t * 32 + (tid & 31), L1.n - 1);
+        const int sl = row >> 6, ln = row & 63;
+        V.o0 = uw1 > 0 ? sl * uw1 : L1.sl_off[sl];
+        V.wd = uw1 > 0 ? uw1 : L1.sl_off[sl + 1] - V.o0;
+        V.d = L1.diag[row];
+        V.i2 = idg2[row >> 3];
 #pragma unroll
         for (int k = 0; k < kL1Pre; k++) {
-            Rw.v[k] = 0.0;
-            Rw.c[k] = 0;
-        }
-        if (tid < 32 && row < L1.n) {
-            const int sl = row >> 6, ln = row & 63;
-            Rw.o0 = L1.sl_off[sl];
-            Rw.w = L1.sl_off[sl + 1] - Rw.o0;
-            Rw.d = L1.diag[row];
-#pragma unroll
-            for (int k = 0; k < kL1Pre; k++)
-                if (k < Rw.w) {
-                    const size_t pos = sell_pos(Rw.o0, k, ln);
-                    Rw.v[k] = L1.val[pos];
-                    Rw.c[k] = L1.col[pos];
-                }
+            const size_t pos = sell_pos(V.o0, min(k, V.wd - 1), ln);  // slice widths are >= 8 = kL1Pre
+            V.v[k] = L1.val[pos];
+            V.c[k] = L1.col[pos];
         }
     };
-    // the first tile's vectors are requested BEFORE the scalars are reduced from the partials
-    Win V0;
-    Row1 Q0;
-    if (t0 < t1) {
-        win_load(t0, V0);
-        row1_load(t0, Q0);
-    }
+    Pre V;
+    if (t0 < t1) pre_load(t0, V);
     if (done) return;
     double al[3] = {0, 0, 0}, be[3] = {0, 0, 0};
     if (MODE != 0) {
         double g3[3], d3[3];
-        load_reduced3(part_g, nparts, g3);
-        load_reduced3(part_d, nparts, d3);
+        load_reduced3x2(part_g, part_d, nparts, g3, d3);
         bool finite = true;
         for (int c = 0; c < 3; c++) {
             const double go = scal[(par ? SC_GAM1 : SC_GAM0) + c], ao = scal[(par ? SC_ALF1 : SC_ALF0) + c];
@@ -142,23 +155,17 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
         }
     }
     double a0 = 0, a1 = 0, a2 = 0;
-    for (int t = t0; t < t1; t++) {
+    // ONE: a workgroup per tile -- straight-line code (see k_cg_apply)
+    auto tile_body = [&](const int t) {
         const int r0 = t * 256;
         const int wlo = max(0, r0 - kWinHalo);
-        Win V;
-        Row1 Rw;
-        if (t == t0) {
-            V = V0;
-            Rw = Q0;
-        } else {
-            win_load(t, V);
-            row1_load(t, Rw);
-        }
+        if (t != t0) pre_load(t, V);
         const int uo = tid >= r0 - wlo ? 0 : 1;  // which slot is the own row
         __syncthreads();  // the previous tile's level-1 rows are done with the window
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int iw = tid + u * kRowBlock, i = wlo + iw;
+            const bool in = iw < kWinLen && i < n;
             double4 r = V.r[u];
             double4 s = V.w[u];
             if (MODE != 0) {
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
                 r.y -= al[1] * s.y;
                 r.z -= al[2] * s.z;
             }
+            if (!in) r = make_double4(0, 0, 0, 0);
             if (u == uo && i < n) {  // own row: p, s, x, r and ||r||^2
                 if (MODE == 0) {
                     X[i] = make_double4(0, 0, 0, 0);
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
             if ((i & 7) == 0 && iw < kWinLen) {
                 const int I = i >> 3, Iw = iw >> 3;
                 const bool live = i < n;
-                const double w = live ? omega * L1.idg[I] : 0.0;
+                const double w = live ? omega * V.w1[u] : 0.0;
                 wb[0][Iw] = c0;
                 wb[1][Iw] = c1;
                 wb[2][Iw] = c2;
@@ -221,13 +229,13 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
             if (row < L1.n) {
 #pragma unroll
                 for (int k = 0; k < kL1Pre; k++) {  // entries requested at the top of the tile
-                    const int ci = min(max(Rw.c[k] - W1lo, 0), kL1Win - 1);  // padding: v = 0
-                    s0 += Rw.v[k] * wxv[0][ci];
-                    s1 += Rw.v[k] * wxv[1][ci];
-                    s2 += Rw.v[k] * wxv[2][ci];
+                    const int ci = min(max(V.c[k] - W1lo, 0), kL1Win - 1);  // padding: v = 0
+                    s0 += V.v[k] * wxv[0][ci];
+                    s1 += V.v[k] * wxv[1][ci];
+                    s2 += V.v[k] * wxv[2][ci];
                 }
-                for (int k = kL1Pre; k < Rw.w; k++) {
-                    const size_t pos = sell_pos(Rw.o0, k, row & 63);
+                for (int k = kL1Pre; k < V.wd; k++) {
+                    const size_t pos = sell_pos(V.o0, k, row & 63);
                     const double v = L1.val[pos];
                     const int ci = min(max(L1.col[pos] - W1lo, 0), kL1Win - 1);
                     s0 += v * wxv[0][ci];
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
                     s2 += v * wxv[2][ci];
                 }
                 const int me = row - W1lo;
-                const double d = Rw.d;
+                const double d = V.d;
                 e0 = wb[0][me] - (s0 + d * wxv[0][me]);
                 e1 = wb[1][me] - (s1 + d * wxv[1][me]);
                 e2 = wb[2][me] - (s2 + d * wxv[2][me]);
@@ -251,10 +259,15 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
                     b2p[ndpad + J] = e1;
                     b2p[2 * ndpad + J] = e2;
                 }
-                const double w = omega * idg2[J];
+                const double w = omega * V.i2;
                 x2[J] = make_double4(w * e0, w * e1, w * e2, 0.0);
             }
         }
+    };
+    if (ONE) {
+        if (t0 < t1) tile_body(t0);
+    } else {
+        for (int t = t0; t < t1; t++) tile_body(t);
     }
     block_sum3_store(a0, a1, a2, part_rr + 4 * blockIdx.x);
     if (MODE != 0 && blockIdx.x == 0 && tid == 0) flags[FL_ITERS] += 1;
@@ -626,18 +639,27 @@ void cg2_launch_update(Graph &g, int mode, int par, int rcur) {
     Level &L2 = g.levels[2];
     const Cg2Bufs B = cg2_bufs(g);
     const int grid = grid_for_rows(L0);
-#define CG_UPD(M)                                                                                        \
-    hipLaunchKernelGGL((k_cg_update<M>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl, g.scal.p, \
-                       par, g.part_rz.p, g.part_pq.p, grid, g.X.p, B.R[rcur], B.R[rcur ^ 1], B.S[rcur],   \
-                       B.S[rcur ^ 1], B.P, B.U, B.W, view_of(L1), L1.b.p, L1.x.p, L2.b.p, L2.x.p,         \
-                       L2.idg.p, g.opt.mg_omega, g.part_rr.p, g.flags.p,                                     \
+    const bool one = (L0.nsl + 3) / 4 <= grid;  // a workgroup per tile
+#define CG_UPD(M, ONE)                                                                                     \
+    hipLaunchKernelGGL((k_cg_update<M, ONE>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl,        \
+                       g.scal.p, par, g.part_rz.p, g.part_pq.p, grid, g.X.p, B.R[rcur], B.R[rcur ^ 1],       \
+                       B.S[rcur], B.S[rcur ^ 1], B.P, B.U, B.W, view_of(L1), L1.uni_w, L1.b.p, L1.x.p,       \
+                       L2.b.p, L2.x.p, L2.idg.p, g.opt.mg_omega, g.part_rr.p, g.flags.p,                     \
                        g.levels.size() == 3 ? g.b2p.p : (double *)nullptr, g.ndense_pad)
+#define CG_UPD1(M)         \
+    do {                   \
+        if (one)           \
+            CG_UPD(M, true);  \
+        else               \
+            CG_UPD(M, false); \
+    } while (0)
     if (mode == 0)
-        CG_UPD(0);
+        CG_UPD1(0);
     else if (mode == 1)
-        CG_UPD(1);
+        CG_UPD1(1);
     else
-        CG_UPD(2);
+        CG_UPD1(2);
+#undef CG_UPD1
 #undef CG_UPD
 }
 
