@@ -205,6 +205,7 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
     g.nu = (int)(n_total - f);
     g.ng = 0;
     g.no = g.nu;
+    if (const char *e = std::getenv("IROTAVG_STALE_SPREAD")) g.stale_spread = std::max(1.0, std::atof(e));  // experiments
     const int rc = build_graph(g, I, QQ, ldqq);
     if (rc != IROTAVG_OK) {
         irotavg_graph_destroy(h);

@@ -836,12 +836,17 @@ __global__ __launch_bounds__(256) void k_band_inverse(LevelView C, int npad, dou
     const int c0 = blockIdx.x * 256;
     if (c0 >= n) return;
     const bool live = c < n;
+    // The substitutions are ISSUE-bound, not latency-bound: 28 waves on the whole chip, one per SIMD, a
+    // few cycles per instruction -- so the row loops are stripped to the recurrence itself (full
+    // batches of U rows without bounds checks, running pointers, masked columns write to a dummy row).
     double yy[BW];  // y(r-1) .. y(r-BW)
 #pragma unroll
     for (int d = 0; d < BW; d++) yy[d] = 0.0;
-    constexpr int U = 8;  // rows per batch: L / D^-1 (LDS, broadcast) and z (global) are read before the
-                          // dependent chain of the batch starts
-    for (int rb = c0; rb < n; rb += U) {  // forward: L y = e_c, z = D^-1 y stored in place of X(r, c)
+    constexpr int U = 8;
+    // columns beyond n ride along on the last live column's address arithmetic and store nothing
+    const int cc = live ? c : n - 1;
+    double *xp = X + (size_t)c0 * npad + cc;
+    auto fwd_rows = [&](int rb, int cnt) {
         double lr[U][W];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -851,59 +856,71 @@ __global__ __launch_bounds__(256) void k_band_inverse(LevelView C, int npad, dou
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int r = rb + u;
-            if (r >= n) break;
-            double y = (r == c) ? 1.0 : 0.0;
+            if (u < cnt) {
+                double y = (rb + u == cc) ? 1.0 : 0.0;
 #pragma unroll
-            for (int d = 0; d < BW; d++) y -= lr[u][d] * yy[d];
-            if (r < c) y = 0.0;
+                for (int d = 0; d < BW; d++) y -= lr[u][d] * yy[d];
+                y = (rb + u < cc) ? 0.0 : y;
 #pragma unroll
-            for (int d = BW - 1; d > 0; d--) yy[d] = yy[d - 1];
-            yy[0] = y;
-            if (live) X[(size_t)r * npad + c] = y * lr[u][BW];
+                for (int d = BW - 1; d > 0; d--) yy[d] = yy[d - 1];
+                yy[0] = y;
+                if (live) *xp = y * lr[u][BW];
+                xp += npad;
+            }
         }
-    }
+    };
+    int rb = c0;
+    for (; rb + U <= n; rb += U) fwd_rows(rb, U);  // forward: L y = e_c, z = D^-1 y stored in place of X(r, c)
+    if (rb < n) fwd_rows(rb, n - rb);
     double xx[BW];  // x(r+1) .. x(r+BW)
 #pragma unroll
     for (int d = 0; d < BW; d++) xx[d] = 0.0;
-    // backward: L' x = z. z comes back from global memory (~2 us per round trip): the NEXT batch's rows
-    // are requested before the current batch's dependent chain runs
-    auto load_z = [&](int rb, double (&z)[U]) {
+    // backward: L' x = z, rows n-1 .. 0. z comes back from global memory: the NEXT batch's rows are
+    // requested before the current batch's dependent chain runs. Rows above the workgroup's first column
+    // hold z = 0 (never stored).
+    xp = X + (size_t)(n - 1) * npad + cc;
+    auto load_z = [&](int rtop, double (&z)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int r = rb - u;
-            z[u] = (live && r >= c0 && r >= 0) ? X[(size_t)r * npad + c] : 0.0;
+            const int r = rtop - u;
+            z[u] = (live && r >= c0) ? X[(size_t)r * npad + c] : 0.0;
         }
     };
-    double zc[U], zn[U];
-    load_z(n - 1, zc);
-    for (int rb = n - 1; rb >= 0; rb -= U) {
+    auto bwd_rows = [&](int rtop, int cnt, const double (&z)[U]) {
         double lc[U][BW];
-        load_z(rb - U, zn);
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int r = rb - u;
+            const int r = rtop - u;
 #pragma unroll
             for (int d = 0; d < BW; d++) {
-                const int q = r + d + 1;  // L(r+d+1, r)
-                lc[u][d] = (r >= 0 && q < n) ? rec[(size_t)q * W + d] : 0.0;
+                const int q = min(max(r + d + 1, 0), n - 1);  // L(r+d+1, r); beyond the last row: times xx = 0
+                lc[u][d] = rec[(size_t)q * W + d];
             }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int r = rb - u;
-            if (r < 0) break;
-            double x = zc[u];
+            if (u < cnt) {
+                double x = z[u];
 #pragma unroll
-            for (int d = 0; d < BW; d++) x -= lc[u][d] * xx[d];
+                for (int d = 0; d < BW; d++) x -= lc[u][d] * xx[d];
 #pragma unroll
-            for (int d = BW - 1; d > 0; d--) xx[d] = xx[d - 1];
-            xx[0] = x;
-            if (live) X[(size_t)r * npad + c] = x;
+                for (int d = BW - 1; d > 0; d--) xx[d] = xx[d - 1];
+                xx[0] = x;
+                if (live) *xp = x;
+                xp -= npad;
+            }
         }
+    };
+    double zc[U], zn[U];
+    int rt = n - 1;
+    load_z(rt, zc);
+    for (; rt - U + 1 >= 0; rt -= U) {
+        load_z(rt - U, zn);
+        bwd_rows(rt, U, zc);
 #pragma unroll
         for (int u = 0; u < U; u++) zc[u] = zn[u];
     }
+    if (rt >= 0) bwd_rows(rt, rt + 1, zc);
 }
 
 template <int BW>
