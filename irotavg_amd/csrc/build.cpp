@@ -58,10 +58,9 @@ static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector
     M.nsl = (n + 63) / 64;
     M.sl_off.assign((size_t)M.nsl + 1, 0);
     M.sl_near.assign((size_t)M.nsl, 0);
-    auto is_near = [&](int r, int c) {
-        const int t0 = (r / 256) * 256;
-        return c >= t0 - kWinHalo && c < t0 + 256 + kWinHalo;
-    };
+    // near = within kWinHalo rows of the row itself: inside the LDS window of EVERY tile that contains
+    // the row, whatever the tiling (256-row tiles of the classic kernels, slice ranges of cgcg.hip)
+    auto is_near = [&](int r, int c) { return c >= r - kWinHalo && c <= r + kWinHalo; };
     auto roundup = [](int w) { return (w + kSellUnroll - 1) / kSellUnroll * kSellUnroll; };
     std::vector<int> width((size_t)M.nsl, 0);
     parallel_for(M.nsl, 256, [&](int64_t s0, int64_t s1, int) {
@@ -482,9 +481,10 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
                     band8 = false;
                     break;
                 }
-        // ... and a workgroup per 256-row tile (<= 512 tiles: up to 131k views). Beyond that the kernels are
-        // bandwidth-bound, not latency-bound, and the classic launches measured faster (1M/20M: 1.88 vs 1.70 G)
-        const bool one_tile = (H[0].n + 255) / 256 <= kMaxParts;
+        // ... and a workgroup per tile of <= 4 slices with at most kMaxParts workgroups (up to 131k views).
+        // Beyond that the kernels are bandwidth-bound, not latency-bound, and the classic launches
+        // measured faster (1M/20M: 1.88 vs 1.70 G)
+        const bool one_tile = (H[0].n + 63) / 64 <= 4 * kMaxParts;
         g.cg2 = (band8 && one_tile && g.ndense > 0 && g.opt.pcg_classic != 1) ? 1 : 0;
         g.dense32 = 0;  // tile slices of the coarse solve read the fp64 inverse; IROTAVG_CG2_FP32_DENSE=1: an fp32 copy
         if (const char *e = getenv("IROTAVG_CG2_FP32_DENSE")) g.dense32 = atoi(e) == 1 ? 1 : 0;

@@ -128,6 +128,18 @@ __device__ __forceinline__ void tile_range(int ntiles, int &t0, int &t1) {
     t1 = (int)(((long long)ntiles * (lb + 1)) / nb);
 }
 
+// the two-launch PCG iteration (cgcg.hip) deals SLICES, not 256-row tiles: workgroup b owns the
+// slices [nsl b / G, nsl (b + 1) / G) -- at most four, G >= nsl / 4 -- so that every CU carries the
+// same number of rows (391 tiles of four slices on 256 CUs leave the CUs that host two of them with
+// twice the bytes: they set the kernel time). Same XCD-aware block order as tile_range.
+__device__ __forceinline__ void slice_range(int nsl, int &s0, int &ns) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    int lb = b;
+    if ((nb & 7) == 0) lb = (b & 7) * (nb >> 3) + (b >> 3);
+    s0 = (int)(((long long)nsl * lb) / nb);
+    ns = (int)(((long long)nsl * (lb + 1)) / nb) - s0;
+}
+
 // Off-diagonal part of (L x)_row for the lane's own row. The slice width is a multiple of
 // kSellUnroll and uniform across the wave. The loop is software-pipelined by hand TWO batches
 // deep: while the gathers of batch k are in flight, the col/val loads of batch k+2 are issued

@@ -14,4 +14,5 @@ names = ["entry", "loads issued", "pcg_check done", "sb staged+barrier", "dense 
          "u window done", "spmv done", "reduced+stored", "dense fma done", "matrix/L1 loads issued"]
 for rep in range(2):
     print(" | ".join("%s %.2f" % (names[k], G.time_kernel(100 + k, 1)) for k in (1, 2, 3, 10, 11, 4, 5, 6, 7, 8, 9)))
+print("grid: first workgroup start %.2f, last workgroup end %.2f (us, relative to the stamped workgroup's entry)" % (G.time_kernel(112, 1), G.time_kernel(113, 1)))
 print("apply us", 1e3 * G.time_kernel(9, 50), "update us", 1e3 * G.time_kernel(10, 50))
