@@ -516,6 +516,81 @@ static void combine_host(Dist &D, double *v, int n, int op) {
     }
 }
 
+// Sharded PCG with Chronopoulos-Gear recurrences (additive top level, >= 2 levels): per iteration ONE
+// all-reduce group ({||r||^2, r.u, u.w}: 3 rows of 4 doubles) and ONE halo exchange (of u). The
+// preconditioner is shard-local (block-Jacobi across shards) as before.
+//   u = M^-1 r | halo(u) | w = L u, partials | all-reduce | convergence test on ||r||^2; alpha, beta;
+//   p = u + beta p, s = w + beta s, x += alpha p, r -= alpha s, restriction
+static int pcg_dist_cg(Dist &D) {
+    const double rtol2 = D.opt.pcg_rtol * D.opt.pcg_rtol;
+    auto rows_grid = [](Graph &g) { return grid_for_rows(g.levels[0]); };
+    // ||r||^2 partials ping-pong between part_rr and part_rz (the update kernel tests one and writes the
+    // other); gamma partials live in part_score (free during a solve), delta in part_pq
+    auto rr_buf = [](Graph &g, int which) { return which ? g.part_rz.p : g.part_rr.p; };
+    int cur = 0;  // which buffer holds ||r||^2 of the current residual
+    for (auto &sp : D.shards) {
+        Graph &g = sp->g;
+        IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, D.stream));
+        launch_cgd_update(g, true, 0, 1, rtol2, nullptr, nullptr, nullptr, rr_buf(g, cur));
+    }
+    int it = 0;
+    int h_flags[FL_COUNT] = {0, 0, 0, 0};
+    const int check = std::max(1, D.opt.pcg_check_every);
+    const int maxit = std::max(1, D.opt.pcg_max_iters);
+    const RowOf rows_a[3] = {+[](Shard &S) { return S.g.part_rr.p; }, +[](Shard &S) { return S.g.part_score.p; },
+                             +[](Shard &S) { return S.g.part_pq.p; }};
+    const RowOf rows_b[3] = {+[](Shard &S) { return S.g.part_rz.p; }, +[](Shard &S) { return S.g.part_score.p; },
+                             +[](Shard &S) { return S.g.part_pq.p; }};
+    auto iteration = [&]() {
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            (void)precondition(g, it == 0, rtol2, false);  // levels[1].y = M1^-1 P0' r (its dot output is not used)
+            launch_form_u(g, g.part_score.p);
+        }
+        halo_exchange(D, HALO_P);  // P holds u
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            launch_spmv(g);  // AP = L u, part_pq = u.w
+            reduce_pair(D, rr_buf(g, cur), rows_grid(g), g.part_score.p, grid_for_elems(g.levels[0].n), g.part_pq.p,
+                        rows_grid(g));
+        }
+        allreduce_rows(D, cur ? rows_b : rows_a, 3);
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            launch_cgd_update(g, false, it & 1, it == 0, rtol2, g.part_score.p, g.part_pq.p, rr_buf(g, cur),
+                              rr_buf(g, cur ^ 1));
+        }
+        cur ^= 1;
+        it++;
+    };
+    int chunk = D.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(D.stats.pcg_iters_last + 1, maxit) : check;
+    while (true) {
+        for (int c = 0; c < chunk; c++) iteration();  // the update of iteration k tests the residual of k - 1
+        chunk = std::max(2, check / 2);
+        IRH_CHECK(hipMemcpyAsync(h_flags, D.shards[0]->g.flags.p, sizeof(int) * FL_COUNT, hipMemcpyDeviceToHost,
+                                 D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+        if (h_flags[FL_DONE] != 0) break;
+        if (it >= maxit) break;
+    }
+    D.stats.pcg_solves += 1;
+    D.stats.pcg_iters += h_flags[FL_ITERS];
+    D.stats.pcg_iters_last = h_flags[FL_ITERS];
+    if (h_flags[FL_DONE] == 2) return IROTAVG_ERR_SOLVER;
+    if (h_flags[FL_DONE] == 0) return IROTAVG_ERR_NOT_CONVERGED;
+    return IROTAVG_OK;
+}
+
+static int pcg_dist_any(Dist &D) {
+    // every LOCAL shard must have the multi-level additive structure; with one shard per process the
+    // choice must also agree across processes: shards are equal-sized ranges of one graph, so the level
+    // count only differs when a range falls below mg_dense_max rows -- decided from the global size
+    bool ok = D.opt.pcg_classic != 1 && D.chunk > std::max(D.opt.mg_dense_max, 1) &&
+              D.nu - (int64_t)(D.world - 1) * D.chunk > std::max(D.opt.mg_dense_max, 1);
+    for (auto &sp : D.shards) ok = ok && sp->g.additive_top && sp->g.levels.size() > 1;
+    return ok ? pcg_dist_cg(D) : pcg_dist(D);
+}
+
 static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double change_th, int *iters,
                      double *runtime, double *trace) {
     if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
@@ -528,7 +603,7 @@ static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double chan
             launch_edge_residual(sp->g);
             assemble(sp->g, 0, sp->g.dw.p, D.opt.dense_always_refresh == 1);
         }
-        rc = pcg_dist(D);
+        rc = pcg_dist_any(D);
         if (rc != IROTAVG_OK) break;
         halo_exchange(D, HALO_X);  // ghost views receive their owners' steps
         double local = 0.0;
@@ -578,7 +653,7 @@ static int l1ra_dist(Dist &D, int max_iters, double change_th, int *iters, doubl
             G.m_global = D.m;
             G.combine = [&D](double *v, int n, int op) { combine_host(D, v, n, op); };
             G.halo_x = [&D]() { halo_exchange(D, HALO_X); };
-            G.solve = [&D]() { return pcg_dist(D); };
+            G.solve = [&D]() { return pcg_dist_any(D); };
             rc = l1decode_group(G, l1_step, kPdXPlane0 + c, nullptr);
         }
         if (rc != IROTAVG_OK) break;

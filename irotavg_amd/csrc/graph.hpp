@@ -127,6 +127,10 @@ void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = n
 void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi, bool check = false, int np_rr = 1,
                     double rtol2 = 0.0);
 PrecInfo precondition(Graph &g, int first, double rtol2, bool check = true);
+// Chronopoulos-Gear pieces of the sharded PCG (solver.hip; buffers: u = P, w = AP, p = P2, s = levels[0].e)
+void launch_form_u(Graph &g, double *part_g);
+void launch_cgd_update(Graph &g, bool init, int par, int first, double rtol2, const double *part_g,
+                       const double *part_d, const double *rr_in, double *rr_out);
 int round_grid(long long gsz);
 int grid_for_rows(const Level &L);
 int grid_for_elems(long long n);

@@ -1012,6 +1012,143 @@ __global__ __launch_bounds__(kRowBlock) void k_pcg_update_restrict2(
     if (!INIT && blockIdx.x == 0 && threadIdx.x == 0) flags[FL_ITERS] += 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chronopoulos-Gear recurrences for the SHARDED PCG (dist.hip): one all-reduce ({||r||^2, r.u, u.w})
+// and one halo exchange (of u) per iteration instead of two all-reduces. Generic row kernels (any
+// aggregate size, far entries allowed); the single-GPU tile-fused form lives in cgcg.hip.
+// ---------------------------------------------------------------------------------------------
+// u = omega D^-1 r + kc P0 y1 (the additive-top preconditioner applied), partial sums of r.u
+__global__ __launch_bounds__(kRowBlock) void k_form_u(int n, int sh, const double4 *__restrict__ R,
+                                                      const double *__restrict__ idg,
+                                                      const double4 *__restrict__ yc, double omega, double kc,
+                                                      double4 *__restrict__ U, double *__restrict__ part_g,
+                                                      const int *__restrict__ flags) {
+    if (flags[FL_DONE]) return;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double4 r = R[i], y = yc[i >> sh];
+        const double w = omega * idg[i];
+        const double4 u = make_double4(w * r.x + kc * y.x, w * r.y + kc * y.y, w * r.z + kc * y.z, 0.0);
+        U[i] = u;
+        a0 += r.x * u.x;
+        a1 += r.y * u.y;
+        a2 += r.z * u.z;
+    }
+    block_sum3_store(a0, a1, a2, part_g + 4 * blockIdx.x);
+}
+
+// INIT: x = 0, r = b: restriction + ||r||^2. Else: convergence test on the (all-reduced) ||r||^2 of the
+// current residual; alpha, beta from the all-reduced gamma = r.u, delta = u.w (row 0 of part_g / part_d);
+// p = u + beta p, s = w + beta s, x += alpha p, r -= alpha s; restriction of r to level 1; ||r||^2
+// partials of the new residual into rr_out (not the array being tested: other workgroups still read it).
+template <bool INIT>
+__global__ __launch_bounds__(kRowBlock) void k_cgd_update(
+    int n, int nsl, int agg, double *__restrict__ scal, int par, const double *__restrict__ part_g,
+    const double *__restrict__ part_d, const double *__restrict__ rr_in, int first, double rtol2,
+    double4 *__restrict__ X, double4 *__restrict__ R, double4 *__restrict__ P, double4 *__restrict__ S,
+    const double4 *__restrict__ U, const double4 *__restrict__ W, double4 *__restrict__ bc,
+    double4 *__restrict__ xc, const double *__restrict__ cidg, double omega, double *__restrict__ rr_out,
+    int *__restrict__ flags) {
+    if (flags[FL_DONE]) return;
+    double al[3] = {0, 0, 0}, be[3] = {0, 0, 0};
+    if (!INIT) {
+        if (pcg_check(rr_in, 1, first, rtol2, scal, flags)) return;  // every workgroup takes the same decision
+        bool finite = true;
+        for (int c = 0; c < 3; c++) {
+            const double g = part_g[c], d = part_d[c];
+            const double go = scal[(par ? SC_GAM1 : SC_GAM0) + c], ao = scal[(par ? SC_ALF1 : SC_ALF0) + c];
+            const bool chain = !first && go > 0.0 && ao > 0.0;
+            be[c] = chain ? g / go : 0.0;
+            const double den = d - (chain ? be[c] * g / ao : 0.0);
+            al[c] = den > 0.0 ? g / den : 0.0;
+            finite = finite && isfinite(g) && isfinite(d);
+        }
+        __syncthreads();  // all reads of scal done before workgroup 0 publishes the new values
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int c = 0; c < 3; c++) {
+                scal[(par ? SC_GAM0 : SC_GAM1) + c] = part_g[c];
+                scal[(par ? SC_ALF0 : SC_ALF1) + c] = al[c];
+            }
+            if (!finite) flags[FL_DONE] = 2;
+        }
+    }
+    const int ntiles = (nsl + 3) / 4;
+    int t0, t1;
+    tile_range(ntiles, t0, t1);
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int t = t0; t < t1; t++) {
+        const int sl = t * 4 + (threadIdx.x >> 6);
+        if (sl < nsl) {
+            const int i = sl * 64 + (threadIdx.x & 63);
+            double4 r = make_double4(0, 0, 0, 0);
+            if (i < n) {
+                r = R[i];
+                if (INIT) {
+                    X[i] = make_double4(0, 0, 0, 0);
+                } else {
+                    const double4 u = U[i], w = W[i];
+                    double4 p = u, s = w;
+                    if (!first) {
+                        const double4 po = P[i], so = S[i];
+                        p.x += be[0] * po.x;
+                        p.y += be[1] * po.y;
+                        p.z += be[2] * po.z;
+                        s.x += be[0] * so.x;
+                        s.y += be[1] * so.y;
+                        s.z += be[2] * so.z;
+                    }
+                    P[i] = p;
+                    S[i] = s;
+                    double4 x = X[i];
+                    x.x += al[0] * p.x;
+                    x.y += al[1] * p.y;
+                    x.z += al[2] * p.z;
+                    X[i] = x;
+                    r.x -= al[0] * s.x;
+                    r.y -= al[1] * s.y;
+                    r.z -= al[2] * s.z;
+                    R[i] = r;
+                }
+                a0 += r.x * r.x;
+                a1 += r.y * r.y;
+                a2 += r.z * r.z;
+            }
+            const double c0 = seg_sum(r.x, agg), c1 = seg_sum(r.y, agg), c2 = seg_sum(r.z, agg);
+            if ((i & (agg - 1)) == 0 && i < n) {
+                const int I = i / agg;
+                bc[I] = make_double4(c0, c1, c2, 0.0);
+                const double w = omega * cidg[I];
+                xc[I] = make_double4(w * c0, w * c1, w * c2, 0.0);
+            }
+        }
+    }
+    block_sum3_store(a0, a1, a2, rr_out + 4 * blockIdx.x);
+    if (!INIT && blockIdx.x == 0 && threadIdx.x == 0) flags[FL_ITERS] += 1;
+}
+
+void launch_form_u(Graph &g, double *part_g) {
+    Level &L0 = g.levels[0];
+    hipLaunchKernelGGL(k_form_u, dim3(grid_for_elems(L0.n)), dim3(kRowBlock), 0, g.stream, L0.n,
+                       __builtin_ctz((unsigned)L0.agg), L0.b.p, L0.idg.p, g.levels[1].y.p, g.opt.mg_omega,
+                       g.opt.mg_kc, g.P.p, part_g, g.flags.p);
+}
+
+// buffers: u = P, w = AP, p = P2, s = levels[0].e, r = levels[0].b
+void launch_cgd_update(Graph &g, bool init, int par, int first, double rtol2, const double *part_g,
+                       const double *part_d, const double *rr_in, double *rr_out) {
+    Level &L0 = g.levels[0];
+    Level &L1 = g.levels[1];
+    const int grid = grid_for_rows(L0);
+    if (init)
+        hipLaunchKernelGGL((k_cgd_update<true>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl, L0.agg,
+                           g.scal.p, par, part_g, part_d, rr_in, first, rtol2, g.X.p + g.ng, L0.b.p, g.P2.p, L0.e.p,
+                           g.P.p, g.AP.p, L1.b.p, L1.x.p, L1.idg.p, g.opt.mg_omega, rr_out, g.flags.p);
+    else
+        hipLaunchKernelGGL((k_cgd_update<false>), dim3(grid), dim3(kRowBlock), 0, g.stream, L0.n, L0.nsl, L0.agg,
+                           g.scal.p, par, part_g, part_d, rr_in, first, rtol2, g.X.p + g.ng, L0.b.p, g.P2.p, L0.e.p,
+                           g.P.p, g.AP.p, L1.b.p, L1.x.p, L1.idg.p, g.opt.mg_omega, rr_out, g.flags.p);
+}
+
 // beta from r.z = (r.z0 partials) + kc * (b1.y1 partials); p = omega D^-1 r + kc * P y1 + beta p
 template <bool CHECK>
 __global__ __launch_bounds__(kRowBlock) void k_pcg_pupdate_add(
