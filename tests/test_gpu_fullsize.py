@@ -177,3 +177,33 @@ def test_lowrank_repair_of_the_dense_inverse(closures):
     assert b["dense_repairs"] == 0 and b["dense_inversions"] >= out[1][0] - 1
     assert a["dense_repairs"] >= 1 and a["dense_inversions"] < b["dense_inversions"]
     assert a["pcg_iters"] <= b["pcg_iters"] + 3 * out[0][0]
+
+
+@pytest.mark.parametrize("n,m,f", [(20000, 300000, 1), (33333, 166665, 4), (131000, 655000, 2)])
+def test_round2_paths_match_round1_paths_on_band_graphs(n, m, f, monkeypatch):
+    """Band graphs with three levels take the round-2 paths: the two-launch Chronopoulos-Gear PCG
+    iteration (cgcg.hip) and the banded inverse of the coarsest operator (dense.hip). l1ra THEN irls --
+    the primal-dual Hessian solves run through the same PCG -- against the round-1 launches with the
+    Gauss-Jordan inverse: identical outer iteration counts, rotations and weights to round-off of the
+    inner tolerance. 131000 views: the largest size with a workgroup per tile (512 workgroups)."""
+    S = synth.make_graph(n, m, 0.0, seed=6)
+    Q0 = mst(S, n)
+    Q0[:f] = S["Qgt"][:f]
+    out = []
+    for classic in (0, 1):
+        if classic:
+            monkeypatch.setenv("IROTAVG_NO_BAND_INVERSE", "1")
+        else:
+            monkeypatch.delenv("IROTAVG_NO_BAND_INVERSE", raising=False)
+        with capi.Graph(S["I"], S["QQ"], n, f, pcg_classic=classic) as G:
+            G.set_rotations(Q0)
+            a = G.l1ra(2, 1e-3)
+            b = G.irls(4, SIG, 100, 1e-3)
+            st = G.stats()
+            assert st["levels"] == 3
+            out.append((a["iters"], b["iters"], a["scores"], G.get_rotations(), G.get_weights(), st))
+    assert out[0][:2] == out[1][:2]
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-7)
+    assert synth.angular_distance(out[0][3], out[1][3]).max() < 1e-9
+    np.testing.assert_allclose(out[0][4], out[1][4], rtol=1e-7)
+    assert out[0][5]["dense_inversions"] >= 1
