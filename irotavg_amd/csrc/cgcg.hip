@@ -599,9 +599,16 @@ Cg2Bufs cg2_bufs(Graph &g) {
 }
 }  // namespace
 
-// workgroups of the two kernels: ~3 slices each (<= 4), a multiple of 8, at most kMaxParts partials
+// workgroups of the two kernels: 4 slices each (3 for some, so that the count is a multiple of 8), at
+// most kMaxParts partials. IROTAVG_CG2_SLICES=3 deals ~3 slices per workgroup (512 workgroups at 100k
+// views: every CU hosts two) -- measured 1 us per iteration SLOWER: a CU's two workgroups then each
+// carry the per-tile overhead (8 rows of the dense inverse, the level-2 right-hand side).
 int cg2_grid(const Level &L0) {
-    long long gsz = (L0.nsl + 2) / 3;
+    static const int per = [] {
+        const char *e = std::getenv("IROTAVG_CG2_SLICES");
+        return e ? std::min(4, std::max(1, std::atoi(e))) : 4;
+    }();
+    long long gsz = (L0.nsl + per - 1) / per;
     gsz = (gsz + 7) & ~7ll;
     gsz = std::min<long long>(gsz, kMaxParts);
     return (int)std::max<long long>(gsz, 1);
