@@ -67,8 +67,8 @@ def kernel_rooflines(G, S, st, sharded=False):
     except capi.IrotavgError:
         pass
     try:  # the two-launch Chronopoulos-Gear iteration (cgcg.hip): band-only graphs with >= 3 levels on one GPU
-        if sharded:
-            raise capi.IrotavgError(capi.ERR_BAD_ARG, "sharded")
+        if sharded or st["levels"] < 3:
+            raise capi.IrotavgError(capi.ERR_BAD_ARG, "not this graph's PCG")
         n1, nd = st["level_rows"][1], st["level_rows"][2]
         nnz1 = st["level_nnz"][1]
         coarse = 2 * 24 * n1 + 12 * nnz1 + 24 * nd + (8 * nd * nd if st["levels"] == 3 else 0)

@@ -515,11 +515,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.part_rr.zero(s);
     g.part_rz.zero(s);
     g.part_score.zero(s);
-    g.scal.alloc(SC_COUNT);
-    g.scal.zero(s);
-    g.flags.alloc(FL_COUNT);
-    g.flags.zero(s);
-    g.h_part.assign((size_t)kMaxParts * 4, 0.0);
+    alloc_state(g);
     IRH_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
     lap("PCG state");
     return IROTAVG_OK;

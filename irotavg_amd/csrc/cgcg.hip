@@ -712,7 +712,8 @@ int pcg_solve_cg2(Graph &g) {
     int rcur = 0;  // which of the two r / s buffers is current
     cg2_launch_update(g, 0, 0, rcur);
     rcur ^= 1;
-    int h_flags[FL_COUNT] = {0, 0, 0, 0};
+    int *h_flags = g.h_flags();
+    for (int c = 0; c < FL_COUNT; c++) h_flags[c] = 0;
     int it = 0;
     const int check = std::max(1, g.opt.pcg_check_every);
     const int maxit = std::max(1, g.opt.pcg_max_iters);
@@ -730,7 +731,7 @@ int pcg_solve_cg2(Graph &g) {
     double best = HUGE_VAL;
     int best_it = 0;
     bool stagnated = false;
-    double h_scal[SC_COUNT];
+    double *h_scal = g.h_scal();
     while (true) {
         for (int c = 0; c < chunk; c++) {
             apply();
@@ -738,9 +739,7 @@ int pcg_solve_cg2(Graph &g) {
         }
         chunk = std::max(2, check / 2);
         apply();  // its prologue tests the convergence of the last update
-        IRH_CHECK(hipMemcpyAsync(h_flags, g.flags.p, sizeof(int) * FL_COUNT, hipMemcpyDeviceToHost, g.stream));
-        IRH_CHECK(hipMemcpyAsync(h_scal, g.scal.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, g.stream));
-        IRH_CHECK(hipStreamSynchronize(g.stream));
+        read_back_state(g);
         if (h_flags[FL_DONE] != 0) break;
         const double cur = std::max(h_scal[SC_RELRES], std::max(h_scal[SC_RELRES + 1], h_scal[SC_RELRES + 2]));
         if (cur < 0.5 * best) {

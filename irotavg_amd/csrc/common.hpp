@@ -160,6 +160,43 @@ struct StreamPool {
     }
 };
 
+// Pinned host staging blocks (hipHostMalloc) for the small device -> host read-backs that steer the
+// solve (PCG done flag + scalars, score partials, reduction partials of l1decode_pd): a copy into
+// pageable memory goes through the runtime's own staging and left the GPU idle ~30 us per host
+// decision (kernel trace, round 2); into pinned memory it is a plain DMA. Fixed-size blocks, recycled.
+struct PinPool {
+    static constexpr size_t kBytes = 64 * 1024;
+    std::mutex mu;
+    std::vector<void *> idle;
+    static PinPool &get() {
+        static PinPool *pool = new PinPool();
+        return *pool;
+    }
+    void *take() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!idle.empty()) {
+                void *p = idle.back();
+                idle.pop_back();
+                return p;
+            }
+        }
+        void *p = nullptr;
+        IRH_CHECK(hipHostMalloc(&p, kBytes, hipHostMallocDefault));
+        std::memset(p, 0, kBytes);
+        return p;
+    }
+    void give(void *p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle.size() < 64) {
+            idle.push_back(p);
+            return;
+        }
+        (void)hipHostFree(p);
+    }
+};
+
 // Device buffer (pooled hipMalloc; sized once per graph, HBM-resident for the handle's life).
 template <typename T>
 struct DevBuf {

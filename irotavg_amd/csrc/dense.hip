@@ -674,8 +674,8 @@ bool dense_is_stale(Graph &g, bool allow_repair) {
     if (C.sell_len > 0)
         hipLaunchKernelGGL(k_value_ratio, dim3(1), dim3(1024), 0, g.stream, C.sell_len, C.val.p,
                            g.dense_ref_val.p, g.part_score.p, 1);
-    double h[4];
-    IRH_CHECK(hipMemcpyAsync(h, g.part_score.p, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+    double *h = g.h_part();  // pinned staging
+    IRH_CHECK(hipMemcpyAsync(h, g.part_score.p, sizeof(double) * 4, hipMemcpyDeviceToHost, g.stream));
     IRH_CHECK(hipStreamSynchronize(g.stream));
     const double lo = h[0], hi = h[1], lod = h[2], hid = h[3];
     if ((lo > 0.0) && (hi < HUGE_VAL) && hi <= g.stale_spread * lo) {

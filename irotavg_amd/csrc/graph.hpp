@@ -89,8 +89,19 @@ struct Graph {
     std::vector<std::unique_ptr<Graph>> l1_clones;
     bool is_clone = false;
 
-    // host staging
-    std::vector<double> h_part;
+    // host staging: one pinned block (PinPool): [0, 4 kMaxParts) doubles = reduction partials,
+    // then SC_COUNT doubles + FL_COUNT ints = the read-back of scal / flags (ONE copy: the flags live
+    // at the tail of the scal allocation)
+    double *hpin = nullptr;
+    double *h_part() { return hpin; }
+    double *h_scal() { return hpin + 4 * kMaxParts; }
+    int *h_flags() { return reinterpret_cast<int *>(hpin + 4 * kMaxParts + SC_COUNT); }
+    ~Graph() {
+        if (hpin) PinPool::get().give(hpin);
+    }
+    Graph() = default;
+    Graph(const Graph &) = delete;
+    Graph &operator=(const Graph &) = delete;
 
     double last_score_sum = 0.0;
     int force_np = 0;  // sharded runs: consumers read this many pre-reduced partial rows (1)
@@ -119,6 +130,9 @@ int time_kernel(Graph &g, int which, int reps, double *ms);
 void release_l1_clones(Graph &g);
 void normalise_rotations(Graph &g);
 void fill(Graph &g, double *p, long long n, double v);
+// device -> pinned host copy of scal + flags (one DMA) and stream synchronisation
+void read_back_state(Graph &g);
+void alloc_state(Graph &g);  // scal + flags (aliased tail) + the pinned block
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true);
 int pcg_solve(Graph &g);
 void launch_spmv(Graph &g);

@@ -351,20 +351,20 @@ static int grid_rows(const Level &L) {
 
 // fixed-order host sum of the first `cols` columns of a partial array
 static void fetch_parts(Graph &g, int nparts, double out[3]) {
-    IRH_CHECK(hipMemcpyAsync(g.h_part.data(), g.pd_part.p, sizeof(double) * 4 * (size_t)nparts,
+    IRH_CHECK(hipMemcpyAsync(g.h_part(), g.pd_part.p, sizeof(double) * 4 * (size_t)nparts,
                              hipMemcpyDeviceToHost, g.stream));
     IRH_CHECK(hipStreamSynchronize(g.stream));
     out[0] = out[1] = out[2] = 0.0;
     for (int b = 0; b < nparts; b++)
-        for (int c = 0; c < 3; c++) out[c] += g.h_part[4 * (size_t)b + c];
+        for (int c = 0; c < 3; c++) out[c] += g.h_part()[4 * (size_t)b + c];
 }
 static double fetch_ext(Graph &g, int nparts, bool is_max) {
-    IRH_CHECK(hipMemcpyAsync(g.h_part.data(), g.pd_part.p, sizeof(double) * 4 * (size_t)nparts,
+    IRH_CHECK(hipMemcpyAsync(g.h_part(), g.pd_part.p, sizeof(double) * 4 * (size_t)nparts,
                              hipMemcpyDeviceToHost, g.stream));
     IRH_CHECK(hipStreamSynchronize(g.stream));
-    double r = g.h_part[0];
+    double r = g.h_part()[0];
     for (int b = 1; b < nparts; b++)
-        r = is_max ? std::max(r, g.h_part[4 * (size_t)b]) : std::min(r, g.h_part[4 * (size_t)b]);
+        r = is_max ? std::max(r, g.h_part()[4 * (size_t)b]) : std::min(r, g.h_part()[4 * (size_t)b]);
     return r;
 }
 
@@ -625,8 +625,7 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
     q.part_pq.alloc_like(g.part_pq, s); q.part_rr.alloc_like(g.part_rr, s);
     q.part_rz.alloc_like(g.part_rz, s); q.part_rz2.alloc_like(g.part_rz2, s);
     q.part_score.alloc_like(g.part_score, s);
-    q.scal.alloc_like(g.scal, s); q.flags.alloc_like(g.flags, s);
-    q.h_part.assign(g.h_part.size(), 0.0);
+    alloc_state(q);
     q.stats = g.stats;
     IRH_CHECK(hipStreamSynchronize(s));
     return c;

@@ -1246,6 +1246,23 @@ __global__ __launch_bounds__(256) void k_fill(long long n, double v, double *__r
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// scal (SC_COUNT doubles) and flags (FL_COUNT ints) share one allocation so that a poll of the solver
+// state is ONE device -> host copy, into the handle's pinned block
+void alloc_state(Graph &g) {
+    static_assert(sizeof(int) * FL_COUNT <= 2 * sizeof(double), "flags tail");
+    g.scal.alloc(SC_COUNT + 2);
+    g.scal.zero(g.stream);
+    g.flags.release();
+    g.flags.p = reinterpret_cast<int *>(g.scal.p + SC_COUNT);
+    g.flags.n = FL_COUNT;
+    g.flags.own = false;
+    if (!g.hpin) g.hpin = static_cast<double *>(PinPool::get().take());
+}
+void read_back_state(Graph &g) {
+    IRH_CHECK(hipMemcpyAsync(g.h_scal(), g.scal.p, sizeof(double) * (SC_COUNT + 2), hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+}
+
 void fill(Graph &g, double *p, long long n, double v) {
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, n, v, p);
 }
@@ -1513,7 +1530,8 @@ int pcg_solve(Graph &g) {
         }
     };
     update(true, 0, nullptr);
-    int h_flags[FL_COUNT] = {0, 0, 0, 0};
+    int *h_flags = g.h_flags();
+    for (int c = 0; c < FL_COUNT; c++) h_flags[c] = 0;
     int it = 0;
     const int check = std::max(1, g.opt.pcg_check_every);
     const int maxit = std::max(1, g.opt.pcg_max_iters);
@@ -1565,7 +1583,7 @@ int pcg_solve(Graph &g) {
     double best = HUGE_VAL;
     int best_it = 0;
     bool stagnated = false;
-    double h_scal[SC_COUNT];
+    double *h_scal = g.h_scal();
     while (true) {
         for (int c = 0; c < chunk; c++) {
             PrecInfo pi = precondition(g, it == 0, rtol2);
@@ -1574,11 +1592,7 @@ int pcg_solve(Graph &g) {
         chunk = std::max(2, check / 2);
         // the convergence test of the last update runs in the next preconditioner prologue
         PrecInfo pi = precondition(g, it == 0, rtol2);
-        IRH_CHECK(hipMemcpyAsync(h_flags, g.flags.p, sizeof(int) * FL_COUNT, hipMemcpyDeviceToHost,
-                                 g.stream));
-        IRH_CHECK(hipMemcpyAsync(h_scal, g.scal.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost,
-                                 g.stream));
-        IRH_CHECK(hipStreamSynchronize(g.stream));
+        read_back_state(g);
         if (h_flags[FL_DONE] != 0) break;
         const double cur = std::max(h_scal[SC_RELRES], std::max(h_scal[SC_RELRES + 1], h_scal[SC_RELRES + 2]));
         if (cur < 0.5 * best) {
@@ -1620,11 +1634,11 @@ double apply_step(Graph &g) {
     const int grid = grid_for_elems(n);
     hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kRowBlock), 0, g.stream, n, g.f, g.ng, g.X.p,
                        g.Q.p, g.part_score.p, 1);
-    IRH_CHECK(hipMemcpyAsync(g.h_part.data(), g.part_score.p, sizeof(double) * 4 * (size_t)grid,
+    IRH_CHECK(hipMemcpyAsync(g.h_part(), g.part_score.p, sizeof(double) * 4 * (size_t)grid,
                              hipMemcpyDeviceToHost, g.stream));
     IRH_CHECK(hipStreamSynchronize(g.stream));
     double s = 0.0;
-    for (int b = 0; b < grid; b++) s += g.h_part[4 * (size_t)b];
+    for (int b = 0; b < grid; b++) s += g.h_part()[4 * (size_t)b];
     g.last_score_sum = s;
     return s / (double)g.no;
 }
