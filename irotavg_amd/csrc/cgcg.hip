@@ -705,7 +705,8 @@ static void cg2_refresh_inv32(Graph &g) {
 }
 
 // PCG on L X = levels[0].b (three columns), two launches per iteration. Same contract as pcg_solve.
-int pcg_solve_cg2(Graph &g) {
+int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
+    if (tail_ran) *tail_ran = false;
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     if (g.levels.size() == 3) cg2_refresh_inv32(g);
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
@@ -724,7 +725,9 @@ int pcg_solve_cg2(Graph &g) {
         it++;
     };
     // poll schedule, stagnation rule: as in pcg_solve (solver.hip)
-    int chunk = g.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(g.stats.pcg_iters_last, maxit) : check;
+    // with a tail the first poll is placed one iteration past the prediction: a solve that needs one
+    // more than the last still comes back in one round trip (surplus launches return at once)
+    int chunk = g.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(g.stats.pcg_iters_last + (tail ? 1 : 0), maxit) : check;
     constexpr int kStallIters = 64;
     const int ax = g.opt.pcg_stall_accept;
     const double accept = ax < 0 ? -1.0 : (ax == 0 ? 1e-6 : std::pow(10.0, -(double)ax));
@@ -732,6 +735,7 @@ int pcg_solve_cg2(Graph &g) {
     int best_it = 0;
     bool stagnated = false;
     double *h_scal = g.h_scal();
+    bool first_poll = true;
     while (true) {
         for (int c = 0; c < chunk; c++) {
             apply();
@@ -739,7 +743,10 @@ int pcg_solve_cg2(Graph &g) {
         }
         chunk = std::max(2, check / 2);
         apply();  // its prologue tests the convergence of the last update
+        if (first_poll && tail) (*tail)();
         read_back_state(g);
+        if (first_poll && tail && tail_ran) *tail_ran = h_flags[FL_DONE] == 1;
+        first_poll = false;
         if (h_flags[FL_DONE] != 0) break;
         const double cur = std::max(h_scal[SC_RELRES], std::max(h_scal[SC_RELRES + 1], h_scal[SC_RELRES + 2]));
         if (cur < 0.5 * best) {

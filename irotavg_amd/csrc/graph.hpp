@@ -118,7 +118,9 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
 // solver entry points (solver.hip)
 void launch_edge_residual(Graph &g);
 int ls_solve(Graph &g);  // assemble (IRLS weights) + PCG; result in g.X
-void launch_update_weights(Graph &g, int cost, double sigma);
+void launch_update_weights(Graph &g, int cost, double sigma, bool gated = false);
+void launch_apply_step(Graph &g, bool gated);
+double finish_apply_step(Graph &g);
 double apply_step(Graph &g);
 int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, int *iters,
              double *runtime, double *trace);
@@ -168,7 +170,9 @@ void pd_prepare_graph(Graph &g);
 void pd_pack_solution(Graph &g);  // pdn planes kPdXPlane0.. -> X (owned rows)
 constexpr int kPdXPlane0 = 3;  // pdn planes 3, 4, 5 hold the three coordinates' solutions (PdnPlane N_X0..)
 // cgcg.hip: the two-launch PCG iteration
-int pcg_solve_cg2(Graph &g);
+// tail: work to enqueue before the FIRST read-back of the solver state (kernels gated on the done flag);
+// *tail_ran tells whether the solve was done at that read-back, i.e. whether the gated kernels ran
+int pcg_solve_cg2(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr);
 void cg2_time_once(Graph &g, int which);
 int cg2_phase_stamps(Graph &g, double *out, int n);
 void cycle_levels(Graph &g, int from);  // solver.hip: levels[from].b/.x -> levels[from].y

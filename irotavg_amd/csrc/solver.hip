@@ -137,7 +137,11 @@ __global__ __launch_bounds__(256) void k_update_weights(long long m, long long m
                                                         const uint8_t *__restrict__ eflag,
                                                         const double *__restrict__ er,
                                                         const double4 *__restrict__ X, int cost,
-                                                        double sigma, double *__restrict__ dw) {
+                                                        double sigma, double *__restrict__ dw,
+                                                        const int *__restrict__ gate) {
+    // gate: launched speculatively behind a PCG whose convergence the host has not read yet -- runs
+    // only if that solve is done (run_irls reads the flag and the score in ONE round trip afterwards)
+    if (gate != nullptr && gate[FL_DONE] != 1) return;
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const uint8_t fl = eflag[k];
@@ -161,11 +165,11 @@ __global__ __launch_bounds__(256) void k_update_weights(long long m, long long m
     dw[k] = robust_weight(cost, sigma, e2, dw[k]);
 }
 
-void launch_update_weights(Graph &g, int cost, double sigma) {
+void launch_update_weights(Graph &g, int cost, double sigma, bool gated) {
     const int grid = (int)((g.m + 255) / 256);
     hipLaunchKernelGGL(k_update_weights, dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
                        (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.eflag.p, g.er.p, g.X.p, cost,
-                       sigma, g.dw.p);
+                       sigma, g.dw.p, gated ? (const int *)g.flags.p : (const int *)nullptr);
 }
 
 // =============================================================================================
@@ -1207,7 +1211,8 @@ __global__ __launch_bounds__(kRowBlock) void k_apply_step(int n, int f, int ngho
                                                        const double4 *__restrict__ X,
                                                        double4 *__restrict__ Q,
                                                        double *__restrict__ part_score,
-                                                       int write) {
+                                                       int write, const int *__restrict__ gate) {
+    if (gate != nullptr && gate[FL_DONE] != 1) return;  // see k_update_weights
     double acc = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double4 x = X[i];
@@ -1629,18 +1634,27 @@ int ls_solve(Graph &g) {
     return rc;
 }
 
-double apply_step(Graph &g) {
+// score, exp map, rotation update: kernel + copy of the score partials into the pinned block (no
+// synchronisation); finish_apply_step sums them once the stream has been synchronised
+void launch_apply_step(Graph &g, bool gated) {
     const int n = g.nu;
     const int grid = grid_for_elems(n);
     hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kRowBlock), 0, g.stream, n, g.f, g.ng, g.X.p,
-                       g.Q.p, g.part_score.p, 1);
+                       g.Q.p, g.part_score.p, 1, gated ? (const int *)g.flags.p : (const int *)nullptr);
     IRH_CHECK(hipMemcpyAsync(g.h_part(), g.part_score.p, sizeof(double) * 4 * (size_t)grid,
                              hipMemcpyDeviceToHost, g.stream));
-    IRH_CHECK(hipStreamSynchronize(g.stream));
+}
+double finish_apply_step(Graph &g) {
+    const int grid = grid_for_elems(g.nu);
     double s = 0.0;
     for (int b = 0; b < grid; b++) s += g.h_part()[4 * (size_t)b];
     g.last_score_sum = s;
     return s / (double)g.no;
+}
+double apply_step(Graph &g) {
+    launch_apply_step(g, false);
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    return finish_apply_step(g);
 }
 
 // ral/l1_irls.cpp:559-752
@@ -1653,10 +1667,31 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     fill(g, g.dw.p, (long long)g.mpad, 1.0);  // weights.setOnes() (:577)
     while (score > change_th && it < max_iters) {  // :590, strict >
         launch_edge_residual(g);
-        rc = ls_solve(g);
-        if (rc != IROTAVG_OK) break;
-        launch_update_weights(g, cost, sigma);
-        score = apply_step(g);
+        if (g.cg2) {
+            // The weight update and the rotation update are enqueued BEHIND the PCG before the host has
+            // read its done flag, gated on that flag: convergence and score come back in one round trip
+            // instead of two (each costs the GPU ~15-30 us of idling). If the solve needs more
+            // iterations than predicted the gated kernels did nothing and run again, ungated.
+            assemble(g, 0, g.dw.p, g.opt.dense_always_refresh == 1);
+            bool tail_ran = false;
+            const std::function<void()> tail = [&]() {
+                launch_update_weights(g, cost, sigma, true);
+                launch_apply_step(g, true);
+            };
+            rc = pcg_solve_cg2(g, &tail, &tail_ran);
+            if (rc != IROTAVG_OK) break;
+            if (tail_ran) {
+                score = finish_apply_step(g);
+            } else {
+                launch_update_weights(g, cost, sigma);
+                score = apply_step(g);
+            }
+        } else {
+            rc = ls_solve(g);
+            if (rc != IROTAVG_OK) break;
+            launch_update_weights(g, cost, sigma);
+            score = apply_step(g);
+        }
         if (trace) trace[it] = score;
         it++;
     }
@@ -1706,7 +1741,7 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         case 10: cg2_time_once(g, 1); break;  // k_cg_update
         case 6:
             hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kRowBlock), 0, g.stream,
-                               g.nu, g.f, g.ng, g.X.p, g.Q.p, g.part_score.p, 0);
+                               g.nu, g.f, g.ng, g.X.p, g.Q.p, g.part_score.p, 0, (const int *)nullptr);
             break;
         default: break;
         }
