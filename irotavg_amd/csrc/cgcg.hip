@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_apply(
     LevelView L, int uw, LevelView L1, int uw1, const double4 *__restrict__ R, double4 *__restrict__ U,
     double4 *__restrict__ Wv, const double4 *__restrict__ b1, const double4 *__restrict__ x1,
     const double *__restrict__ b2p, const double4 *__restrict__ y2g, const ET *__restrict__ Einv,
-    int nd, int ndpad, double dscale, double omega, double kc, double *__restrict__ part_g,
+    int nd, int ndpad, double dscale_host, int dscale_dev, double omega, double kc, double *__restrict__ part_g,
     double *__restrict__ part_d, const double *__restrict__ part_rr, int np_rr, int first, double rtol2,
     double *__restrict__ scal, int *__restrict__ flags, long long *dbg) {
 #define CG_STAMP(k) \
@@ -285,6 +285,8 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_apply(
     if (dbg != nullptr && threadIdx.x == 0)  // span of the whole grid: first workgroup start, last end
         atomicMin(reinterpret_cast<unsigned long long *>(dbg + 12), (unsigned long long)wall_clock64());
     const int done = flags[FL_DONE];
+    // scale of the re-used dense inverse: known to the host, or decided on the device just before this solve
+    const double dscale = dscale_dev ? scal[SC_DSCALE] : dscale_host;
     __shared__ double wx[kWinLen], wy[kWinLen], wz[kWinLen];
     __shared__ double ex[3][kL1Ext], ey[3][kL1Win], y2s[3][8];
     extern __shared__ double sb[];  // YMODE 2: 3 * ndpad, the level-2 right-hand side
@@ -635,7 +637,7 @@ void cg2_launch_update(Graph &g, int mode, int par, int rcur) {
 #undef CG_UPD
 }
 
-void cg2_launch_apply(Graph &g, int first, int rcur, double rtol2, long long *dbg = nullptr) {
+void cg2_launch_apply(Graph &g, int first, int rcur, double rtol2, long long *dbg = nullptr, bool dev_scale = false) {
     Level &L0 = g.levels[0];
     Level &L1 = g.levels[1];
     Level &L2 = g.levels[2];
@@ -647,7 +649,7 @@ void cg2_launch_apply(Graph &g, int first, int rcur, double rtol2, long long *db
 #define CG_APPLY2(ET, EP, NJ, NB)                                                                             \
     hipLaunchKernelGGL((k_cg_apply<2, ET, NJ, NB>), dim3(grid), dim3(kRowBlock), shm, g.stream, view_of(L0),    \
                        L0.uni_w, view_of(L1), L1.uni_w, B.R[rcur], B.U, B.W, L1.b.p, L1.x.p, g.b2p.p,           \
-                       (const double4 *)nullptr, EP, g.ndense, g.ndense_pad, g.dense_scale, g.opt.mg_omega,     \
+                       (const double4 *)nullptr, EP, g.ndense, g.ndense_pad, g.dense_scale, dev_scale ? 1 : 0, g.opt.mg_omega, \
                        g.opt.mg_kc, g.part_rz.p, g.part_pq.p, g.part_rr.p, grid, first, rtol2, g.scal.p,        \
                        g.flags.p, dbg)
         if (g.dense32) {
@@ -679,7 +681,7 @@ void cg2_launch_apply(Graph &g, int first, int rcur, double rtol2, long long *db
         cycle_levels(g, 2);
         hipLaunchKernelGGL((k_cg_apply<1, double, 1, 0>), dim3(grid), dim3(kRowBlock), 0, g.stream, view_of(L0),
                            L0.uni_w, view_of(L1), L1.uni_w, B.R[rcur], B.U, B.W, L1.b.p, L1.x.p,
-                           (const double *)nullptr, L2.y.p, (const double *)nullptr, L2.n, 0, 1.0, g.opt.mg_omega,
+                           (const double *)nullptr, L2.y.p, (const double *)nullptr, L2.n, 0, 1.0, 0, g.opt.mg_omega,
                            g.opt.mg_kc, g.part_rz.p, g.part_pq.p, g.part_rr.p, grid, first, rtol2, g.scal.p,
                            g.flags.p, dbg);
     }
@@ -705,11 +707,11 @@ static void cg2_refresh_inv32(Graph &g) {
 }
 
 // PCG on L X = levels[0].b (three columns), two launches per iteration. Same contract as pcg_solve.
-int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
+int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran, bool device_scale) {
     if (tail_ran) *tail_ran = false;
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     if (g.levels.size() == 3) cg2_refresh_inv32(g);
-    IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
+    IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * 2, g.stream));  // FL_DONE, FL_ITERS (not FL_STALE)
     int rcur = 0;  // which of the two r / s buffers is current
     cg2_launch_update(g, 0, 0, rcur);
     rcur ^= 1;
@@ -718,7 +720,7 @@ int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
     int it = 0;
     const int check = std::max(1, g.opt.pcg_check_every);
     const int maxit = std::max(1, g.opt.pcg_max_iters);
-    auto apply = [&]() { cg2_launch_apply(g, it == 0, rcur, rtol2); };
+    auto apply = [&]() { cg2_launch_apply(g, it == 0, rcur, rtol2, nullptr, device_scale); };
     auto update = [&]() {
         cg2_launch_update(g, it == 0 ? 1 : 2, it & 1, rcur);
         rcur ^= 1;

@@ -313,12 +313,14 @@ enum ScalIdx : int {
     SC_GAM1 = 20,
     SC_ALF0 = 24,
     SC_ALF1 = 28,
-    SC_COUNT = 32
+    SC_DSCALE = 32,  // scale of the (re-used) dense inverse decided on the device (dense_check_async)
+    SC_COUNT = 36
 };
 // int flags block
 enum FlagIdx : int {
     FL_DONE = 0,   // 0 running, 1 converged, 2 breakdown (non-finite scalar)
     FL_ITERS = 1,  // PCG iterations performed
+    FL_STALE = 2,  // dense_check_async: the coarse operator changed non-uniformly (re-invert next time)
     FL_COUNT = 4
 };
 

@@ -662,6 +662,64 @@ static bool dense_lowrank_repair(Graph &g, double c) {
 // around one factor c, E_now ~ c E_ref and E_ref^-1 / c is reused; if only the diagonal does and
 // few off-diagonal entries deviate (`allow_repair`), the inverse is repaired by a low-rank update;
 // otherwise the caller re-inverts. Returns true when a full refresh is needed.
+// The same test in ONE launch with the decision taken on the device, for callers that do not want to
+// wait for it (run_irls on the two-launch PCG path): ratios now / ref over the coarse diagonal and the
+// coarse off-diagonal values; if they all lie within `spread` of one factor the scale of the re-used
+// inverse goes to scal[SC_DSCALE] (k_cg_apply reads it there) and flags[FL_STALE] = 0, otherwise
+// FL_STALE = 1 and the scale stays. A stale inverse costs PCG iterations, never accuracy, so the host
+// reads the verdict with the solve's own read-back and re-inverts before the NEXT solve.
+__global__ __launch_bounds__(1024) void k_stale_check(long long nd, const double *__restrict__ dnow,
+                                                      const double *__restrict__ dref, long long nv,
+                                                      const double *__restrict__ vnow,
+                                                      const double *__restrict__ vref, double spread,
+                                                      double *__restrict__ scal, int *__restrict__ flags) {
+    __shared__ double smin[16], smax[16];
+    double lo = HUGE_VAL, hi = 0.0;
+    auto visit = [&](double v, double r) {
+        if (r != 0.0 && v != 0.0) {
+            const double q = v / r;
+            if (q > 0.0) {
+                lo = fmin(lo, q);
+                hi = fmax(hi, q);
+            } else {
+                hi = HUGE_VAL;
+            }
+        } else if ((r != 0.0) != (v != 0.0)) {
+            hi = HUGE_VAL;  // an entry appeared or vanished
+        }
+    };
+    for (long long i = threadIdx.x; i < nd; i += blockDim.x) visit(dnow[i], dref[i]);
+    for (long long i = threadIdx.x; i < nv; i += blockDim.x) visit(vnow[i], vref[i]);
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, o, 64));
+        hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = lo;
+        smax[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+            lo = fmin(lo, smin[w]);
+            hi = fmax(hi, smax[w]);
+        }
+        if (lo > 0.0 && hi < HUGE_VAL && hi <= spread * lo) {
+            scal[SC_DSCALE] = 1.0 / sqrt(lo * hi);
+            flags[FL_STALE] = 0;
+        } else {
+            flags[FL_STALE] = 1;
+        }
+    }
+}
+
+void dense_check_async(Graph &g) {
+    Level &C = g.levels.back();
+    hipLaunchKernelGGL(k_stale_check, dim3(1), dim3(1024), 0, g.stream, (long long)C.n, C.diag.p, g.dense_ref_diag.p,
+                       (long long)(g.dense_ref_val.n >= (size_t)C.sell_len ? C.sell_len : 0), C.val.p,
+                       g.dense_ref_val.p, g.stale_spread, g.scal.p, g.flags.p);
+}
+
 bool dense_is_stale(Graph &g, bool allow_repair) {
     if (g.ndense <= 0) return false;
     if (!g.dense_valid) return true;

@@ -51,6 +51,7 @@ struct Graph {
     int ndense = 0, ndense_pad = 0;
     int dense_bw = 0;  // half-bandwidth of the coarsest operator's pattern (build.cpp)
     bool dense_valid = false, dense_fresh = false;
+    bool dense_stale_pending = false;  // an asynchronous check (dense_check_async) asked for a re-inversion
     double dense_scale = 1.0, stale_spread = 1.1;
     DevBuf<double> dense_ref_diag, dense_ref_val;  // coarse operator the current inverse was computed from
     // parked inverses: l1decode keeps one per primal-dual iteration index, because the Hessian of
@@ -136,6 +137,7 @@ void fill(Graph &g, double *p, long long n, double v);
 void read_back_state(Graph &g);
 void alloc_state(Graph &g);  // scal + flags (aliased tail) + the pinned block
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true);
+void assemble_values(Graph &g, int mode, const double *wsrc);  // the value refresh alone (no dense-level decision)
 int pcg_solve(Graph &g);
 void launch_spmv(Graph &g);
 void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = nullptr,
@@ -172,7 +174,8 @@ constexpr int kPdXPlane0 = 3;  // pdn planes 3, 4, 5 hold the three coordinates'
 // cgcg.hip: the two-launch PCG iteration
 // tail: work to enqueue before the FIRST read-back of the solver state (kernels gated on the done flag);
 // *tail_ran tells whether the solve was done at that read-back, i.e. whether the gated kernels ran
-int pcg_solve_cg2(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr);
+int pcg_solve_cg2(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr,
+                  bool device_scale = false);  // device_scale: the inverse's scale is read from scal[SC_DSCALE]
 void cg2_time_once(Graph &g, int which);
 int cg2_phase_stamps(Graph &g, double *out, int n);
 void cycle_levels(Graph &g, int from);  // solver.hip: levels[from].b/.x -> levels[from].y
@@ -189,6 +192,7 @@ bool window_fits_wave(int nv, int f, int ne);
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);
 bool dense_is_stale(Graph &g, bool allow_repair = false);
+void dense_check_async(Graph &g);  // same test, decision on the device (scal[SC_DSCALE], flags[FL_STALE])
 int dense_apply_grid(const Graph &g);
 void dense_apply(Graph &g, const double4 *b, double4 *y, bool check, bool dot, double *part_dot,
                  int np_rr, int first, double rtol2);

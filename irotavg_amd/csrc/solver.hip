@@ -1316,6 +1316,17 @@ int grid_for_elems(long long n) { return round_grid((n + kRowBlock - 1) / kRowBl
 
 // refresh all matrix values from per-edge weights: mode 0 = IRLS (d^2, rhs), mode 1 = L1 Hessian
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
+    assemble_values(g, mode, wsrc);
+    if (refresh_dense || dense_is_stale(g, mode == 0)) {
+        dense_refresh(g);
+        g.dense_valid = true;
+        g.dense_fresh = true;
+    } else {
+        g.dense_fresh = false;
+    }
+}
+
+void assemble_values(Graph &g, int mode, const double *wsrc) {
     Level &L0 = g.levels[0];
     const int grid = grid_for_rows(L0);
     if (mode == 0) {
@@ -1342,13 +1353,6 @@ void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
         hipLaunchKernelGGL(k_coarse_diag, dim3((C.nsl * 64 + kRowBlock - 1) / kRowBlock),
                            dim3(kRowBlock), 0, g.stream, view_of(C), F.n, F.agg, F.excess.p,
                            C.excess.p, C.diag.p, C.idg.p);
-    }
-    if (refresh_dense || dense_is_stale(g, mode == 0)) {
-        dense_refresh(g);
-        g.dense_valid = true;
-        g.dense_fresh = true;
-    } else {
-        g.dense_fresh = false;
     }
 }
 
@@ -1672,13 +1676,35 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
             // read its done flag, gated on that flag: convergence and score come back in one round trip
             // instead of two (each costs the GPU ~15-30 us of idling). If the solve needs more
             // iterations than predicted the gated kernels did nothing and run again, ungated.
-            assemble(g, 0, g.dw.p, g.opt.dense_always_refresh == 1);
+            // ... and the staleness verdict on the dense inverse rides on the same round trip: the check runs
+            // on the device (dense_check_async) and a re-inversion it asks for happens before the NEXT
+            // solve (a stale inverse costs PCG iterations, never accuracy)
+            assemble_values(g, 0, g.dw.p);
+            bool spec = false;
+            if (g.ndense > 0) {
+                if (!g.dense_valid || g.dense_stale_pending || g.opt.dense_always_refresh == 1) {
+                    dense_refresh(g);
+                    g.dense_valid = true;
+                    g.dense_fresh = true;
+                    g.dense_stale_pending = false;
+                } else {
+                    dense_check_async(g);
+                    g.dense_fresh = false;
+                    spec = true;
+                }
+            }
             bool tail_ran = false;
             const std::function<void()> tail = [&]() {
                 launch_update_weights(g, cost, sigma, true);
                 launch_apply_step(g, true);
             };
-            rc = pcg_solve_cg2(g, &tail, &tail_ran);
+            rc = pcg_solve_cg2(g, &tail, &tail_ran, spec);
+            if (spec) {
+                if (g.h_flags()[FL_STALE])
+                    g.dense_stale_pending = true;
+                else
+                    g.dense_scale = g.h_scal()[SC_DSCALE];
+            }
             if (rc != IROTAVG_OK) break;
             if (tail_ran) {
                 score = finish_apply_step(g);
