@@ -11,8 +11,13 @@
  * ral/l1_irls.hpp:30,32 fail to include) and ships no expected outputs for its one fixture
  * (ral/data/ravg_input.txt), no unit tests and no known-answer vectors. This oracle is pinned
  * only by (1) analytic known answers (tests/test_oracle_kat.py), (2) an independent
- * NumPy/SciPy twin (oracle/np_twin.py, SuperLU solves) and (3) sanity values recorded in
- * SURVEY.md 8(c) for the fixture. See DESIGN.md "Oracle".
+ * NumPy/SciPy twin (oracle/np_twin.py, SuperLU solves), (3) sanity values recorded in
+ * SURVEY.md 8(c) for the fixture and (4) a check of its normal-equation solves against the
+ * reference's FORMULATION -- the least-squares form by dense Householder QR / minimum-norm lstsq,
+ * incl. a characterisation of the rank-deficient cases (tests/test_oracle_lsform.py).
+ * tools/ref_golden/ is the recipe that would pin it (build the unmodified reference where Eigen and
+ * SuiteSparse exist, commit its outputs, tests/test_ref_golden.py consumes them). See DESIGN.md
+ * "Oracle".
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
  *
