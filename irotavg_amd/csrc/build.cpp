@@ -268,6 +268,26 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     H[0].rowptr = std::move(rowptr);
     H[0].col = std::move(col);
     const int max_levels = std::max(1, std::min(g.opt.mg_levels_max, (int)kMaxLevels));
+    // A graph without far (loop-closure) entries on one GPU can run its PCG iteration as two launches
+    // (cgcg.hip), which needs aggregates of 8 on levels 0 AND 1. The rule below would stop level 1 short
+    // (aggregates of 2 or 4 that just reach the dense level: 20k views -> 2500 -> 1250) and leave such a
+    // graph on the slowest path (six launches per iteration): measured 389 vs 667 M edge-updates/s at
+    // 20k / 400k, 1223 vs 1669 M at 60k / 1.2M, for two more PCG iterations per solve.
+    bool band0 = g.ng == 0 && g.opt.mg_multiplicative_top != 1 && g.opt.no_fused_pspmv != 1 &&
+                 g.opt.pcg_classic != 1 && (H[0].n + 63) / 64 <= 4 * kMaxParts;
+    if (band0) {
+        std::atomic<bool> far(false);
+        const HostLevel &h0 = H[0];
+        parallel_for(h0.n, 4096, [&](int64_t r0, int64_t r1, int) {
+            for (int r = (int)r0; r < (int)r1 && !far; r++)
+                for (int t = h0.rowptr[r]; t < h0.rowptr[r + 1]; t++)
+                    if (h0.col[t] < r - kWinHalo || h0.col[t] > r + kWinHalo) {
+                        far = true;
+                        break;
+                    }
+        });
+        band0 = !far;
+    }
     while ((int)H.size() < max_levels && H.back().n > g.opt.mg_dense_max) {
         HostLevel &F = H.back();
         const int64_t fnnz = F.rowptr[F.n];
@@ -276,8 +296,10 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         if (agg <= 0) {
             (void)fnnz;
             agg = 8;  // few, large steps: every extra level costs two latency-bound sweeps per cycle
-            // do not overshoot the dense level: the smallest factor that reaches it
-            for (int s2 = 2; s2 < agg; s2 *= 2)
+            // do not overshoot the dense level: the smallest factor that reaches it -- except on level 1
+            // of a graph that can take the two-launch iteration (see band0 above)
+            const bool keep8 = band0 && H.size() == 2 && (F.n + 7) / 8 >= 64;
+            for (int s2 = 2; s2 < agg && !keep8; s2 *= 2)
                 if ((F.n + s2 - 1) / s2 <= g.opt.mg_dense_max) {
                     agg = s2;
                     break;

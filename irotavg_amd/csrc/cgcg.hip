@@ -748,9 +748,18 @@ int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran, b
         if (first_poll && tail) (*tail)();
         read_back_state(g);
         if (first_poll && tail && tail_ran) *tail_ran = h_flags[FL_DONE] == 1;
+        if (first_poll && device_scale && h_flags[FL_DONE] == 0 && h_flags[FL_STALE] != 0) {
+            // speculation on a re-used dense inverse that turned out stale, and the solve is slower than
+            // predicted: hand it back (run_irls re-inverts and solves again)
+            g.stats.pcg_iters += it;
+            return IROTAVG_RETRY_STALE;
+        }
         first_poll = false;
         if (h_flags[FL_DONE] != 0) break;
         const double cur = std::max(h_scal[SC_RELRES], std::max(h_scal[SC_RELRES + 1], h_scal[SC_RELRES + 2]));
+        if (std::getenv("IROTAVG_PCG_TRACE") && (it < 80 || it % 100 < 4))
+            std::fprintf(stderr, "[pcg cg2]   it %d relres %.3e %.3e %.3e alpha %.3e %.3e gamma %.3e\n", it, h_scal[SC_RELRES],
+                         h_scal[SC_RELRES + 1], h_scal[SC_RELRES + 2], h_scal[SC_ALF0], h_scal[SC_ALF1], h_scal[SC_GAM0]);
         if (cur < 0.5 * best) {
             best = cur;
             best_it = it;
@@ -765,6 +774,8 @@ int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran, b
     g.stats.pcg_iters += stagnated ? it : h_flags[FL_ITERS];
     g.stats.pcg_iters_last = stagnated ? it : h_flags[FL_ITERS];
     for (int c = 0; c < 3; c++) g.stats.last_relres[c] = h_scal[SC_RELRES + c];
+    if (std::getenv("IROTAVG_PCG_TRACE"))
+        std::fprintf(stderr, "[pcg cg2] clone %d iters %d enqueued %d\n", g.is_clone ? 1 : 0, h_flags[FL_ITERS], it);
     if (h_flags[FL_DONE] == 2) return IROTAVG_ERR_SOLVER;
     if (stagnated) {
         g.stats.pcg_stagnated += 1;

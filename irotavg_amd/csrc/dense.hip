@@ -704,12 +704,11 @@ __global__ __launch_bounds__(1024) void k_stale_check(long long nd, const double
             lo = fmin(lo, smin[w]);
             hi = fmax(hi, smax[w]);
         }
-        if (lo > 0.0 && hi < HUGE_VAL && hi <= spread * lo) {
-            scal[SC_DSCALE] = 1.0 / sqrt(lo * hi);
-            flags[FL_STALE] = 0;
-        } else {
-            flags[FL_STALE] = 1;
-        }
+        // the scale follows the operator even when the verdict is 'stale' (the geometric mean of the
+        // ratios keeps the coarse correction at the right magnitude: a stale inverse at scale 1 after the
+        // weights went from 1 to 1e4 is no preconditioner at all -- measured 2000 iterations)
+        if (lo > 0.0 && hi < HUGE_VAL) scal[SC_DSCALE] = 1.0 / sqrt(lo * hi);
+        flags[FL_STALE] = (lo > 0.0 && hi < HUGE_VAL && hi <= spread * lo) ? 0 : 1;
     }
 }
 

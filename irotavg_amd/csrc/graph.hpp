@@ -171,6 +171,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck);
 void pd_prepare_graph(Graph &g);
 void pd_pack_solution(Graph &g);  // pdn planes kPdXPlane0.. -> X (owned rows)
 constexpr int kPdXPlane0 = 3;  // pdn planes 3, 4, 5 hold the three coordinates' solutions (PdnPlane N_X0..)
+constexpr int IROTAVG_RETRY_STALE = 100;  // internal: pcg_solve_cg2 gave a speculative solve back (see run_irls)
 // cgcg.hip: the two-launch PCG iteration
 // tail: work to enqueue before the FIRST read-back of the solver state (kernels gated on the done flag);
 // *tail_ran tells whether the solve was done at that read-back, i.e. whether the gated kernels ran

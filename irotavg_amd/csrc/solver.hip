@@ -1257,6 +1257,9 @@ void alloc_state(Graph &g) {
     static_assert(sizeof(int) * FL_COUNT <= 2 * sizeof(double), "flags tail");
     g.scal.alloc(SC_COUNT + 2);
     g.scal.zero(g.stream);
+    const double one = 1.0;
+    IRH_CHECK(hipMemcpyAsync(g.scal.p + SC_DSCALE, &one, sizeof(double), hipMemcpyHostToDevice, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
     g.flags.release();
     g.flags.p = reinterpret_cast<int *>(g.scal.p + SC_COUNT);
     g.flags.n = FL_COUNT;
@@ -1691,6 +1694,10 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                     dense_check_async(g);
                     g.dense_fresh = false;
                     spec = true;
+                    // the right-hand side is consumed by the solve (the residual ping-pongs through its
+                    // buffer): keep a copy in case the speculation has to be taken back
+                    IRH_CHECK(hipMemcpyAsync(g.levels[0].x.p, g.levels[0].b.p, sizeof(double4) * (size_t)g.levels[0].n,
+                                             hipMemcpyDeviceToDevice, g.stream));
                 }
             }
             bool tail_ran = false;
@@ -1704,6 +1711,17 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                     g.dense_stale_pending = true;
                 else
                     g.dense_scale = g.h_scal()[SC_DSCALE];
+            }
+            if (rc == IROTAVG_RETRY_STALE) {
+                // the verdict was 'stale' AND the solve did not converge in the predicted number of
+                // iterations: re-invert now and solve again from the saved right-hand side
+                dense_refresh(g);
+                g.dense_valid = true;
+                g.dense_fresh = true;
+                g.dense_stale_pending = false;
+                IRH_CHECK(hipMemcpyAsync(g.levels[0].b.p, g.levels[0].x.p, sizeof(double4) * (size_t)g.levels[0].n,
+                                         hipMemcpyDeviceToDevice, g.stream));
+                rc = pcg_solve_cg2(g, &tail, &tail_ran, false);
             }
             if (rc != IROTAVG_OK) break;
             if (tail_ran) {

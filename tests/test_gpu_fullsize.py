@@ -142,7 +142,10 @@ def test_fused_pcg_launches_match_the_separate_kernels(n, m, levels, f, p):
             out[key] = (r["iters"], G.get_rotations(), G.get_weights(), st["pcg_iters"])
     for k in (1, 2):
         assert out[0][0] == out[k][0]
-        assert abs(out[0][3] - out[k][3]) <= 2 * out[0][0]
+        # the default keeps aggregates of 8 on level 1 (what the two-launch iteration needs), the variants
+        # stop level 1 at the dense level's size (aggregates of 2-4): different hierarchies, so the PCG
+        # iteration totals differ -- by up to ~45 % on the narrowest bands here (m / n = 5)
+        assert out[0][3] <= 1.6 * out[k][3] + 2 * out[0][0]
         assert synth.angular_distance(out[0][1], out[k][1]).max() < 1e-10
         np.testing.assert_allclose(out[0][2], out[k][2], rtol=1e-8)
     if p == 0.0:
@@ -207,3 +210,33 @@ def test_round2_paths_match_round1_paths_on_band_graphs(n, m, f, monkeypatch):
     assert synth.angular_distance(out[0][3], out[1][3]).max() < 1e-9
     np.testing.assert_allclose(out[0][4], out[1][4], rtol=1e-7)
     assert out[0][5]["dense_inversions"] >= 1
+
+
+@pytest.mark.parametrize("cost", range(14))
+def test_every_cost_on_the_two_launch_path_matches_oracle(cost):
+    """All 14 robust costs on a three-level band graph (the two-launch PCG path with its speculative
+    pieces: weight / rotation update gated behind the solve, staleness verdict of the dense inverse
+    taken on the device and acted on one iteration later). 2 % of the edges carry a 0.3 rad error:
+    Talwar's exact zeros, Huber's stale weights and the redescending costs then change the coarse
+    operator NON-uniformly -- the 'stale' branch -- and must still give the oracle's iteration counts,
+    rotations and weights. Start: ground truth perturbed by 0.02 rad (a converged front-end)."""
+    n, m = 17000, 204000
+    S = synth.make_graph(n, m, 0.0, seed=40 + cost)
+    rng = np.random.default_rng(cost)
+    QQ = S["QQ"].copy()
+    bad = rng.choice(len(QQ), size=len(QQ) // 50, replace=False)
+    QQ[bad] = synth.qmul(synth.qexp(rng.normal(scale=0.3, size=(len(bad), 3))), QQ[bad])
+    Q0 = synth.qmul(synth.qexp(rng.normal(scale=0.02, size=(n, 3))), S["Qgt"])
+    Q0[0] = S["Qgt"][0]
+    ro = O.irls(QQ, S["I"], Q0, 1, cost, SIG, 4, 1e-3)
+    with capi.Graph(S["I"], QQ, n, 1) as G:
+        G.time_kernel(9, 1)          # raises unless this graph's PCG is the two-launch iteration
+        G.set_rotations(Q0)
+        r = G.irls(cost, SIG, 4, 1e-3)
+        st = G.stats()
+        Qg, wg = G.get_rotations(), G.get_weights()
+    assert st["levels"] == 3 and st["pcg_stagnated"] == 0
+    assert r["iters"] == ro["iters"]
+    np.testing.assert_allclose(r["scores"], ro["scores"][:r["iters"]], rtol=1e-6)
+    assert synth.angular_distance(Qg, ro["Q"]).max() < 1e-7
+    np.testing.assert_allclose(wg, ro["weights"], rtol=1e-6, atol=1e-10)
