@@ -34,6 +34,7 @@
 
 namespace irh {
 
+constexpr int kCg2GiveUp = 400;  // iterations after which a two-launch solve is handed to the classic recurrences
 constexpr int kL1Pre = 8;   // entries of a level-1 row requested up front (a band graph's row has <= 8)
 
 // ---------------------------------------------------------------------------------------------
@@ -144,7 +145,11 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
             const double go = scal[(par ? SC_GAM1 : SC_GAM0) + c], ao = scal[(par ? SC_ALF1 : SC_ALF0) + c];
             const bool chain = MODE == 2 && go > 0.0 && ao > 0.0;
             be[c] = chain ? g3[c] / go : 0.0;
-            const double den = d3[c] - (chain ? be[c] * g3[c] / ao : 0.0);
+            double den = d3[c] - (chain ? be[c] * g3[c] / ao : 0.0);
+            if (chain && !(den > 0.0)) {  // p'Lp <= 0 from the recurrence: rounding on an ill-conditioned
+                be[c] = 0.0;              // system -- restart the direction (p = u: delta = u'Lu > 0)
+                den = d3[c];
+            }
             al[c] = den > 0.0 ? g3[c] / den : 0.0;  // gamma = 0: the column is solved exactly
             finite = finite && isfinite(g3[c]) && isfinite(d3[c]);
         }
@@ -712,6 +717,11 @@ int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran, b
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     if (g.levels.size() == 3) cg2_refresh_inv32(g);
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * 2, g.stream));  // FL_DONE, FL_ITERS (not FL_STALE)
+    // the right-hand side is consumed (the residual ping-pongs through its buffer): keep a copy -- a
+    // speculative solve may be handed back (run_irls), and a system on which the Chronopoulos-Gear
+    // recurrences stall is solved again by the classic ones (3 MB, ~3 us)
+    IRH_CHECK(hipMemcpyAsync(g.levels[0].x.p, g.levels[0].b.p, sizeof(double4) * (size_t)g.levels[0].n,
+                             hipMemcpyDeviceToDevice, g.stream));
     int rcur = 0;  // which of the two r / s buffers is current
     cg2_launch_update(g, 0, 0, rcur);
     rcur ^= 1;
@@ -768,6 +778,18 @@ int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran, b
             break;
         }
         if (it >= maxit) break;
+        const char *ge = std::getenv("IROTAVG_CG2_GIVEUP");  // tests force the hand-over
+        const int giveup = ge ? std::max(1, std::atoi(ge)) : kCg2GiveUp;
+        if (it >= giveup) {
+            // s = L p and r are carried by recurrences here; on a badly conditioned system their rounding
+            // can stall the iteration far above the tolerance. The classic recurrences (one more launch
+            // per iteration, q = L p computed) are the robust path: start over with them.
+            if (std::getenv("IROTAVG_PCG_TRACE")) std::fprintf(stderr, "[pcg cg2] giving up at %d iterations -> classic\n", it);
+            g.stats.pcg_iters += it;
+            IRH_CHECK(hipMemcpyAsync(g.levels[0].b.p, g.levels[0].x.p, sizeof(double4) * (size_t)g.levels[0].n,
+                                     hipMemcpyDeviceToDevice, g.stream));
+            return pcg_solve_classic(g);
+        }
         update();  // not converged: that application is the next iteration's
     }
     g.stats.pcg_solves += 1;

@@ -139,6 +139,7 @@ void alloc_state(Graph &g);  // scal + flags (aliased tail) + the pinned block
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true);
 void assemble_values(Graph &g, int mode, const double *wsrc);  // the value refresh alone (no dense-level decision)
 int pcg_solve(Graph &g);
+int pcg_solve_classic(Graph &g);  // the round-1 recurrences (separate launches), whatever Graph::cg2 says
 void launch_spmv(Graph &g);
 void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = nullptr,
                    const double4 *rin = nullptr, double4 *rout = nullptr);

@@ -1063,7 +1063,11 @@ __global__ __launch_bounds__(kRowBlock) void k_cgd_update(
             const double go = scal[(par ? SC_GAM1 : SC_GAM0) + c], ao = scal[(par ? SC_ALF1 : SC_ALF0) + c];
             const bool chain = !first && go > 0.0 && ao > 0.0;
             be[c] = chain ? g / go : 0.0;
-            const double den = d - (chain ? be[c] * g / ao : 0.0);
+            double den = d - (chain ? be[c] * g / ao : 0.0);
+            if (chain && !(den > 0.0)) {  // see k_cg_update: restart the direction
+                be[c] = 0.0;
+                den = d;
+            }
             al[c] = den > 0.0 ? g / den : 0.0;
             finite = finite && isfinite(g) && isfinite(d);
         }
@@ -1525,6 +1529,10 @@ void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi, bool check
 // iterations; kernels enqueued past convergence return immediately.
 int pcg_solve(Graph &g) {
     if (g.cg2) return pcg_solve_cg2(g);
+    return pcg_solve_classic(g);
+}
+
+int pcg_solve_classic(Graph &g) {
     Level &L0 = g.levels[0];
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     const int gr = grid_for_rows(L0);
@@ -1694,10 +1702,6 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                     dense_check_async(g);
                     g.dense_fresh = false;
                     spec = true;
-                    // the right-hand side is consumed by the solve (the residual ping-pongs through its
-                    // buffer): keep a copy in case the speculation has to be taken back
-                    IRH_CHECK(hipMemcpyAsync(g.levels[0].x.p, g.levels[0].b.p, sizeof(double4) * (size_t)g.levels[0].n,
-                                             hipMemcpyDeviceToDevice, g.stream));
                 }
             }
             bool tail_ran = false;

@@ -240,3 +240,24 @@ def test_every_cost_on_the_two_launch_path_matches_oracle(cost):
     np.testing.assert_allclose(r["scores"], ro["scores"][:r["iters"]], rtol=1e-6)
     assert synth.angular_distance(Qg, ro["Q"]).max() < 1e-7
     np.testing.assert_allclose(wg, ro["weights"], rtol=1e-6, atol=1e-10)
+
+
+def test_two_launch_solve_hands_over_to_the_classic_recurrences(monkeypatch):
+    """A two-launch (Chronopoulos-Gear) solve that has not converged after kCg2GiveUp iterations is
+    solved again by the classic recurrences from the saved right-hand side. Forced here by setting the
+    limit to 10: same IRLS iterations and rotations as the undisturbed run."""
+    n, m = 70000, 700000
+    S = synth.make_graph(n, m, 0.0, seed=3)
+    Q0 = mst(S, n)
+    out = []
+    for limit in (None, "10"):
+        if limit:
+            monkeypatch.setenv("IROTAVG_CG2_GIVEUP", limit)
+        with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+            G.time_kernel(9, 1)      # this graph's PCG is the two-launch iteration
+            G.set_rotations(Q0)
+            r = G.irls(4, SIG, 100, 1e-3)
+            out.append((r["iters"], G.get_rotations(), G.stats()["pcg_iters"]))
+    assert out[0][0] == out[1][0]
+    assert out[1][2] > out[0][2]                  # the abandoned iterations are counted
+    assert synth.angular_distance(out[0][1], out[1][1]).max() < 1e-10
