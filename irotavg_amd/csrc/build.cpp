@@ -51,6 +51,7 @@ struct SellMap {
     int nsl = 0;
     std::vector<int> sl_off, sl_near;  // nsl + 1, nsl
     std::vector<int> pos;              // per CSR slot
+    std::vector<int> kidx;             // per CSR slot: entry index within its SELL row
     long long len = 0;                 // 64 * sl_off[nsl]
 };
 static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector<int> &col) {
@@ -81,6 +82,7 @@ static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector
     for (int sl = 0; sl < M.nsl; sl++) M.sl_off[sl + 1] = M.sl_off[sl] + width[sl];
     M.len = 64ll * M.sl_off[M.nsl];
     M.pos.resize((size_t)rowptr[n]);
+    M.kidx.resize((size_t)rowptr[n]);
     parallel_for(n, 4096, [&](int64_t r0, int64_t r1, int) {
         for (int r = (int)r0; r < (int)r1; r++) {
             const int sl = r >> 6, lane = r & 63;
@@ -88,6 +90,7 @@ static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector
             for (int t = rowptr[r]; t < rowptr[r + 1]; t++) {
                 const int k = is_near(r, col[t]) ? kn++ : kf++;
                 M.pos[t] = (int)sell_pos(M.sl_off[sl], k, lane);
+                M.kidx[t] = k;
             }
         }
     });
@@ -418,6 +421,25 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
                 for (int64_t t = a; t < b; t++) seid[M.pos[t]] = slot_eid[t];
             });
             g.slot_eid.upload(seid, s);
+            // k_assemble0w: per slice, the first edge of the run it stages in LDS = the lowest edge id
+            // among the slice's near entries (a view sequence: the edges of the slice's first view)
+            std::vector<int> te0((size_t)M.nsl, 0);
+            parallel_for(M.nsl, 256, [&](int64_t s0, int64_t s1, int) {
+                for (int sl = (int)s0; sl < (int)s1; sl++) {
+                    uint32_t lo = 0xffffffffu;
+                    for (int r = sl * 64; r < std::min(h.n, sl * 64 + 64); r++)
+                        for (int t = h.rowptr[r]; t < h.rowptr[r + 1]; t++)
+                            if (h.col[t] >= r - kWinHalo && h.col[t] <= r + kWinHalo) lo = std::min(lo, slot_eid[t] >> 1);
+                    te0[(size_t)sl] = lo == 0xffffffffu ? 0 : (int)lo;
+                }
+            });
+            g.tile_e0.upload(te0, s);
+            g.asm_windowed = getenv("IROTAVG_ASM_CLASSIC") ? 0 : 1;
+            g.asm_l1_fused = 0;
+            if (H.size() < 2) {  // no level 1: the kernel still reads a (dummy) level-1 index per pair
+                std::vector<uint8_t> cs((size_t)M.len, 255);
+                g.slot_cs.upload(cs, s);
+            }
             IRH_CHECK(hipStreamSynchronize(s));
         }
         L.excess.alloc((size_t)M.nsl * 64);
@@ -431,6 +453,26 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
             parallel_for((int64_t)h.cidx.size(), 65536, [&](int64_t a, int64_t b, int) {
                 for (int64_t q = a; q < b; q++) cidx2[q] = prev.pos[h.cidx[q]];
             });
+            L.crow.upload(h.rowptr, s);
+            L.max_row = 0;
+            for (int r = 0; r < h.n; r++) L.max_row = std::max(L.max_row, h.rowptr[r + 1] - h.rowptr[r]);
+            if (lev == 1) {
+                // level-1 entry index of every level-0 SELL position (k_assemble0w sums level 1 on the way
+                // when level 0 aggregates by 8 and no level-1 row has more than 8 entries)
+                std::vector<uint8_t> cs((size_t)prev.len, 255);
+                std::atomic<bool> wide(false);
+                parallel_for((int64_t)h.rowptr[h.n], 16384, [&](int64_t a, int64_t b, int) {
+                    for (int64_t c = a; c < b; c++) {
+                        const int k = M.kidx[(size_t)c];
+                        if (k >= 8) wide = true;
+                        for (int q = h.cptr[(size_t)c]; q < h.cptr[(size_t)c + 1]; q++)
+                            cs[(size_t)prev.pos[(size_t)h.cidx[(size_t)q]]] = (uint8_t)std::min(k, 255);
+                    }
+                });
+                g.slot_cs.upload(cs, s);
+                g.asm_l1_fused = (g.asm_windowed && H[0].agg == 8 && !wide) ? 1 : 0;
+                IRH_CHECK(hipStreamSynchronize(s));
+            }
             L.cptr.upload(h.cptr, s);
             L.cidx.upload(cidx2, s);
             L.cpos.upload(M.pos, s);

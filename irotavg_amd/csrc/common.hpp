@@ -357,6 +357,8 @@ struct Level {
     // value refresh from the finer level: coarse entry c (CSR order) sums the finer SELL
     // positions cidx[cptr[c]..cptr[c+1]) and is stored at SELL position cpos[c]
     DevBuf<int> cptr, cidx, cpos;
+    DevBuf<int> crow;   // CSR row pointers of the coarse entries (k_coarse_level)
+    int max_row = 0;    // longest row (entries)
     // multigrid work vectors (double4 with 3 active components)
     DevBuf<double4> b, x, y, e;
 };

@@ -30,6 +30,10 @@ struct Graph {
     DevBuf<double4> Qsnap;
 
     // level-0 adjacency extras (CSR itself lives in levels[0])
+    DevBuf<uint8_t> slot_cs;    // per level-0 SELL position: entry index in the level-1 row it sums into (255: none)
+    DevBuf<int> tile_e0;        // per level-0 slice: first edge of the window k_assemble0w stages in LDS
+    int asm_windowed = 1;       // K3 by k_assemble0w (IROTAVG_ASM_CLASSIC=1: edge_pack + assemble0 + coarse kernels)
+    int asm_l1_fused = 0;       // ... which also refreshes level 1 (aggregates of 8, level-1 rows of <= 8 entries)
     DevBuf<uint32_t> slot_eid;  // SELL layout of level 0: (edge id << 1) | (row is the j endpoint); ~0u = padding
     DevBuf<int> bptr;           // per row: boundary slots (other endpoint fixed / self loop)
     DevBuf<uint32_t> beid;

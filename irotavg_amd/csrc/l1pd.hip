@@ -597,6 +597,8 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
     q.qq.alias(g.qq); q.er.alias(g.er); q.dw.alias(g.dw); q.Q.alias(g.Q);
     q.slot_eid.alias(g.slot_eid); q.bptr.alias(g.bptr); q.beid.alias(g.beid);
     q.bflag.alias(g.bflag); q.bghost.alias(g.bghost);
+    q.slot_cs.alias(g.slot_cs); q.tile_e0.alias(g.tile_e0);
+    q.asm_windowed = g.asm_windowed; q.asm_l1_fused = g.asm_l1_fused;
     q.bval.alloc_like(g.bval, s);
     q.PG.alloc_like(g.PG, s);
     q.levels.resize(g.levels.size());
@@ -606,7 +608,8 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
         B.n = A.n; B.nnz = A.nnz; B.agg = A.agg; B.nsl = A.nsl; B.sell_len = A.sell_len;
         B.max_near = A.max_near; B.uni_w = A.uni_w;
         B.sl_off.alias(A.sl_off); B.sl_near.alias(A.sl_near); B.col.alias(A.col);
-        B.cptr.alias(A.cptr); B.cidx.alias(A.cidx); B.cpos.alias(A.cpos);
+        B.cptr.alias(A.cptr); B.cidx.alias(A.cidx); B.cpos.alias(A.cpos); B.crow.alias(A.crow);
+        B.max_row = A.max_row;
         B.val.alloc_like(A.val, s); B.excess.alloc_like(A.excess, s);
         B.diag.alloc_like(A.diag, s); B.idg.alloc_like(A.idg, s);
         B.b.alloc_like(A.b, s); B.x.alloc_like(A.x, s); B.y.alloc_like(A.y, s); B.e.alloc_like(A.e, s);

@@ -278,6 +278,256 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0(
     }
 }
 
+// K3, windowed form: ONE launch replaces k_edge_pack + k_assemble0 + (band graphs) the level-1 value and
+// diagonal kernels. A workgroup owns one 64-row slice. The edges its rows touch are, on a view sequence,
+// ONE contiguous run of the edge list (edges are stored by their later view: rows [r, r + 64) with
+// w predecessors each touch the edges of views [r, r + 64 + w)), so the workgroup stages that run --
+// w_e = d_e^2 and w_e r_e, 40 B per edge read once, coalesced -- in LDS and the row walk gathers from
+// LDS instead of from a 64 MB record array written by a kernel of its own (PMC before: 3.2 x the
+// algorithmic traffic over the three launches). The window start comes from the build (lowest edge id
+// among the slice's near entries); an entry whose edge lies outside the window (loop closures) is
+// gathered from global memory, so any graph is handled. The four waves split the slice's entry pairs;
+// their partial row sums are combined in wave order (deterministic).
+// L1 = true: level 0 aggregates by 8 and every level-1 row has at most 8 entries (band graphs): the
+// 8 x 8 level-1 values under the slice are accumulated on the way (each (wave, row) owns its LDS
+// accumulators: no atomics) and the level-1 diagonal is formed here, too.
+constexpr int kAsmWin = 1664;  // edges staged per slice: (64 + 19) * 19 = 1577 at 100k views / 2M edges
+constexpr int kAsmCW = 8;      // level-1 entries per row handled in the fused form
+
+template <int MODE, bool L1>
+__global__ __launch_bounds__(kRowBlock) void k_assemble0w(
+    int n, int nsl, long long m, long long mpad, const int *__restrict__ sl_off,
+    const uint32_t *__restrict__ slot_eid, const uint8_t *__restrict__ slot_cs,
+    const int *__restrict__ tile_e0, const int *__restrict__ bptr, const uint32_t *__restrict__ beid,
+    const uint8_t *__restrict__ bflag, const double *__restrict__ wsrc, const double *__restrict__ er,
+    double *__restrict__ val, double *__restrict__ excess, double *__restrict__ diag,
+    double *__restrict__ idg, double4 *__restrict__ rhs, double *__restrict__ bval, int n1,
+    const int *__restrict__ sl_off1, double *__restrict__ val1, double *__restrict__ excess1,
+    double *__restrict__ diag1, double *__restrict__ idg1) {
+    __shared__ double sT[MODE == 0 ? 4 : 1][kAsmWin];
+    __shared__ double part[MODE == 0 ? 4 : 1][4][64];
+    __shared__ double acc1[L1 ? 4 : 1][L1 ? kAsmCW : 1][64];
+    __shared__ double sEx[64];
+    const int nb = gridDim.x, b = blockIdx.x;  // nb is a multiple of 8: neighbouring slices share an XCD (L2)
+    const int sl = (b & 7) * (nb >> 3) + (b >> 3);
+    if (sl >= nsl) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e0 = tile_e0[sl];
+    const int row = sl * 64 + lane;
+    const int o0 = sl_off[sl], np = (sl_off[sl + 1] - o0) / 2;
+    const uint2 *__restrict__ se_p = reinterpret_cast<const uint2 *>(slot_eid) + (size_t)(o0 / 2) * 64 + lane;
+    const uint16_t *__restrict__ cs_p = reinterpret_cast<const uint16_t *>(slot_cs) + (size_t)(o0 / 2) * 64 + lane;
+    double2 *__restrict__ v_p = reinterpret_cast<double2 *>(val) + (size_t)(o0 / 2) * 64 + lane;
+    constexpr int PB = 6;  // pairs in flight per wave (rows of up to 48 entries in one batch)
+    uint2 se[PB];
+    uint32_t cc[PB];
+    auto load_batch = [&](int p0) {  // entry pairs p0, p0 + 4, ... of this wave
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            const int p = p0 + 4 * u;
+            se[u] = make_uint2(0xffffffffu, 0xffffffffu);
+            cc[u] = 0xffffu;
+            if (p < np) {
+                se[u] = se_p[(size_t)p * 64];
+                if (L1) cc[u] = cs_p[(size_t)p * 64];
+            }
+        }
+    };
+    load_batch(wave);  // in flight while the window is staged
+    {
+        constexpr int NQ = (kAsmWin + kRowBlock - 1) / kRowBlock;
+        double rw[NQ], rx[NQ], ry[NQ], rz[NQ];
+#pragma unroll
+        for (int it = 0; it < NQ; it++) {  // all loads first
+            const int q = tid + it * kRowBlock;
+            const long long e = (long long)e0 + q;
+            rw[it] = rx[it] = ry[it] = rz[it] = 0.0;
+            if (q < kAsmWin && e < m) {
+                rw[it] = wsrc[e];
+                if (MODE == 0) {
+                    rx[it] = er[e];
+                    ry[it] = er[mpad + e];
+                    rz[it] = er[2 * mpad + e];
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NQ; it++) {
+            const int q = tid + it * kRowBlock;
+            if (q < kAsmWin) {
+                const double w = MODE == 0 ? rw[it] * rw[it] : rw[it];
+                sT[0][q] = w;
+                if (MODE == 0) {
+                    sT[1][q] = w * rx[it];
+                    sT[2][q] = w * ry[it];
+                    sT[3][q] = w * rz[it];
+                }
+            }
+        }
+    }
+    if (L1) {
+#pragma unroll
+        for (int c = 0; c < kAsmCW; c++) acc1[wave][c][lane] = 0.0;
+    }
+    __syncthreads();
+    auto fetch = [&](uint32_t e, double &w, double &x, double &y, double &z) {
+        const uint32_t q = e - (uint32_t)e0;
+        if (q < (uint32_t)kAsmWin) {
+            w = sT[0][q];
+            if (MODE == 0) {
+                x = sT[1][q];
+                y = sT[2][q];
+                z = sT[3][q];
+            }
+        } else {
+            w = wsrc[e];
+            if (MODE == 0) {
+                w *= w;
+                x = w * er[e];
+                y = w * er[mpad + e];
+                z = w * er[2 * mpad + e];
+            }
+        }
+    };
+    double sw = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+    for (int p0 = wave; p0 < np; p0 += 4 * PB) {
+        if (p0 != wave) load_batch(p0);
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            const int p = p0 + 4 * u;
+            if (p >= np) break;
+            double wv[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t s = h ? se[u].y : se[u].x;
+                double w = 0.0, x = 0.0, y = 0.0, z = 0.0;
+                if (s != 0xffffffffu) fetch(s >> 1, w, x, y, z);
+                if (MODE == 0) {
+                    const double sg = (s & 1u) ? 1.0 : -1.0;
+                    b0 += sg * x;
+                    b1 += sg * y;
+                    b2 += sg * z;
+                }
+                sw += w;
+                wv[h] = w;
+                if (L1) {
+                    const uint32_t c = (cc[u] >> (8 * h)) & 255u;
+                    if (c < (uint32_t)kAsmCW) acc1[wave][c][lane] -= w;
+                }
+            }
+            v_p[(size_t)p * 64] = make_double2(-wv[0], -wv[1]);
+        }
+    }
+    part[0][wave][lane] = sw;
+    if (MODE == 0) {
+        part[1][wave][lane] = b0;
+        part[2][wave][lane] = b1;
+        part[3][wave][lane] = b2;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double ex = 0.0;
+        if (row < n) {
+            sw = ((part[0][0][lane] + part[0][1][lane]) + part[0][2][lane]) + part[0][3][lane];
+            if (MODE == 0) {
+                b0 = ((part[1][0][lane] + part[1][1][lane]) + part[1][2][lane]) + part[1][3][lane];
+                b1 = ((part[2][0][lane] + part[2][1][lane]) + part[2][2][lane]) + part[2][3][lane];
+                b2 = ((part[3][0][lane] + part[3][1][lane]) + part[3][2][lane]) + part[3][3][lane];
+            }
+            for (int s = bptr[row]; s < bptr[row + 1]; s++) {
+                const uint8_t fl = bflag[s];
+                if (!(fl & (MODE == 0 ? BF_IRLS : BF_L1H))) {
+                    bval[s] = 0.0;
+                    continue;
+                }
+                const uint32_t se = beid[s];
+                double wk, x = 0.0, y = 0.0, z = 0.0;
+                fetch(se >> 1, wk, x, y, z);
+                if (MODE == 0) {
+                    const double sg = (se & 1u) ? 1.0 : -1.0;
+                    b0 += sg * x;
+                    b1 += sg * y;
+                    b2 += sg * z;
+                } else if (fl & BF_NEG) {
+                    wk = -wk;
+                }
+                bval[s] = wk;
+                ex += wk;
+            }
+            const double d = sw + ex;
+            excess[row] = ex;
+            diag[row] = d;
+            idg[row] = d > 0.0 ? 1.0 / d : 0.0;
+            if (MODE == 0) rhs[row] = make_double4(b0, b1, b2, 0.0);
+        }
+        if (L1) sEx[lane] = ex;
+    }
+    if (!L1) return;
+    __syncthreads();
+    if (wave == 0) {
+        // lane = (aggregate a, level-1 entry c): sum of the 8 rows x 4 waves in a fixed order
+        const int a = lane >> 3, c = lane & 7;
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int wv = 0; wv < 4; wv++) v += acc1[wv][c][a * 8 + r];
+        const int I = sl * 8 + a;
+        const bool liveI = I < n1;
+        int o1 = 0, w1 = 0;
+        if (liveI) {
+            o1 = sl_off1[I >> 6];
+            w1 = sl_off1[(I >> 6) + 1] - o1;
+        }
+        if (liveI && c < w1) val1[sell_pos(o1, c, I & 63)] = v;
+        const double sv = seg_sum(v, 8);
+        if (liveI && c == 0) {
+            double ex = 0.0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) ex += sEx[a * 8 + r];
+            const double d = ex - sv;
+            excess1[I] = ex;
+            diag1[I] = d;
+            idg1[I] = d > 0.0 ? 1.0 / d : 0.0;
+        }
+    }
+}
+
+// value + diagonal refresh of a coarse level with SHORT rows (band graphs below level 1) in one launch:
+// 8 lanes per coarse row walk its entries in CSR order (each entry = sum of the finer SELL positions
+// listed for it), then form the diagonal from the aggregate's excess and the row sum.
+__global__ __launch_bounds__(kRowBlock) void k_coarse_level(LevelView C, const int *__restrict__ crow,
+                                                            const int *__restrict__ cptr,
+                                                            const int *__restrict__ cidx,
+                                                            const int *__restrict__ cpos,
+                                                            const double *__restrict__ fval, double *__restrict__ cval,
+                                                            int nf, int agg, const double *__restrict__ fexcess,
+                                                            double *__restrict__ cexcess, double *__restrict__ cdiag,
+                                                            double *__restrict__ cidg) {
+    const int I = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7;
+    const bool live = I < C.n;
+    double sv = 0.0;
+    if (live) {
+        for (int c = crow[I]; c < crow[I + 1]; c++) {
+            double s = 0.0;
+            for (int q = cptr[c] + l; q < cptr[c + 1]; q += 8) s += fval[cidx[q]];
+            s = seg_sum(s, 8);
+            if (l == 0) cval[cpos[c]] = s;
+            sv += s;
+        }
+    }
+    double ex = 0.0;
+    if (live)
+        for (int q = I * agg + l; q < min(nf, (I + 1) * agg); q += 8) ex += fexcess[q];
+    ex = seg_sum(ex, 8);
+    if (live && l == 0) {
+        const double d = ex - sv;
+        cexcess[I] = ex;
+        cdiag[I] = d;
+        cidg[I] = d > 0.0 ? 1.0 / d : 0.0;
+    }
+}
+
 // coarse off-diagonal values: entry c (CSR order) = sum of the finer SELL positions listed for
 // it, stored at its own SELL position. 8 lanes per entry.
 __global__ __launch_bounds__(kRowBlock) void k_coarse_vals(int nent, const int *__restrict__ cptr,
@@ -1336,7 +1586,28 @@ void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
 void assemble_values(Graph &g, int mode, const double *wsrc) {
     Level &L0 = g.levels[0];
     const int grid = grid_for_rows(L0);
-    if (mode == 0) {
+    size_t first_coarse = 1;
+    if (g.asm_windowed) {
+        // one workgroup per slice, the grid padded to a multiple of 8 (XCD-chunked slice order)
+        const int gw = (L0.nsl + 7) / 8 * 8;
+        const bool l1 = g.asm_l1_fused != 0;
+        Level *C1 = g.levels.size() > 1 ? &g.levels[1] : nullptr;
+#define IRH_ASM_ARGS                                                                                         \
+    L0.n, L0.nsl, (long long)g.m, (long long)g.mpad, L0.sl_off.p, g.slot_eid.p, g.slot_cs.p, g.tile_e0.p,    \
+        g.bptr.p, g.beid.p, g.bflag.p, wsrc, g.er.p, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p,     \
+        g.bval.p, l1 ? C1->n : 0, l1 ? C1->sl_off.p : nullptr, l1 ? C1->val.p : nullptr,                    \
+        l1 ? C1->excess.p : nullptr, l1 ? C1->diag.p : nullptr, l1 ? C1->idg.p : nullptr
+        if (mode == 0 && l1)
+            hipLaunchKernelGGL((k_assemble0w<0, true>), dim3(gw), dim3(kRowBlock), 0, g.stream, IRH_ASM_ARGS);
+        else if (mode == 0)
+            hipLaunchKernelGGL((k_assemble0w<0, false>), dim3(gw), dim3(kRowBlock), 0, g.stream, IRH_ASM_ARGS);
+        else if (l1)
+            hipLaunchKernelGGL((k_assemble0w<1, true>), dim3(gw), dim3(kRowBlock), 0, g.stream, IRH_ASM_ARGS);
+        else
+            hipLaunchKernelGGL((k_assemble0w<1, false>), dim3(gw), dim3(kRowBlock), 0, g.stream, IRH_ASM_ARGS);
+#undef IRH_ASM_ARGS
+        if (l1) first_coarse = 2;
+    } else if (mode == 0) {
         if (g.T.n < (size_t)g.mpad) g.T.alloc((size_t)g.mpad);
         hipLaunchKernelGGL(k_edge_pack, dim3((unsigned)((g.m + 255) / 256)), dim3(256), 0, g.stream,
                            (long long)g.m, (long long)g.mpad, wsrc, g.er.p, g.T.p);
@@ -1349,9 +1620,15 @@ void assemble_values(Graph &g, int mode, const double *wsrc) {
                            (const double4 *)nullptr, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p,
                            g.bval.p);
     }
-    for (size_t l = 1; l < g.levels.size(); l++) {
+    for (size_t l = first_coarse; l < g.levels.size(); l++) {
         Level &F = g.levels[l - 1];
         Level &C = g.levels[l];
+        if (g.asm_windowed && C.max_row <= 16 && C.crow.n > 0) {
+            hipLaunchKernelGGL(k_coarse_level, dim3((C.n * 8 + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,
+                               g.stream, view_of(C), C.crow.p, C.cptr.p, C.cidx.p, C.cpos.p, F.val.p, C.val.p,
+                               F.n, F.agg, F.excess.p, C.excess.p, C.diag.p, C.idg.p);
+            continue;
+        }
         if (C.nnz > 0) {
             const int grid2 = round_grid((C.nnz + 31) / 32);
             hipLaunchKernelGGL(k_coarse_vals, dim3(grid2), dim3(kRowBlock), 0, g.stream, C.nnz,
@@ -1771,7 +2048,7 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         switch (which) {
         case 1: launch_edge_residual(g); break;
         case 2: launch_update_weights(g, IROTAVG_GEMAN_MCCLURE, 5 * IRH_PI / 180.0); break;
-        case 3: assemble(g, 0, g.dw.p, false); break;
+        case 3: assemble_values(g, 0, g.dw.p); break;  // K3 proper (no staleness test of the dense inverse)
         case 7: dense_refresh(g); break;
         case 4:
             launch_spmv(g);

@@ -261,3 +261,36 @@ def test_two_launch_solve_hands_over_to_the_classic_recurrences(monkeypatch):
     assert out[0][0] == out[1][0]
     assert out[1][2] > out[0][2]                  # the abandoned iterations are counted
     assert synth.angular_distance(out[0][1], out[1][1]).max() < 1e-10
+
+
+@pytest.mark.parametrize("n,m,f,p", [(20000, 400000, 1, 0.0),      # level 1 refreshed inside k_assemble0w
+                                     (20000, 400000, 3, 0.01),     # loop closures: out-of-window gathers
+                                     (3000, 12000, 2, 0.0),        # thin band, short hierarchy
+                                     (600, 9000, 1, 0.05)])
+def test_windowed_assembly_matches_the_three_launch_form(n, m, f, p, monkeypatch):
+    """K3 as one launch (k_assemble0w: the slice's run of the edge list staged in LDS, level 1 summed on
+    the way) against edge_pack + assemble0 + coarse kernels (IROTAVG_ASM_CLASSIC=1): the same weighted
+    solve, the same l1ra + irls result. Both forms are checked against the oracle's mat-vec in
+    test_normal_equation_residual_and_k1; this pins them to each other on more shapes."""
+    S = synth.make_graph(n, m, p, seed=5)
+    Q0 = np.zeros((n, 4)); Q0[:, 3] = 1; Q0[:f] = S["Qgt"][:f]
+    ral.init_mst(Q0, S["QQ"], S["I"], f)
+    w = np.random.default_rng(1).uniform(0.1, 4.0, size=m)
+    out = []
+    for classic in (False, True):
+        if classic:
+            monkeypatch.setenv("IROTAVG_ASM_CLASSIC", "1")
+        with capi.Graph(S["I"], S["QQ"], n, f) as G:
+            G.set_rotations(Q0)
+            G.edge_residual()
+            G.set_weights(w)
+            X = G.ls_solve()
+            G.set_rotations(Q0)
+            r1 = G.l1ra(3, 1e-3)
+            r2 = G.irls(4, SIG, 100, 1e-3)
+            out.append((X, r1["iters"], r2["iters"], G.get_rotations(), G.get_weights()))
+    scale = np.abs(out[0][0]).max()
+    np.testing.assert_allclose(out[0][0], out[1][0], atol=1e-9 * scale, rtol=0)
+    assert out[0][1:3] == out[1][1:3]
+    assert synth.angular_distance(out[0][3], out[1][3]).max() < 1e-9
+    np.testing.assert_allclose(out[0][4], out[1][4], rtol=1e-7)
