@@ -40,3 +40,31 @@ def test_two_processes_rccl_on_one_device():
         tail = (r.stdout + r.stderr)[-1500:]
         pytest.skip("RCCL refused two ranks on one device (expected on a 1-GPU box): ..." + tail[-400:])
     assert "DIST_WORKER_OK" in r.stdout
+
+
+def test_bench_runs_with_two_ranks():
+    """bench.py's own N > 1 branch (sharding, timing protocol, max over ranks, the JSON line), two ranks
+    sharing the box's one GPU (IROTAVG_BENCH_SHARE_GPU=1). RCCL refuses two ranks on one device, so this
+    also exercises the fall-back every rank takes together when the library's communicator cannot be
+    formed: the same sharded solver over the host-staged transport."""
+    import json
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["IROTAVG_BENCH_SHARE_GPU"] = "1"
+    common = ["--views", "20000", "--edges", "300000", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extra"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2"] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    two = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=420, cwd=ROOT)
+    one = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["value"] > 0
+    assert two["iters_to_converge"] == one["iters_to_converge"]
+    assert "2 contiguous ranges" in two["config"]["parallelism"]
+    np_ = __import__("numpy")
+    np_.testing.assert_allclose(two["final_scores"], one["final_scores"], rtol=1e-6)
