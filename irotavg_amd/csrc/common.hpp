@@ -288,6 +288,7 @@ constexpr int kMaxLevels = 16;
 // ties to a fixed view -- what SPQR's rank detection / the oracle's Cholesky decide, too.
 constexpr double kDeadTol = 1e-13;
 constexpr int kSellUnroll = 8;  // slice widths are multiples of this (batch size of the row loops)
+constexpr int kBandMax = 4;     // coarsest operators up to this half-bandwidth are inverted by the banded kernels (dense.hip)
 
 // per-edge flag bits (host-built; see build.cpp)
 enum : uint8_t {

@@ -792,7 +792,6 @@ void dense_select_slot(Graph &g, int slot) {
 //     workgroup's columns).
 // A pivot not above kDeadTol x the largest diagonal entry is dead: that unknown solves to 0 (the
 // same rule as the dense sweep). ~0.1 ms instead of 1.0 ms.
-constexpr int kBandMax = 4;
 template <int BW>
 __global__ __launch_bounds__(256) void k_band_inverse(LevelView C, int npad, double *__restrict__ X) {
     // LDS: one record per row, W doubles (16-byte aligned): l[0..BW-1] (l[d-1] = L(r, r-d)), then 1 / d(r)

@@ -1988,10 +1988,20 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
             };
             rc = pcg_solve_cg2(g, &tail, &tail_ran, spec);
             if (spec) {
-                if (g.h_flags()[FL_STALE])
-                    g.dense_stale_pending = true;
-                else
+                // 'stale' only says that the coarse operator moved away from the inverted one by more than
+                // `stale_spread`; what that costs is known, too: this solve just ran with it. Re-invert for
+                // the next solve only if it needed clearly more iterations than the last solve on a fresh
+                // inverse did -- an inversion is worth ~10 (banded) / ~20 (dense sweep) PCG iterations and
+                // IRLS typically has one or two solves left when the weights have settled this far.
+                if (g.h_flags()[FL_STALE]) {
+                    const int64_t slack = (g.dense_bw >= 1 && g.dense_bw <= kBandMax) ? 4 : 8;
+                    g.dense_stale_pending = rc != IROTAVG_OK || g.its_fresh <= 0 ||
+                                            g.stats.pcg_iters_last > g.its_fresh + slack;
+                } else {
                     g.dense_scale = g.h_scal()[SC_DSCALE];
+                }
+            } else if (rc == IROTAVG_OK && g.ndense > 0) {
+                g.its_fresh = g.stats.pcg_iters_last;
             }
             if (rc == IROTAVG_RETRY_STALE) {
                 // the verdict was 'stale' AND the solve did not converge in the predicted number of
@@ -2003,6 +2013,7 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                 IRH_CHECK(hipMemcpyAsync(g.levels[0].b.p, g.levels[0].x.p, sizeof(double4) * (size_t)g.levels[0].n,
                                          hipMemcpyDeviceToDevice, g.stream));
                 rc = pcg_solve_cg2(g, &tail, &tail_ran, false);
+                if (rc == IROTAVG_OK) g.its_fresh = g.stats.pcg_iters_last;
             }
             if (rc != IROTAVG_OK) break;
             if (tail_ran) {
