@@ -423,8 +423,9 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
             g.slot_eid.upload(seid, s);
             // k_assemble0w: per slice, the first edge of the run it stages in LDS = the lowest edge id
             // among the slice's near entries (a view sequence: the edges of the slice's first view)
+            g.asm_windowed = getenv("IROTAVG_ASM_CLASSIC") ? 0 : 1;
             std::vector<int> te0((size_t)M.nsl, 0);
-            parallel_for(M.nsl, 256, [&](int64_t s0, int64_t s1, int) {
+            if (g.asm_windowed) parallel_for(M.nsl, 256, [&](int64_t s0, int64_t s1, int) {
                 for (int sl = (int)s0; sl < (int)s1; sl++) {
                     uint32_t lo = 0xffffffffu;
                     for (int r = sl * 64; r < std::min(h.n, sl * 64 + 64); r++)
@@ -434,7 +435,6 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
                 }
             });
             g.tile_e0.upload(te0, s);
-            g.asm_windowed = getenv("IROTAVG_ASM_CLASSIC") ? 0 : 1;
             g.asm_l1_fused = 0;
             if (H.size() < 2) {  // no level 1: the kernel still reads a (dummy) level-1 index per pair
                 std::vector<uint8_t> cs((size_t)M.len, 255);
@@ -456,7 +456,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
             L.crow.upload(h.rowptr, s);
             L.max_row = 0;
             for (int r = 0; r < h.n; r++) L.max_row = std::max(L.max_row, h.rowptr[r + 1] - h.rowptr[r]);
-            if (lev == 1) {
+            if (lev == 1 && g.asm_windowed) {
                 // level-1 entry index of every level-0 SELL position (k_assemble0w sums level 1 on the way
                 // when level 0 aggregates by 8 and no level-1 row has more than 8 entries)
                 std::vector<uint8_t> cs((size_t)prev.len, 255);
