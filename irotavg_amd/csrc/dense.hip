@@ -72,6 +72,44 @@ __device__ __forceinline__ void gj_invert32(double (&d)[GJB], int l, double thr)
     for (int j = 0; j < GJB; j++) d[j] *= sc;
 }
 
+// The same inversion with TWO lanes per row and the pivot data broadcast through LDS: lane l + 32 h
+// (l = row, h = 0 / 1) holds columns [16 h, 16 h + 16) of row l. Per pivot k the two lanes of row k
+// publish their halves of the pivot row, the 32 lanes that own column k publish a(r, k), and after one
+// wave-local LDS round trip every lane has its row's multiplier and its half of the pivot row: 16 fma
+// per pivot instead of 32 and no v_readlane (two per fma above; they, not the fma, set the 13 us).
+// Row k is scaled by the same fma as the others (multiplier (p - 1) / p: a_kj - ((p - 1) / p) a_kj =
+// a_kj / p), so the wave never diverges; column k is patched afterwards by its owners. LDS operations of a
+// wave execute in order, so one buffer serves every pivot. `buf`: 64 doubles.
+__device__ __forceinline__ void gj_invert32_split(double (&d)[GJB / 2], int l, int h, double thr,
+                                                  double *buf) {
+    double *rowb = buf, *colb = buf + GJB;
+#pragma unroll
+    for (int k = 0; k < GJB; k++) {
+        constexpr int HALF = GJB / 2;
+        const int hk = k / HALF, jk = k % HALF;
+        if (h == hk) colb[l] = d[jk];
+        if (l == k) {
+#pragma unroll
+            for (int j = 0; j < HALF; j++) rowb[HALF * h + j] = d[j];
+        }
+        asm volatile("" ::: "memory");  // the wave's LDS operations execute in order: a compiler fence is enough
+        __builtin_amdgcn_wave_barrier();
+        const double ark = colb[l];
+        const double piv = rowb[k];
+        double pr[HALF];
+#pragma unroll
+        for (int j = 0; j < HALF; j++) pr[j] = rowb[HALF * h + j];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const double ip = (piv > thr && piv > 0.0) ? rcp_newton(piv) : 0.0;
+        const bool me = l == k;
+        const double m = me ? (ip != 0.0 ? (piv - 1.0) * ip : 1.0) : ark * ip;
+#pragma unroll
+        for (int j = 0; j < HALF; j++) d[j] = fma(-m, pr[j], d[j]);
+        if (h == hk) d[jk] = me ? ip : -(ark * ip);
+    }
+}
+
 // E (npad x npad, row-major, zeroed beforehand) from the SELL level: E = diag + offdiag;
 // identity on the padding rows. One lane per row: a row's entries are written by its owner only.
 __global__ __launch_bounds__(kRowBlock) void k_dense_build(LevelView C, int npad,
@@ -227,6 +265,7 @@ __global__ __launch_bounds__(GJ_LA_THREADS, 4) void k_gj_update_la(
     __shared__ double Cs[GJT][GJB + 1];
     __shared__ double Rs[GJB][GJT + 4];   // Rt_k chunk; later the updated rows of block k+1
     __shared__ double Dv[GJB][GJB + 1];   // Rt_k[:, cols k+1], then D', then D'^-1
+    __shared__ double Pv[2 * GJB];        // pivot row / pivot column of the inversion in flight
     const int nt = npad / GJT;
     const int k1 = k0 + GJB, k2 = k0 + 2 * GJB;  // first row/column of blocks k+1, k+2
     const int tn = k1 / GJT;                     // tile index of block k+1 (rows and columns)
@@ -329,17 +368,15 @@ __global__ __launch_bounds__(GJ_LA_THREADS, 4) void k_gj_update_la(
         }
         __syncthreads();
     }
-    if (inverter) {  // invert D' in registers (gj_invert32)
-        const int l = tid & 31;  // lanes 32..63 mirror lanes 0..31 (keeps the wave uniform)
-        double d[GJB];
+    if (inverter) {  // invert D' in registers, two lanes per row (gj_invert32_split)
+        const int l = tid & 31, h = (tid >> 5) & 1;
+        double d[GJB / 2];
 #pragma unroll
-        for (int j = 0; j < GJB; j++) d[j] = Dv[l][j];
-        gj_invert32(d, l, kDeadTol * maxdiag[0]);
+        for (int j = 0; j < GJB / 2; j++) d[j] = Dv[l][GJB / 2 * h + j];
+        gj_invert32_split(d, l, h, kDeadTol * maxdiag[0], Pv);
         __syncthreads();  // (1) the update waves are done with the Rt_k chunk in Rs
-        if ((tid & 63) < GJB) {
 #pragma unroll
-            for (int j = 0; j < GJB; j++) Dv[l][j] = d[j];
-        }
+        for (int j = 0; j < GJB / 2; j++) Dv[l][GJB / 2 * h + j] = d[j];
     } else {
         double acc[4][4];
 #pragma unroll

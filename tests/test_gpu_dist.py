@@ -31,7 +31,7 @@ def test_loopback_sharded_equals_unsharded(world, p_loop):
         Qb, wb = D.get_rotations(into=Q0), D.get_weights()
         st = D.stats()
     assert a["iters"] == b["iters"]
-    np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-6)
+    np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-6, atol=1e-9)  # rad; the last score is ~1e-5
     assert synth.angular_distance(Qa, Qb).max() < 1e-8
     assert not np.isnan(wb).any()                      # every edge belongs to some shard
     np.testing.assert_allclose(wa, wb, rtol=1e-6)
