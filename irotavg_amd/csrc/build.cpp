@@ -291,7 +291,17 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         });
         band0 = !far;
     }
-    while ((int)H.size() < max_levels && H.back().n > g.opt.mg_dense_max) {
+    // A dense level of more than ~1500 rows costs more per PCG iteration (its 8 n^2-byte apply) than a third
+    // level with the two-launch iteration saves: a band graph of >= 18 edges per view whose level 1 has
+    // 1536..2048 rows coarsens once more (16k views / 320k edges: 348 -> 557 M edge-updates/s; at 15 edges per
+    // view the extra iterations of three levels eat the gain, at 4 they double)
+    const bool tune = getenv("IROTAVG_NO_SMALL_TUNING") == nullptr;
+    auto go_on = [&]() {
+        if (H.back().n > g.opt.mg_dense_max) return true;
+        return tune && band0 && H.size() == 2 && H.back().n >= 1536 && (H.back().n + 7) / 8 >= 64 &&
+               H[0].rowptr[H[0].n] >= 36ll * H[0].n;
+    };
+    while ((int)H.size() < max_levels && go_on()) {
         HostLevel &F = H.back();
         const int64_t fnnz = F.rowptr[F.n];
         // aggregate = `agg` contiguous rows, a power of two <= 64 so it never straddles a slice
@@ -302,7 +312,10 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
             // do not overshoot the dense level: the smallest factor that reaches it -- except on level 1
             // of a graph that can take the two-launch iteration (see band0 above)
             const bool keep8 = band0 && H.size() == 2 && (F.n + 7) / 8 >= 64;
-            for (int s2 = 2; s2 < agg && !keep8; s2 *= 2)
+            // ... and on level 0 when aggregates of 8 still leave >= 512 dense rows (5k views: 625 dense rows
+            // instead of 1250: 125 -> 157 M)
+            const bool keep8_0 = tune && H.size() == 1 && (F.n + 7) / 8 >= 512;
+            for (int s2 = 2; s2 < agg && !keep8 && !keep8_0; s2 *= 2)
                 if ((F.n + s2 - 1) / s2 <= g.opt.mg_dense_max) {
                     agg = s2;
                     break;
