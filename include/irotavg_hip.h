@@ -54,7 +54,9 @@ typedef struct irotavg_options {
                             that reaches the dense level) */
     int mg_agg;          /* aggregate size of the other levels (0 = choose; default) */
     int mg_dense_max;    /* coarsening stops at <= this many rows; that level is inverted densely
-                            (blocked Gauss-Jordan on the GPU) and applied exactly; default and cap 2048 */
+                            (blocked Gauss-Jordan on the GPU) and applied exactly; cap 2048;
+                            0 (default) = chosen from the graph: 2048, or 1100 for a graph with
+                            loop closures and <= 70k views (the sweep runs in most IRLS iterations) */
     double mg_omega;     /* damped-Jacobi factor; default 0.7 */
     double mg_kc;        /* coarse-correction scale (over-correction of the piecewise-constant aggregates);
                             0 (default) = choose: 2.0 for a graph without loop closures, 1.6 otherwise */

@@ -271,6 +271,27 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     H[0].rowptr = std::move(rowptr);
     H[0].col = std::move(col);
     const int max_levels = std::max(1, std::min(g.opt.mg_levels_max, (int)kMaxLevels));
+    const bool tune = getenv("IROTAVG_NO_SMALL_TUNING") == nullptr;
+    if (g.opt.mg_dense_max <= 0) {
+        // The dense level is re-inverted whenever the weights move non-uniformly. For a band graph that is the
+        // cheap banded inverse and rare; with loop closures it is the full Gauss-Jordan sweep (n/32 block
+        // steps of ~21 us) in almost every IRLS iteration, and up to ~70k views a level of 550..1100 rows
+        // behind an aggregation factor of 16..64 costs 2-5 more PCG iterations but half the sweep
+        // (10k/150k: 5.9 -> 4.7 ms, 16k: 9.1 -> 6.0 ms, 30k: 11.5 -> 8.5 ms per irls call; at 100k views the
+        // factor would be 128 and the iterations double: 2048 stays)
+        std::atomic<bool> far(false);
+        const HostLevel &h0 = H[0];
+        if (tune && h0.n <= 70400)
+            parallel_for(h0.n, 4096, [&](int64_t r0, int64_t r1, int) {
+                for (int r = (int)r0; r < (int)r1 && !far; r++)
+                    for (int t = h0.rowptr[r]; t < h0.rowptr[r + 1]; t++)
+                        if (h0.col[t] < r - kWinHalo || h0.col[t] > r + kWinHalo) {
+                            far = true;
+                            break;
+                        }
+            });
+        g.opt.mg_dense_max = far ? 1100 : 2048;
+    }
     // A graph without far (loop-closure) entries on one GPU can run its PCG iteration as two launches
     // (cgcg.hip), which needs aggregates of 8 on levels 0 AND 1. The rule below would stop level 1 short
     // (aggregates of 2 or 4 that just reach the dense level: 20k views -> 2500 -> 1250) and leave such a
@@ -295,7 +316,6 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     // level with the two-launch iteration saves: a band graph of >= 18 edges per view whose level 1 has
     // 1536..2048 rows coarsens once more (16k views / 320k edges: 348 -> 557 M edge-updates/s; at 15 edges per
     // view the extra iterations of three levels eat the gain, at 4 they double)
-    const bool tune = getenv("IROTAVG_NO_SMALL_TUNING") == nullptr;
     auto go_on = [&]() {
         if (H.back().n > g.opt.mg_dense_max) return true;
         return tune && band0 && H.size() == 2 && H.back().n >= 1536 && (H.back().n + 7) / 8 >= 64 &&
@@ -321,6 +341,11 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
                     break;
                 }
         }
+        // loop-closure graphs (dense level capped at 1100 above): two levels with aggregates of 16 beat three
+        // with 8 x 2 by ~5 % where both reach the cap (8.8k-17.6k views)
+        if (tune && H.size() == 1 && g.opt.mg_agg0 <= 0 && g.opt.mg_dense_max == 1100 && (F.n + 7) / 8 > 1100 &&
+            (F.n + 15) / 16 <= 1100)
+            agg = 16;
         agg = std::min(pow2floor(std::max(agg, 2)), 64);
         F.agg = agg;
         HostLevel C;

@@ -58,7 +58,7 @@ void irotavg_default_options(irotavg_options *o) {
     o->mg_levels_max = 16;
     o->mg_agg0 = 0;
     o->mg_agg = 0;
-    o->mg_dense_max = 2048;
+    o->mg_dense_max = 0;  // choose from the graph structure (build.cpp): 2048, or 1100 with loop closures
     o->mg_omega = 0.7;
     o->mg_kc = 0.0;  // choose from the graph structure (build.cpp)
     o->device = -1;
@@ -192,7 +192,6 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
         irotavg_default_options(&g.opt);
     if (g.opt.pcg_rtol <= 0) g.opt.pcg_rtol = 1e-10;
     if (g.opt.mg_omega <= 0) g.opt.mg_omega = 0.7;
-    if (g.opt.mg_dense_max <= 0) g.opt.mg_dense_max = 2048;
     if (g.opt.mg_levels_max <= 0) g.opt.mg_levels_max = 16;
     if (g.opt.pcg_max_iters <= 0) g.opt.pcg_max_iters = 2000;
     if (g.opt.pcg_check_every <= 0) g.opt.pcg_check_every = 8;
