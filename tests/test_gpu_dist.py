@@ -104,3 +104,27 @@ def test_loopback_sharded_l1ra_then_irls_equals_unsharded(world, p_loop):
     assert synth.angular_distance(Q1, Qb1).max() < 1e-8
     assert synth.angular_distance(Qa, Qb).max() < 1e-8
     np.testing.assert_allclose(wa, wb, rtol=1e-6)
+
+
+@pytest.mark.parametrize("p_loop", [0.0, 0.02])
+def test_config4_size_eight_shards_match_the_oracle_checked_handle(p_loop):
+    """BASELINE config 4's workload (the 100k-view / 2M-edge graph in 8 vertex-range shards), all shards on
+    the one GPU of a test box (loopback transport): same IRLS iteration count, scores, rotations and weights
+    as the unsharded handle, which tests/test_gpu_fullsize.py checks against the oracle on this very graph
+    (full IRLS for p_loop = 0, normal-equation residual by the oracle's mat-vec for 0.02)."""
+    n, m = 100000, 2000000
+    S, Q0 = problem(n, m, p_loop, 1)
+    with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+        G.set_rotations(Q0)
+        a = G.irls(4, SIG, 100, 1e-3)
+        Qa, wa = G.get_rotations(), G.get_weights()
+    with capi.DistGraph(S["I"], S["QQ"], n, 1, 8) as D:
+        D.set_rotations(Q0)
+        b = D.irls(4, SIG, 100, 1e-3)
+        Qb, wb = D.get_rotations(into=Q0.copy()), D.get_weights()
+        st = D.stats()
+    assert a["iters"] == b["iters"]
+    np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-6, atol=1e-9)
+    assert synth.angular_distance(Qa, Qb).max() < 1e-7
+    np.testing.assert_allclose(wa, wb, rtol=1e-5, atol=1e-9)
+    assert st["pcg_iters"] > 0
