@@ -49,6 +49,7 @@ struct Graph {
     int dense32 = 0;            // 1: k_cg_apply reads an fp32 copy of the inverse (IROTAVG_CG2_FP32_DENSE=1; measured
                                 // 2-3 % faster, not worth a preconditioner whose definiteness rests on fp32 rounding)
     DevBuf<double> dense_wr, dense_wc;  // Gauss-Jordan panels (32 x npad, npad x 32), two of each
+    DevBuf<double> dense_chol;          // scratch of dense_direct_solve: the operator twice (factor, copy)
     DevBuf<double> dense_wb;            // scratch of the low-rank repair (Z, W, S, S^-1, entry list)
     int dense_repairs_in_a_row = 0;     // since the last full inversion
     DevBuf<double> dense_la;            // look-ahead: two snapshots of upcoming 32 x 32 diagonal blocks
@@ -199,6 +200,7 @@ bool window_fits_wave(int nv, int f, int ne);
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);
 bool dense_is_stale(Graph &g, bool allow_repair = false);
+bool dense_direct_solve(Graph &g);  // last resort of a single-level graph: Cholesky solve of levels[0].b -> X
 void dense_check_async(Graph &g);  // same test, decision on the device (scal[SC_DSCALE], flags[FL_STALE])
 int dense_apply_grid(const Graph &g);
 void dense_apply(Graph &g, const double4 *b, double4 *y, bool check, bool dot, double *part_dot,

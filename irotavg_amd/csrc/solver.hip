@@ -1922,7 +1922,24 @@ int pcg_solve_classic(Graph &g) {
 // when the change is a nearly uniform factor. Depends on data only (deterministic).
 int ls_solve(Graph &g) {
     assemble(g, 0, g.dw.p, g.opt.dense_always_refresh == 1);
-    const int rc = pcg_solve(g);
+    int rc = pcg_solve(g);
+    auto failed = [&]() { return rc == IROTAVG_ERR_NOT_CONVERGED || rc == IROTAVG_ERR_SOLVER; };
+    // The reference's direct solvers always return an answer. Two more attempts before an error code:
+    // (1) the solve ran on a re-used or repaired coarse inverse: re-invert and solve again (a repaired inverse
+    //     is exact only up to the `stale_spread` band on the entries it did not touch -- enough to stall an
+    //     ill-conditioned solve: fuzz seed 31 case 511);
+    // (2) a single small level: the backward-stable Cholesky solve (dense.hip, k_chol_solve).
+    if (failed() && g.ndense > 0 && !g.dense_fresh) {
+        assemble(g, 0, g.dw.p, true);
+        rc = pcg_solve(g);
+    }
+    if (failed()) {
+        assemble_values(g, 0, g.dw.p);  // the right-hand side again (the PCG consumed it)
+        if (dense_direct_solve(g)) {
+            g.stats.pcg_stagnated += 1;  // a solve accepted outside the PCG's own criterion
+            rc = IROTAVG_OK;
+        }
+    }
     return rc;
 }
 
