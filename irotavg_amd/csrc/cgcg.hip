@@ -45,28 +45,40 @@ constexpr int kL1Pre = 8;   // entries of a level-1 row requested up front (a ba
 // ---------------------------------------------------------------------------------------------
 // every thread obtains the fixed-order sums of TWO partial arrays in one pass (one round trip to memory
 // and one pair of barriers instead of two: this sits at the head of k_cg_update's dependency chain)
-__device__ __forceinline__ void load_reduced3x2(const double *pa, const double *pb, int nparts, double a[3],
-                                                double b[3]) {
-    __shared__ double sm[6][4];
+struct Part3x2 {
+    double v[6];
+};
+// the loads (issued with the kernel's other loads, at the top) ...
+__device__ __forceinline__ Part3x2 load_parts3x2(const double *pa, const double *pb, int nparts) {
+    Part3x2 P;
+#pragma unroll
+    for (int c = 0; c < 6; c++) P.v[c] = 0.0;
     const int t = threadIdx.x;
     if (t < 256) {
-        double v[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int q = t + 256 * h;
             if (q < nparts) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    v[c] += pa[4 * q + c];
-                    v[3 + c] += pb[4 * q + c];
+                    P.v[c] += pa[4 * q + c];
+                    P.v[3 + c] += pb[4 * q + c];
                 }
             }
         }
+    }
+    return P;
+}
+// ... and the fixed-order reduction, where the scalars are needed
+__device__ __forceinline__ void reduce_parts3x2(Part3x2 P, double a[3], double b[3]) {
+    __shared__ double sm[6][4];
+    const int t = threadIdx.x;
+    if (t < 256) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) v[c] = wave_sum(v[c]);
+        for (int c = 0; c < 6; c++) P.v[c] = wave_sum(P.v[c]);
         if ((t & 63) == 0) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) sm[c][t >> 6] = v[c];
+            for (int c = 0; c < 6; c++) sm[c][t >> 6] = P.v[c];
         }
     }
     __syncthreads();
@@ -135,11 +147,13 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
         l1v[k] = L1.val[pos];
         l1c[k] = L1.col[pos];
     }
+    Part3x2 parts;
+    if (MODE != 0) parts = load_parts3x2(part_g, part_d, nparts);  // in flight with everything above
     if (done) return;
     double al[3] = {0, 0, 0}, be[3] = {0, 0, 0};
     if (MODE != 0) {
         double g3[3], d3[3];
-        load_reduced3x2(part_g, part_d, nparts, g3, d3);
+        reduce_parts3x2(parts, g3, d3);
         bool finite = true;
         for (int c = 0; c < 3; c++) {
             const double go = scal[(par ? SC_GAM1 : SC_GAM0) + c], ao = scal[(par ? SC_ALF1 : SC_ALF0) + c];
