@@ -22,9 +22,10 @@ struct WinParams {
     int nv, f, ne;
     int l1_max, irls_max, cost;
     double change_th, sigma;
+    int seq;  // k_window_wave stores it into WinResult::seq LAST (system scope): the host polls for it
 };
 struct WinResult {
-    int l1_iters, irls_iters, status, pad;
+    int l1_iters, irls_iters, status, seq;
     double l1_score, irls_score;
 };
 
@@ -1017,12 +1018,18 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams P, const i
     __syncthreads();
     for (int i = tid; i < nv; i += SM_THREADS) Qg[i] = sQ[i];
     if (wave == 0 && ek) weights[lane] = d;
+    // The outputs live in pinned host memory; the sequence number goes out last, after a system-scope fence
+    // of every thread: a host that sees it sees everything (window_solve polls it instead of waiting for
+    // the runtime's completion signal)
+    __threadfence_system();
+    __syncthreads();
     if (tid == 0) {
         out->l1_iters = l1_iters;
         out->irls_iters = iter;
         out->status = status;
         out->l1_score = l1_score;
         out->irls_score = score;
+        __hip_atomic_store(&out->seq, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1033,6 +1040,7 @@ struct WindowSolver {
     unsigned char *host = nullptr;   // pinned, device-visible
     unsigned char *hdev = nullptr;   // the same block as the device sees it
     size_t cap = 0;
+    int seq = 0;       // sequence number of the last wave-kernel launch
     bool attr_set = false;
     ~WindowSolver() {
         if (host) (void)hipHostFree(host);
@@ -1073,15 +1081,17 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
     if (ws.cap < total) {
         ws.dev.alloc(total);
         if (ws.host) (void)hipHostFree(ws.host);
-        IRH_CHECK(hipHostMalloc((void **)&ws.host, total, hipHostMallocMapped));
+        IRH_CHECK(hipHostMalloc((void **)&ws.host, total, hipHostMallocMapped | hipHostMallocCoherent));  // fine-grained: the kernel's stores are visible to the polling host while it runs
         IRH_CHECK(hipHostGetDevicePointer((void **)&ws.hdev, ws.host, 0));
         ws.cap = total;
     }
     std::memcpy(ws.host + oI, I, sizeof(int32_t) * 2 * (size_t)ne);
     std::memcpy(ws.host + oQQ, QQ_aos, sizeof(double) * 4 * (size_t)ne);
     std::memcpy(ws.host + oQ, Q_aos, sizeof(double) * 4 * (size_t)nv);
-    WinParams P{nv, f, ne, l1_max, irls_max, cost, change_th, sigma};
+    WinParams P{nv, f, ne, l1_max, irls_max, cost, change_th, sigma, 0};
     if (wave) {
+        P.seq = ++ws.seq == 0 ? ++ws.seq : ws.seq;  // never 0 ...
+        reinterpret_cast<WinResult *>(ws.host + oR)->seq = 0;  // ... which is what the host leaves there
         // the wave kernel touches its inputs once and its outputs once: it works directly on the
         // pinned (device-visible) staging block -- launch + synchronise, no copy commands
         hipLaunchKernelGGL(k_window_wave, dim3(1), dim3(SM_THREADS), 0, ws.stream, P,
@@ -1089,7 +1099,18 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
                            (double4 *)(ws.hdev + oQ), (double *)(ws.hdev + oW),
                            (WinResult *)(ws.hdev + oR));
         IRH_CHECK(hipGetLastError());
-        IRH_CHECK(hipStreamSynchronize(ws.stream));
+        // completion: poll the sequence number the kernel stores last into the pinned block (the runtime's
+        // own wait costs 5-10 us of a 60 us call); after 2 ms, or if the kernel died, the stream is synchronised
+        volatile int *seqp = &reinterpret_cast<WinResult *>(ws.host + oR)->seq;
+        const double t0 = now_seconds();
+        bool seen = false;
+        while (!(seen = __atomic_load_n(const_cast<int *>(seqp), __ATOMIC_ACQUIRE) == P.seq)) {
+            if (now_seconds() - t0 > 2e-3) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (!seen) IRH_CHECK(hipStreamSynchronize(ws.stream));
     } else {
         IRH_CHECK(hipMemcpyAsync(ws.dev.p, ws.host, oW, hipMemcpyHostToDevice, ws.stream));
         const size_t shm = win_lds_bytes(nv, ne, nv - f);
