@@ -17,28 +17,9 @@
 
 namespace irh {
 
-// The host phases below are loops over edges, rows or slices with independent iterations: they run
-// on up to 16 host threads (contiguous chunks; every result is independent of the thread count --
-// where a serial loop defined an order, the order is restored by sorting on the edge id).
-template <class F>
-static void parallel_for(int64_t n, int64_t min_chunk, F &&fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    int T = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, n / std::max<int64_t>(1, min_chunk)));
-    if (const char *e = getenv("IROTAVG_BUILD_THREADS")) T = std::min(16, std::max(1, atoi(e)));
-    if (T <= 1) {
-        fn((int64_t)0, n, 0);
-        return;
-    }
-    std::vector<std::thread> th;
-    const int64_t step = (n + T - 1) / T;
-    for (int t = 1; t < T; t++) {
-        const int64_t b = std::min(n, t * step), e = std::min(n, b + step);
-        if (b < e) th.emplace_back([&fn, b, e, t]() { fn(b, e, t); });
-    }
-    fn((int64_t)0, std::min(n, step), 0);
-    for (auto &x : th) x.join();
-}
-
+// parallel_for (common.hpp): the host phases below are loops over edges, rows or slices with independent
+// iterations: they run on up to 16 host threads (contiguous chunks; every result is independent of the thread
+// count -- where a serial loop defined an order, the order is restored by sorting on the edge id).
 static int pow2floor(int v) {
     int p = 1;
     while (2 * p <= v) p *= 2;

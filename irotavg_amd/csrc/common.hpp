@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/irotavg_hip.h"
@@ -363,5 +364,34 @@ struct Level {
     // multigrid work vectors (double4 with 3 active components)
     DevBuf<double4> b, x, y, e;
 };
+
+// The host phases below are loops over edges, rows or slices with independent iterations: they run
+// on up to 16 host threads (contiguous chunks; every result is independent of the thread count --
+// where a serial loop defined an order, the order is restored by sorting on the edge id).
+template <class F>
+inline void parallel_for(int64_t n, int64_t min_chunk, F &&fn) {
+    if (n < 2 * std::max<int64_t>(1, min_chunk)) {  // the common small case (sliding windows): no look-ups at all
+        fn((int64_t)0, n, 0);
+        return;
+    }
+    static const unsigned hw = std::thread::hardware_concurrency();
+    const char *fe = getenv("IROTAVG_BUILD_THREADS");  // read every time: the thread-count test changes it
+    const int forced = fe ? std::min(16, std::max(1, atoi(fe))) : 0;
+    int T = (int)std::min<int64_t>(std::max(1u, std::min(hw, 16u)), std::max<int64_t>(1, n / std::max<int64_t>(1, min_chunk)));
+    if (forced) T = forced;
+    if (T <= 1) {
+        fn((int64_t)0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t step = (n + T - 1) / T;
+    for (int t = 1; t < T; t++) {
+        const int64_t b = std::min(n, t * step), e = std::min(n, b + step);
+        if (b < e) th.emplace_back([&fn, b, e, t]() { fn(b, e, t); });
+    }
+    fn((int64_t)0, std::min(n, step), 0);
+    for (auto &x : th) x.join();
+}
+
 
 }  // namespace irh

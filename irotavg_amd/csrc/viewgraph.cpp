@@ -77,6 +77,14 @@ struct irotavg_viewgraph {
     std::vector<Mat3> pose;                      // absolute rotation per view (Pose::R)
     std::vector<char> fixed;                     // m_fixed_mask
     std::vector<int> mark;                       // rot_avg scratch: view id -> row, -1 outside a call
+    // rot_avg's work arrays, kept between calls: a global re-solve at 75k views spent 5 ms returning 25 MB to
+    // the OS on exit and as much again faulting the pages back in on the next call
+    struct Scratch {
+        std::vector<int32_t> I;
+        std::vector<double> qq, Q, QQ, Qa;
+        std::vector<int> vertices, i2v;
+        std::vector<long> off;
+    } scratch;
     // per view j: its connections to LOWER ids i < j (the only direction rot_avg walks, :1290-1300),
     // ascending i, with R_ij and its quaternion (converted once, at connect time)
     struct Conn {
@@ -188,6 +196,13 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     if (!vg || win_size <= 2) return IROTAVG_ERR_BAD_ARG;  // assert(winSize > 2) :1265
     irotavg_rotavg_info loc{};
     const bool timing = std::getenv("IROTAVG_ROTAVG_TIMING") != nullptr;
+    struct Total {
+        bool on;
+        double t0;
+        ~Total() {
+            if (on) std::fprintf(stderr, "[rot_avg] %-28s %8.3f ms\n", "total (incl. clean-up)", 1e3 * (irh::now_seconds() - t0));
+        }
+    } total{timing, irh::now_seconds()};
     double tl = irh::now_seconds();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -204,9 +219,12 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     }
     // ---- local connections (:1282-1307): for the last `win` views, edges with i < j.
     // `vertices` of the reference is a std::set<int> (ascending ids); here: a mark array + sort.
-    std::vector<int32_t> I;
-    std::vector<double> qq;  // per edge [x y z w]
-    std::vector<int> vertices;
+    std::vector<int32_t> &I = vg->scratch.I;
+    std::vector<double> &qq = vg->scratch.qq;  // per edge [x y z w]
+    std::vector<int> &vertices = vg->scratch.vertices;
+    I.clear();
+    qq.clear();
+    vertices.clear();
     std::vector<int> &v2i = vg->mark;  // -1 unseen, -2 seen, >= 0 row in Q after relabelling
     struct Unmark {  // the scratch map is persistent (O(window) work per call): restore on exit
         std::vector<int> &map;
@@ -221,16 +239,30 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
             vertices.push_back(x);
         }
     };
-    for (long t = m - win; t < m; t++) {
-        const int j = (int)t;  // frame id == view index (src/IRotAvg.cpp:280-284)
-        for (const auto &c : vg->conn[j]) {
-            I.push_back(c.i);
-            I.push_back(j);
-            touch(c.i);
-            touch(j);
-            qq.insert(qq.end(), c.q, c.q + 4);
+    // edge k of the call = the k-th connection in (view ascending, lower endpoint ascending) order: offsets
+    // first, then the views fill their runs side by side (a global re-solve walks 300k connections)
+    std::vector<long> &off = vg->scratch.off;
+    off.assign((size_t)win + 1, 0);
+    for (long t = 0; t < win; t++) off[(size_t)t + 1] = off[(size_t)t] + (long)vg->conn[(size_t)(m - win + t)].size();
+    I.resize((size_t)2 * off[(size_t)win]);
+    qq.resize((size_t)4 * off[(size_t)win]);
+    irh::parallel_for((int64_t)win, 4096, [&](int64_t a, int64_t b, int) {
+        for (int64_t t = a; t < b; t++) {
+            const int j = (int)(m - win + t);  // frame id == view index (src/IRotAvg.cpp:280-284)
+            size_t e = (size_t)off[(size_t)t];
+            for (const auto &c : vg->conn[(size_t)j]) {
+                I[2 * e] = c.i;
+                I[2 * e + 1] = j;
+                for (int q = 0; q < 4; q++) qq[4 * e + q] = c.q[q];
+                e++;
+            }
         }
-    }
+    });
+    for (long t = m - win; t < m; t++)
+        for (const auto &c : vg->conn[(size_t)t]) {
+            touch(c.i);
+            touch((int)t);
+        }
     std::sort(vertices.begin(), vertices.end());
     const long ne = (long)qq.size() / 4, nv = (long)vertices.size();
     if (ne < win) {  // :1313-1316
@@ -247,7 +279,8 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     int f = (int)nv - win;
     for (int x : vertices)
         if (x >= m - win && vg->fixed[x]) f++;
-    std::vector<int> i2v((size_t)nv);
+    std::vector<int> &i2v = vg->scratch.i2v;
+    i2v.assign((size_t)nv, 0);
     int t = 0, k = f;
     for (int x : vertices) {
         if (x >= m - win && !vg->fixed[x]) {
@@ -258,15 +291,21 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
             v2i[x] = t++;
         }
     }
-    for (auto &e : I) e = v2i[e];
+    irh::parallel_for((int64_t)I.size(), 65536, [&](int64_t a, int64_t b, int) {
+        for (int64_t q = a; q < b; q++) I[(size_t)q] = v2i[I[(size_t)q]];
+    });
     // ---- Q (:1365-1386)
-    std::vector<double> Q((size_t)4 * nv);
-    for (int x : vertices) {
-        double q[4];
-        rmat2quat(vg->pose[x].m, q);
-        const int r = v2i[x];
-        for (int c = 0; c < 4; c++) Q[(size_t)c * nv + r] = q[c];
-    }
+    std::vector<double> &Q = vg->scratch.Q;
+    Q.resize((size_t)4 * nv);  // every entry is written below
+    irh::parallel_for((int64_t)nv, 4096, [&](int64_t a, int64_t b, int) {
+        for (int64_t p = a; p < b; p++) {
+            const int x = vertices[(size_t)p];
+            double q[4];
+            rmat2quat(vg->pose[x].m, q);
+            const int r = v2i[x];
+            for (int c = 0; c < 4; c++) Q[(size_t)c * nv + r] = q[c];
+        }
+    });
     if (f == 0) {  // :1382-1386
         Q[0] = 0;
         Q[nv] = 0;
@@ -280,9 +319,12 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
         if (info) *info = loc;
         return IROTAVG_OK;
     }
-    std::vector<double> QQ((size_t)4 * ne);
-    for (long e = 0; e < ne; e++)
-        for (int c = 0; c < 4; c++) QQ[(size_t)c * ne + e] = qq[(size_t)4 * e + c];
+    std::vector<double> &QQ = vg->scratch.QQ;
+    QQ.resize((size_t)4 * ne);
+    irh::parallel_for((int64_t)ne, 32768, [&](int64_t a, int64_t b, int) {
+        for (int64_t e = a; e < b; e++)
+            for (int c = 0; c < 4; c++) QQ[(size_t)c * ne + e] = qq[(size_t)4 * e + c];
+    });
     lap("window extraction + packing");
     // ---- solve (:1396-1417): no init_mst (refine from the current poses); l1ra 100 iterations,
     // then irls Geman-McClure, sigma 5 deg, 100 iterations, change_th 1e-3
@@ -293,7 +335,8 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
         if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
         try {
             if (!vg->win) vg->win = irh::window_solver_new();
-            std::vector<double> Qa((size_t)4 * nv);
+            std::vector<double> &Qa = vg->scratch.Qa;
+            Qa.resize((size_t)4 * nv);
             for (long r = 0; r < nv; r++)
                 for (int c = 0; c < 4; c++) Qa[(size_t)4 * r + c] = Q[(size_t)c * nv + r];
             const double t0 = irh::now_seconds();
