@@ -244,6 +244,16 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     std::vector<long> &off = vg->scratch.off;
     off.assign((size_t)win + 1, 0);
     for (long t = 0; t < win; t++) off[(size_t)t + 1] = off[(size_t)t] + (long)vg->conn[(size_t)(m - win + t)].size();
+    // a stream's global re-solves grow from call to call: half as much again, so that most calls find room
+    auto room = [](auto &v, size_t need) {
+        if (v.capacity() < need) v.reserve(need + need / 2);
+    };
+    room(I, (size_t)2 * off[(size_t)win]);
+    room(qq, (size_t)4 * off[(size_t)win]);
+    room(vg->scratch.QQ, (size_t)4 * off[(size_t)win]);
+    room(vertices, (size_t)std::min<long>(m, 2 * off[(size_t)win]));
+    room(vg->scratch.i2v, (size_t)std::min<long>(m, 2 * off[(size_t)win]));
+    room(vg->scratch.Q, (size_t)4 * std::min<long>(m, 2 * off[(size_t)win]));
     I.resize((size_t)2 * off[(size_t)win]);
     qq.resize((size_t)4 * off[(size_t)win]);
     irh::parallel_for((int64_t)win, 4096, [&](int64_t a, int64_t b, int) {
