@@ -13,6 +13,11 @@
 // i.e. a panel (Rt and a copy of C) and a rank-32 update per step. The update kernel of step k also
 // produces the panel of step k+1 (look-ahead, k_gj_update_la): the serial 32 x 32 inversion then
 // overlaps the bandwidth-bound bulk of the update -- one launch per step instead of two.
+//
+// Also here: the banded inverse of a coarsest operator without loop closures (k_band_inverse), the
+// low-rank repair of an inverse whose operator changed in a few long-range entries (dense_lowrank_repair),
+// the staleness tests (dense_is_stale, dense_check_async) and the last resort of a small single-level
+// system whose explicit inverse has lost its accuracy (k_chol_solve).
 #include <algorithm>
 #include <cmath>
 #include <vector>
