@@ -9,6 +9,10 @@
 #include <map>
 #include <mutex>
 #include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/irotavg_hip.h"
@@ -365,7 +369,85 @@ struct Level {
     DevBuf<double4> b, x, y, e;
 };
 
-// The host phases below are loops over edges, rows or slices with independent iterations: they run
+// Worker threads for the host phases of the graph build and of rot_avg. Spawning and joining 15 threads
+// costs 0.34 ms on the GPU box's host, a build has ~17 such loops and a global re-solve in a stream runs one
+// every few hundred frames: 15 persistent workers take a job through one mutex / condition variable, spin
+// briefly between jobs (the loops of a build follow each other within microseconds) and otherwise sleep.
+// One job at a time (a second caller, e.g. one of l1ra's host threads, spawns threads as before); a process
+// forked after the pool was created does the same (the workers do not exist in the child). The pool is never
+// destroyed: its threads are detached and end with the process.
+class HostPool {
+public:
+    static constexpr int kWorkers = 15;
+    static HostPool &get() {
+        static HostPool *p = new HostPool();
+        return *p;
+    }
+    // fn(t) for t = 1 .. T-1 on the workers and fn(0) on the caller; false if the pool is busy or unusable
+    template <class F>
+    bool run(int T, F &&fn) {
+        if (T - 1 > kWorkers || getpid() != pid_) return false;
+        std::unique_lock<std::mutex> one(busy_, std::try_to_lock);
+        if (!one.owns_lock()) return false;
+        std::function<void(int)> job = [&fn](int t) { fn(t); };
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &job;
+            want_ = T - 1;
+            remaining_.store(T - 1, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        fn(0);
+        for (int spin = 0; remaining_.load(std::memory_order_acquire) != 0; spin++) {
+            if (spin > 2000) std::this_thread::yield();
+        }
+        return true;
+    }
+
+private:
+    HostPool() : pid_(getpid()) {
+        for (int w = 0; w < kWorkers; w++) std::thread([this, w] { loop(w); }).detach();
+    }
+    void loop(int w) {
+        unsigned seen = 0;
+        for (;;) {
+            // spin for a while, then sleep on the condition variable
+            bool got = false;
+            for (int spin = 0; spin < 20000; spin++) {
+                if (gen_.load(std::memory_order_acquire) != seen) {
+                    got = true;
+                    break;
+                }
+            }
+            if (!got) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+            }
+            const std::function<void(int)> *job;
+            int want;
+            {
+                std::lock_guard<std::mutex> lk(m_);  // job_ / want_ are published under the mutex
+                seen = gen_.load(std::memory_order_acquire);
+                job = job_;
+                want = want_;
+            }
+            if (w < want) {
+                (*job)(w + 1);
+                remaining_.fetch_sub(1, std::memory_order_release);
+            }
+        }
+    }
+    const pid_t pid_;
+    std::mutex m_, busy_;
+    std::condition_variable cv_;
+    std::atomic<unsigned> gen_{0};
+    std::atomic<int> remaining_{0};
+    const std::function<void(int)> *job_ = nullptr;
+    int want_ = 0;
+};
+
+// The host phases of the build are loops over edges, rows or slices with independent iterations: they run
 // on up to 16 host threads (contiguous chunks; every result is independent of the thread count --
 // where a serial loop defined an order, the order is restored by sorting on the edge id).
 template <class F>
@@ -383,13 +465,15 @@ inline void parallel_for(int64_t n, int64_t min_chunk, F &&fn) {
         fn((int64_t)0, n, 0);
         return;
     }
-    std::vector<std::thread> th;
     const int64_t step = (n + T - 1) / T;
-    for (int t = 1; t < T; t++) {
+    auto chunk = [&](int t) {
         const int64_t b = std::min(n, t * step), e = std::min(n, b + step);
-        if (b < e) th.emplace_back([&fn, b, e, t]() { fn(b, e, t); });
-    }
-    fn((int64_t)0, std::min(n, step), 0);
+        if (b < e) fn(b, e, t);
+    };
+    if (!getenv("IROTAVG_NO_HOST_POOL") && HostPool::get().run(T, chunk)) return;
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back([&chunk, t]() { chunk(t); });
+    chunk(0);
     for (auto &x : th) x.join();
 }
 
