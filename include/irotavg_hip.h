@@ -35,7 +35,9 @@ extern "C" {
 #define IROTAVG_ERR_NOMEM (-5)
 #define IROTAVG_ERR_HIP (-6)
 #define IROTAVG_ERR_NO_DEVICE (-7)
-#define IROTAVG_ERR_NOT_CONVERGED (-8) /* inner PCG hit its iteration cap */
+#define IROTAVG_ERR_NOT_CONVERGED (-8) /* inner PCG hit its iteration cap -- after irls has re-inverted a re-used
+                                          coarse inverse and, on a single level of <= 1024 views, tried the dense
+                                          Cholesky solve; the iterate reached so far is left in place */
 
 /* ral/l1_irls.hpp:56-57 -- the integer values are ABI */
 enum irotavg_cost {
