@@ -294,3 +294,30 @@ def test_windowed_assembly_matches_the_three_launch_form(n, m, f, p, monkeypatch
     assert out[0][1:3] == out[1][1:3]
     assert synth.angular_distance(out[0][3], out[1][3]).max() < 1e-9
     np.testing.assert_allclose(out[0][4], out[1][4], rtol=1e-7)
+
+
+@pytest.mark.parametrize("n,deg,p", [(4200, 15, 0.01), (12500, 20, 0.0), (16000, 15, 0.01), (30000, 20, 0.01)])
+def test_result_does_not_depend_on_the_hierarchy_rules(n, deg, p, monkeypatch):
+    """build.cpp picks the multigrid hierarchy from the graph (dense level of <= 1100 rows with loop closures,
+    aggregates of 8 / 16 on small graphs, a third level behind a 1536-2048 row level 1): a preconditioner
+    choice -- l1ra + irls must give the same iteration counts, rotations and weights with the rules switched
+    off (IROTAVG_NO_SMALL_TUNING=1)."""
+    S = synth.make_graph(n, n * deg, p, seed=1)
+    Q0 = np.zeros((n, 4)); Q0[:, 3] = 1; Q0[:2] = S["Qgt"][:2]
+    ral.init_mst(Q0, S["QQ"], S["I"], 2)
+    out = []
+    for off in (True, False):
+        if off:
+            monkeypatch.setenv("IROTAVG_NO_SMALL_TUNING", "1")
+        else:
+            monkeypatch.delenv("IROTAVG_NO_SMALL_TUNING")
+        with capi.Graph(S["I"], S["QQ"], n, 2) as G:
+            G.set_rotations(Q0)
+            a = G.l1ra(2, 1e-3)
+            b = G.irls(4, SIG, 100, 1e-3)
+            st = G.stats()
+            out.append((a["iters"], b["iters"], G.get_rotations(), G.get_weights(), st["level_rows"][:st["levels"]]))
+    assert out[0][4] != out[1][4]                      # the rules did change the hierarchy
+    assert out[0][:2] == out[1][:2]
+    assert synth.angular_distance(out[0][2], out[1][2]).max() < 1e-9
+    np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-8)
