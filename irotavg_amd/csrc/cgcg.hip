@@ -104,8 +104,11 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
     double4 *__restrict__ Sout, double4 *__restrict__ P, const double4 *__restrict__ U,
     const double4 *__restrict__ W, LevelView L1, int uw1, double4 *__restrict__ b1, double4 *__restrict__ x1,
     double4 *__restrict__ b2, double4 *__restrict__ x2, const double *__restrict__ idg2, double omega,
-    double *__restrict__ part_rr, int *__restrict__ flags, double *__restrict__ b2p, int ndpad) {
-    const int done = flags[FL_DONE];
+    double *__restrict__ part_rr, int *__restrict__ flags, double *__restrict__ b2p, int ndpad,
+    double4 *__restrict__ bsave) {
+    // MODE 0 starts a solve: it does not look at the done flag of the previous one, it clears it (and the
+    // iteration counter), and it leaves a copy of the right-hand side in `bsave` -- a memset and a copy command less
+    const int done = MODE == 0 ? 0 : flags[FL_DONE];
     __shared__ double wb[3][kL1Win], wxv[3][kL1Win];
     int s0, ns;
     slice_range(nsl, s0, ns);
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
             if (u == uo && has_own) {  // own row: p, s, x, r and ||r||^2
                 if (MODE == 0) {
                     X[i] = make_double4(0, 0, 0, 0);
+                    if (bsave != nullptr) bsave[i] = r;
                 } else {
                     double4 p = vu;
                     if (MODE == 2) {
@@ -279,7 +283,14 @@ __global__ __launch_bounds__(kRowBlock, 2) void k_cg_update(
         }
     }
     block_sum3_store(a0, a1, a2, part_rr + 4 * blockIdx.x);
-    if (MODE != 0 && blockIdx.x == 0 && tid == 0) flags[FL_ITERS] += 1;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (MODE == 0) {
+            flags[FL_DONE] = 0;
+            flags[FL_ITERS] = 0;
+        } else {
+            flags[FL_ITERS] += 1;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -646,7 +657,7 @@ void cg2_launch_update(Graph &g, int mode, int par, int rcur) {
                        par, g.part_rz.p, g.part_pq.p, grid, g.X.p, B.R[rcur], B.R[rcur ^ 1], B.S[rcur],      \
                        B.S[rcur ^ 1], B.P, B.U, B.W, view_of(L1), L1.uni_w, L1.b.p, L1.x.p, L2.b.p, L2.x.p,  \
                        L2.idg.p, g.opt.mg_omega, g.part_rr.p, g.flags.p,                                     \
-                       g.levels.size() == 3 ? g.b2p.p : (double *)nullptr, g.ndense_pad)
+                       g.levels.size() == 3 ? g.b2p.p : (double *)nullptr, g.ndense_pad, L0.x.p)
     if (mode == 0)
         CG_UPD(0);
     else if (mode == 1)
@@ -730,12 +741,9 @@ int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran, b
     if (tail_ran) *tail_ran = false;
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     if (g.levels.size() == 3) cg2_refresh_inv32(g);
-    IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * 2, g.stream));  // FL_DONE, FL_ITERS (not FL_STALE)
-    // the right-hand side is consumed (the residual ping-pongs through its buffer): keep a copy -- a
-    // speculative solve may be handed back (run_irls), and a system on which the Chronopoulos-Gear
-    // recurrences stall is solved again by the classic ones (3 MB, ~3 us)
-    IRH_CHECK(hipMemcpyAsync(g.levels[0].x.p, g.levels[0].b.p, sizeof(double4) * (size_t)g.levels[0].n,
-                             hipMemcpyDeviceToDevice, g.stream));
+    // k_cg_update<0> clears FL_DONE / FL_ITERS (not FL_STALE) and keeps a copy of the right-hand side in
+    // levels[0].x (the residual ping-pongs through its buffer): a speculative solve may be handed back
+    // (run_irls), and a system on which the Chronopoulos-Gear recurrences stall is solved again by the classic ones
     int rcur = 0;  // which of the two r / s buffers is current
     cg2_launch_update(g, 0, 0, rcur);
     rcur ^= 1;
