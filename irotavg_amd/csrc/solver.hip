@@ -503,16 +503,38 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_level(LevelView C, const i
                                                             const double *__restrict__ fval, double *__restrict__ cval,
                                                             int nf, int agg, const double *__restrict__ fexcess,
                                                             double *__restrict__ cexcess, double *__restrict__ cdiag,
-                                                            double *__restrict__ cidg) {
+                                                            double *__restrict__ cidg, const double *__restrict__ refv,
+                                                            const double *__restrict__ refd, double spread,
+                                                            unsigned long long *__restrict__ mm,
+                                                            double *__restrict__ scal, int *__restrict__ flags) {
     const int I = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7;
     const bool live = I < C.n;
+    // refv != nullptr: this is the dense level and the caller wants the staleness verdict on its inverse (what
+    // k_stale_check computes in a launch of its own): ratios new / reference of every entry and diagonal
+    double lo = HUGE_VAL, hi = 0.0;
+    auto visit = [&](double v, double r) {
+        if (r != 0.0 && v != 0.0) {
+            const double q = v / r;
+            if (q > 0.0) {
+                lo = fmin(lo, q);
+                hi = fmax(hi, q);
+            } else {
+                hi = HUGE_VAL;
+            }
+        } else if ((r != 0.0) != (v != 0.0)) {
+            hi = HUGE_VAL;  // an entry appeared or vanished
+        }
+    };
     double sv = 0.0;
     if (live) {
         for (int c = crow[I]; c < crow[I + 1]; c++) {
             double s = 0.0;
             for (int q = cptr[c] + l; q < cptr[c + 1]; q += 8) s += fval[cidx[q]];
             s = seg_sum(s, 8);
-            if (l == 0) cval[cpos[c]] = s;
+            if (l == 0) {
+                cval[cpos[c]] = s;
+                if (refv != nullptr) visit(s, refv[cpos[c]]);
+            }
             sv += s;
         }
     }
@@ -525,6 +547,42 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_level(LevelView C, const i
         cexcess[I] = ex;
         cdiag[I] = d;
         cidg[I] = d > 0.0 ? 1.0 / d : 0.0;
+        if (refv != nullptr) visit(d, refd[I]);
+    }
+    if (refv == nullptr) return;
+    // min / max over the grid: workgroup reduction, then atomics on the bit patterns (non-negative doubles order
+    // like their bits; min and max do not depend on the order of arrival); the last workgroup writes the verdict
+    __shared__ double smin[kRowBlock / 64], smax[kRowBlock / 64];
+    __shared__ int last;
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, o, 64));
+        hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = lo;
+        smax[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kRowBlock / 64; w++) {
+            lo = fmin(lo, smin[w]);
+            hi = fmax(hi, smax[w]);
+        }
+        atomicMin(mm, (unsigned long long)__double_as_longlong(lo));
+        atomicMax(mm + 1, (unsigned long long)__double_as_longlong(hi));
+        __threadfence();
+        last = atomicAdd(mm + 2, 1ull) == (unsigned long long)gridDim.x - 1 ? 1 : 0;
+        if (last) {
+            __threadfence();
+            const double glo = __longlong_as_double((long long)atomicAdd(mm, 0ull));
+            const double ghi = __longlong_as_double((long long)atomicAdd(mm + 1, 0ull));
+            // (same statements as k_stale_check) the scale follows the operator even when the verdict is 'stale'
+            if (glo > 0.0 && ghi < HUGE_VAL) scal[SC_DSCALE] = 1.0 / sqrt(glo * ghi);
+            flags[FL_STALE] = (glo > 0.0 && ghi < HUGE_VAL && ghi <= spread * glo) ? 0 : 1;
+            mm[0] = (unsigned long long)__double_as_longlong(HUGE_VAL);  // ready for the next check
+            mm[1] = 0ull;
+            mm[2] = 0ull;
+        }
     }
 }
 
@@ -1624,9 +1682,21 @@ void assemble_values(Graph &g, int mode, const double *wsrc) {
         Level &F = g.levels[l - 1];
         Level &C = g.levels[l];
         if (g.asm_windowed && C.max_row <= 16 && C.crow.n > 0) {
+            // the last level of a graph whose inverse is about to be re-used: the staleness verdict rides along
+            const bool chk = g.asm_check_stale && l + 1 == g.levels.size() && g.ndense > 0 &&
+                             g.dense_ref_val.n >= (size_t)C.sell_len && C.sell_len > 0;
+            if (chk && g.dense_mm.n < 3) {
+                g.dense_mm.alloc(3);
+                const unsigned long long init[3] = {0x7ff0000000000000ull, 0ull, 0ull};  // +inf, 0, 0
+                IRH_CHECK(hipMemcpyAsync(g.dense_mm.p, init, sizeof(init), hipMemcpyHostToDevice, g.stream));
+                IRH_CHECK(hipStreamSynchronize(g.stream));
+            }
             hipLaunchKernelGGL(k_coarse_level, dim3((C.n * 8 + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,
                                g.stream, view_of(C), C.crow.p, C.cptr.p, C.cidx.p, C.cpos.p, F.val.p, C.val.p,
-                               F.n, F.agg, F.excess.p, C.excess.p, C.diag.p, C.idg.p);
+                               F.n, F.agg, F.excess.p, C.excess.p, C.diag.p, C.idg.p,
+                               chk ? g.dense_ref_val.p : (const double *)nullptr, g.dense_ref_diag.p, g.stale_spread,
+                               chk ? g.dense_mm.p : (unsigned long long *)nullptr, g.scal.p, g.flags.p);
+            if (chk) g.asm_check_done = true;
             continue;
         }
         if (C.nnz > 0) {
@@ -1984,7 +2054,11 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
             // ... and the staleness verdict on the dense inverse rides on the same round trip: the check runs
             // on the device (dense_check_async) and a re-inversion it asks for happens before the NEXT
             // solve (a stale inverse costs PCG iterations, never accuracy)
+            // will the inverse be re-used? then the assembly's last launch also delivers the verdict on it
+            g.asm_check_stale = g.ndense > 0 && g.dense_valid && !g.dense_stale_pending && g.opt.dense_always_refresh != 1;
+            g.asm_check_done = false;
             assemble_values(g, 0, g.dw.p);
+            g.asm_check_stale = false;
             bool spec = false;
             if (g.ndense > 0) {
                 if (!g.dense_valid || g.dense_stale_pending || g.opt.dense_always_refresh == 1) {
@@ -1993,7 +2067,7 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                     g.dense_fresh = true;
                     g.dense_stale_pending = false;
                 } else {
-                    dense_check_async(g);
+                    if (!g.asm_check_done) dense_check_async(g);
                     g.dense_fresh = false;
                     spec = true;
                 }
