@@ -59,6 +59,8 @@ struct Graph {
     int64_t its_fresh = 0;             // PCG iterations of the last solve that ran on a freshly inverted coarse operator
     bool asm_check_stale = false, asm_check_done = false;  // run_irls <-> assemble_values: verdict inside k_coarse_level
     DevBuf<unsigned long long> dense_mm;  // min / max / ticket of that verdict
+    int stale_streak = 0;              // consecutive 'stale' verdicts of IRLS solves (assemble() in solver.hip)
+    unsigned stale_skips = 0;
     bool dense_stale_pending = false;  // an asynchronous check (dense_check_async) asked for a re-inversion
     double dense_scale = 1.0, stale_spread = 1.1;
     DevBuf<double> dense_ref_diag, dense_ref_val;  // coarse operator the current inverse was computed from

@@ -1632,7 +1632,19 @@ int grid_for_elems(long long n) { return round_grid((n + kRowBlock - 1) / kRowBl
 // refresh all matrix values from per-edge weights: mode 0 = IRLS (d^2, rhs), mode 1 = L1 Hessian
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
     assemble_values(g, mode, wsrc);
-    if (refresh_dense || dense_is_stale(g, mode == 0)) {
+    // IRLS on a graph with loop closures re-inverts in every iteration: after two 'stale'
+    // verdicts in a row the test (three small launches + a host round trip, ~40 us) is skipped three times out
+    // of four and the inverse refreshed straight away
+    bool assume_stale = false;
+    if (!refresh_dense && mode == 0 && g.ndense > 0 && g.dense_valid && g.stale_streak >= 2) {
+        assume_stale = (g.stale_skips++ & 3) != 3;
+    }
+    bool stale = refresh_dense || assume_stale;
+    if (!stale) {
+        stale = dense_is_stale(g, mode == 0);
+        if (mode == 0) g.stale_streak = stale ? g.stale_streak + 1 : 0;
+    }
+    if (stale) {
         dense_refresh(g);
         g.dense_valid = true;
         g.dense_fresh = true;
