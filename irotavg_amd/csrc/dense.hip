@@ -143,6 +143,38 @@ __global__ __launch_bounds__(kRowBlock) void k_dense_build(LevelView C, int npad
     }
 }
 
+// The same for a COARSE level (every (row, column) pair occurs once: the coarse patterns are merged at build
+// time, so plain stores into the zeroed matrix suffice -- level 0 can hold duplicate edges and keeps the
+// read-modify-write kernel above): one workgroup per slice, one thread per SELL position. The row-per-lane
+// kernel spent 80 us at 1563 rows on its dependent load / store chains, once per inversion.
+__global__ __launch_bounds__(kRowBlock) void k_dense_build_coarse(LevelView C, int npad, double *__restrict__ E,
+                                                                  double *__restrict__ maxdiag) {
+    const int sl = blockIdx.x, tid = threadIdx.x;
+    if (sl >= C.nsl) {  // the padding rows: identity
+        for (int i = C.n + (sl - C.nsl) * kRowBlock + tid; i < npad; i += (gridDim.x - C.nsl) * kRowBlock) E[(size_t)i * npad + i] = 1.0;
+        return;
+    }
+    const int o0 = C.sl_off[sl], w = C.sl_off[sl + 1] - o0;
+    if (tid < 64) {
+        const int i = sl * 64 + tid;
+        double dm = 0.0;
+        if (i < C.n) {
+            const double d = C.diag[i];
+            E[(size_t)i * npad + i] = d;
+            dm = fmax(d, 0.0);
+        }
+        for (int o = 32; o > 0; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+        if (tid == 0 && dm > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long *>(maxdiag), (unsigned long long)__double_as_longlong(dm));
+    }
+    for (int idx = tid; idx < w * 64; idx += kRowBlock) {
+        const int k = idx >> 6, lane = idx & 63, row = sl * 64 + lane;
+        const size_t p = sell_pos(o0, k, lane);
+        const double v = C.val[p];
+        if (v != 0.0 && row < C.n) E[(size_t)row * npad + C.col[p]] = v;
+    }
+}
+
 // panel kernel of block step k: every workgroup inverts D = A_kk (32 x 32) by itself -- ONE wave,
 // one lane per row, the row in registers, 32 fully unrolled scalar Gauss-Jordan steps with the
 // pivot row broadcast by lane reads: no barriers, ~3 us (a barrier-per-step LDS version costs
@@ -1208,8 +1240,12 @@ void dense_refresh(Graph &g) {
     }
     if (g.dense_maxdiag.n < 1) g.dense_maxdiag.alloc(1);
     IRH_CHECK(hipMemsetAsync(g.dense_maxdiag.p, 0, sizeof(double), g.stream));
-    hipLaunchKernelGGL(k_dense_build, dim3((npad + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,
-                       g.stream, V, npad, g.dense_inv.p, g.dense_maxdiag.p);
+    if (g.levels.size() > 1)
+        hipLaunchKernelGGL(k_dense_build_coarse, dim3(C.nsl + 1), dim3(kRowBlock), 0, g.stream, V, npad, g.dense_inv.p,
+                           g.dense_maxdiag.p);
+    else
+        hipLaunchKernelGGL(k_dense_build, dim3((npad + kRowBlock - 1) / kRowBlock), dim3(kRowBlock), 0,
+                           g.stream, V, npad, g.dense_inv.p, g.dense_maxdiag.p);
     const int nchunk = npad / GJT;
     if (nchunk < 2 || std::getenv("IROTAVG_GJ_NO_LOOKAHEAD")) {
         for (int k0 = 0; k0 < npad; k0 += GJB) {
