@@ -128,7 +128,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
 
 // solver entry points (solver.hip)
 void launch_edge_residual(Graph &g);
-int ls_solve(Graph &g);  // assemble (IRLS weights) + PCG; result in g.X
+int ls_solve(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr);  // assemble (IRLS weights) + PCG; result in g.X
 void launch_update_weights(Graph &g, int cost, double sigma, bool gated = false);
 void launch_apply_step(Graph &g, bool gated);
 double finish_apply_step(Graph &g);
@@ -148,8 +148,8 @@ void read_back_state(Graph &g);
 void alloc_state(Graph &g);  // scal + flags (aliased tail) + the pinned block
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true);
 void assemble_values(Graph &g, int mode, const double *wsrc);  // the value refresh alone (no dense-level decision)
-int pcg_solve(Graph &g);
-int pcg_solve_classic(Graph &g);  // the round-1 recurrences (separate launches), whatever Graph::cg2 says
+int pcg_solve(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr);
+int pcg_solve_classic(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr);  // the round-1 recurrences (separate launches), whatever Graph::cg2 says
 void launch_spmv(Graph &g);
 void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = nullptr,
                    const double4 *rin = nullptr, double4 *rout = nullptr);

@@ -610,26 +610,32 @@ __global__ __launch_bounds__(kRowBlock) void k_coarse_vals(int nent, const int *
     }
 }
 
-// coarse diagonal: excess_c = sum of the aggregate's excess, diag_c = excess_c - sum(row values)
+// coarse diagonal: excess_c = sum of the aggregate's excess, diag_c = excess_c - sum(row values). Eight lanes
+// per coarse row (a row of a loop-closure graph's level 1 is ~30-50 entry-columns wide: one lane per row walked
+// them in sequence, 12 us per level)
 __global__ __launch_bounds__(kRowBlock) void k_coarse_diag(LevelView C, int nf, int agg,
                                                            const double *__restrict__ fexcess,
                                                            double *__restrict__ cexcess,
                                                            double *__restrict__ cdiag,
                                                            double *__restrict__ cidg) {
-    const int I = blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= C.nsl * 64) return;
-    const int sl = I >> 6, lane = I & 63;
-    const int o0 = C.sl_off[sl], w = C.sl_off[sl + 1] - o0;
-    double sv = 0.0;
-    for (int k = 0; k < w; k++) sv += C.val[sell_pos(o0, k, lane)];
-    if (I >= C.n) return;
-    double ex = 0.0;
-    const int v0 = I * agg, v1 = min(nf, v0 + agg);
-    for (int q = v0; q < v1; q++) ex += fexcess[q];
-    const double d = ex - sv;
-    cexcess[I] = ex;
-    cdiag[I] = d;
-    cidg[I] = d > 0.0 ? 1.0 / d : 0.0;
+    const int I = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7;
+    const bool live = I < C.n;
+    double sv = 0.0, ex = 0.0;
+    if (live) {
+        const int sl = I >> 6, lane = I & 63;
+        const int o0 = C.sl_off[sl], w = C.sl_off[sl + 1] - o0;
+        for (int k = l; k < w; k += 8) sv += C.val[sell_pos(o0, k, lane)];
+        const int v0 = I * agg, v1 = min(nf, v0 + agg);
+        for (int q = v0 + l; q < v1; q += 8) ex += fexcess[q];
+    }
+    sv = seg_sum(sv, 8);
+    ex = seg_sum(ex, 8);
+    if (live && l == 0) {
+        const double d = ex - sv;
+        cexcess[I] = ex;
+        cdiag[I] = d;
+        cidg[I] = d > 0.0 ? 1.0 / d : 0.0;
+    }
 }
 
 // =============================================================================================
@@ -1716,7 +1722,7 @@ void assemble_values(Graph &g, int mode, const double *wsrc) {
             hipLaunchKernelGGL(k_coarse_vals, dim3(grid2), dim3(kRowBlock), 0, g.stream, C.nnz,
                                C.cptr.p, C.cidx.p, C.cpos.p, F.val.p, C.val.p);
         }
-        hipLaunchKernelGGL(k_coarse_diag, dim3((C.nsl * 64 + kRowBlock - 1) / kRowBlock),
+        hipLaunchKernelGGL(k_coarse_diag, dim3((C.n * 8 + kRowBlock - 1) / kRowBlock),
                            dim3(kRowBlock), 0, g.stream, view_of(C), F.n, F.agg, F.excess.p,
                            C.excess.p, C.diag.p, C.idg.p);
     }
@@ -1886,12 +1892,15 @@ void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi, bool check
 // Iteration k: [precondition (its first kernel tests convergence of the previous update)] ->
 // p-update -> q = L p -> x/r update. The host polls the done flag every pcg_check_every
 // iterations; kernels enqueued past convergence return immediately.
-int pcg_solve(Graph &g) {
-    if (g.cg2) return pcg_solve_cg2(g);
-    return pcg_solve_classic(g);
+int pcg_solve(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
+    if (g.cg2) return pcg_solve_cg2(g, tail, tail_ran, false);
+    return pcg_solve_classic(g, tail, tail_ran);
 }
 
-int pcg_solve_classic(Graph &g) {
+// `tail`: work to run once the solve has converged, enqueued behind the first convergence test and gated on the
+// done flag by its own kernels (run_irls: weight update + rotation update); *tail_ran tells whether it took effect.
+int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
+    if (tail_ran) *tail_ran = false;
     Level &L0 = g.levels[0];
     const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
     const int gr = grid_for_rows(L0);
@@ -1962,6 +1971,7 @@ int pcg_solve_classic(Graph &g) {
     double best = HUGE_VAL;
     int best_it = 0;
     bool stagnated = false;
+    bool first_poll = true;
     double *h_scal = g.h_scal();
     while (true) {
         for (int c = 0; c < chunk; c++) {
@@ -1971,7 +1981,11 @@ int pcg_solve_classic(Graph &g) {
         chunk = std::max(2, check / 2);
         // the convergence test of the last update runs in the next preconditioner prologue
         PrecInfo pi = precondition(g, it == 0, rtol2);
+        const bool with_tail = tail != nullptr && first_poll;
+        if (with_tail) (*tail)();  // gated on the flag that test just wrote
         read_back_state(g);
+        if (with_tail && tail_ran) *tail_ran = h_flags[FL_DONE] == 1;
+        first_poll = false;
         if (h_flags[FL_DONE] != 0) break;
         const double cur = std::max(h_scal[SC_RELRES], std::max(h_scal[SC_RELRES + 1], h_scal[SC_RELRES + 2]));
         if (cur < 0.5 * best) {
@@ -2002,9 +2016,10 @@ int pcg_solve_classic(Graph &g) {
 // much as ~25 PCG iterations. After the coarse values are refreshed, dense_is_stale() compares the
 // coarse diagonal with the one the inverse was computed from; the inverse is re-used (rescaled)
 // when the change is a nearly uniform factor. Depends on data only (deterministic).
-int ls_solve(Graph &g) {
+int ls_solve(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
+    if (tail_ran) *tail_ran = false;
     assemble(g, 0, g.dw.p, g.opt.dense_always_refresh == 1);
-    int rc = pcg_solve(g);
+    int rc = pcg_solve(g, tail, tail_ran);
     auto failed = [&]() { return rc == IROTAVG_ERR_NOT_CONVERGED || rc == IROTAVG_ERR_SOLVER; };
     // The reference's direct solvers always return an answer. Two more attempts before an error code:
     // (1) the solve ran on a re-used or repaired coarse inverse: re-invert and solve again (a repaired inverse
@@ -2126,10 +2141,21 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                 score = apply_step(g);
             }
         } else {
-            rc = ls_solve(g);
+            // the same one-round-trip scheme on the classic launches: weight and rotation update ride behind the
+            // first convergence test, gated on its verdict
+            bool tail_ran = false;
+            const std::function<void()> tail = [&]() {
+                launch_update_weights(g, cost, sigma, true);
+                launch_apply_step(g, true);
+            };
+            rc = ls_solve(g, &tail, &tail_ran);
             if (rc != IROTAVG_OK) break;
-            launch_update_weights(g, cost, sigma);
-            score = apply_step(g);
+            if (tail_ran) {
+                score = finish_apply_step(g);
+            } else {
+                launch_update_weights(g, cost, sigma);
+                score = apply_step(g);
+            }
         }
         if (trace) trace[it] = score;
         it++;
