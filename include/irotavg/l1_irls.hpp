@@ -6,14 +6,16 @@
  * -lirotavg_hip instead of ral/l1_irls.cpp + SuiteSparse.
  *
  * Types: when Eigen is available (the reference's own dependency) the shim uses the reference's
- * typedefs (ral/l1_irls.hpp:43-51) so call sites compile unchanged; otherwise it provides minimal
- * column-major containers with the same element access (`Q(i, c)`, `.rows()`, `.data()`).
+ * typedefs (ral/l1_irls.hpp:43-51: Long, SpMat, Mat, Vec, Vec3, Vec4, Quat, T, I_t) so call sites
+ * compile unchanged; otherwise it provides minimal stand-ins with the members those call sites use
+ * (`Q(i, c)`, `Q.row(i) << ...`, `.rows()`, `.data()`, `Quat(w,x,y,z).normalized().toRotationMatrix()`).
  * Errors the reference answers with exit(-1) do the same here (message on stderr), unless
  * IROTAVG_SHIM_THROW is defined, in which case a std::runtime_error is thrown.
  */
 #ifndef IROTAVG_L1_IRLS_SHIM_HPP
 #define IROTAVG_L1_IRLS_SHIM_HPP
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
@@ -57,6 +59,10 @@ typedef long Long;
 typedef Eigen::SparseMatrix<double, Eigen::ColMajor, Long> SpMat;
 typedef Eigen::MatrixXd Mat;
 typedef Eigen::VectorXd Vec;
+typedef Eigen::Vector3d Vec3;    /* ral/l1_irls.hpp:46 */
+typedef Eigen::Vector4d Vec4;    /* :47 */
+typedef Eigen::Quaterniond Quat; /* :48 -- used by the caller's write-back, src/ViewGraph.cpp:1426 */
+typedef Eigen::Triplet<double> T; /* :49 */
 inline long shim_ld(const Mat &M) { return (long)M.outerStride(); }
 #else
 typedef long Long;
@@ -72,6 +78,23 @@ public:
     const double *data() const { return d_.data(); }
     double &operator()(long i, long j) { return d_[(size_t)(j * r_ + i)]; }
     double operator()(long i, long j) const { return d_[(size_t)(j * r_ + i)]; }
+    /* `Q.row(k) << x, y, z, w;` (src/ViewGraph.cpp:1378,1384,1392) */
+    class RowInit {
+    public:
+        RowInit(Mat &m, long i) : m_(m), i_(i), j_(0) {}
+        RowInit &operator<<(double v) { m_(i_, j_++) = v; return *this; }
+        RowInit &operator,(double v) { m_(i_, j_++) = v; return *this; }
+    private:
+        Mat &m_;
+        long i_, j_;
+    };
+    RowInit row(long i) { return RowInit(*this, i); }
+    void transposeInPlace() { /* src/ViewGraph.cpp:1430 */
+        Mat t(c_, r_);
+        for (long i = 0; i < r_; i++)
+            for (long j = 0; j < c_; j++) t(j, i) = (*this)(i, j);
+        *this = t;
+    }
 private:
     long r_, c_;
     std::vector<double> d_;
@@ -88,6 +111,63 @@ public:
     void setOnes() { for (auto &v : d_) v = 1.0; }
 private:
     std::vector<double> d_;
+};
+/* ral/l1_irls.hpp:46-49 without Eigen: fixed-size vectors, a (row, col, value) triplet and the part of
+ * Eigen::Quaterniond the reference's callers use (src/ViewGraph.cpp:1426-1429: construction from
+ * (w, x, y, z), normalized(), toRotationMatrix() as a column-major 3x3 Mat). */
+struct Vec3 {
+    double v[3];
+    Vec3() : v{0, 0, 0} {}
+    Vec3(double a, double b, double c) : v{a, b, c} {}
+    double &operator()(long i) { return v[i]; }
+    double operator()(long i) const { return v[i]; }
+    double *data() { return v; }
+    const double *data() const { return v; }
+};
+struct Vec4 {
+    double v[4];
+    Vec4() : v{0, 0, 0, 0} {}
+    Vec4(double a, double b, double c, double d) : v{a, b, c, d} {}
+    double &operator()(long i) { return v[i]; }
+    double operator()(long i) const { return v[i]; }
+    double *data() { return v; }
+    const double *data() const { return v; }
+};
+class T {
+public:
+    T() : r_(0), c_(0), v_(0.0) {}
+    T(long r, long c, double v) : r_(r), c_(c), v_(v) {}
+    long row() const { return r_; }
+    long col() const { return c_; }
+    double value() const { return v_; }
+private:
+    long r_, c_;
+    double v_;
+};
+class Quat {
+public:
+    Quat() : w_(1), x_(0), y_(0), z_(0) {}
+    Quat(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
+    double w() const { return w_; }
+    double x() const { return x_; }
+    double y() const { return y_; }
+    double z() const { return z_; }
+    Quat normalized() const {
+        const double n = std::sqrt(w_ * w_ + x_ * x_ + y_ * y_ + z_ * z_);
+        return n > 0.0 ? Quat(w_ / n, x_ / n, y_ / n, z_ / n) : *this;
+    }
+    void normalize() { *this = normalized(); }
+    Mat toRotationMatrix() const {
+        const double q[4] = {x_, y_, z_, w_};
+        double R[9];
+        irotavg_quat2rmat(q, R); /* row-major */
+        Mat M(3, 3);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) M(i, j) = R[3 * i + j];
+        return M;
+    }
+private:
+    double w_, x_, y_, z_;
 };
 /* CSC incidence matrix as make_A returns it (ral/l1_irls.cpp:755-780) */
 struct SpMat {
