@@ -102,6 +102,16 @@ int ora_ls_solve(long m, long n_total, int f, const int *I, const double *weight
 void ora_normal_matvec(long m, long n_total, int f, const int *I, const double *weights,
                        const double *X, double *Y);
 
+/* Which stand-in for SuiteSparse solves the linear systems (both solve the same normal equations):
+ * 0 = chosen by the graph (sparse Cholesky, sparse_chol.c, unless there are more than 5000 unknowns
+ * and the envelope work of the natural ordering exceeds 1e10 -- view sequences with thousands of
+ * loop closures -- then Gauss-Seidel-preconditioned CG to a true relative residual of 1e-13,
+ * sparse_pcg.c),
+ * 1 = Cholesky, 2 = PCG. Environment ORA_SOLVER=chol|pcg does the same when the mode is 0. */
+void ora_set_solver(int mode);
+void ora_solver_stats(long *chol_solves, long *pcg_solves, long *pcg_iters, double *pcg_worst_relres,
+                      int reset);
+
 /* src/ViewGraph.cpp:1175-1203 : row-major 3x3 -> [x y z w] */
 void ora_rmat2quat(const double R[9], double q[4]);
 /* src/ViewGraph.cpp:1426-1433 : normalised quaternion [x y z w] -> row-major 3x3 */

@@ -27,7 +27,8 @@ _lp = C.POINTER(C.c_long)
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in
-            ("ral_oracle.c", "sparse_chol.c", "irotavg_oracle.h", "sparse_chol.h")]
+            ("ral_oracle.c", "sparse_chol.c", "sparse_pcg.c", "irotavg_oracle.h", "sparse_chol.h",
+             "sparse_pcg.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so)
                                                for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
@@ -69,7 +70,26 @@ def lib():
         L.ora_rmat2quat.argtypes = [_dp, _dp]
         L.ora_quat2rmat.restype = None
         L.ora_quat2rmat.argtypes = [_dp, _dp]
+        L.ora_set_solver.restype = None
+        L.ora_set_solver.argtypes = [C.c_int]
+        L.ora_solver_stats.restype = None
+        L.ora_solver_stats.argtypes = [_lp, _lp, _lp, _dp, C.c_int]
     return _LIB
+
+
+SOLVER_AUTO, SOLVER_CHOLESKY, SOLVER_PCG = 0, 1, 2
+
+
+def set_solver(mode):
+    """Which stand-in for SuiteSparse the oracle's solves use (irotavg_oracle.h: ora_set_solver)."""
+    lib().ora_set_solver(int(mode))
+
+
+def solver_stats(reset=False):
+    a, b, c = C.c_long(0), C.c_long(0), C.c_long(0)
+    d = C.c_double(0)
+    lib().ora_solver_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(d), 1 if reset else 0)
+    return dict(chol_solves=a.value, pcg_solves=b.value, pcg_iters=c.value, pcg_worst_relres=d.value)
 
 
 def _d(a):

@@ -13,6 +13,7 @@
 #include <time.h>
 
 #include "sparse_chol.h"
+#include "sparse_pcg.h"
 
 #define ORA_PI 3.141592653589793238462643383279502884 /* EIGEN_PI */
 
@@ -206,8 +207,32 @@ typedef struct {
     double *Ax;
     long *diag_pos;  /* position of the diagonal entry of column c */
     long *edge_pos;  /* 2 per edge: positions of (i,j) and (j,i) entries, or -1 */
-    ora_chol *chol;
+    ora_chol *chol;  /* direct solve (sparse_chol.c) ... */
+    ora_pcg *pcg;    /* ... or, when its fill would be prohibitive, the iterative one (sparse_pcg.c) */
 } lap_sys;
+
+/* which of the two stand-ins for SuiteSparse solves the systems: 0 = by the graph (Cholesky unless
+ * there are more than ORA_PCG_MIN_ROWS unknowns AND the envelope work of the natural ordering -- sum
+ * of squared envelope heights -- exceeds ORA_ENVELOPE_MAX: band graph of 1M views, 20 wide: 4e8;
+ * 10k views with 3000 loop closures: 3e10, 105 s per l1ra(2)+irls by Cholesky, 7 s by PCG),
+ * 1 = Cholesky, 2 = PCG. Tests force 2 to validate the PCG against the Cholesky on sizes both can do. */
+#define ORA_ENVELOPE_MAX 1.0e10
+#define ORA_PCG_MIN_ROWS 5000
+static int g_solver_mode = 0;
+static long g_pcg_solves = 0, g_pcg_iters = 0, g_chol_solves = 0;
+static double g_pcg_worst_relres = 0.0;
+void ora_set_solver(int mode) { g_solver_mode = mode; }
+void ora_solver_stats(long *chol_solves, long *pcg_solves, long *pcg_iters, double *pcg_worst_relres,
+                      int reset) {
+    if (chol_solves) *chol_solves = g_chol_solves;
+    if (pcg_solves) *pcg_solves = g_pcg_solves;
+    if (pcg_iters) *pcg_iters = g_pcg_iters;
+    if (pcg_worst_relres) *pcg_worst_relres = g_pcg_worst_relres;
+    if (reset) {
+        g_pcg_solves = g_pcg_iters = g_chol_solves = 0;
+        g_pcg_worst_relres = 0.0;
+    }
+}
 
 static void lap_free(lap_sys *S) {
     if (!S) return;
@@ -217,6 +242,7 @@ static void lap_free(lap_sys *S) {
     free(S->diag_pos);
     free(S->edge_pos);
     ora_chol_free(S->chol);
+    ora_pcg_free(S->pcg);
     free(S);
 }
 
@@ -261,12 +287,42 @@ static lap_sys *lap_build(long m, long n_total, int f, const int *I) {
         }
     }
     free(cnt);
-    S->chol = ora_chol_analyze(nu, S->Ap, S->Ai);
-    if (!S->chol) {
+    int use_pcg = g_solver_mode == 2;
+    if (g_solver_mode == 0) {
+        const char *e = getenv("ORA_SOLVER");
+        if (e && e[0] == 'p')
+            use_pcg = 1;
+        else if (!(e && e[0] == 'c'))
+            use_pcg = nu > ORA_PCG_MIN_ROWS && ora_envelope(nu, S->Ap, S->Ai) > ORA_ENVELOPE_MAX;
+    }
+    if (use_pcg)
+        S->pcg = ora_pcg_alloc(nu);
+    else
+        S->chol = ora_chol_analyze(nu, S->Ap, S->Ai);
+    if (!S->chol && !S->pcg) {
         lap_free(S);
         return NULL;
     }
     return S;
+}
+
+/* "factorise" the values in S->Ax; returns the number of dead unknowns */
+static long lap_factor(lap_sys *S) {
+    if (S->pcg) return ora_pcg_setup(S->pcg, S->Ap, S->Ai, S->Ax);
+    return ora_chol_factor(S->chol, S->Ap, S->Ai, S->Ax);
+}
+
+static int lap_solve(lap_sys *S, const double *b, double *x) {
+    if (S->pcg) {
+        int rc = ora_pcg_solve(S->pcg, S->Ap, S->Ai, S->Ax, b, x);
+        g_pcg_solves++;
+        g_pcg_iters += S->pcg->iters_last;
+        if (S->pcg->relres_last > g_pcg_worst_relres) g_pcg_worst_relres = S->pcg->relres_last;
+        return rc ? ORA_ERR_SOLVER : ORA_OK;
+    }
+    ora_chol_solve(S->chol, b, x);
+    g_chol_solves++;
+    return ORA_OK;
 }
 
 /* H = A' diag(s) A with A from make_A (edge-drop quirk included): what SPQR implicitly
@@ -426,11 +482,27 @@ static int weighted_ls(lap_sys *S, long m, int f, const int *I, const double *we
     const long nu = S->nu;
     for (long k = 0; k < m; k++) s_tmp[k] = weights[k] * weights[k];
     lap_fill_AtSA(S, m, f, I, s_tmp);
-    ora_chol_factor(S->chol, S->Ap, S->Ai, S->Ax);
+    lap_factor(S);
+    if (S->pcg) { /* the three columns share the passes over the matrix */
+        double *B = (double *)malloc(sizeof(double) * (size_t)(3 * nu > 0 ? 3 * nu : 1));
+        if (!B) return ORA_ERR_NOMEM;
+        for (int c = 0; c < 3; c++) {
+            for (long k = 0; k < m; k++) y_tmp[k] = s_tmp[k] * w[c * ldw + k];
+            At_mul(m, nu, f, I, y_tmp, B + c * nu);
+        }
+        int rc = ora_pcg_solve_multi(S->pcg, S->Ap, S->Ai, S->Ax, 3, B, nu, X, nu);
+        free(B);
+        g_pcg_solves += 3;
+        g_pcg_iters += S->pcg->iters_last;
+        if (S->pcg->relres_last > g_pcg_worst_relres) g_pcg_worst_relres = S->pcg->relres_last;
+        (void)b_tmp;
+        return rc ? ORA_ERR_SOLVER : ORA_OK;
+    }
     for (int c = 0; c < 3; c++) {
         for (long k = 0; k < m; k++) y_tmp[k] = s_tmp[k] * w[c * ldw + k];
         At_mul(m, nu, f, I, y_tmp, b_tmp);
-        ora_chol_solve(S->chol, b_tmp, X + c * nu);
+        int rc = lap_solve(S, b_tmp, X + c * nu);
+        if (rc != ORA_OK) return rc;
     }
     return ORA_OK;
 }
@@ -508,7 +580,8 @@ int ora_irls(long m, long n_total, int f, const int *I, const double *QQ, long l
         ora_delta_rel(m, I, QQ, ldqq, Q, ldq, w, m);
         ora_log_map(m, w, m);
         /* :596-612 -- least squares with rows scaled by `weights` */
-        weighted_ls(S, m, f, I, weights, w, m, W, s_tmp, y_tmp, b_tmp);
+        rc = weighted_ls(S, m, f, I, weights, w, m, W, s_tmp, y_tmp, b_tmp);
+        if (rc != ORA_OK) break; /* the iterative stand-in gave up (never seen; the direct one cannot) */
         /* :614 -- E = A*W3 - w(:,0:3), with make_A's A */
         for (long k = 0; k < m; k++) e2v[k] = 0.0;
         for (int c = 0; c < 3; c++) {
@@ -650,9 +723,9 @@ static int l1decode_pd_core(lap_sys *S, pd_work *P, long m, int f, const int *I,
         for (long i = 0; i < nu; i++) P->w1p[i] = P->w1[i] - P->w1p[i]; /* :306 */
         /* :308-319 -- H11p = AtA*sigx reshaped, solved by UMFPACK in the reference */
         lap_fill_AtA_times(S, m, f, I, P->sigx);
-        long ndead = ora_chol_factor(S->chol, S->Ap, S->Ai, S->Ax);
+        long ndead = lap_factor(S);
         if (ndead > 0) return ORA_ERR_SOLVER;
-        ora_chol_solve(S->chol, P->w1p, P->dx);
+        if (lap_solve(S, P->w1p, P->dx) != ORA_OK) return ORA_ERR_SOLVER;
         for (long i = 0; i < nu; i++)
             if (!isfinite(P->dx[i])) return ORA_ERR_SOLVER;
         A_mul(m, f, I, P->dx, P->Adx); /* :324 */
