@@ -97,6 +97,8 @@ typedef struct irotavg_stats {
     int64_t pcg_stagnated;   /* solves accepted at a stalled residual above pcg_rtol (see pcg_stall_accept) */
     int64_t dense_inversions; /* full inversions of the dense coarse level */
     int64_t dense_repairs;    /* low-rank (Woodbury) repairs of that inverse instead of an inversion */
+    int64_t pcg_handed_over;  /* solves whose single-reduction (Chronopoulos-Gear) recurrences stalled and that were
+                                 repeated with the classic recurrences from the saved right-hand side */
 } irotavg_stats;
 
 /* ---------------------------------------------------------------------------------------------

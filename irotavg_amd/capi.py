@@ -51,7 +51,8 @@ class Stats(C.Structure):
                 ("seconds_irls", C.c_double), ("seconds_l1ra", C.c_double), ("levels", C.c_int),
                 ("level_rows", C.c_int64 * 16), ("level_nnz", C.c_int64 * 16),
                 ("last_relres", C.c_double * 3), ("pcg_stagnated", C.c_int64),
-                ("dense_inversions", C.c_int64), ("dense_repairs", C.c_int64)]
+                ("dense_inversions", C.c_int64), ("dense_repairs", C.c_int64),
+                ("pcg_handed_over", C.c_int64)]
 
 
 class RotAvgInfo(C.Structure):
@@ -539,4 +540,5 @@ class DistGraph:
         check(lib().irotavg_dist_get_stats(self._h, C.byref(s)), "dist_get_stats")
         return dict(pcg_solves=s.pcg_solves, pcg_iters=s.pcg_iters, pcg_iters_last=s.pcg_iters_last,
                     outer_iters=s.outer_iters, edge_updates=s.edge_updates, seconds_irls=s.seconds_irls,
-                    levels=s.levels, level_rows=list(s.level_rows)[:s.levels])
+                    levels=s.levels, level_rows=list(s.level_rows)[:s.levels],
+                    pcg_handed_over=s.pcg_handed_over)

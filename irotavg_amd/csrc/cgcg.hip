@@ -808,6 +808,10 @@ int pcg_solve_cg2(Graph &g, const std::function<void()> *tail, bool *tail_ran, b
             // per iteration, q = L p computed) are the robust path: start over with them.
             if (std::getenv("IROTAVG_PCG_TRACE")) std::fprintf(stderr, "[pcg cg2] giving up at %d iterations -> classic\n", it);
             g.stats.pcg_iters += it;
+            g.stats.pcg_handed_over += 1;
+            // the classic launches take the scale of a re-used inverse from the host copy; in device_scale
+            // mode the kernels above read the device's SC_DSCALE, which the host copy lags behind
+            if (device_scale && h_scal[SC_DSCALE] > 0.0) g.dense_scale = h_scal[SC_DSCALE];
             IRH_CHECK(hipMemcpyAsync(g.levels[0].b.p, g.levels[0].x.p, sizeof(double4) * (size_t)g.levels[0].n,
                                      hipMemcpyDeviceToDevice, g.stream));
             return pcg_solve_classic(g);

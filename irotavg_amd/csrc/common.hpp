@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -384,12 +385,25 @@ public:
         return *p;
     }
     // fn(t) for t = 1 .. T-1 on the workers and fn(0) on the caller; false if the pool is busy or unusable
+    // (the caller then spawns threads). A job that is itself running inside a pool job -- on a worker, or
+    // on the caller thread inside fn(0) -- is refused by a thread-local flag (try_lock on a mutex the
+    // thread already owns would be undefined behaviour). An exception thrown by fn on a worker is caught
+    // there and rethrown on the caller once every chunk has ended.
     template <class F>
     bool run(int T, F &&fn) {
-        if (T - 1 > kWorkers || getpid() != pid_) return false;
+        if (T - 1 > kWorkers || getpid() != pid_ || inside()) return false;
         std::unique_lock<std::mutex> one(busy_, std::try_to_lock);
         if (!one.owns_lock()) return false;
-        std::function<void(int)> job = [&fn](int t) { fn(t); };
+        std::exception_ptr err;
+        std::mutex err_mu;
+        std::function<void(int)> job = [&fn, &err, &err_mu](int t) {
+            try {
+                fn(t);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (!err) err = std::current_exception();
+            }
+        };
         {
             std::lock_guard<std::mutex> lk(m_);
             job_ = &job;
@@ -398,14 +412,21 @@ public:
             gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        fn(0);
+        inside() = true;
+        job(0);
+        inside() = false;
         for (int spin = 0; remaining_.load(std::memory_order_acquire) != 0; spin++) {
             if (spin > 2000) std::this_thread::yield();
         }
+        if (err) std::rethrow_exception(err);
         return true;
     }
 
 private:
+    static bool &inside() {
+        static thread_local bool in_job = false;
+        return in_job;
+    }
     HostPool() : pid_(getpid()) {
         for (int w = 0; w < kWorkers; w++) std::thread([this, w] { loop(w); }).detach();
     }
@@ -433,7 +454,9 @@ private:
                 want = want_;
             }
             if (w < want) {
-                (*job)(w + 1);
+                inside() = true;
+                (*job)(w + 1);  // never throws (run() wraps fn)
+                inside() = false;
                 remaining_.fetch_sub(1, std::memory_order_release);
             }
         }

@@ -531,6 +531,10 @@ static int pcg_dist_cg(Dist &D) {
     for (auto &sp : D.shards) {
         Graph &g = sp->g;
         IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, D.stream));
+        // the right-hand side is kept in levels[0].x (unused with an additive top level): a solve whose
+        // recurrences stall is handed to the classic ones from there (see below)
+        IRH_CHECK(hipMemcpyAsync(g.levels[0].x.p, g.levels[0].b.p, sizeof(double4) * (size_t)g.levels[0].n,
+                                 hipMemcpyDeviceToDevice, D.stream));
         launch_cgd_update(g, true, 0, 1, rtol2, nullptr, nullptr, nullptr, rr_buf(g, cur));
     }
     int it = 0;
@@ -563,15 +567,49 @@ static int pcg_dist_cg(Dist &D) {
         cur ^= 1;
         it++;
     };
+    // Chronopoulos-Gear carries r and s = Lp by recurrence, without residual replacement: on an
+    // ill-conditioned system (weights over many decades) they can stall far above the tolerance where the
+    // classic recurrences still converge (cgcg.hip, pcg_solve_cg2). Same safety net as there: after `giveup`
+    // iterations, or when the residual has not halved for kStall iterations, the solve restarts with the
+    // classic sharded recurrences from the saved right-hand side. The decision is taken from all-reduced
+    // values (flags and relative residual are identical on every rank), so all ranks agree.
+    const char *ge = std::getenv("IROTAVG_CG2_GIVEUP");  // tests force the hand-over
+    const int giveup = ge ? std::max(1, std::atoi(ge)) : 400;
+    constexpr int kStall = 96;
+    double best = HUGE_VAL;
+    int best_it = 0;
+    bool hand_over = false;
+    double h_rel[4] = {0, 0, 0, 0};
     int chunk = D.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(D.stats.pcg_iters_last + 1, maxit) : check;
     while (true) {
         for (int c = 0; c < chunk; c++) iteration();  // the update of iteration k tests the residual of k - 1
         chunk = std::max(2, check / 2);
         IRH_CHECK(hipMemcpyAsync(h_flags, D.shards[0]->g.flags.p, sizeof(int) * FL_COUNT, hipMemcpyDeviceToHost,
                                  D.stream));
+        IRH_CHECK(hipMemcpyAsync(h_rel, D.shards[0]->g.scal.p + SC_RELRES, sizeof(double) * 3, hipMemcpyDeviceToHost,
+                                 D.stream));
         IRH_CHECK(hipStreamSynchronize(D.stream));
         if (h_flags[FL_DONE] != 0) break;
+        const double now = std::max(h_rel[0], std::max(h_rel[1], h_rel[2]));
+        if (now < 0.5 * best) {
+            best = now;
+            best_it = it;
+        }
+        if (it >= giveup || it - best_it >= kStall) {
+            hand_over = true;
+            break;
+        }
         if (it >= maxit) break;
+    }
+    if (hand_over || h_flags[FL_DONE] == 2) {
+        D.stats.pcg_iters += h_flags[FL_ITERS];
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            IRH_CHECK(hipMemcpyAsync(g.levels[0].b.p, g.levels[0].x.p, sizeof(double4) * (size_t)g.levels[0].n,
+                                     hipMemcpyDeviceToDevice, D.stream));
+        }
+        D.stats.pcg_handed_over += 1;
+        return pcg_dist(D);
     }
     D.stats.pcg_solves += 1;
     D.stats.pcg_iters += h_flags[FL_ITERS];

@@ -2133,6 +2133,20 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                 rc = pcg_solve_cg2(g, &tail, &tail_ran, false);
                 if (rc == IROTAVG_OK) g.its_fresh = g.stats.pcg_iters_last;
             }
+            if ((rc == IROTAVG_ERR_NOT_CONVERGED || rc == IROTAVG_ERR_SOLVER) && g.ndense > 0 && !g.dense_fresh) {
+                // ls_solve's safety net on this path, too (irotavg_hip.h: NOT_CONVERGED only after these attempts):
+                // the solve ran on a re-used coarse inverse -- re-invert, restore the right-hand side and solve
+                // again with the classic recurrences
+                dense_refresh(g);
+                g.dense_valid = true;
+                g.dense_fresh = true;
+                g.dense_stale_pending = false;
+                IRH_CHECK(hipMemcpyAsync(g.levels[0].b.p, g.levels[0].x.p, sizeof(double4) * (size_t)g.levels[0].n,
+                                         hipMemcpyDeviceToDevice, g.stream));
+                tail_ran = false;
+                rc = pcg_solve_classic(g);
+                if (rc == IROTAVG_OK) g.its_fresh = 0;  // not comparable with a two-launch count
+            }
             if (rc != IROTAVG_OK) break;
             if (tail_ran) {
                 score = finish_apply_step(g);

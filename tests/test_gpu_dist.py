@@ -128,3 +128,30 @@ def test_config4_size_eight_shards_match_the_oracle_checked_handle(p_loop):
     assert synth.angular_distance(Qa, Qb).max() < 1e-7
     np.testing.assert_allclose(wa, wb, rtol=1e-5, atol=1e-9)
     assert st["pcg_iters"] > 0
+
+
+def test_sharded_single_reduction_solve_hands_over_to_the_classic_recurrences(monkeypatch):
+    """The sharded Chronopoulos-Gear PCG (one all-reduce per iteration) carries r and s = Lp by recurrence;
+    a solve that stalls (or passes the give-up limit) restarts with the classic sharded recurrences from
+    the saved right-hand side -- the decision comes from all-reduced values, so every rank takes it.
+    Forced by a limit of 6 iterations; the result must still be the ORACLE's."""
+    from oracle import oracle as O
+    n, m = 20000, 300000
+    S, Q0 = problem(n, m, 0.0, 1, seed=2)
+    ro = O.irls(S["QQ"], S["I"], Q0, 1, 4, SIG, 50, 1e-3)
+    out = []
+    for limit in (None, "6"):
+        if limit:
+            monkeypatch.setenv("IROTAVG_CG2_GIVEUP", limit)
+        with capi.DistGraph(S["I"], S["QQ"], n, 1, 4) as D:
+            D.set_rotations(Q0)
+            r = D.irls(4, SIG, 50, 1e-3)
+            out.append((r, D.get_rotations(into=Q0.copy()), D.get_weights(), D.stats()))
+    assert out[0][3]["pcg_handed_over"] == 0
+    assert out[1][3]["pcg_handed_over"] == out[1][3]["pcg_solves"] > 0
+    assert out[1][3]["pcg_iters"] > out[0][3]["pcg_iters"]      # the abandoned iterations are counted
+    for r, Q, w, _ in out:
+        assert r["iters"] == ro["iters"]
+        np.testing.assert_allclose(r["scores"], ro["scores"], rtol=1e-5)
+        assert synth.angular_distance(Q, ro["Q"]).max() < 1e-7
+        np.testing.assert_allclose(w, ro["weights"], rtol=1e-5)
