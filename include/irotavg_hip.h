@@ -295,6 +295,12 @@ int irotavg_dist_irls(irotavg_dist *d, int cost, double sigma, int max_iters, do
 int irotavg_dist_l1ra(irotavg_dist *d, int max_iters, double change_th, int *iters, double *runtime,
                       double *score_trace);
 int irotavg_dist_get_stats(irotavg_dist *d, irotavg_stats *out);
+/* What the sharded handle actually runs on, so that a scaling run can be checked: info[0] = wire
+ * (0 loopback: all shards in this process, 1 RCCL, 2 the caller's host-staged transport), info[1] = ranks of
+ * the RCCL communicator as RCCL reports them (ncclCommCount; 0 without one), info[2] = shards held by this
+ * process, info[3] = world size the graph is partitioned for, info[4] = ghost views of this process's
+ * shards (halo rows received per exchange), info[5] = peers of shard 0, info[6], info[7] = 0. */
+int irotavg_dist_info(irotavg_dist *d, int64_t info[8]);
 int irotavg_dist_plan(irotavg_dist *d, int local_index, int64_t counts[6], int *peers, int *send_cnt,
                       int *recv_cnt, int cap);
 /* host-only partition plan of one rank (no GPU): see irotavg_amd/csrc/dist.hip */

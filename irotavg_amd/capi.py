@@ -31,7 +31,7 @@ SYMBOLS = [
     "irotavg_viewgraph_get_pose", "irotavg_viewgraph_set_pose", "irotavg_viewgraph_rot_avg",
     "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
-    "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_plan", "irotavg_dist_plan_host",
+    "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_info", "irotavg_dist_plan", "irotavg_dist_plan_host",
     "irotavg_dist_l1ra", "irotavg_dist_create_hosted",
     "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_trim_memory", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
 ]
@@ -163,6 +163,7 @@ def lib():
     L.irotavg_dist_create_hosted.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(Transport), C.c_int64,
                                              C.c_int64, C.c_int, _ip, _dp, C.c_int64, C.POINTER(Options)]
     L.irotavg_dist_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.irotavg_dist_info.argtypes = [vp, C.POINTER(C.c_int64)]
     L.irotavg_dist_plan.argtypes = [vp, C.c_int, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.c_int]
     L.irotavg_dist_plan_host.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _ip, _i64p,
@@ -534,6 +535,13 @@ class DistGraph:
         if rc != OK and rc not in allow_rc:
             raise IrotavgError(rc, "irotavg_dist_l1ra")
         return dict(rc=rc, iters=iters.value, runtime=rt.value, scores=trace[:iters.value].copy())
+
+    def info(self):
+        """wire / RCCL communicator size / local shards / world / ghost views (irotavg_dist_info)."""
+        v = (C.c_int64 * 8)()
+        check(lib().irotavg_dist_info(self._h, v), "dist_info")
+        return dict(wire=["loopback", "rccl", "host-staged"][v[0]], rccl_comm_ranks=int(v[1]),
+                    local_shards=int(v[2]), world=int(v[3]), ghost_views=int(v[4]), peers=int(v[5]))
 
     def stats(self):
         s = Stats()

@@ -913,6 +913,25 @@ int irotavg_dist_l1ra(irotavg_dist *h, int max_iters, double change_th, int *ite
     API_CATCH
 }
 
+int irotavg_dist_info(irotavg_dist *h, int64_t info[8]) {
+    if (!h || !info) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Dist &D = h->D;
+    for (int i = 0; i < 8; i++) info[i] = 0;
+    info[0] = D.hosted ? 2 : (D.use_rccl ? 1 : 0);
+    if (D.use_rccl && D.comm) {
+        int cnt = 0;
+        NCCL_CHECK(ncclCommCount(D.comm, &cnt));
+        info[1] = cnt;
+    }
+    info[2] = (int64_t)D.shards.size();
+    info[3] = D.world;
+    for (auto &sp : D.shards) info[4] += sp->g.ng;
+    info[5] = D.shards.empty() ? 0 : (int64_t)D.shards[0]->peers.size();
+    return IROTAVG_OK;
+    API_CATCH
+}
+
 int irotavg_dist_get_stats(irotavg_dist *h, irotavg_stats *out) {
     if (!h || !out) return IROTAVG_ERR_BAD_ARG;
     *out = h->D.stats;

@@ -93,8 +93,13 @@ def band_loop_topology(n, m, p_loop, rng):
     return I, is_loop[order], w
 
 
-def make_graph(n, m, p_loop=0.0, sigma_n=0.01, p_out=0.05, seed=0):
-    """Returns dict(I, QQ, Qgt, is_loop, is_outlier, w) -- QQ, Qgt are (rows,4) [x y z w]."""
+def make_graph(n, m, p_loop=0.0, sigma_n=0.01, p_out=0.05, seed=0, p_band_out=0.0, band_out_scale=0.3):
+    """Returns dict(I, QQ, Qgt, is_loop, is_outlier, w) -- QQ, Qgt are (rows,4) [x y z w].
+
+    p_band_out > 0 (not part of SURVEY.md 8(d)'s generator, whose outliers are loop edges only): that
+    share of ALL edges additionally carries a rotation error of N(0, band_out_scale^2 I) rad -- the
+    robust weights of a band-only graph then move non-uniformly. Drawn from its own generator, so the
+    rest of the graph is the same as without it."""
     rng = np.random.default_rng(seed)
     Qgt = rng.normal(size=(n, 4))
     Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
@@ -111,5 +116,10 @@ def make_graph(n, m, p_loop=0.0, sigma_n=0.01, p_out=0.05, seed=0):
         R /= np.linalg.norm(R, axis=1, keepdims=True)
         QQ[sel] = R
         is_out[sel] = True
+    if p_band_out > 0:
+        rng2 = np.random.default_rng([seed, 0xBAD])
+        bad = rng2.choice(mm, size=int(round(p_band_out * mm)), replace=False)
+        QQ[bad] = qmul(qexp(rng2.normal(scale=band_out_scale, size=(len(bad), 3))), QQ[bad])
+        is_out[bad] = True
     return dict(I=I, QQ=QQ, Qgt=Qgt, is_loop=is_loop, is_outlier=is_out, w=w, n=n, m=mm,
                 p_loop=p_loop, seed=seed)

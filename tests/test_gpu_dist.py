@@ -148,7 +148,7 @@ def test_sharded_single_reduction_solve_hands_over_to_the_classic_recurrences(mo
             r = D.irls(4, SIG, 50, 1e-3)
             out.append((r, D.get_rotations(into=Q0.copy()), D.get_weights(), D.stats()))
     assert out[0][3]["pcg_handed_over"] == 0
-    assert out[1][3]["pcg_handed_over"] == out[1][3]["pcg_solves"] > 0
+    assert 1 <= out[1][3]["pcg_handed_over"] <= out[1][3]["pcg_solves"]   # the limit acts at a poll of the host
     assert out[1][3]["pcg_iters"] > out[0][3]["pcg_iters"]      # the abandoned iterations are counted
     for r, Q, w, _ in out:
         assert r["iters"] == ro["iters"]

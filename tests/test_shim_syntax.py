@@ -33,7 +33,7 @@ static int like_the_demo() {
     I.push_back(std::make_pair(0, 2));            // a cycle that does not close: non-zero residuals
     const long m = (long)I.size();
     Mat QQ(m, 4), Q(n, 4);
-    for (long k = 0; k < QQ.rows(); k++) QQ.row(k) << 0.01 * (double)(k + 1), 0.002, 0, 1;
+    for (long k = 0; k < QQ.rows(); k++) QQ.row(k) << 0.01 * (double)(k + 1), 0.002, -0.005, 1;
     Q.row(0) << 0, 0, 0, 1;                       // ral/test.cpp:279
     init_mst(Q, QQ, I, f);                        // :286
     SpMat A = make_A(n, f, I);                    // :288
@@ -61,7 +61,9 @@ static double like_the_viewgraph(long num_of_vertices, long num_of_edges, int f)
         f = 1;
     }
     irotavg::Mat QQ(num_of_edges, 4);
-    for (long i = 0; i < num_of_edges; i++) QQ.row(i) << 0.01 * (double)(i + 1), 0, 0.003, 1;  // :1392
+    for (long i = 0; i < num_of_edges; i++) QQ.row(i) << 0.01 * (double)(i + 1), 0.004 * (double)(2 - i), 0.003, 1;  // :1392
+    // (every coordinate needs a non-zero residual: an all-zero one makes l1decode_pd divide by zero --
+    //  in the reference, too: ral/l1_irls.cpp:245-281, then exit(-1) at :153)
     irotavg::SpMat A = irotavg::make_A((int)num_of_vertices, f, I);          // :1400
     const double change_th = .001;
     const int l1_iters = 100;
