@@ -193,6 +193,14 @@ int irotavg_graph_l1decode_pd(irotavg_graph *g, const double *y, int pdmaxiter, 
  * IROTAVG_ERR_BAD_ARG if this graph's PCG does not use it). */
 int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_per_launch);
 
+/* Testing aid: fingerprint of the handle's static structure -- every index array the build produces (edge
+ * streams, boundary slots, per level the SELL-64 pattern and the value-refresh maps) as one 64-bit FNV-1a hash
+ * each, followed by the scalars that choose kernels (level shapes, far-entry count, fused-assembly / two-launch
+ * flags, dense level size and bandwidth). The handle is built on the device (irotavg_amd/csrc/gbuild.hip) or,
+ * with IROTAVG_HOST_BUILD=1, for shards and for small graphs, on the host (build.cpp): both must give the same
+ * fingerprint (tests/test_gpu_build.py). Returns the number of values written (<= cap) or a negative error. */
+int irotavg_graph_fingerprint(irotavg_graph *g, uint64_t *out, int cap);
+
 /* ---------------------------------------------------------------------------------------------
  * View-graph side: OpenCV-free counterpart of ViewGraph / Pose (src/ViewGraph.hpp:54-75,
  * src/Pose.hpp:35-59). Rotations are row-major 3x3 doubles (cv::Matx33d layout). Connections

@@ -23,7 +23,7 @@ SYMBOLS = [
     "irotavg_graph_quat_normalised", "irotavg_graph_get_stats", "irotavg_graph_reset_stats",
     "irotavg_graph_synchronize", "irotavg_graph_edge_residual", "irotavg_graph_get_residuals",
     "irotavg_graph_ls_solve", "irotavg_graph_update_weights", "irotavg_graph_apply_step",
-    "irotavg_graph_l1decode_pd", "irotavg_graph_time_kernel", "irotavg_version",
+    "irotavg_graph_l1decode_pd", "irotavg_graph_time_kernel", "irotavg_graph_fingerprint", "irotavg_version",
     "irotavg_device_count", "irotavg_error_string",
     "irotavg_viewgraph_create", "irotavg_viewgraph_destroy", "irotavg_viewgraph_add_view",
     "irotavg_viewgraph_num_views", "irotavg_viewgraph_connect", "irotavg_viewgraph_fix_pose",
@@ -124,6 +124,7 @@ def lib():
     L.irotavg_graph_apply_step.argtypes = [vp, _dp]
     L.irotavg_graph_l1decode_pd.argtypes = [vp, _dp, C.c_int, _dp, C.POINTER(C.c_int)]
     L.irotavg_graph_time_kernel.argtypes = [vp, C.c_int, C.c_int, _dp]
+    L.irotavg_graph_fingerprint.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.irotavg_viewgraph_create.argtypes = [C.POINTER(vp), C.POINTER(Options)]
     L.irotavg_viewgraph_destroy.argtypes = [vp]
     L.irotavg_viewgraph_destroy.restype = None
@@ -339,6 +340,14 @@ class Graph:
         check(lib().irotavg_graph_l1decode_pd(self._h, _d(y), pdmaxiter, _d(x), C.byref(stuck)),
               "l1decode_pd")
         return x, stuck.value
+
+    def fingerprint(self):
+        """Hashes of every structural array + the kernel-choosing scalars (irotavg_graph_fingerprint)."""
+        out = (C.c_uint64 * 512)()
+        n = lib().irotavg_graph_fingerprint(self._h, out, 512)
+        if n < 0:
+            raise IrotavgError(n, "fingerprint")
+        return [int(out[i]) for i in range(n)]
 
     def time_kernel(self, which, reps=20):
         ms = C.c_double(0)

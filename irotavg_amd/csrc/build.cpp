@@ -78,14 +78,91 @@ static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector
     return M;
 }
 
+// The shape of the hierarchy: rows and aggregation factor of every level, from the size of the graph, its
+// level-0 entry count and whether level 0 has far (loop-closure) entries. Also fixes g.opt.mg_dense_max when
+// it was left to the library. Pure arithmetic: the host build and the device build (gbuild.hip) share it.
+HierPlan plan_hierarchy(Graph &g, int n0, int64_t nnz0, bool far0) {
+    HierPlan P;
+    P.n.push_back(n0);
+    const int max_levels = std::max(1, std::min(g.opt.mg_levels_max, (int)kMaxLevels));
+    const bool tune = getenv("IROTAVG_NO_SMALL_TUNING") == nullptr;
+    if (g.opt.mg_dense_max <= 0) {
+        // The dense level is re-inverted whenever the weights move non-uniformly. For a band graph that is the
+        // cheap banded inverse and rare; with loop closures it is the full Gauss-Jordan sweep (n/32 block
+        // steps of ~21 us) in almost every IRLS iteration, and up to ~70k views a level of 550..1100 rows
+        // behind an aggregation factor of 16..64 costs 2-5 more PCG iterations but half the sweep
+        // (10k/150k: 5.9 -> 4.7 ms, 16k: 9.1 -> 6.0 ms, 30k: 11.5 -> 8.5 ms per irls call; at 100k views the
+        // factor would be 128 and the iterations double: 2048 stays)
+        g.opt.mg_dense_max = (tune && n0 <= 70400 && far0) ? 1100 : 2048;
+    }
+    // A graph without far (loop-closure) entries on one GPU can run its PCG iteration as two launches
+    // (cgcg.hip), which needs aggregates of 8 on levels 0 AND 1. The rule below would stop level 1 short
+    // (aggregates of 2 or 4 that just reach the dense level: 20k views -> 2500 -> 1250) and leave such a
+    // graph on the slowest path (six launches per iteration): measured 389 vs 667 M edge-updates/s at
+    // 20k / 400k, 1223 vs 1669 M at 60k / 1.2M, for two more PCG iterations per solve.
+    const bool band0 = g.ng == 0 && g.opt.mg_multiplicative_top != 1 && g.opt.no_fused_pspmv != 1 &&
+                       g.opt.pcg_classic != 1 && (n0 + 63) / 64 <= 4 * kMaxParts && !far0;
+    // A dense level of more than ~1500 rows costs more per PCG iteration (its 8 n^2-byte apply) than a third
+    // level with the two-launch iteration saves: a band graph of >= 18 edges per view whose level 1 has
+    // 1536..2048 rows coarsens once more (16k views / 320k edges: 348 -> 557 M edge-updates/s; at 15 edges per
+    // view the extra iterations of three levels eat the gain, at 4 they double)
+    auto go_on = [&]() {
+        if (P.n.back() > g.opt.mg_dense_max) return true;
+        return tune && band0 && P.n.size() == 2 && P.n.back() >= 1536 && (P.n.back() + 7) / 8 >= 64 &&
+               nnz0 >= 36ll * n0;
+    };
+    while ((int)P.n.size() < max_levels && go_on()) {
+        const int Fn = P.n.back();
+        const size_t depth = P.n.size();
+        // aggregate = `agg` contiguous rows, a power of two <= 64 so it never straddles a slice
+        int agg = (depth == 1) ? g.opt.mg_agg0 : g.opt.mg_agg;
+        if (agg <= 0) {
+            agg = 8;  // few, large steps: every extra level costs two latency-bound sweeps per cycle
+            // do not overshoot the dense level: the smallest factor that reaches it -- except on level 1
+            // of a graph that can take the two-launch iteration (see band0 above)
+            const bool keep8 = band0 && depth == 2 && (Fn + 7) / 8 >= 64;
+            // ... and on level 0 when aggregates of 8 still leave >= 512 dense rows (5k views: 625 dense rows
+            // instead of 1250: 125 -> 157 M)
+            const bool keep8_0 = tune && depth == 1 && (Fn + 7) / 8 >= 512;
+            for (int s2 = 2; s2 < agg && !keep8 && !keep8_0; s2 *= 2)
+                if ((Fn + s2 - 1) / s2 <= g.opt.mg_dense_max) {
+                    agg = s2;
+                    break;
+                }
+        }
+        // loop-closure graphs (dense level capped at 1100 above): two levels with aggregates of 16 beat three
+        // with 8 x 2 by ~5 % where both reach the cap (8.8k-17.6k views)
+        if (tune && depth == 1 && g.opt.mg_agg0 <= 0 && g.opt.mg_dense_max == 1100 && (Fn + 7) / 8 > 1100 &&
+            (Fn + 15) / 16 <= 1100)
+            agg = 16;
+        agg = std::min(pow2floor(std::max(agg, 2)), 64);
+        P.agg.push_back(agg);
+        P.n.push_back((Fn + agg - 1) / agg);
+    }
+    P.agg.push_back(0);  // the coarsest level aggregates no further
+    return P;
+}
+
 int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
+    // Patterns on the device (gbuild.hip) for a single-GPU graph that is large enough to fill it; on the host for
+    // shards (ghost views) and small graphs (sliding windows that miss the single-kernel path: a few hundred
+    // edges are built faster than a dozen launches are issued). IROTAVG_HOST_BUILD=1 / =0 force either.
+    const char *e = getenv("IROTAVG_HOST_BUILD");
+    const bool host = e ? atoi(e) != 0 : (g.ng > 0 || g.m < 20000);
+    return host ? build_graph_host(g, I, QQ, ldqq) : build_graph_device(g, I, QQ, ldqq);
+}
+
+int build_graph_host(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     const bool timing = getenv("IROTAVG_BUILD_TIMING") != nullptr;
     double tlast = now_seconds();
     auto lap = [&](const char *what) {
         if (!timing) return;
         const double t = now_seconds();
-        std::fprintf(stderr, "[irotavg_hip build] %-28s %8.2f ms\n", what, 1e3 * (t - tlast));
-        tlast = t;
+        (void)hipStreamSynchronize(g.stream);  // attribute queued uploads to the phase that issued them
+        const double t2 = now_seconds();
+        std::fprintf(stderr, "[irotavg_hip build] %-28s %8.2f ms host + %6.2f ms queued\n", what, 1e3 * (t - tlast),
+                     1e3 * (t2 - t));
+        tlast = t2;
     };
     const int64_t m = g.m;
     const int f = g.f;
@@ -251,36 +328,9 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     H[0].n = nu;
     H[0].rowptr = std::move(rowptr);
     H[0].col = std::move(col);
-    const int max_levels = std::max(1, std::min(g.opt.mg_levels_max, (int)kMaxLevels));
-    const bool tune = getenv("IROTAVG_NO_SMALL_TUNING") == nullptr;
-    if (g.opt.mg_dense_max <= 0) {
-        // The dense level is re-inverted whenever the weights move non-uniformly. For a band graph that is the
-        // cheap banded inverse and rare; with loop closures it is the full Gauss-Jordan sweep (n/32 block
-        // steps of ~21 us) in almost every IRLS iteration, and up to ~70k views a level of 550..1100 rows
-        // behind an aggregation factor of 16..64 costs 2-5 more PCG iterations but half the sweep
-        // (10k/150k: 5.9 -> 4.7 ms, 16k: 9.1 -> 6.0 ms, 30k: 11.5 -> 8.5 ms per irls call; at 100k views the
-        // factor would be 128 and the iterations double: 2048 stays)
-        std::atomic<bool> far(false);
-        const HostLevel &h0 = H[0];
-        if (tune && h0.n <= 70400)
-            parallel_for(h0.n, 4096, [&](int64_t r0, int64_t r1, int) {
-                for (int r = (int)r0; r < (int)r1 && !far; r++)
-                    for (int t = h0.rowptr[r]; t < h0.rowptr[r + 1]; t++)
-                        if (h0.col[t] < r - kWinHalo || h0.col[t] > r + kWinHalo) {
-                            far = true;
-                            break;
-                        }
-            });
-        g.opt.mg_dense_max = far ? 1100 : 2048;
-    }
-    // A graph without far (loop-closure) entries on one GPU can run its PCG iteration as two launches
-    // (cgcg.hip), which needs aggregates of 8 on levels 0 AND 1. The rule below would stop level 1 short
-    // (aggregates of 2 or 4 that just reach the dense level: 20k views -> 2500 -> 1250) and leave such a
-    // graph on the slowest path (six launches per iteration): measured 389 vs 667 M edge-updates/s at
-    // 20k / 400k, 1223 vs 1669 M at 60k / 1.2M, for two more PCG iterations per solve.
-    bool band0 = g.ng == 0 && g.opt.mg_multiplicative_top != 1 && g.opt.no_fused_pspmv != 1 &&
-                 g.opt.pcg_classic != 1 && (H[0].n + 63) / 64 <= 4 * kMaxParts;
-    if (band0) {
+    // far (loop-closure) entries on level 0? -- decides the dense level's size and which PCG kernels can run
+    bool far0 = false;
+    {
         std::atomic<bool> far(false);
         const HostLevel &h0 = H[0];
         parallel_for(h0.n, 4096, [&](int64_t r0, int64_t r1, int) {
@@ -291,43 +341,12 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
                         break;
                     }
         });
-        band0 = !far;
+        far0 = far;
     }
-    // A dense level of more than ~1500 rows costs more per PCG iteration (its 8 n^2-byte apply) than a third
-    // level with the two-launch iteration saves: a band graph of >= 18 edges per view whose level 1 has
-    // 1536..2048 rows coarsens once more (16k views / 320k edges: 348 -> 557 M edge-updates/s; at 15 edges per
-    // view the extra iterations of three levels eat the gain, at 4 they double)
-    auto go_on = [&]() {
-        if (H.back().n > g.opt.mg_dense_max) return true;
-        return tune && band0 && H.size() == 2 && H.back().n >= 1536 && (H.back().n + 7) / 8 >= 64 &&
-               H[0].rowptr[H[0].n] >= 36ll * H[0].n;
-    };
-    while ((int)H.size() < max_levels && go_on()) {
+    const HierPlan plan = plan_hierarchy(g, H[0].n, (int64_t)H[0].rowptr[H[0].n], far0);
+    while (H.size() < plan.n.size()) {
         HostLevel &F = H.back();
-        const int64_t fnnz = F.rowptr[F.n];
-        // aggregate = `agg` contiguous rows, a power of two <= 64 so it never straddles a slice
-        int agg = (H.size() == 1) ? g.opt.mg_agg0 : g.opt.mg_agg;
-        if (agg <= 0) {
-            (void)fnnz;
-            agg = 8;  // few, large steps: every extra level costs two latency-bound sweeps per cycle
-            // do not overshoot the dense level: the smallest factor that reaches it -- except on level 1
-            // of a graph that can take the two-launch iteration (see band0 above)
-            const bool keep8 = band0 && H.size() == 2 && (F.n + 7) / 8 >= 64;
-            // ... and on level 0 when aggregates of 8 still leave >= 512 dense rows (5k views: 625 dense rows
-            // instead of 1250: 125 -> 157 M)
-            const bool keep8_0 = tune && H.size() == 1 && (F.n + 7) / 8 >= 512;
-            for (int s2 = 2; s2 < agg && !keep8 && !keep8_0; s2 *= 2)
-                if ((F.n + s2 - 1) / s2 <= g.opt.mg_dense_max) {
-                    agg = s2;
-                    break;
-                }
-        }
-        // loop-closure graphs (dense level capped at 1100 above): two levels with aggregates of 16 beat three
-        // with 8 x 2 by ~5 % where both reach the cap (8.8k-17.6k views)
-        if (tune && H.size() == 1 && g.opt.mg_agg0 <= 0 && g.opt.mg_dense_max == 1100 && (F.n + 7) / 8 > 1100 &&
-            (F.n + 15) / 16 <= 1100)
-            agg = 16;
-        agg = std::min(pow2floor(std::max(agg, 2)), 64);
+        int agg = plan.agg[H.size() - 1];
         F.agg = agg;
         HostLevel C;
         C.n = (F.n + agg - 1) / agg;
@@ -515,6 +534,47 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         prev = std::move(M);
     }
     lap("SELL conversion + uploads");
+    // what the common tail needs to know about the patterns
+    BuildTail T;
+    T.nlev = (int)H.size();
+    for (size_t l = 0; l < H.size() && l < (size_t)kMaxLevels; l++) T.agg[l] = H[l].agg;
+    {
+        const HostLevel &hd = H.back();
+        int bw = 0;
+        for (int r = 0; r < hd.n; r++)
+            for (int t = hd.rowptr[r]; t < hd.rowptr[r + 1]; t++) bw = std::max(bw, std::abs(hd.col[t] - r));
+        T.dense_bw = bw;
+    }
+    if (H.size() >= 3) {
+        bool ok = true;
+        const HostLevel &h1 = H[1];
+        for (int r = 0; r < h1.n && ok; r++) {
+            const int lo = (r / 32) * 32 - 8, hi = (r / 32) * 32 + 40;
+            for (int t = h1.rowptr[r]; t < h1.rowptr[r + 1]; t++)
+                if (h1.col[t] < lo || h1.col[t] >= hi) {
+                    ok = false;
+                    break;
+                }
+        }
+        bool band8 = ok;
+        for (int r = 0; r < h1.n && band8; r++)
+            for (int t = h1.rowptr[r]; t < h1.rowptr[r + 1]; t++)
+                if (h1.col[t] < r - 8 || h1.col[t] > r + 8) {
+                    band8 = false;
+                    break;
+                }
+        T.l1_window_ok = ok;
+        T.l1_band8 = band8;
+    }
+    const int rc_tail = finish_build(g, T);
+    lap("PCG state");
+    return rc_tail;
+}
+
+// The tail of a build, shared by the host path above and the device path (gbuild.hip): dense level,
+// which PCG kernels this graph takes, PCG state.
+int finish_build(Graph &g, const BuildTail &T) {
+    hipStream_t s = g.stream;
     // dense inverse of the coarsest level (only when it is small enough and there is a hierarchy)
     g.ndense = 0;
     g.ndense_pad = 0;
@@ -529,11 +589,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
         g.dense_ref_diag.alloc((size_t)g.ndense_pad);
         // half-bandwidth of the coarsest operator: a banded one (view sequences without loop closures: 1-3)
         // is inverted by a banded LDL' + one substitution per column instead of the dense sweep (dense.hip)
-        const HostLevel &hd = H.back();
-        int bw = 0;
-        for (int r = 0; r < hd.n; r++)
-            for (int t = hd.rowptr[r]; t < hd.rowptr[r + 1]; t++) bw = std::max(bw, std::abs(hd.col[t] - r));
-        g.dense_bw = bw;
+        g.dense_bw = T.dense_bw;
     }
     g.additive_top = g.opt.mg_multiplicative_top == 1 ? 0 : 1;
     // Can the PCG update also do the down-sweep of level 1 (k_pcg_update_restrict2)? Aggregates of 8
@@ -541,33 +597,18 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     // the 48-row window the update kernel holds in LDS.
     g.l1_fused = 0;
     g.cg2 = 0;
-    if (g.additive_top && H.size() >= 3 && H[0].agg == 8 && H[1].agg == 8 && g.ng == 0 &&
+    if (g.additive_top && T.nlev >= 3 && T.agg[0] == 8 && T.agg[1] == 8 && g.ng == 0 &&
         g.l0_far_entries == 0 && g.opt.no_fused_pspmv != 1) {
-        bool ok = true;
-        const HostLevel &h1 = H[1];
-        for (int r = 0; r < h1.n && ok; r++) {
-            const int lo = (r / 32) * 32 - 8, hi = (r / 32) * 32 + 40;
-            for (int t = h1.rowptr[r]; t < h1.rowptr[r + 1]; t++)
-                if (h1.col[t] < lo || h1.col[t] >= hi) {
-                    ok = false;
-                    break;
-                }
-        }
+        const bool ok = T.l1_window_ok;
         g.l1_fused = ok ? 1 : 0;
         // the two-launch iteration (cgcg.hip) also runs the level-1 UP-sweep inside a level-0 kernel:
         // the 48 level-1 rows under a tile window need all their neighbours within the 64 extended
         // rows, i.e. within 8 rows
-        bool band8 = ok;
-        for (int r = 0; r < h1.n && band8; r++)
-            for (int t = h1.rowptr[r]; t < h1.rowptr[r + 1]; t++)
-                if (h1.col[t] < r - 8 || h1.col[t] > r + 8) {
-                    band8 = false;
-                    break;
-                }
+        const bool band8 = ok && T.l1_band8;
         // ... and a workgroup per tile of <= 4 slices with at most kMaxParts workgroups (up to 131k views).
         // Beyond that the kernels are bandwidth-bound, not latency-bound, and the classic launches
         // measured faster (1M/20M: 1.88 vs 1.70 G)
-        const bool one_tile = (H[0].n + 63) / 64 <= 4 * kMaxParts;
+        const bool one_tile = (g.levels[0].n + 63) / 64 <= 4 * kMaxParts;
         g.cg2 = (band8 && one_tile && g.ndense > 0 && g.opt.pcg_classic != 1) ? 1 : 0;
         g.dense32 = 0;  // tile slices of the coarse solve read the fp64 inverse; IROTAVG_CG2_FP32_DENSE=1: an fp32 copy
         if (const char *e = getenv("IROTAVG_CG2_FP32_DENSE")) g.dense32 = atoi(e) == 1 ? 1 : 0;
@@ -599,8 +640,7 @@ int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
     g.part_rz.zero(s);
     g.part_score.zero(s);
     alloc_state(g);
-    IRH_CHECK(hipStreamSynchronize(s));  // host vectors above go out of scope
-    lap("PCG state");
+    IRH_CHECK(hipStreamSynchronize(s));  // host vectors of the callers go out of scope
     return IROTAVG_OK;
 }
 

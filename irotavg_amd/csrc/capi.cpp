@@ -447,6 +447,73 @@ int irotavg_graph_l1decode_pd(irotavg_graph *h, const double *y, int pdmaxiter, 
     API_CATCH
 }
 
+int irotavg_graph_fingerprint(irotavg_graph *h, uint64_t *out, int cap) {
+    if (!h || !out || cap < 0) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    Graph &g = h->g;
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    std::vector<uint64_t> v;
+    std::vector<unsigned char> host;
+    auto fnv = [](const unsigned char *p, size_t n) {
+        uint64_t hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < n; i++) hsh = (hsh ^ p[i]) * 1099511628211ull;
+        return hsh;
+    };
+    auto arr = [&](const void *dev, size_t bytes) {
+        if (!dev || bytes == 0) {
+            v.push_back(0);
+            return;
+        }
+        host.resize(bytes);
+        IRH_CHECK(hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost));
+        v.push_back(fnv(host.data(), bytes));
+    };
+    auto last_int = [&](const int *dev, size_t idx) {
+        int x = 0;
+        if (dev) IRH_CHECK(hipMemcpy(&x, dev + idx, sizeof(int), hipMemcpyDeviceToHost));
+        return x;
+    };
+    const size_t mp = (size_t)g.mpad;
+    arr(g.ei.p, 4 * mp);
+    arr(g.ej.p, 4 * mp);
+    arr(g.eflag.p, mp);
+    arr(g.qq.p, 8 * 4 * mp);
+    arr(g.bptr.p, 4 * ((size_t)g.no + 1));
+    const size_t nb = (size_t)last_int(g.bptr.p, (size_t)g.no);
+    arr(g.beid.p, 4 * nb);
+    arr(g.bflag.p, nb);
+    arr(g.bghost.p, 4 * nb);
+    const Level &L0 = g.levels[0];
+    arr(g.slot_eid.p, 4 * (size_t)L0.sell_len);
+    arr(g.slot_cs.p, g.slot_cs.p ? (size_t)L0.sell_len : 0);
+    arr(g.tile_e0.p, 4 * (size_t)L0.nsl);
+    v.push_back((uint64_t)g.levels.size());
+    for (size_t l = 0; l < g.levels.size(); l++) {
+        const Level &L = g.levels[l];
+        for (long long x : {(long long)L.n, (long long)L.nnz, (long long)L.agg, (long long)L.nsl, L.sell_len,
+                            (long long)L.max_near, (long long)L.uni_w, (long long)(l > 0 ? L.max_row : 0)})
+            v.push_back((uint64_t)x);
+        arr(L.sl_off.p, 4 * ((size_t)L.nsl + 1));
+        arr(L.sl_near.p, 4 * (size_t)L.nsl);
+        arr(L.col.p, 4 * (size_t)L.sell_len);
+        if (l > 0) {
+            arr(L.crow.p, 4 * ((size_t)L.n + 1));
+            arr(L.cptr.p, 4 * ((size_t)L.nnz + 1));
+            const size_t nv = (size_t)last_int(L.cptr.p, (size_t)L.nnz);
+            arr(L.cidx.p, 4 * nv);
+            arr(L.cpos.p, 4 * (size_t)L.nnz);
+        }
+    }
+    for (long long x : {g.l0_far_entries, (long long)g.asm_windowed, (long long)g.asm_l1_fused, (long long)g.l1_fused,
+                        (long long)g.cg2, (long long)g.ndense, (long long)g.ndense_pad, (long long)g.dense_bw,
+                        (long long)g.opt.mg_dense_max, (long long)(g.opt.mg_kc * 1000.0 + 0.5), (long long)g.additive_top})
+        v.push_back((uint64_t)x);
+    const int nout = (int)std::min<size_t>(v.size(), (size_t)cap);
+    for (int i = 0; i < nout; i++) out[i] = v[(size_t)i];
+    return nout;
+    API_CATCH
+}
+
 int irotavg_graph_time_kernel(irotavg_graph *h, int which, int reps, double *ms) {
     if (!h || !ms || reps <= 0) return IROTAVG_ERR_BAD_ARG;
     API_TRY
@@ -462,17 +529,31 @@ int irotavg_irls(int64_t m, int64_t n_total, int f, const int32_t *I, const doub
                  double change_th, double *weights, int *iters, double *runtime) {
     if (!Q || !weights || !iters || !runtime) return IROTAVG_ERR_BAD_ARG;
     if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
+    const bool timing = std::getenv("IROTAVG_BUILD_TIMING") != nullptr;
+    double t0 = now_seconds();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t = now_seconds();
+        std::fprintf(stderr, "[irotavg_hip one-shot] %-22s %8.2f ms\n", what, 1e3 * (t - t0));
+        t0 = t;
+    };
     irotavg_graph *h = nullptr;
     int rc = irotavg_graph_create(&h, m, n_total, f, I, QQ, ldqq, nullptr);
     if (rc != IROTAVG_OK) return rc;
+    lap("graph_create");
     rc = irotavg_graph_set_rotations(h, Q, ldq);
+    lap("set_rotations");
     if (rc == IROTAVG_OK)
         rc = irotavg_graph_irls(h, cost, sigma, max_iters, change_th, iters, runtime, nullptr);
+    lap("irls");
     if (rc == IROTAVG_OK || rc == IROTAVG_ERR_NOT_CONVERGED) {
         (void)irotavg_graph_get_rotations(h, Q, ldq);
+        lap("get_rotations");
         (void)irotavg_graph_get_weights(h, weights);
+        lap("get_weights");
     }
     irotavg_graph_destroy(h);
+    lap("destroy");
     return rc;
 }
 

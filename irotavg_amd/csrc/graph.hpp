@@ -123,8 +123,22 @@ struct PrecInfo {
     int np_rz = 0, np_rz2 = 0;
 };
 
-// build.cpp
+// build.cpp (patterns on the host) / gbuild.hip (patterns on the device)
+struct BuildTail {          // what the common tail of a build needs to know about the patterns
+    int nlev = 1;
+    int agg[kMaxLevels] = {0};
+    int dense_bw = 0;           // half-bandwidth of the coarsest level's pattern
+    bool l1_window_ok = false;  // every level-1 neighbour of a row within the 48-row window of its 32-row block
+    bool l1_band8 = false;      // ... and within 8 rows
+};
+struct HierPlan {
+    std::vector<int> n, agg;  // rows and aggregation factor per level (agg of the coarsest level: 0)
+};
+HierPlan plan_hierarchy(Graph &g, int n0, int64_t nnz0, bool far0);
 int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
+int build_graph_host(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
+int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
+int finish_build(Graph &g, const BuildTail &T);
 
 // solver entry points (solver.hip)
 void launch_edge_residual(Graph &g);

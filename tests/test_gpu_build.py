@@ -1,0 +1,103 @@
+"""The device build of the graph handle (irotavg_amd/csrc/gbuild.hip) against the host build (build.cpp):
+the SAME structure -- every index array bit for bit (irotavg_graph_fingerprint) -- and therefore bitwise the
+same solves, on band graphs, graphs with loop closures, several fixed views, make_A's quirk edges, duplicate
+edges, self loops, reversed edges and every hierarchy depth."""
+import numpy as np
+import pytest
+
+from irotavg_amd import capi, ral, synth
+
+pytestmark = pytest.mark.gpu
+SIG = 5 * np.pi / 180
+
+
+def start(S, n, f):
+    Q = np.zeros((n, 4)); Q[:, 3] = 1; Q[:f] = S["Qgt"][:f]
+    ral.init_mst(Q, S["QQ"], S["I"], f)
+    return Q
+
+
+def both(I, QQ, n, f, Q0, monkeypatch, l1=0, **opts):
+    out = []
+    for host in ("1", "0"):
+        monkeypatch.setenv("IROTAVG_HOST_BUILD", host)
+        with capi.Graph(I, QQ, n, f, **opts) as G:
+            fp = G.fingerprint()
+            G.set_rotations(Q0)
+            a = G.l1ra(l1, 1e-3) if l1 else None
+            r = G.irls(4, SIG, 30, 1e-3)
+            out.append((fp, a, r, G.get_rotations(), G.get_weights(), G.stats()))
+    return out
+
+
+def same(out):
+    (fa, aa, ra, Qa, wa, sa), (fb, ab, rb, Qb, wb, sb) = out
+    assert len(fa) == len(fb)
+    assert fa == fb, [i for i in range(len(fa)) if fa[i] != fb[i]]
+    assert ra["iters"] == rb["iters"] and sa["pcg_iters"] == sb["pcg_iters"]
+    np.testing.assert_array_equal(ra["scores"], rb["scores"])
+    np.testing.assert_array_equal(Qa, Qb)
+    np.testing.assert_array_equal(wa, wb)
+    if aa is not None:
+        assert aa["iters"] == ab["iters"]
+        np.testing.assert_array_equal(aa["scores"], ab["scores"])
+
+
+@pytest.mark.parametrize("n,m,p,f", [(100000, 2000000, 0.0, 1), (100000, 2000000, 0.02, 1), (10000, 150000, 0.02, 1),
+                                     (20000, 400000, 0.0, 3), (33333, 166665, 0.0, 4), (5000, 60000, 0.01, 1),
+                                     (3000, 30000, 0.0, 1), (1500, 20000, 0.1, 2), (131000, 655000, 0.0, 2),
+                                     (16397, 163970, 0.0, 1)])
+def test_device_build_equals_host_build(n, m, p, f, monkeypatch):
+    S = synth.make_graph(n, m, p, seed=11)
+    same(both(S["I"], S["QQ"], n, f, start(S, n, f), monkeypatch, l1=1 if n <= 20000 else 0))
+
+
+def test_device_build_on_awkward_edge_lists(monkeypatch):
+    """Shuffled edge order, reversed pairs (i > j), duplicate edges, self loops, edges between fixed views, edges
+    whose SECOND endpoint is fixed (make_A drops the row, make_AtA keeps the diagonal term) -- the cases the host
+    build's comments single out."""
+    n, m, f = 6000, 80000, 5
+    S = synth.make_graph(n, m, 0.05, seed=5)
+    rng = np.random.default_rng(0)
+    I, QQ = S["I"].copy(), S["QQ"].copy()
+    rev = rng.random(len(I)) < 0.3
+    I[rev] = I[rev][:, ::-1]
+    QQ[rev] = synth.qconj(QQ[rev])
+    dup = rng.choice(len(I), 500, replace=False)
+    I = np.vstack([I, I[dup]]); QQ = np.vstack([QQ, QQ[dup]])
+    loops = rng.integers(0, n, 50)
+    I = np.vstack([I, np.stack([loops, loops], 1)]); QQ = np.vstack([QQ, np.tile([[0, 0, 0, 1.0]], (50, 1))])
+    I = np.vstack([I, [[0, 1], [2, 1], [3, 4]]]); QQ = np.vstack([QQ, np.tile([[0, 0, 0, 1.0]], (3, 1))])  # fixed-fixed
+    perm = rng.permutation(len(I))
+    I, QQ = np.ascontiguousarray(I[perm]).astype(np.int32), QQ[perm]
+    Q0 = synth.qmul(synth.qexp(rng.normal(scale=0.05, size=(n, 3))), S["Qgt"])
+    Q0[:f] = S["Qgt"][:f]
+    # (irls only: a self loop puts -sigma on the diagonal of the L1 Hessian, ral/l1_irls.cpp:825-843, which the
+    #  reference's LU tolerates and a CG does not -- not what this test is about)
+    same(both(I, QQ, n, f, Q0, monkeypatch, l1=0))
+
+
+def test_device_build_rejects_bad_indices(monkeypatch):
+    monkeypatch.setenv("IROTAVG_HOST_BUILD", "0")
+    S = synth.make_graph(3000, 30000, 0.0, seed=1)
+    I = S["I"].copy()
+    I[17, 1] = 3000
+    with pytest.raises(capi.IrotavgError) as e:
+        capi.Graph(I, S["QQ"], 3000, 1)
+    assert e.value.code == capi.ERR_BAD_ARG
+
+
+def test_one_shot_call_takes_the_device_build_and_matches_the_handle(monkeypatch):
+    """irotavg_irls from host buffers (the reference's signature) = handle creation by the device build + solve."""
+    n, m = 30000, 450000
+    S = synth.make_graph(n, m, 0.01, seed=2)
+    Q0 = start(S, n, 1)
+    res = []
+    for host in ("1", "0"):
+        monkeypatch.setenv("IROTAVG_HOST_BUILD", host)
+        Q, w = Q0.copy(), np.zeros(m)
+        it, _ = ral.irls(S["QQ"], S["I"], None, 4, SIG, Q, 1, 100, 1e-3, w)
+        res.append((it, Q, w))
+    assert res[0][0] == res[1][0]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
