@@ -483,18 +483,28 @@ def main():
             # what a caller of the drop-in irotavg_irls pays with HOST buffers: graph build (adjacency,
             # hierarchy, SELL) + upload + the same solve + download, per call (the resident
             # figure above is the amortised / incremental case)
-            from irotavg_amd import ral
-            reps = 3
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                Qh = Q0.copy()
-                wh = np.zeros(S["m"])
-                it1, _rt = ral.irls(S["QQ"], S["I"], None, 4, SIG, Qh, 1, 100, 1e-3, wh)
-            d1 = time.perf_counter() - t1
+            # The C call itself on arrays that already have the reference's layout (Eigen column-major Mat, int32
+            # pairs): what a C++ caller of irotavg::irls pays. (Until round 2 this went through irotavg_amd/ral.py,
+            # whose NumPy layout conversions -- 10-15 ms at this size -- were inside the timed region.)
+            import ctypes as C
+            QQf, Ie = capi.fmat(S["QQ"]), capi.edges(S["I"])
+            reps = 5
+            d1 = 0.0
+            for rep in range(reps + 1):
+                Qf, wh = capi.fmat(Q0), np.zeros(S["m"])
+                it_c, rt_c = C.c_int(0), C.c_double(0)
+                t1 = time.perf_counter()
+                rc1 = capi.lib().irotavg_irls(S["m"], S["n"], 1, capi._i(Ie), capi._d(QQf), S["m"], 4, SIG, capi._d(Qf),
+                                              S["n"], 100, 1e-3, capi._d(wh), C.byref(it_c), C.byref(rt_c))
+                if rep > 0:
+                    d1 += time.perf_counter() - t1
+                assert rc1 == 0
+            it1 = it_c.value
             line["also_one_shot_host_buffers"] = {
                 "value": S["m"] * it1 * reps / d1, "unit": "edge-updates/s", "ms_per_call": 1e3 * d1 / reps,
-                "iters_to_converge": it1,
-                "note": "irotavg_irls from host pointers: handle creation + PCIe both ways inside the timed region"}
+                "iters_to_converge": it1, "irls_ms_inside": 1e3 * rt_c.value,
+                "note": "irotavg_irls from host pointers (pageable memory): handle creation by the device build "
+                        "(gbuild.hip) + PCIe both ways + the solve inside the timed region; one untimed call first"}
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(S, Q0, args.p_loop)
             ss = suitesparse_baseline(S, Q0)

@@ -265,8 +265,9 @@ int irotavg_graph_set_rotations(irotavg_graph *h, const double *Q, int64_t ldq) 
     API_TRY
     Graph &g = h->g;
     std::vector<double4> aos((size_t)g.n_total);
-    for (int64_t i = 0; i < g.n_total; i++)
-        aos[i] = make_double4(Q[i], Q[ldq + i], Q[2 * ldq + i], Q[3 * ldq + i]);
+    parallel_for(g.n_total, 8192, [&](int64_t a, int64_t b, int) {
+        for (int64_t i = a; i < b; i++) aos[i] = make_double4(Q[i], Q[ldq + i], Q[2 * ldq + i], Q[3 * ldq + i]);
+    });
     g.Q.upload(aos.data(), aos.size(), g.stream);
     IRH_CHECK(hipStreamSynchronize(g.stream));
     return IROTAVG_OK;
@@ -281,12 +282,14 @@ int irotavg_graph_get_rotations(irotavg_graph *h, double *Q, int64_t ldq) {
     IRH_CHECK(hipMemcpyAsync(aos.data(), g.Q.p, sizeof(double4) * aos.size(), hipMemcpyDeviceToHost,
                              g.stream));
     IRH_CHECK(hipStreamSynchronize(g.stream));
-    for (int64_t i = 0; i < g.n_total; i++) {
-        Q[i] = aos[i].x;
-        Q[ldq + i] = aos[i].y;
-        Q[2 * ldq + i] = aos[i].z;
-        Q[3 * ldq + i] = aos[i].w;
-    }
+    parallel_for(g.n_total, 8192, [&](int64_t a, int64_t b, int) {
+        for (int64_t i = a; i < b; i++) {
+            Q[i] = aos[i].x;
+            Q[ldq + i] = aos[i].y;
+            Q[2 * ldq + i] = aos[i].z;
+            Q[3 * ldq + i] = aos[i].w;
+        }
+    });
     return IROTAVG_OK;
     API_CATCH
 }
