@@ -54,7 +54,10 @@ static SellMap sell_map(int n, const std::vector<int> &rowptr, const std::vector
                 wn = std::max(wn, nn);
                 wf = std::max(wf, rowptr[r + 1] - rowptr[r] - nn);
             }
-            wn = roundup(wn);
+            // never narrower than one batch: the row kernels request the first kSellUnroll entries of a row before
+            // they know its length (a slice of views without a free neighbour -- e.g. a star around the fixed view
+            // -- would otherwise be zero wide and those requests would land in front of the array)
+            wn = std::max(roundup(wn), kSellUnroll);
             wf = roundup(wf);
             M.sl_near[sl] = wn;
             width[sl] = wn + wf;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kT) void k_gb_slice_width(int n, int nsl, const int
         nf = max(nf, __shfl_xor(nf, o, 64));
     }
     if (lane == 0) {
-        const int wn = (nn + kSellUnroll - 1) / kSellUnroll * kSellUnroll;
+        const int wn = max((nn + kSellUnroll - 1) / kSellUnroll * kSellUnroll, kSellUnroll);  // see build.cpp
         const int wf = (nf + kSellUnroll - 1) / kSellUnroll * kSellUnroll;
         sl_near[sl] = wn;
         width[sl] = wn + wf;

@@ -77,6 +77,37 @@ def test_device_build_on_awkward_edge_lists(monkeypatch):
     same(both(I, QQ, n, f, Q0, monkeypatch, l1=0))
 
 
+def test_device_build_degenerate_shapes(monkeypatch):
+    """Shapes at the edges of the device build: (a) a small dense multigraph (300 views, 25000 edges: one dense
+    level, thousands of duplicate edges per pair); (b) a star around the fixed view (no matrix entry at all: every
+    edge is a boundary slot, the operator is its diagonal); (c) a single free view."""
+    rng = np.random.default_rng(3)
+    # (a)
+    n, m, f = 300, 25000, 2
+    Qgt = rng.normal(size=(n, 4)); Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+    I = np.stack([rng.integers(0, n, m), rng.integers(0, n, m)], 1).astype(np.int32)
+    I[:n - 1] = np.stack([np.arange(n - 1), np.arange(1, n)], 1)          # connected
+    QQ = synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(m, 3))), synth.qmul(Qgt[I[:, 1]], synth.qconj(Qgt[I[:, 0]])))
+    Q0 = synth.qmul(synth.qexp(rng.normal(scale=0.05, size=(n, 3))), Qgt); Q0[:f] = Qgt[:f]
+    same(both(I, QQ, n, f, Q0, monkeypatch))
+    # (b)
+    n, f = 25001, 1
+    Qgt = rng.normal(size=(n, 4)); Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+    I = np.stack([np.zeros(n - 1, np.int64), np.arange(1, n)], 1).astype(np.int32)
+    QQ = synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(n - 1, 3))), synth.qmul(Qgt[I[:, 1]], synth.qconj(Qgt[I[:, 0]])))
+    Q0 = synth.qmul(synth.qexp(rng.normal(scale=0.05, size=(n, 3))), Qgt); Q0[:f] = Qgt[:f]
+    out = both(I, QQ, n, f, Q0, monkeypatch)
+    same(out)
+    assert synth.angular_distance(out[1][3], Qgt).max() < 0.05
+    # (c)
+    n, m, f = 3, 21000, 2
+    Qgt = rng.normal(size=(n, 4)); Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+    I = np.stack([rng.integers(0, 2, m), np.full(m, 2)], 1).astype(np.int32)
+    QQ = synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(m, 3))), synth.qmul(Qgt[I[:, 1]], synth.qconj(Qgt[I[:, 0]])))
+    Q0 = Qgt.copy(); Q0[2] = synth.qmul(synth.qexp(np.array([[0.05, -0.02, 0.01]])), Qgt[2:3])[0]
+    same(both(I, QQ, n, f, Q0, monkeypatch))
+
+
 def test_device_build_rejects_bad_indices(monkeypatch):
     monkeypatch.setenv("IROTAVG_HOST_BUILD", "0")
     S = synth.make_graph(3000, 30000, 0.0, seed=1)

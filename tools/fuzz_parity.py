@@ -172,10 +172,15 @@ def main():
     ap.add_argument("--small-share", type=float, default=0.4, help="share of cases with n <= 20 (window kernels)")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--large", action="store_true", help="multi-level graphs (2100..3500 views) instead")
+    ap.add_argument("--device-build", action="store_true",
+                    help="build every handle on the device (gbuild.hip); by default graphs below 20000 edges are "
+                         "built on the host")
     ap.add_argument("--max-capped", type=int, default=-1,
                     help="runs at the IRLS iteration cap that may lie between --tol and 1e-4 rad before the "
                          "campaign fails; default: 2 + cases // 500 (recorded baseline: 4 in 5300 cases, DESIGN.md 2)")
     a = ap.parse_args()
+    if a.device_build:
+        os.environ["IROTAVG_HOST_BUILD"] = "0"
     import warnings
     warnings.simplefilter("error")   # a NOT_CONVERGED that ral.py would soften to a warning is a failure here
     rng = np.random.default_rng(a.seed)
