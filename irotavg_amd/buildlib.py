@@ -23,8 +23,9 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     extra = [os.path.join(os.path.dirname(HERE), "tools", "l1_irls.cpp"),
+             os.path.join(os.path.dirname(HERE), "tools", "stream_bench.cpp"),
              os.path.join(os.path.dirname(HERE), "include", "irotavg", "l1_irls.hpp")]
-    if not os.path.exists(CLI) or any(os.path.getmtime(e) > t for e in extra if os.path.exists(e)):
+    if not os.path.exists(CLI) or not os.path.exists(os.path.join(os.path.dirname(CLI), "stream_bench")) or any(os.path.getmtime(e) > t for e in extra if os.path.exists(e)):
         return True
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS
                if os.path.exists(os.path.join(CSRC, f)))
@@ -62,6 +63,13 @@ def build_cli(verbose=False):
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     src = os.path.join(os.path.dirname(HERE), "tools", "l1_irls.cpp")
     cmd = ["g++", "-O2", "-std=c++11", "-DIROTAVG_SHIM_NO_EIGEN", src, "-o", CLI, "-L" + HERE,
+           "-lirotavg_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    # the native driver of BASELINE.json config 5 (tools/stream_bench.cpp over the C ABI)
+    src = os.path.join(os.path.dirname(HERE), "tools", "stream_bench.cpp")
+    cmd = ["g++", "-O2", "-std=c++11", src, "-o", os.path.join(os.path.dirname(CLI), "stream_bench"), "-L" + HERE,
            "-lirotavg_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))

@@ -61,3 +61,19 @@ def test_all_arguments(tmp_path):
     Q, w = graphio.read_l1_irls_out(str(out), 1832)
     assert synth.angular_distance(Q, O.quat_normalised(b["Q"], 1)).max() < 1e-8
     np.testing.assert_allclose(w, b["weights"], rtol=1e-7)
+
+
+@pytest.mark.gpu
+def test_native_stream_driver_small():
+    """tools/stream_bench.cpp (BASELINE config 5 driven by a native loop over the view-graph C ABI) at a small size:
+    one JSON line, every window solved, the global re-solves on the loop closures ran, error at the noise level."""
+    import json
+    from irotavg_amd import buildlib
+    buildlib.build()
+    exe = os.path.join(os.path.dirname(buildlib.CLI), "stream_bench")
+    r = subprocess.run([exe, "600", "900", "3", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["streamed_views"] == 900 and d["loop_closures"] == 3
+    assert d["views_per_s"] > 1000
+    assert d["mean_angular_error_rad"] < 0.03 and d["max_angular_error_rad"] < 0.1
