@@ -238,6 +238,12 @@ int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]
  * Sub-problems with <= 64 free views / <= 640 edges (every rotAvg(10) call) run as ONE kernel
  * launch (irotavg_amd/csrc/window.hip); larger ones through the graph handle path. */
 int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotavg_info *info);
+/* The same for n DIFFERENT view-graphs at once (a server that tracks many sequences; the reference has one graph
+ * per process, src/IRotAvg.cpp). The windows of different graphs are independent: those that fit the wave-resident
+ * kernel (every rotAvg(10) of a sequence linked to <= 4 predecessors) are solved by ONE launch with a workgroup per
+ * window -- one window alone keeps 1 of the 256 compute units busy --, the others run one by one. Results are
+ * those of n separate irotavg_viewgraph_rot_avg calls. infos: n entries or NULL. Returns the first error. */
+int irotavg_viewgraph_rot_avg_batch(irotavg_viewgraph *const *vgs, int n, int win_size, irotavg_rotavg_info *infos);
 
 /* rmat2quat (src/ViewGraph.cpp:1175-1203) / q.normalized().toRotationMatrix() (:1426-1433);
  * row-major R, q = [x y z w] */

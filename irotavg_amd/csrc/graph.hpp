@@ -214,6 +214,15 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
                  double *Q_aos, double *weights, int l1_max, int irls_max, int cost, double sigma,
                  double change_th, int *l1_iters, int *irls_iters, int kernel = 0);
 bool window_fits_wave(int nv, int f, int ne);
+struct WinBatchItem {  // one problem of a batched launch: inputs as window_solve takes them, Q_aos updated in place
+    int nv, f, ne;
+    const int32_t *I;
+    const double *QQ_aos;
+    double *Q_aos;
+    int l1_iters, irls_iters, status;
+};
+int window_solve_batch(WindowSolver &ws, int nb, WinBatchItem *items, int l1_max, int irls_max, int cost, double sigma,
+                       double change_th);
 // dense.hip
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);

@@ -96,10 +96,32 @@ struct irotavg_viewgraph {
     irotavg_options opt;
     irotavg_rotavg_info last{};
     irh::WindowSolver *win = nullptr;  // persistent staging of the single-kernel window solve
+    // a window extracted by rot_avg whose solve was deferred to a batched launch (irotavg_viewgraph_rot_avg_batch)
+    struct Pending {
+        bool on = false;
+        int f = 0;
+        long nv = 0, ne = 0;
+        irotavg_rotavg_info loc{};
+    } pending;
     ~irotavg_viewgraph() {
         if (win) irh::window_solver_delete(win);
     }
 };
+
+namespace {
+constexpr int kRotAvgDeferred = 1000;      // internal return code of rot_avg: window packed, solve deferred
+thread_local bool tl_defer_windows = false;  // set by irotavg_viewgraph_rot_avg_batch around its extraction calls
+
+// write-back for k >= f (src/ViewGraph.cpp:1420-1434): q.normalized().toRotationMatrix() into the views' poses
+void rotavg_writeback(irotavg_viewgraph *vg, int f, long nv) {
+    const std::vector<double> &Q = vg->scratch.Q;
+    const std::vector<int> &i2v = vg->scratch.i2v;
+    for (long r = f; r < nv; r++) {
+        const double q[4] = {Q[(size_t)r], Q[(size_t)(nv + r)], Q[(size_t)(2 * nv + r)], Q[(size_t)(3 * nv + r)]};
+        quat2rmat(q, vg->pose[(size_t)i2v[(size_t)r]].m);
+    }
+}
+}  // namespace
 
 extern "C" {
 
@@ -349,6 +371,18 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
             Qa.resize((size_t)4 * nv);
             for (long r = 0; r < nv; r++)
                 for (int c = 0; c < 4; c++) Qa[(size_t)4 * r + c] = Q[(size_t)c * nv + r];
+            if (tl_defer_windows && irh::window_fits_wave((int)nv, f, (int)ne)) {
+                // one of several independent windows: the caller solves them in ONE launch and finishes this call
+                loc.n_views = (int)nv;
+                loc.n_edges = (int)ne;
+                loc.n_fixed = f;
+                vg->pending.on = true;
+                vg->pending.f = f;
+                vg->pending.nv = nv;
+                vg->pending.ne = ne;
+                vg->pending.loc = loc;
+                return kRotAvgDeferred;
+            }
             const double t0 = irh::now_seconds();
             rc = irh::window_solve(*vg->win, (int)nv, f, (int)ne, I.data(), qq.data(), Qa.data(), nullptr,
                                    100, 100, IROTAVG_GEMAN_MCCLURE, 5 * M_PI / 180.0, change_th,
@@ -385,14 +419,88 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
         return rc;
     }
     // ---- write-back for k >= f (:1420-1434)
-    for (long r = f; r < nv; r++) {
-        const double q[4] = {Q[r], Q[nv + r], Q[2 * nv + r], Q[3 * nv + r]};
-        quat2rmat(q, vg->pose[i2v[r]].m);
-    }
+    rotavg_writeback(vg, f, nv);
     lap("write-back");
     vg->last = loc;
     if (info) *info = loc;
     return IROTAVG_OK;
+}
+
+// rotAvg for SEVERAL independent view-graphs at once (a server tracking many sequences): each graph's window is
+// extracted as irotavg_viewgraph_rot_avg does, the windows that fit the wave-resident kernel (every rotAvg(10) of
+// a sequence linked to <= 4 predecessors) are solved by ONE launch with a workgroup per window -- a single window
+// keeps one of the 256 compute units busy --, the others (global re-solves) run one by one, then every graph's poses
+// are written back. Results are those of n separate calls. infos: n entries or NULL. Returns the first error.
+int irotavg_viewgraph_rot_avg_batch(irotavg_viewgraph *const *vgs, int n, int win_size, irotavg_rotavg_info *infos) {
+    if (!vgs || n < 0) return IROTAVG_ERR_BAD_ARG;
+    for (int b = 0; b < n; b++)
+        if (!vgs[b]) return IROTAVG_ERR_BAD_ARG;
+    for (int a = 0; a < n; a++)
+        for (int b = a + 1; b < n; b++)
+            if (vgs[a] == vgs[b]) return IROTAVG_ERR_BAD_ARG;  // windows of one graph depend on each other
+    int first_err = IROTAVG_OK;
+    std::vector<irh::WinBatchItem> items;
+    std::vector<int> owner;
+    struct Undefer {
+        ~Undefer() { tl_defer_windows = false; }
+    } undefer;
+    tl_defer_windows = true;
+    for (int b = 0; b < n; b++) {
+        irotavg_viewgraph *vg = vgs[b];
+        vg->pending.on = false;
+        irotavg_rotavg_info loc{};
+        const int rc = irotavg_viewgraph_rot_avg(vg, win_size, &loc);
+        if (rc == kRotAvgDeferred) {
+            irh::WinBatchItem it{};
+            it.nv = (int)vg->pending.nv;
+            it.f = vg->pending.f;
+            it.ne = (int)vg->pending.ne;
+            it.I = vg->scratch.I.data();
+            it.QQ_aos = vg->scratch.qq.data();
+            it.Q_aos = vg->scratch.Qa.data();
+            items.push_back(it);
+            owner.push_back(b);
+        } else {
+            if (infos) infos[b] = loc;
+            if (rc != IROTAVG_OK && first_err == IROTAVG_OK) first_err = rc;
+        }
+    }
+    tl_defer_windows = false;
+    if (items.empty()) return first_err;
+    if (irotavg_device_count() <= 0) return IROTAVG_ERR_NO_DEVICE;
+    int rc = IROTAVG_OK;
+    try {
+        irotavg_viewgraph *host = vgs[owner[0]];
+        if (!host->win) host->win = irh::window_solver_new();
+        const double t0 = irh::now_seconds();
+        rc = irh::window_solve_batch(*host->win, (int)items.size(), items.data(), 100, 100, IROTAVG_GEMAN_MCCLURE,
+                                     5 * M_PI / 180.0, .001);
+        const double dt = irh::now_seconds() - t0;
+        for (size_t k = 0; k < items.size(); k++) {
+            irotavg_viewgraph *vg = vgs[owner[k]];
+            irotavg_rotavg_info loc = vg->pending.loc;
+            vg->pending.on = false;
+            loc.l1_iters = items[k].l1_iters;
+            loc.irls_iters = items[k].irls_iters;
+            loc.irls_runtime = dt;  // the whole batch ran in the one launch
+            if (items[k].status == IROTAVG_OK) {
+                const long nv = items[k].nv;
+                std::vector<double> &Q = vg->scratch.Q;
+                const std::vector<double> &Qa = vg->scratch.Qa;
+                for (long r = 0; r < nv; r++)
+                    for (int c = 0; c < 4; c++) Q[(size_t)c * nv + r] = Qa[(size_t)4 * r + c];
+                rotavg_writeback(vg, items[k].f, nv);
+                vg->last = loc;
+            } else if (first_err == IROTAVG_OK) {
+                first_err = items[k].status;
+            }
+            if (infos) infos[owner[k]] = loc;
+        }
+    } catch (...) {
+        return IROTAVG_ERR_HIP;
+    }
+    if (rc != IROTAVG_OK && first_err == IROTAVG_OK) first_err = rc;
+    return first_err;
 }
 
 // rmat2quat (src/ViewGraph.cpp:1175-1203) and q.normalized().toRotationMatrix() (:1426-1433) for

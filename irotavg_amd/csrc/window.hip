@@ -824,11 +824,25 @@ __device__ int sm_l1decode(const SmLane &E, const double y, const int pdmaxiter,
     return 0;
 }
 
-__global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams P, const int2 *__restrict__ Ig,
+// BATCH: workgroup b solves the b-th of several INDEPENDENT windows (one per view-graph of a multi-session
+// server: irotavg_viewgraph_rot_avg_batch) -- its parameters come from Pb[b] and its arrays lie b * stride bytes
+// behind the first problem's. A single window is the kernel-argument form (no extra round trip for P).
+template <bool BATCH>
+__global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const WinParams *__restrict__ Pb,
+                                                           size_t stride, const int2 *__restrict__ Ig,
                                                            const double4 *__restrict__ QQ,
                                                            double4 *__restrict__ Qg,
                                                            double *__restrict__ weights,
                                                            WinResult *__restrict__ out) {
+    const WinParams P = BATCH ? *reinterpret_cast<const WinParams *>(reinterpret_cast<const unsigned char *>(Pb) + stride * blockIdx.x) : Pk;
+    if (BATCH) {
+        const size_t off = stride * blockIdx.x;
+        Ig = reinterpret_cast<const int2 *>(reinterpret_cast<const unsigned char *>(Ig) + off);
+        QQ = reinterpret_cast<const double4 *>(reinterpret_cast<const unsigned char *>(QQ) + off);
+        Qg = reinterpret_cast<double4 *>(reinterpret_cast<unsigned char *>(Qg) + off);
+        weights = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(weights) + off);
+        out = reinterpret_cast<WinResult *>(reinterpret_cast<unsigned char *>(out) + off);
+    }
     __shared__ double4 sQ[WIN_MAX_NV];
     __shared__ double sW[3][SM_MAX_NU];
     __shared__ double sH[3][SM_MAX_NU][SM_MAX_NU + 1];
@@ -1042,7 +1056,10 @@ struct WindowSolver {
     size_t cap = 0;
     int seq = 0;       // sequence number of the last wave-kernel launch
     bool attr_set = false;
+    unsigned char *bhost = nullptr, *bhdev = nullptr;  // pinned block of the batched form (window_solve_batch)
+    size_t bcap = 0;
     ~WindowSolver() {
+        if (bhost) (void)hipHostFree(bhost);
         if (host) (void)hipHostFree(host);
         if (stream) StreamPool::get().give(stream);
     }
@@ -1094,7 +1111,8 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
         reinterpret_cast<WinResult *>(ws.host + oR)->seq = 0;  // ... which is what the host leaves there
         // the wave kernel touches its inputs once and its outputs once: it works directly on the
         // pinned (device-visible) staging block -- launch + synchronise, no copy commands
-        hipLaunchKernelGGL(k_window_wave, dim3(1), dim3(SM_THREADS), 0, ws.stream, P,
+        hipLaunchKernelGGL((k_window_wave<false>), dim3(1), dim3(SM_THREADS), 0, ws.stream, P,
+                           (const WinParams *)nullptr, (size_t)0,
                            (const int2 *)(ws.hdev + oI), (const double4 *)(ws.hdev + oQQ),
                            (double4 *)(ws.hdev + oQ), (double *)(ws.hdev + oW),
                            (WinResult *)(ws.hdev + oR));
@@ -1133,6 +1151,74 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
     if (l1_iters) *l1_iters = R.l1_iters;
     if (irls_iters) *irls_iters = R.irls_iters;
     return R.status;
+}
+
+// Several independent window problems in ONE launch (one workgroup each): every problem must fit the
+// wave-resident kernel. Layout of the pinned block: nb slots of `stride` bytes [I | QQ | Q | weights | result | params].
+int window_solve_batch(WindowSolver &ws, int nb, WinBatchItem *items, int l1_max, int irls_max, int cost, double sigma,
+                       double change_th) {
+    if (nb <= 0) return IROTAVG_OK;
+    for (int b = 0; b < nb; b++)
+        if (!window_fits_wave(items[b].nv, items[b].f, items[b].ne)) return IROTAVG_ERR_BAD_ARG;
+    if (!ws.stream) ws.stream = StreamPool::get().take();
+    const size_t oI = 0, oQQ = oI + sizeof(int2) * (size_t)SM_MAX_NE;
+    const size_t oQ = oQQ + sizeof(double4) * (size_t)SM_MAX_NE;
+    const size_t oW = oQ + sizeof(double4) * (size_t)WIN_MAX_NV;
+    const size_t oR = oW + sizeof(double) * (size_t)SM_MAX_NE;
+    const size_t oP = oR + sizeof(WinResult);
+    const size_t stride = (oP + sizeof(WinParams) + 255) & ~(size_t)255;
+    const size_t total = stride * (size_t)nb;
+    if (ws.bcap < total) {
+        if (ws.bhost) (void)hipHostFree(ws.bhost);
+        ws.bhost = nullptr;
+        IRH_CHECK(hipHostMalloc((void **)&ws.bhost, total + total / 2, hipHostMallocMapped | hipHostMallocCoherent));
+        IRH_CHECK(hipHostGetDevicePointer((void **)&ws.bhdev, ws.bhost, 0));
+        ws.bcap = total + total / 2;
+    }
+    ws.seq = ++ws.seq == 0 ? ++ws.seq : ws.seq;
+    for (int b = 0; b < nb; b++) {
+        unsigned char *h = ws.bhost + stride * (size_t)b;
+        const WinBatchItem &it = items[b];
+        std::memcpy(h + oI, it.I, sizeof(int32_t) * 2 * (size_t)it.ne);
+        std::memcpy(h + oQQ, it.QQ_aos, sizeof(double) * 4 * (size_t)it.ne);
+        std::memcpy(h + oQ, it.Q_aos, sizeof(double) * 4 * (size_t)it.nv);
+        WinParams P{it.nv, it.f, it.ne, l1_max, irls_max, cost, change_th, sigma, ws.seq};
+        std::memcpy(h + oP, &P, sizeof(P));
+        reinterpret_cast<WinResult *>(h + oR)->seq = 0;
+    }
+    hipLaunchKernelGGL((k_window_wave<true>), dim3(nb), dim3(SM_THREADS), 0, ws.stream, WinParams{},
+                       (const WinParams *)(ws.bhdev + oP), stride, (const int2 *)(ws.bhdev + oI),
+                       (const double4 *)(ws.bhdev + oQQ), (double4 *)(ws.bhdev + oQ), (double *)(ws.bhdev + oW),
+                       (WinResult *)(ws.bhdev + oR));
+    IRH_CHECK(hipGetLastError());
+    // completion: every workgroup stores the launch's sequence number last (see window_solve)
+    const double t0 = now_seconds();
+    bool all = false;
+    int next = 0;
+    while (!all) {
+        while (next < nb && __atomic_load_n(&reinterpret_cast<WinResult *>(ws.bhost + stride * (size_t)next + oR)->seq,
+                                            __ATOMIC_ACQUIRE) == ws.seq)
+            next++;
+        all = next == nb;
+        if (!all && now_seconds() - t0 > 5e-3) break;
+#if defined(__x86_64__)
+        if (!all) __builtin_ia32_pause();
+#endif
+    }
+    if (!all) IRH_CHECK(hipStreamSynchronize(ws.stream));
+    int rc = IROTAVG_OK;
+    for (int b = 0; b < nb; b++) {
+        unsigned char *h = ws.bhost + stride * (size_t)b;
+        WinBatchItem &it = items[b];
+        WinResult R;
+        std::memcpy(&R, h + oR, sizeof(R));
+        std::memcpy(it.Q_aos, h + oQ, sizeof(double) * 4 * (size_t)it.nv);
+        it.l1_iters = R.l1_iters;
+        it.irls_iters = R.irls_iters;
+        it.status = R.status;
+        if (R.status != IROTAVG_OK && rc == IROTAVG_OK) rc = R.status;
+    }
+    return rc;
 }
 
 WindowSolver *window_solver_new() { return new WindowSolver(); }

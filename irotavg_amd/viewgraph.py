@@ -89,6 +89,16 @@ class ViewGraph:
         capi.check(capi.lib().irotavg_viewgraph_save_poses(self._h, str(filename).encode(), tp), "savePoses")
 
 
+def rotAvgBatch(graphs, winSize):
+    """rotAvg for several DIFFERENT view-graphs at once (irotavg_viewgraph_rot_avg_batch): the windows that fit the
+    wave-resident kernel are solved by one launch, a workgroup per window. Returns one info dict per graph."""
+    n = len(graphs)
+    hs = (C.c_void_p * n)(*[g._h for g in graphs])
+    infos = (capi.RotAvgInfo * n)()
+    capi.check(capi.lib().irotavg_viewgraph_rot_avg_batch(hs, n, int(winSize), infos), "rotAvgBatch")
+    return [{k: getattr(infos[b], k) for k, _ in capi.RotAvgInfo._fields_} for b in range(n)]
+
+
 def rmat2quat(R):
     """src/ViewGraph.cpp:1175-1203; row-major 3x3 -> [x y z w]."""
     r = np.ascontiguousarray(R, dtype=np.float64).reshape(9)

@@ -77,3 +77,9 @@ def test_native_stream_driver_small():
     assert d["streamed_views"] == 900 and d["loop_closures"] == 3
     assert d["views_per_s"] > 1000
     assert d["mean_angular_error_rad"] < 0.03 and d["max_angular_error_rad"] < 0.1
+    # five independent sessions in lock-step: their windows share one launch per step (irotavg_viewgraph_rot_avg_batch)
+    r = subprocess.run([exe, "600", "900", "2", "1", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d5 = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d5["sessions"] == 5 and d5["loop_closures"] == 10
+    assert d5["mean_angular_error_rad"] < 0.03 and d5["max_angular_error_rad"] < 0.1

@@ -239,3 +239,67 @@ def test_config5_full_size_stream_properties():
     assert d["streamed_views"] == 50000 and d["loop_closures"] == 10
     assert d["mean_angular_error_rad"] < 0.02 and d["max_angular_error_rad"] < 0.2
     assert d["views_per_s"] > 1000.0
+
+
+@pytest.mark.gpu
+def test_batched_rotavg_over_independent_graphs_equals_separate_calls():
+    """irotavg_viewgraph_rot_avg_batch: S view-graphs (different sequences, different lengths, one of them with a
+    loop closure whose global re-solve does not fit the window kernel) advanced in lock-step -- one launch per step for
+    all the windows -- give bit-for-bit the poses and iteration counts of S graphs advanced by separate rotAvg calls;
+    one of the sessions is also held against the oracle."""
+    from irotavg_amd.viewgraph import rotAvgBatch
+    S, n = 7, 45
+    seqs = [build_sequence(n + 3 * s, seed=20 + s, n_loops=(2 if s == 3 else 0)) for s in range(S)]
+    A = [ViewGraph() for _ in range(S)]      # batched
+    B = [ViewGraph() for _ in range(S)]      # one by one
+    vo = ViewGraphOracle()                   # session 0
+    by_new = []
+    for Qgt, rel in seqs:
+        d = {}
+        for (i, j), R in rel.items():
+            d.setdefault(j, []).append((i, R))
+        by_new.append(d)
+    for v in range(n + 3 * (S - 1)):
+        active = [s for s in range(S) if v < n + 3 * s]
+        loops = {}
+        for s in active:
+            Qgt, rel = seqs[s]
+            if v == 0:
+                R0 = rot(Qgt[0])
+            else:
+                i, R = sorted(by_new[s][v], key=lambda t: -t[0])[0]
+                R0 = R @ B[s].R(i)
+            for G in (A[s], B[s]) + ((vo,) if s == 0 else ()):
+                G.addView(R0)
+            loop = False
+            for (i, R) in by_new[s].get(v, []):
+                for G in (A[s], B[s]) + ((vo,) if s == 0 else ()):
+                    G.connect(i, v, R)
+                loop = loop or (v - i > 4)
+            if v % 20 == 0:
+                for G in (A[s], B[s]) + ((vo,) if s == 0 else ()):
+                    G.fixPose(v, rot(Qgt[v]))
+            loops[s] = loop
+        # sessions with a loop closure take the global re-solve on their own, the others share one launch
+        for s in active:
+            if loops[s]:
+                ia, ib = A[s].rotAvg(5000000), B[s].rotAvg(5000000)
+                assert (ia["l1_iters"], ia["irls_iters"]) == (ib["l1_iters"], ib["irls_iters"])
+        rest = [s for s in active if not loops[s]]
+        infos = rotAvgBatch([A[s] for s in rest], 10)
+        for s, ia in zip(rest, infos):
+            ib = B[s].rotAvg(10)
+            assert ia["skipped"] == ib["skipped"]
+            if not ia["skipped"]:
+                assert (ia["n_views"], ia["n_edges"], ia["n_fixed"], ia["l1_iters"], ia["irls_iters"]) == \
+                       (ib["n_views"], ib["n_edges"], ib["n_fixed"], ib["l1_iters"], ib["irls_iters"]), (v, s, ia, ib)
+        if 0 in active:
+            vo.rotAvg(5000000 if loops[0] else 10)
+    for s in range(S):
+        for v in range(n + 3 * s):
+            np.testing.assert_array_equal(A[s].R(v), B[s].R(v))
+    for v in range(n):
+        np.testing.assert_allclose(A[0].R(v), vo.R[v], atol=1e-7)
+    # the same graph twice in one batch is refused: its windows depend on each other
+    with pytest.raises(capi.IrotavgError):
+        rotAvgBatch([A[0], A[0]], 10)

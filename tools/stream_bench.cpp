@@ -4,7 +4,11 @@
 // frame and rotAvg(5000000) on a loop closure). tools/bench_incremental.py is the same experiment with a Python
 // loop, whose interpreter overhead (~20 us per view) is a quarter of its time; this program measures the library.
 //
-//   stream_bench [warm_views [streamed_views [loop_closures [seed]]]]      -> one JSON line
+//   stream_bench [warm_views [streamed_views [loop_closures [seed [sessions]]]]]      -> one JSON line
+//
+// sessions > 1: that many INDEPENDENT sequences (a server tracking several cameras) advanced in lock-step; the
+// rotAvg(10) windows of a step are solved by ONE launch (irotavg_viewgraph_rot_avg_batch, a workgroup per window),
+// loop-closure re-solves one by one. views_per_s is then the aggregate over all sessions.
 //
 // Synthetic front-end: ground-truth rotations ~ uniform, relative rotations with N(0, 0.01^2) rad of noise, the
 // initial pose of a new view chained from its predecessor; measurements are generated before the timed loop.
@@ -49,100 +53,136 @@ static R9 matmul(const R9 &a, const R9 &b) {
 }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+struct Session {
+    irotavg_viewgraph *vg = nullptr;
+    std::vector<Q4> gt;
+    std::vector<R9> rrel;                       // 4 per streamed view
+    std::vector<std::pair<int, R9>> loop_edge;  // per view: (from, R) or (-1, .)
+};
+
 int main(int argc, char **argv) {
     const int warm = argc > 1 ? std::atoi(argv[1]) : 50000, stream = argc > 2 ? std::atoi(argv[2]) : 50000;
     const int loops = argc > 3 ? std::atoi(argv[3]) : 10;
     const unsigned seed = argc > 4 ? (unsigned)std::atoi(argv[4]) : 0u;
+    const int sessions = argc > 5 ? std::max(1, std::atoi(argv[5])) : 1;
     const int n = warm + stream, fix_every = 20;
     const double noise = 0.01;
     if (irotavg_device_count() <= 0) {
         std::fprintf(stderr, "stream_bench: no HIP device (the library has no CPU path)\n");
         return 2;
     }
-    std::mt19937_64 rng(seed);
-    std::normal_distribution<double> nd(0.0, 1.0);
-    std::vector<Q4> gt((size_t)n);
-    for (auto &q : gt) {
-        q = Q4{nd(rng), nd(rng), nd(rng), nd(rng)};
-        const double s = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-        q = Q4{q.x / s, q.y / s, q.z / s, q.w / s};
-    }
-    auto rel = [&](int i, int j) {  // R_ij with R_j = R_ij R_i, noisy
-        return rmat(qmul(qexp(noise * nd(rng), noise * nd(rng), noise * nd(rng)), qmul(gt[(size_t)j], qconj(gt[(size_t)i]))));
-    };
-    std::set<int> loop_at;
-    {
-        std::uniform_int_distribution<int> pick(warm + 100, n - 1);
-        while ((int)loop_at.size() < std::min(loops, stream - 100)) loop_at.insert(pick(rng));
-    }
-    irotavg_viewgraph *vg = nullptr;
-    if (irotavg_viewgraph_create(&vg, nullptr) != IROTAVG_OK) return 3;
-    const double tb = now();
-    for (int v = 0; v < warm; v++) {  // poses as a converged run would have left them
-        const R9 r0 = rmat(qmul(qexp(noise * nd(rng), noise * nd(rng), noise * nd(rng)), gt[(size_t)v]));
-        irotavg_viewgraph_add_view(vg, r0.m);
-        for (int d = 1; d <= std::min(4, v); d++) {
-            const R9 rij = rel(v - d, v);
-            irotavg_viewgraph_connect(vg, v - d, v, rij.m);
+    std::vector<Session> S((size_t)sessions);
+    double warm_s = 0;
+    for (int sx = 0; sx < sessions; sx++) {
+        Session &Z = S[(size_t)sx];
+        std::mt19937_64 rng(seed + 7919u * (unsigned)sx);
+        std::normal_distribution<double> nd(0.0, 1.0);
+        Z.gt.resize((size_t)n);
+        for (auto &q : Z.gt) {
+            q = Q4{nd(rng), nd(rng), nd(rng), nd(rng)};
+            const double s = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+            q = Q4{q.x / s, q.y / s, q.z / s, q.w / s};
         }
-        if (v % fix_every == 0) {
-            const R9 g = rmat(gt[(size_t)v]);
-            irotavg_viewgraph_fix_pose(vg, v, g.m);
+        auto rel = [&](int i, int j) {  // R_ij with R_j = R_ij R_i, noisy
+            return rmat(qmul(qexp(noise * nd(rng), noise * nd(rng), noise * nd(rng)),
+                             qmul(Z.gt[(size_t)j], qconj(Z.gt[(size_t)i]))));
+        };
+        std::set<int> loop_at;
+        if (stream > 200) {
+            std::uniform_int_distribution<int> pick(warm + 100, n - 1);
+            while ((int)loop_at.size() < std::min(loops, stream - 100)) loop_at.insert(pick(rng));
         }
-    }
-    const double warm_s = now() - tb;
-    // the front-end's measurements of the streamed part, generated up front
-    std::vector<R9> rrel((size_t)stream * 4);
-    for (int v = warm; v < n; v++)
-        for (int d = 1; d <= 4; d++) rrel[(size_t)(v - warm) * 4 + (d - 1)] = rel(v - d, v);
-    std::vector<std::pair<int, R9>> loop_edge((size_t)n, {-1, R9{}});
-    for (int v : loop_at) {
-        std::uniform_int_distribution<int> from(0, std::max(1, v - 1000) - 1);  // at least 1000 views back when there are that many
-        const int u = from(rng);
-        loop_edge[(size_t)v] = {u, rel(u, v)};
+        if (irotavg_viewgraph_create(&Z.vg, nullptr) != IROTAVG_OK) return 3;
+        const double tb = now();
+        for (int v = 0; v < warm; v++) {  // poses as a converged run would have left them
+            const R9 r0 = rmat(qmul(qexp(noise * nd(rng), noise * nd(rng), noise * nd(rng)), Z.gt[(size_t)v]));
+            irotavg_viewgraph_add_view(Z.vg, r0.m);
+            for (int d = 1; d <= std::min(4, v); d++) {
+                const R9 rij = rel(v - d, v);
+                irotavg_viewgraph_connect(Z.vg, v - d, v, rij.m);
+            }
+            if (v % fix_every == 0) {
+                const R9 g = rmat(Z.gt[(size_t)v]);
+                irotavg_viewgraph_fix_pose(Z.vg, v, g.m);
+            }
+        }
+        warm_s += now() - tb;
+        // the front-end's measurements of the streamed part, generated up front
+        Z.rrel.resize((size_t)stream * 4);
+        for (int v = warm; v < n; v++)
+            for (int d = 1; d <= 4; d++) Z.rrel[(size_t)(v - warm) * 4 + (d - 1)] = rel(v - d, v);
+        Z.loop_edge.assign((size_t)n, {-1, R9{}});
+        for (int v : loop_at) {
+            std::uniform_int_distribution<int> from(0, std::max(1, v - 1000) - 1);  // at least 1000 views back when there are that many
+            const int u = from(rng);
+            Z.loop_edge[(size_t)v] = {u, rel(u, v)};
+        }
     }
     std::vector<double> lat_local, lat_global;
     lat_local.reserve((size_t)stream);
     long long edges_solved = 0;
+    std::vector<irotavg_viewgraph *> batch((size_t)sessions);
+    std::vector<irotavg_rotavg_info> infos((size_t)sessions);
     const double t0 = now();
     for (int v = warm; v < n; v++) {
-        R9 prev;
-        irotavg_viewgraph_get_pose(vg, v - 1, prev.m);
-        const R9 &r1 = rrel[(size_t)(v - warm) * 4];
-        const R9 init = matmul(r1, prev);  // the front-end's initial pose
-        irotavg_viewgraph_add_view(vg, init.m);
-        for (int d = 1; d <= 4; d++) irotavg_viewgraph_connect(vg, v - d, v, rrel[(size_t)(v - warm) * 4 + (d - 1)].m);
-        const bool loop = loop_edge[(size_t)v].first >= 0;
-        if (loop) irotavg_viewgraph_connect(vg, loop_edge[(size_t)v].first, v, loop_edge[(size_t)v].second.m);
-        if (v % fix_every == 0) {
-            const R9 g = rmat(gt[(size_t)v]);
-            irotavg_viewgraph_fix_pose(vg, v, g.m);
+        int nb = 0;
+        for (int sx = 0; sx < sessions; sx++) {
+            Session &Z = S[(size_t)sx];
+            R9 prev;
+            irotavg_viewgraph_get_pose(Z.vg, v - 1, prev.m);
+            const R9 &r1 = Z.rrel[(size_t)(v - warm) * 4];
+            const R9 init = matmul(r1, prev);  // the front-end's initial pose
+            irotavg_viewgraph_add_view(Z.vg, init.m);
+            for (int d = 1; d <= 4; d++)
+                irotavg_viewgraph_connect(Z.vg, v - d, v, Z.rrel[(size_t)(v - warm) * 4 + (d - 1)].m);
+            const bool loop = Z.loop_edge[(size_t)v].first >= 0;
+            if (loop) irotavg_viewgraph_connect(Z.vg, Z.loop_edge[(size_t)v].first, v, Z.loop_edge[(size_t)v].second.m);
+            if (v % fix_every == 0) {
+                const R9 g = rmat(Z.gt[(size_t)v]);
+                irotavg_viewgraph_fix_pose(Z.vg, v, g.m);
+            }
+            if (loop || sessions == 1) {
+                irotavg_rotavg_info info{};
+                const double t = now();
+                const int rc = irotavg_viewgraph_rot_avg(Z.vg, loop ? 5000000 : 10, &info);
+                (loop ? lat_global : lat_local).push_back(now() - t);
+                if (rc != IROTAVG_OK) {
+                    std::fprintf(stderr, "stream_bench: rot_avg failed at view %d: %s\n", v, irotavg_error_string(rc));
+                    return 4;
+                }
+                if (!info.skipped) edges_solved += (long long)info.n_edges * std::max(info.irls_iters, 1);
+            } else {
+                batch[(size_t)nb++] = Z.vg;
+            }
         }
-        irotavg_rotavg_info info{};
-        const double t = now();
-        const int rc = irotavg_viewgraph_rot_avg(vg, loop ? 5000000 : 10, &info);
-        (loop ? lat_global : lat_local).push_back(now() - t);
-        if (rc != IROTAVG_OK) {
-            std::fprintf(stderr, "stream_bench: rot_avg failed at view %d: %s\n", v, irotavg_error_string(rc));
-            return 4;
+        if (nb > 0) {  // the windows of the other sessions: one launch
+            const double t = now();
+            const int rc = irotavg_viewgraph_rot_avg_batch(batch.data(), nb, 10, infos.data());
+            lat_local.push_back(now() - t);
+            if (rc != IROTAVG_OK) {
+                std::fprintf(stderr, "stream_bench: rot_avg_batch failed at view %d: %s\n", v, irotavg_error_string(rc));
+                return 4;
+            }
+            for (int b = 0; b < nb; b++)
+                if (!infos[(size_t)b].skipped) edges_solved += (long long)infos[(size_t)b].n_edges * std::max(infos[(size_t)b].irls_iters, 1);
         }
-        if (!info.skipped) edges_solved += (long long)info.n_edges * std::max(info.irls_iters, 1);
     }
     const double dt = now() - t0;
     double err_sum = 0, err_max = 0;
     int err_n = 0;
-    for (int v = warm; v < n; v += 97) {
-        R9 r;
-        irotavg_viewgraph_get_pose(vg, v, r.m);
-        const R9 g = rmat(gt[(size_t)v]);
-        double tr = 0;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) tr += r.m[3 * i + j] * g.m[3 * i + j];
-        const double a = std::acos(std::min(1.0, std::max(-1.0, (tr - 1) / 2)));
-        err_sum += a;
-        err_max = std::max(err_max, a);
-        err_n++;
-    }
+    for (int sx = 0; sx < sessions; sx++)
+        for (int v = warm; v < n; v += 97) {
+            R9 r;
+            irotavg_viewgraph_get_pose(S[(size_t)sx].vg, v, r.m);
+            const R9 g = rmat(S[(size_t)sx].gt[(size_t)v]);
+            double tr = 0;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) tr += r.m[3 * i + j] * g.m[3 * i + j];
+            const double a = std::acos(std::min(1.0, std::max(-1.0, (tr - 1) / 2)));
+            err_sum += a;
+            err_max = std::max(err_max, a);
+            err_n++;
+        }
     auto mean = [](const std::vector<double> &x) {
         double s = 0;
         for (double v : x) s += v;
@@ -150,13 +190,13 @@ int main(int argc, char **argv) {
     };
     std::sort(lat_local.begin(), lat_local.end());
     const double p99 = lat_local.empty() ? 0.0 : lat_local[(size_t)(0.99 * (double)(lat_local.size() - 1))];
-    std::printf("{\"mode\": \"incremental\", \"driver\": \"native (tools/stream_bench.cpp)\", \"warm_views\": %d, "
+    std::printf("{\"mode\": \"incremental\", \"driver\": \"native (tools/stream_bench.cpp)\", \"sessions\": %d, \"warm_views\": %d, "
                 "\"streamed_views\": %d, \"loop_closures\": %d, \"views_per_s\": %.1f, \"seconds\": %.4f, "
                 "\"warm_build_seconds\": %.3f, \"local_rotavg_ms_mean\": %.5f, \"local_rotavg_ms_p99\": %.5f, "
                 "\"global_rotavg_ms_mean\": %.3f, \"irls_edge_updates_per_s\": %.1f, \"mean_angular_error_rad\": %.6f, "
                 "\"max_angular_error_rad\": %.6f}\n",
-                warm, stream, (int)lat_global.size(), stream / dt, dt, warm_s, 1e3 * mean(lat_local), 1e3 * p99,
-                1e3 * mean(lat_global), (double)edges_solved / dt, err_sum / std::max(err_n, 1), err_max);
-    irotavg_viewgraph_destroy(vg);
+                sessions, warm, stream, (int)lat_global.size(), (double)stream * sessions / dt, dt, warm_s, 1e3 * mean(lat_local),
+                1e3 * p99, 1e3 * mean(lat_global), (double)edges_solved / dt, err_sum / std::max(err_n, 1), err_max);
+    for (auto &Z : S) irotavg_viewgraph_destroy(Z.vg);
     return 0;
 }
