@@ -801,6 +801,22 @@ void dense_check_async(Graph &g) {
                        g.dense_ref_val.p, g.stale_spread, g.scal.p, g.flags.p);
 }
 
+// Keep the current inverse whatever the entry ratios say and only follow the operator's scale (geometric mean of
+// the diagonal ratios): for a solve whose operator is known to have moved little (assemble(), solver.hip: the last
+// IRLS step was tiny, so the robust weights have settled). false: no usable scale (a diagonal entry vanished).
+bool dense_rescale_only(Graph &g) {
+    if (g.ndense <= 0 || !g.dense_valid) return false;
+    Level &C = g.levels.back();
+    hipLaunchKernelGGL(k_value_ratio, dim3(1), dim3(1024), 0, g.stream, (long long)C.n, C.diag.p, g.dense_ref_diag.p,
+                       g.part_score.p, 0);
+    double *h = g.h_part();
+    IRH_CHECK(hipMemcpyAsync(h, g.part_score.p, sizeof(double) * 2, hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    if (!(h[0] > 0.0) || !(h[1] < HUGE_VAL)) return false;
+    g.dense_scale = 1.0 / std::sqrt(h[0] * h[1]);
+    return true;
+}
+
 bool dense_is_stale(Graph &g, bool allow_repair) {
     if (g.ndense <= 0) return false;
     if (!g.dense_valid) return true;

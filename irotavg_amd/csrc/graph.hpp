@@ -115,6 +115,7 @@ struct Graph {
     Graph &operator=(const Graph &) = delete;
 
     double last_score_sum = 0.0;
+    double irls_settle = -1.0;  // run_irls: > 0 while the last step was small enough for the weights to have settled (assemble())
     int force_np = 0;  // sharded runs: consumers read this many pre-reduced partial rows (1)
     irotavg_stats stats{};
 };
@@ -227,6 +228,7 @@ int window_solve_batch(WindowSolver &ws, int nb, WinBatchItem *items, int l1_max
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);
 bool dense_is_stale(Graph &g, bool allow_repair = false);
+bool dense_rescale_only(Graph &g);
 bool dense_direct_solve(Graph &g);  // last resort of a single-level graph: Cholesky solve of levels[0].b -> X
 void dense_check_async(Graph &g);  // same test, decision on the device (scal[SC_DSCALE], flags[FL_STALE])
 int dense_apply_grid(const Graph &g);

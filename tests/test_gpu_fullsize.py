@@ -156,12 +156,38 @@ def test_fused_pcg_launches_match_the_separate_kernels(n, m, levels, f, p):
         assert int(S["is_loop"].sum()) > 0
 
 
+def test_settled_irls_iterations_keep_the_coarse_inverse(monkeypatch):
+    """Once the IRLS step has fallen below 20 x change_th the robust weights have settled (only down-weighted
+    outliers still swing, and they no longer matter): the coarse inverse is kept and only rescaled instead of
+    re-inverted (round 3). Same iteration counts and -- the inverse is a preconditioner component only -- the same
+    rotations and weights as with IROTAVG_NO_SETTLE=1; fewer inversions, at most a few more PCG iterations."""
+    n, m = 30000, 450000
+    S = synth.make_graph(n, m, 0.02, seed=3)
+    Q0 = mst(S, n)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("IROTAVG_NO_SETTLE", "1")
+        with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+            G.set_rotations(Q0)
+            r = G.irls(4, SIG, 100, 1e-3)
+            out.append((r, G.get_rotations(), G.get_weights(), G.stats()))
+    (ra, Qa, wa, sa), (rb, Qb, wb, sb) = out
+    assert ra["iters"] == rb["iters"] and ra["iters"] >= 4
+    np.testing.assert_allclose(ra["scores"], rb["scores"], rtol=1e-6)
+    assert synth.angular_distance(Qa, Qb).max() < 1e-9
+    np.testing.assert_allclose(wa, wb, rtol=1e-7)
+    assert sa["dense_inversions"] < sb["dense_inversions"] == rb["iters"]
+    assert sa["pcg_iters"] <= sb["pcg_iters"] + 6
+
+
 @pytest.mark.parametrize("closures", [3, 40])
-def test_lowrank_repair_of_the_dense_inverse(closures):
+def test_lowrank_repair_of_the_dense_inverse(closures, monkeypatch):
     """A sequence with a few loop closures: between IRLS iterations only the closures' long-range
     coarse entries move non-uniformly, and the dense inverse is repaired by a Woodbury update
     instead of being recomputed. Same IRLS iterations, same PCG effort, same rotations as with
     no_lowrank_repair = 1; the counters show that repairs replaced inversions."""
+    monkeypatch.setenv("IROTAVG_NO_SETTLE", "1")   # this test is about the repair: every iteration tests its inverse
     n, m = 40000, 596000
     S = synth.make_graph(n, m, closures / m, seed=8)
     assert int(S["is_loop"].sum()) == closures
