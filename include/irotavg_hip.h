@@ -77,6 +77,11 @@ typedef struct irotavg_options {
                                   <= 64 deviating long-range entries are repaired by a low-rank update) */
     int pcg_classic;           /* 1: the PCG iteration always runs as separate launches (default 0: on one
                                   GPU a graph without loop closures runs it as two launches, cgcg.hip) */
+    int band_direct;           /* a graph whose edges between free views all span <= 32 views (a sequence without
+                                  loop closures) has a banded operator; on one GPU its linear systems are then
+                                  solved DIRECTLY by block cyclic reduction (bcr.hip) instead of the PCG:
+                                  0 (default) = when it has more than 2048 free views (smaller graphs are one
+                                  dense level already), 1 = whenever the band allows, -1 = never */
 } irotavg_options;
 
 void irotavg_default_options(irotavg_options *opt);
@@ -99,6 +104,9 @@ typedef struct irotavg_stats {
     int64_t dense_repairs;    /* low-rank (Woodbury) repairs of that inverse instead of an inversion */
     int64_t pcg_handed_over;  /* solves whose single-reduction (Chronopoulos-Gear) recurrences stalled and that were
                                  repeated with the classic recurrences from the saved right-hand side */
+    int64_t direct_solves;    /* linear systems solved by the banded direct solver (options.band_direct) */
+    int64_t band;             /* half-bandwidth of the operator found at creation (-1: not looked at), and ... */
+    int64_t band_block;       /* ... the block size of the direct solver (0: the solves run through the PCG) */
 } irotavg_stats;
 
 /* ---------------------------------------------------------------------------------------------

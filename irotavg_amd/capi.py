@@ -43,7 +43,8 @@ class Options(C.Structure):
                 ("mg_levels_max", C.c_int), ("mg_agg0", C.c_int), ("mg_agg", C.c_int),
                 ("mg_dense_max", C.c_int), ("mg_omega", C.c_double), ("mg_kc", C.c_double),
                 ("device", C.c_int), ("mg_multiplicative_top", C.c_int), ("dense_always_refresh", C.c_int),
-                ("no_window_kernel", C.c_int), ("pcg_stall_accept", C.c_int), ("no_fused_pspmv", C.c_int), ("no_lowrank_repair", C.c_int), ("pcg_classic", C.c_int)]
+                ("no_window_kernel", C.c_int), ("pcg_stall_accept", C.c_int), ("no_fused_pspmv", C.c_int), ("no_lowrank_repair", C.c_int), ("pcg_classic", C.c_int),
+                ("band_direct", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -53,7 +54,8 @@ class Stats(C.Structure):
                 ("level_rows", C.c_int64 * 16), ("level_nnz", C.c_int64 * 16),
                 ("last_relres", C.c_double * 3), ("pcg_stagnated", C.c_int64),
                 ("dense_inversions", C.c_int64), ("dense_repairs", C.c_int64),
-                ("pcg_handed_over", C.c_int64)]
+                ("pcg_handed_over", C.c_int64), ("direct_solves", C.c_int64), ("band", C.c_int64),
+                ("band_block", C.c_int64)]
 
 
 class RotAvgInfo(C.Structure):

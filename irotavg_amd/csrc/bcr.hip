@@ -1,0 +1,607 @@
+// bcr.hip -- direct solve of a BANDED level-0 operator (a view sequence without loop closures: every view is
+// linked to a bounded number of predecessors) by block cyclic reduction. Replaces the sparse factorisations
+// of the reference on such graphs: SuiteSparseQR in irls (ral/l1_irls.cpp:536-556) and UMFPACK in
+// l1decode_pd (ral/l1_irls.cpp:131-184) -- no iteration, no preconditioner, no tolerance.
+//
+// The operator A = A' D^2 A (IRLS) or the primal-dual Hessian (L1RA) of a graph whose edges (i, j) all have
+// |i - j| <= b is a symmetric positive definite band matrix of half-bandwidth b. With B >= b rows per block
+// it is block tridiagonal: D_i = A[i, i] (B x B), G_i = A[i, i + 1] (B x B). A workgroup takes a CHUNK of
+// eight consecutive blocks and eliminates seven of them in nested-dissection order (0 2 4 6 | 1 5 | 3),
+// one wave per block, leaving block 7 -- the separator -- coupled to the separator of the chunk before
+// it. Eliminating block i between its current neighbours a (left) and c (right):
+//     W = D_i^-1 [ P' | Q | R_i ],  P = A[a, i], Q = A[i, c]            (B x (2B + 3), kept for the way back)
+//     D_a -= P W_P,  A[a, c] = -P W_Q,  R_a -= P W_R,   D_c -= Q' W_Q,  R_c -= Q' W_R
+// The separators form a block tridiagonal system an eighth the size: the same kernel again, until at
+// most eight blocks are left (100k views, B = 24: 4167 -> 521 -> 66 -> 9 -> 2 blocks). The way back is
+// x_i = W_R - W_P x_a - W_Q x_c level by level. No host round trip anywhere: a solve is ~10 launches.
+//
+// What the hardware dictated: the B^3 work (five products per block) runs on the matrix cores
+// (v_mfma_f64_16x16x4_f64: operands are distributed over the lanes, so no operand is broadcast through
+// LDS -- with vector FMAs every value of P, Q and D^-1 would have to reach all 64 lanes, and eight waves
+// per CU saturate the LDS port with that); the accumulator layout of one product IS the B-operand layout
+// of the next (row = 4 reg + lane / 16), so W never leaves the registers between the two. D_i^-1 is
+// formed by a symmetric sweep (Gauss-Jordan without pivoting: SPD) on a register tile per lane, pivot
+// column exchanged by lane permutes. A pivot not above kDeadTol x its original diagonal entry is dead
+// (an isolated view, a floating component): its unknown solves to 0, as everywhere else in this library.
+#include "graph.hpp"
+#include "kernels.hpp"
+
+namespace irh {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct BcrLevel {
+    int nb = 0;   // blocks
+    int nch = 0;  // chunks of eight
+    DevBuf<double> W;                             // nch * 7 blocks of B x (2B + 3)
+    DevBuf<double> sepD, sepR, extD, extR, extG;  // per chunk: what the next level is assembled from
+    DevBuf<double> x;                             // nch * 8 blocks of B x 3 (levels >= 1)
+};
+struct BcrState {
+    int B = 0;
+    std::vector<BcrLevel> lev;
+    DevBuf<double> xtop;  // B x 3: the last separator
+};
+
+void BcrDeleter::operator()(BcrState *p) const { delete p; }
+
+__device__ __forceinline__ double bcr_readlane(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// In-place inverse of the SPD B x B matrix Dm (LDS, row-major) by one wave. Lane (a, b) = (lane / 8,
+// lane % 8) holds the elements (a + 8 tr, b + 8 tc). Symmetric sweep: after pivot k the tile holds
+// -(inverse) on the swept part; only column k is exchanged (the matrix stays symmetric).
+template <int B>
+__device__ __forceinline__ void bcr_invert(double *Dm, int lane) {
+    constexpr int T = B / 8;
+    const int a = lane >> 3, b = lane & 7;
+    double t[T][T], od[T];
+#pragma unroll
+    for (int tr = 0; tr < T; tr++)
+#pragma unroll
+        for (int tc = 0; tc < T; tc++) t[tr][tc] = Dm[(a + 8 * tr) * B + b + 8 * tc];
+#pragma unroll
+    for (int tr = 0; tr < T; tr++) od[tr] = t[tr][tr];  // the diagonal where a == b
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        const int kb = k & 7, kt = k >> 3;
+        const int dl = (kb << 3) | kb;
+        const double p = bcr_readlane(t[kt][kt], dl);
+        const double ref = bcr_readlane(od[kt], dl);
+        const double pinv = (p > kDeadTol * ref) ? 1.0 / p : 0.0;
+        double cr[T], cc[T];
+#pragma unroll
+        for (int tr = 0; tr < T; tr++) cr[tr] = __shfl(t[tr][kt], (a << 3) | kb, 64);
+#pragma unroll
+        for (int tc = 0; tc < T; tc++) cc[tc] = __shfl(t[tc][kt], (b << 3) | kb, 64);
+#pragma unroll
+        for (int tr = 0; tr < T; tr++) {
+            const bool rk = (a + 8 * tr) == k;
+            const double crp = cr[tr] * pinv;
+#pragma unroll
+            for (int tc = 0; tc < T; tc++) {
+                const bool ck = (b + 8 * tc) == k;
+                const double upd = fma(-crp, cc[tc], t[tr][tc]);
+                t[tr][tc] = rk ? (ck ? -pinv : cc[tc] * pinv) : (ck ? crp : upd);
+            }
+        }
+    }
+#pragma unroll
+    for (int tr = 0; tr < T; tr++)
+#pragma unroll
+        for (int tc = 0; tc < T; tc++) Dm[(a + 8 * tr) * B + b + 8 * tc] = -t[tr][tc];
+}
+
+template <int B>
+struct BcrDim {
+    static constexpr int NC = 2 * B + 3;        // columns of W: P' | Q | R
+    static constexpr int MT = (B + 15) / 16;    // 16-row tiles of a block
+    static constexpr int NT = (NC + 15) / 16;   // 16-column tiles of W
+    static constexpr int KS = B / 4;            // k-steps of a product over a block
+    static constexpr int NT0 = B / 16;          // first column tile that holds a column of W_Q
+};
+
+// A-operand of the 16x16x4 product for row tile mt, k-step s: element (16 mt + lane % 16, 4 s + lane / 16) of the
+// row-major B x B matrix M, or of its transpose; rows beyond B read as zero.
+template <int B, bool TRANS>
+__device__ __forceinline__ void bcr_load_a(const double *M, int lane, double (&aop)[BcrDim<B>::MT][BcrDim<B>::KS]) {
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < BcrDim<B>::MT; mt++) {
+        const int i = 16 * mt + li;
+        const int ic = i < B ? i : B - 1;
+#pragma unroll
+        for (int s = 0; s < BcrDim<B>::KS; s++) {
+            const int k = 4 * s + lk;
+            const double v = TRANS ? M[k * B + ic] : M[ic * B + k];
+            aop[mt][s] = i < B ? v : 0.0;
+        }
+    }
+}
+
+// out[mt][nt] += A (registers) x W (accumulator tiles of a previous product used as B-operands: register r of
+// tile (mt, nt) holds the rows 16 mt + 4 r + lane / 16, i.e. k-step 4 mt + r)
+template <int B, int NTA>
+__device__ __forceinline__ void bcr_mul_w(const double (&aop)[BcrDim<B>::MT][BcrDim<B>::KS],
+                                          const v4d (&w)[BcrDim<B>::MT][BcrDim<B>::NT],
+                                          v4d (&out)[BcrDim<B>::MT][BcrDim<B>::NT]) {
+    typedef BcrDim<B> Dm;
+#pragma unroll
+    for (int nt = NTA; nt < Dm::NT; nt++)
+#pragma unroll
+        for (int s = 0; s < Dm::KS; s++) {
+            const double bop = w[s >> 2][nt][s & 3];
+#pragma unroll
+            for (int mt = 0; mt < Dm::MT; mt++)
+                out[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mt][s], bop, out[mt][nt], 0, 0, 0);
+        }
+}
+
+// One block elimination by one wave. sD / sG / sR: the chunk's LDS arrays (see k_bcr_reduce).
+// Phase 1 (PH == 0): D_i^-1, W, W -> global, updates of the right neighbour. Phase 2 (PH == 1): updates of the
+// left neighbour. W stays in the caller's registers between the two (a workgroup barrier lies in between).
+template <int B>
+struct BcrElim {
+    typedef BcrDim<B> Dm;
+    v4d w[Dm::MT][Dm::NT];
+
+    __device__ __forceinline__ void phase1(double *Di, const double *P, bool hasP, const double *Q, const double *Ri,
+                                           double *Dc, double *Rc, double *Wg, const double *zero, int lane) {
+        bcr_invert<B>(Di, lane);
+        // W = Di^-1 [P' | Q | R]
+        double aop[Dm::MT][Dm::KS];
+        bcr_load_a<B, false>(Di, lane, aop);
+        const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int mt = 0; mt < Dm::MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < Dm::NT; nt++) w[mt][nt] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int nt = 0; nt < Dm::NT; nt++) {
+            const int j = 16 * nt + lj;
+            const double *base = zero;
+            int stride = 0;
+            if (j < B) {
+                if (hasP) {
+                    base = P + j * B;  // column j of P' = row j of P
+                    stride = 1;
+                }
+            } else if (j < 2 * B) {
+                base = Q + (j - B);
+                stride = B;
+            } else if (j < Dm::NC) {
+                base = Ri + (j - 2 * B);
+                stride = 3;
+            }
+#pragma unroll
+            for (int s = 0; s < Dm::KS; s++) {
+                const double bop = base[(4 * s + lk) * stride];
+#pragma unroll
+                for (int mt = 0; mt < Dm::MT; mt++)
+                    w[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mt][s], bop, w[mt][nt], 0, 0, 0);
+            }
+        }
+        // W -> global (the way back reads it)
+#pragma unroll
+        for (int mt = 0; mt < Dm::MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < Dm::NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * mt + 4 * r + lk, c = 16 * nt + lj;
+                    if (row < B && c < Dm::NC) Wg[row * Dm::NC + c] = w[mt][nt][r];
+                }
+        // right neighbour: D_c -= Q' W_Q, R_c -= Q' W_R
+        bcr_load_a<B, true>(Q, lane, aop);
+        v4d out[Dm::MT][Dm::NT];
+#pragma unroll
+        for (int mt = 0; mt < Dm::MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < Dm::NT; nt++) out[mt][nt] = v4d{0.0, 0.0, 0.0, 0.0};
+        bcr_mul_w<B, Dm::NT0>(aop, w, out);
+#pragma unroll
+        for (int mt = 0; mt < Dm::MT; mt++)
+#pragma unroll
+            for (int nt = Dm::NT0; nt < Dm::NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * mt + 4 * r + lk, c = 16 * nt + lj;
+                    if (row < B) {
+                        if (c >= B && c < 2 * B)
+                            Dc[row * B + c - B] -= out[mt][nt][r];
+                        else if (c >= 2 * B && c < Dm::NC)
+                            Rc[row * 3 + c - 2 * B] -= out[mt][nt][r];
+                    }
+                }
+    }
+
+    // left neighbour: D_a -= P W_P (assigned when `assign`: the chunk's first contribution to the separator
+    // before it), A[a, c] = -P W_Q written over P, R_a -= P W_R
+    __device__ __forceinline__ void phase2(double *P, double *Da, bool assign, double *Ra, int lane) {
+        double aop[Dm::MT][Dm::KS];
+        bcr_load_a<B, false>(P, lane, aop);
+        v4d out[Dm::MT][Dm::NT];
+#pragma unroll
+        for (int mt = 0; mt < Dm::MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < Dm::NT; nt++) out[mt][nt] = v4d{0.0, 0.0, 0.0, 0.0};
+        bcr_mul_w<B, 0>(aop, w, out);
+        const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int mt = 0; mt < Dm::MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < Dm::NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * mt + 4 * r + lk, c = 16 * nt + lj;
+                    if (row < B) {
+                        const double v = out[mt][nt][r];
+                        if (c < B)
+                            Da[row * B + c] = assign ? -v : Da[row * B + c] - v;
+                        else if (c < 2 * B)
+                            P[row * B + c - B] = -v;
+                        else if (c < Dm::NC)
+                            Ra[row * 3 + c - 2 * B] -= v;
+                    }
+                }
+    }
+};
+
+// One chunk of eight blocks per workgroup (256 threads = 4 waves).
+// L0: the blocks are gathered from the level-0 SELL operator (off-diagonals), its diagonal and right-hand side;
+// otherwise from the separator data of the level below (block j of this level = chunk j of that one):
+//   D_j = sepD[j] + extD[j + 1],  R_j = sepR[j] + extR[j + 1],  G_j = extG[j + 1].
+// Output per chunk c: W (seven blocks), sepD / sepR (block 7 after the eliminations), extD / extR (what the
+// chunk's eliminations subtract from the separator of chunk c - 1), extG (coupling of that separator to block 7).
+// TOP (one chunk, nothing before it): block 7 is solved and written to xtop.
+template <int B, bool L0, bool TOP>
+__global__ __launch_bounds__(256, (B <= 24 ? 2 : 1)) void k_bcr_reduce(
+    int nb, int n, const int *__restrict__ sl_off, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ diag, const double4 *__restrict__ rhs, const double *__restrict__ inD,
+    const double *__restrict__ inR, const double *__restrict__ inXD, const double *__restrict__ inXR,
+    const double *__restrict__ inXG, double *__restrict__ W, double *__restrict__ sepD, double *__restrict__ sepR,
+    double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop) {
+    typedef BcrDim<B> Dm;
+    constexpr int BB = B * B;
+    __shared__ double sD[8][BB];   // sD[0] becomes the chunk's contribution to the separator before it
+    __shared__ double sG[8][BB];   // slot 0: coupling (separator before the chunk) -> block 0; slot j + 1: block j -> j + 1
+    __shared__ double sR[9][B * 3];  // slot 0: contribution to the right-hand side of the separator before the chunk
+    __shared__ double sZ[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.x;
+    const bool hasExt = chunk > 0;
+
+    // ---- load ----
+    for (int e = tid; e < 8 * BB; e += 256) {
+        (&sD[0][0])[e] = 0.0;
+        (&sG[0][0])[e] = 0.0;
+    }
+    for (int e = tid; e < 9 * B * 3; e += 256) (&sR[0][0])[e] = 0.0;
+    if (tid < 2) sZ[tid] = 0.0;
+    __syncthreads();
+    if (L0) {
+        const int row0 = chunk * 8 * B;
+        for (int t = tid; t < 8 * B; t += 256) {
+            const int row = row0 + t, blk = t / B, r = t - blk * B;
+            if (row < n) {
+                const int sl = row >> 6, ln = row & 63;
+                const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
+                const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(col) + (size_t)(o0 / 2) * 64 + ln;
+                const double2 *__restrict__ vp = reinterpret_cast<const double2 *>(val) + (size_t)(o0 / 2) * 64 + ln;
+                for (int q = 0; q < w / 2; q++) {
+                    const int2 cc = cp[(size_t)q * 64];
+                    const double2 vv = vp[(size_t)q * 64];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int c = h ? cc.y : cc.x;
+                        const double v = h ? vv.y : vv.x;
+                        if (v == 0.0) continue;
+                        const int gc = c - row0;
+                        if (gc < 0) {
+                            if (blk == 0 && gc >= -B) sG[0][(gc + B) * B + r] += v;
+                        } else if (gc < 8 * B) {
+                            const int cb = gc / B, cj = gc - cb * B;
+                            if (cb == blk)
+                                sD[blk][r * B + cj] += v;
+                            else if (cb == blk + 1)
+                                sG[blk + 1][r * B + cj] += v;
+                        }
+                    }
+                }
+                sD[blk][r * B + r] += diag[row];
+                const double4 bb = rhs[row];
+                sR[blk + 1][r * 3 + 0] = bb.x;
+                sR[blk + 1][r * 3 + 1] = bb.y;
+                sR[blk + 1][r * 3 + 2] = bb.z;
+            } else {
+                sD[blk][r * B + r] = 1.0;
+            }
+        }
+    } else {
+        for (int i = 0; i < 8; i++) {
+            const int gb = chunk * 8 + i;
+            if (gb < nb) {
+                const bool nxt = gb + 1 < nb;
+                for (int e = tid; e < BB; e += 256) {
+                    sD[i][e] = inD[(size_t)gb * BB + e] + (nxt ? inXD[(size_t)(gb + 1) * BB + e] : 0.0);
+                    if (i < 7 && nxt) sG[i + 1][e] = inXG[(size_t)(gb + 1) * BB + e];
+                }
+                for (int e = tid; e < B * 3; e += 256)
+                    sR[i + 1][e] = inR[(size_t)gb * B * 3 + e] + (nxt ? inXR[(size_t)(gb + 1) * B * 3 + e] : 0.0);
+            } else {
+                for (int e = tid; e < B; e += 256) sD[i][e * B + e] = 1.0;
+            }
+        }
+        if (hasExt)
+            for (int e = tid; e < BB; e += 256) sG[0][e] = inXG[(size_t)chunk * 8 * BB + e];
+    }
+    __syncthreads();
+
+    // ---- three rounds of eliminations: (0 2 4 6) (1 5) (3) ----
+    BcrElim<B> E;
+#pragma unroll
+    for (int rnd = 0; rnd < 3; rnd++) {
+        int i = -1, a = -1, c = 7;
+        if (rnd == 0) {
+            i = 2 * wave;
+            a = i - 1;
+            c = i + 1;
+        } else if (rnd == 1) {
+            if (wave < 2) {
+                i = 1 + 4 * wave;
+                a = wave == 0 ? -1 : 3;
+                c = wave == 0 ? 3 : 7;
+            }
+        } else if (wave == 0) {
+            i = 3;
+            a = -1;
+            c = 7;
+        }
+        const bool active = i >= 0 && chunk * 8 + i < nb;
+        const bool hasP = a >= 0 || hasExt;
+        if (active)
+            E.phase1(sD[i], sG[a + 1], hasP, sG[i + 1], sR[i + 1], sD[c], sR[c + 1],
+                     W + ((size_t)chunk * 7 + i) * B * Dm::NC, sZ, lane);
+        __syncthreads();
+        if (active && hasP) E.phase2(sG[a + 1], a >= 0 ? sD[a] : sD[0], a < 0 && rnd == 0, sR[a + 1], lane);
+        __syncthreads();
+    }
+
+    // ---- store ----
+    if (TOP) {
+        if (wave == 0) {
+            if (7 < nb) {
+                bcr_invert<B>(sD[7], lane);
+                for (int o = lane; o < B * 3; o += 64) {
+                    const int k = o / 3, q = o - 3 * k;
+                    double s = 0.0;
+                    for (int cidx = 0; cidx < B; cidx++) s += sD[7][k * B + cidx] * sR[8][cidx * 3 + q];
+                    xtop[o] = s;
+                }
+            } else {
+                for (int o = lane; o < B * 3; o += 64) xtop[o] = 0.0;
+            }
+        }
+    } else {
+        for (int e = tid; e < BB; e += 256) {
+            sepD[(size_t)chunk * BB + e] = sD[7][e];
+            if (hasExt) {
+                extD[(size_t)chunk * BB + e] = sD[0][e];
+                extG[(size_t)chunk * BB + e] = sG[0][e];
+            }
+        }
+        for (int e = tid; e < B * 3; e += 256) {
+            sepR[(size_t)chunk * B * 3 + e] = sR[8][e];
+            if (hasExt) extR[(size_t)chunk * B * 3 + e] = sR[0][e];
+        }
+    }
+}
+
+// The way back for one chunk: x_7 and the separator before the chunk come from the coarser level.
+template <int B, bool L0>
+__global__ __launch_bounds__(256) void k_bcr_back(int nb, int n, const double *__restrict__ W,
+                                                   const double *__restrict__ xc, double *__restrict__ xl,
+                                                   double4 *__restrict__ X) {
+    typedef BcrDim<B> Dm;
+    __shared__ double sX[9][B * 3];  // slot 0: separator before the chunk; slot j + 1: block j
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.x;
+    for (int e = tid; e < 9 * B * 3; e += 256) (&sX[0][0])[e] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < B * 3; e += 256) {
+        sX[8][e] = xc[(size_t)chunk * B * 3 + e];
+        if (chunk > 0) sX[0][e] = xc[(size_t)(chunk - 1) * B * 3 + e];
+    }
+    __syncthreads();
+    const int lk = lane >> 4, lp = lane & 15;
+#pragma unroll
+    for (int rnd = 2; rnd >= 0; rnd--) {
+        int i = -1, a = -1, c = 7;
+        if (rnd == 0) {
+            i = 2 * wave;
+            a = i - 1;
+            c = i + 1;
+        } else if (rnd == 1) {
+            if (wave < 2) {
+                i = 1 + 4 * wave;
+                a = wave == 0 ? -1 : 3;
+                c = wave == 0 ? 3 : 7;
+            }
+        } else if (wave == 0) {
+            i = 3;
+        }
+        if (i >= 0 && chunk * 8 + i < nb) {
+            const double *__restrict__ Wi = W + ((size_t)chunk * 7 + i) * B * Dm::NC;
+            const double *xa = sX[a + 1], *xcn = sX[c + 1];
+            for (int it = 0; it < B / 4; it++) {
+                const int k = 4 * it + lk;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                for (int cidx = lp; cidx < Dm::NC; cidx += 16) {
+                    const double wv = Wi[k * Dm::NC + cidx];
+                    if (cidx < B) {
+                        s0 -= wv * xa[cidx * 3 + 0];
+                        s1 -= wv * xa[cidx * 3 + 1];
+                        s2 -= wv * xa[cidx * 3 + 2];
+                    } else if (cidx < 2 * B) {
+                        s0 -= wv * xcn[(cidx - B) * 3 + 0];
+                        s1 -= wv * xcn[(cidx - B) * 3 + 1];
+                        s2 -= wv * xcn[(cidx - B) * 3 + 2];
+                    } else {
+                        const int q = cidx - 2 * B;
+                        s0 += q == 0 ? wv : 0.0;
+                        s1 += q == 1 ? wv : 0.0;
+                        s2 += q == 2 ? wv : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s0 += __shfl_xor(s0, o, 64);
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (lp == 0) {
+                    sX[i + 1][k * 3 + 0] = s0;
+                    sX[i + 1][k * 3 + 1] = s1;
+                    sX[i + 1][k * 3 + 2] = s2;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (L0) {
+        const int row0 = chunk * 8 * B;
+        for (int t = tid; t < 8 * B; t += 256) {
+            const int row = row0 + t;
+            if (row < n) {
+                const double *xs = &sX[1][0] + t * 3;
+                X[row] = double4{xs[0], xs[1], xs[2], 0.0};
+            }
+        }
+    } else {
+        for (int e = tid; e < 8 * B * 3; e += 256) xl[(size_t)chunk * 8 * B * 3 + e] = (&sX[1][0])[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static void bcr_alloc(Graph &g) {
+    if (g.bcr) return;
+    g.bcr.reset(new BcrState());
+    BcrState &S = *g.bcr;
+    S.B = g.bcr_B;
+    const int B = S.B, NC = 2 * B + 3;
+    int nb = (g.levels[0].n + B - 1) / B;
+    for (;;) {
+        S.lev.emplace_back();
+        BcrLevel &L = S.lev.back();
+        L.nb = nb;
+        L.nch = (nb + 7) / 8;
+        L.W.alloc((size_t)L.nch * 7 * B * NC);
+        if (S.lev.size() > 1) L.x.alloc((size_t)L.nch * 8 * B * 3);
+        if (nb <= 8) break;
+        L.sepD.alloc((size_t)L.nch * B * B);
+        L.extD.alloc((size_t)L.nch * B * B);
+        L.extG.alloc((size_t)L.nch * B * B);
+        L.sepR.alloc((size_t)L.nch * B * 3);
+        L.extR.alloc((size_t)L.nch * B * 3);
+        nb = L.nch;
+    }
+    S.xtop.alloc((size_t)B * 3);
+}
+
+template <int B>
+static void bcr_run(Graph &g, int only) {
+    BcrState &S = *g.bcr;
+    Level &L0 = g.levels[0];
+    hipStream_t st = g.stream;
+    const int nl = (int)S.lev.size();
+    for (int l = 0; l < nl; l++) {
+        if (only >= 0 && only != l) continue;
+        BcrLevel &L = S.lev[l];
+        const BcrLevel *F = l > 0 ? &S.lev[l - 1] : nullptr;
+        const bool top = l == nl - 1;
+#define IRH_BCR_ARGS                                                                                             \
+    L.nb, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p, L0.b.p, F ? F->sepD.p : nullptr,                      \
+        F ? F->sepR.p : nullptr, F ? F->extD.p : nullptr, F ? F->extR.p : nullptr, F ? F->extG.p : nullptr, L.W.p, \
+        L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p
+        if (l == 0 && top)
+            hipLaunchKernelGGL((k_bcr_reduce<B, true, true>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);
+        else if (l == 0)
+            hipLaunchKernelGGL((k_bcr_reduce<B, true, false>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);
+        else if (top)
+            hipLaunchKernelGGL((k_bcr_reduce<B, false, true>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);
+        else
+            hipLaunchKernelGGL((k_bcr_reduce<B, false, false>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);
+#undef IRH_BCR_ARGS
+    }
+    for (int l = nl - 1; l >= 0; l--) {
+        if (only >= 0 && only != 100 + l) continue;
+        BcrLevel &L = S.lev[l];
+        const double *xc = l == nl - 1 ? S.xtop.p : S.lev[l + 1].x.p;
+        if (l == 0)
+            hipLaunchKernelGGL((k_bcr_back<B, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L0.n, L.W.p, xc,
+                               (double *)nullptr, g.X.p + g.ng);
+        else
+            hipLaunchKernelGGL((k_bcr_back<B, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L0.n, L.W.p, xc, L.x.p,
+                               (double4 *)nullptr);
+    }
+}
+
+// levels[0] values, diagonal and right-hand side (assemble_values) -> g.X. Asynchronous; only >= 0 launches one
+// kernel alone (bench: 0.. the reductions, 100.. the ways back).
+int bcr_solve(Graph &g, int only) {
+    if (!g.bcr_B) return IROTAVG_ERR_BAD_ARG;
+    bcr_alloc(g);
+    switch (g.bcr_B) {
+    case 8: bcr_run<8>(g, only); break;
+    case 16: bcr_run<16>(g, only); break;
+    case 24: bcr_run<24>(g, only); break;
+    case 32: bcr_run<32>(g, only); break;
+    default: return IROTAVG_ERR_BAD_ARG;
+    }
+    if (only < 0) g.stats.direct_solves += 1;
+    return IROTAVG_OK;
+}
+
+int bcr_levels(Graph &g) {
+    if (!g.bcr_B) return 0;
+    bcr_alloc(g);
+    return (int)g.bcr->lev.size();
+}
+
+// Decides whether the handle's solves run here: one GPU, every edge between two free views within 32 views
+// (ral's I is 0-based; row = view - f), enough rows for the hierarchy of the iterative solver to exist at all
+// (smaller graphs are one dense level = a direct solve already). opt.band_direct: 0 choose, 1 whenever the band
+// allows, -1 never; IROTAVG_BAND_DIRECT overrides the option.
+void bcr_plan(Graph &g, const int32_t *I) {
+    g.bcr_B = 0;
+    g.band0 = -1;
+    int mode = g.opt.band_direct;
+    if (const char *e = std::getenv("IROTAVG_BAND_DIRECT")) mode = std::atoi(e);
+    if (mode < 0 || g.ng > 0 || g.levels.empty() || g.levels[0].n < 1) return;
+    const int f = g.f;
+    std::atomic<int> band(0);
+    parallel_for(g.m, 65536, [&](int64_t k0, int64_t k1, int) {
+        int bmax = 0;
+        for (int64_t k = k0; k < k1; k++) {
+            const int i = I[2 * k], j = I[2 * k + 1];
+            if (i >= f && j >= f) bmax = std::max(bmax, std::abs(i - j));
+        }
+        int cur = band.load();
+        while (bmax > cur && !band.compare_exchange_weak(cur, bmax)) {
+        }
+    });
+    g.band0 = band.load();
+    if (g.band0 > 32) return;
+    if (mode == 0 && g.levels[0].n <= 2048) return;
+    g.bcr_B = g.band0 <= 8 ? 8 : g.band0 <= 16 ? 16 : g.band0 <= 24 ? 24 : 32;
+}
+
+}  // namespace irh

@@ -210,6 +210,7 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
         irotavg_graph_destroy(h);
         return rc;
     }
+    bcr_plan(g, I);  // a banded operator is solved directly (bcr.hip)
     *out = h;
     return IROTAVG_OK;
     }
@@ -364,6 +365,8 @@ int irotavg_graph_quat_normalised(irotavg_graph *h) {
 int irotavg_graph_get_stats(irotavg_graph *h, irotavg_stats *out) {
     if (!h || !out) return IROTAVG_ERR_BAD_ARG;
     *out = h->g.stats;
+    out->band = h->g.band0;
+    out->band_block = h->g.bcr_B;
     return IROTAVG_OK;
 }
 

@@ -8,6 +8,11 @@
 
 namespace irh {
 
+struct BcrState;  // bcr.hip: buffers of the direct solve of a banded level-0 operator
+struct BcrDeleter {
+    void operator()(BcrState *p) const;
+};
+
 struct Graph {
     int64_t m = 0, n_total = 0, mpad = 0;
     // Local vertex order is [fixed | ghost | owned]. f = fixed views, ng = ghost views (free
@@ -113,6 +118,11 @@ struct Graph {
     Graph() = default;
     Graph(const Graph &) = delete;
     Graph &operator=(const Graph &) = delete;
+
+    // direct solve of a banded level-0 operator by block cyclic reduction (bcr.hip): block size (8 / 16 / 24 / 32;
+    // 0 = the solves run through the PCG) and the half-bandwidth found at creation (-1: not looked at)
+    int bcr_B = 0, band0 = -1;
+    std::unique_ptr<BcrState, BcrDeleter> bcr;
 
     double last_score_sum = 0.0;
     double irls_settle = -1.0;  // run_irls: > 0 while the last step was small enough for the weights to have settled (assemble())
@@ -224,6 +234,10 @@ struct WinBatchItem {  // one problem of a batched launch: inputs as window_solv
 };
 int window_solve_batch(WindowSolver &ws, int nb, WinBatchItem *items, int l1_max, int irls_max, int cost, double sigma,
                        double change_th);
+// bcr.hip
+void bcr_plan(Graph &g, const int32_t *I);  // sets Graph::bcr_B / band0 (capi.cpp, after the build)
+int bcr_solve(Graph &g, int only = -1);     // levels[0] values / diagonal / right-hand side -> g.X, asynchronous
+int bcr_levels(Graph &g);
 // dense.hip
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);

@@ -470,7 +470,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
             // (measured at 100k/2M: the entry ratios against (p, t-1) span 2-20x in the first outer
             // iterations and <1.5x from the ~7th on; accepting up to kPdSpread costs ~1 PCG iteration
             // per solve and saves most inversions of a long l1ra run)
-            dense_select_slot(g, std::min(pditer - 1, kPdSlots - 1));
+            if (!g.bcr_B) dense_select_slot(g, std::min(pditer - 1, kPdSlots - 1));
             {
                 const double keep = g.stale_spread;
                 g.stale_spread = kPdSpread;
@@ -562,7 +562,7 @@ static int l1decode_core(Graph &g, const double *y, int pdmaxiter, int xplane, i
     PdGroup G;
     G.mem.push_back(PdMember{&g, nullptr, y});
     G.m_global = g.m;
-    G.solve = [&g]() { return pcg_solve(g); };
+    G.solve = [&g]() { return g.bcr_B ? bcr_solve(g) : pcg_solve(g); };
     return l1decode_group(G, pdmaxiter, xplane, stuck);
 }
 
@@ -628,6 +628,8 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
     q.l0_far_entries = g.l0_far_entries;
     q.l1_fused = g.l1_fused;
     q.cg2 = g.cg2;
+    q.bcr_B = g.bcr_B;
+    q.band0 = g.band0;
     q.dense32 = g.dense32;
     q.b2p.alloc_like(g.b2p, s);
     q.kc_auto = g.kc_auto;
@@ -707,6 +709,8 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
             g.stats.pcg_iters += q.stats.pcg_iters;
             g.stats.pcg_iters_last = q.stats.pcg_iters_last;
             g.stats.pcg_stagnated += q.stats.pcg_stagnated;
+            g.stats.direct_solves += q.stats.direct_solves;
+            q.stats.direct_solves = 0;
             g.stats.dense_inversions += q.stats.dense_inversions;
             q.stats.dense_inversions = 0;
             q.stats.pcg_solves = 0;

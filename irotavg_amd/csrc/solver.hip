@@ -1638,6 +1638,7 @@ int grid_for_elems(long long n) { return round_grid((n + kRowBlock - 1) / kRowBl
 // refresh all matrix values from per-edge weights: mode 0 = IRLS (d^2, rhs), mode 1 = L1 Hessian
 void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
     assemble_values(g, mode, wsrc);
+    if (g.bcr_B) return;  // banded operator, solved directly (bcr.hip): no coarse levels, no dense inverse
     // IRLS on a graph with loop closures re-inverts in every iteration: after two 'stale'
     // verdicts in a row the test (three small launches + a host round trip, ~40 us) is skipped three times out
     // of four and the inverse refreshed straight away
@@ -1675,7 +1676,7 @@ void assemble_values(Graph &g, int mode, const double *wsrc) {
     if (g.asm_windowed) {
         // one workgroup per slice, the grid padded to a multiple of 8 (XCD-chunked slice order)
         const int gw = (L0.nsl + 7) / 8 * 8;
-        const bool l1 = g.asm_l1_fused != 0;
+        const bool l1 = g.asm_l1_fused != 0 && !g.bcr_B;
         Level *C1 = g.levels.size() > 1 ? &g.levels[1] : nullptr;
 #define IRH_ASM_ARGS                                                                                         \
     L0.n, L0.nsl, (long long)g.m, (long long)g.mpad, L0.sl_off.p, g.slot_eid.p, g.slot_cs.p, g.tile_e0.p,    \
@@ -1705,6 +1706,7 @@ void assemble_values(Graph &g, int mode, const double *wsrc) {
                            (const double4 *)nullptr, L0.val.p, L0.excess.p, L0.diag.p, L0.idg.p, L0.b.p,
                            g.bval.p);
     }
+    if (g.bcr_B) return;  // the direct solver reads level 0 only
     for (size_t l = first_coarse; l < g.levels.size(); l++) {
         Level &F = g.levels[l - 1];
         Level &C = g.levels[l];
@@ -2028,6 +2030,7 @@ int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ra
 int ls_solve(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
     if (tail_ran) *tail_ran = false;
     assemble(g, 0, g.dw.p, g.opt.dense_always_refresh == 1);
+    if (g.bcr_B) return bcr_solve(g);  // asynchronous; a non-finite result shows in the score of the step
     int rc = pcg_solve(g, tail, tail_ran);
     auto failed = [&]() { return rc == IROTAVG_ERR_NOT_CONVERGED || rc == IROTAVG_ERR_SOLVER; };
     // The reference's direct solvers always return an answer. Two more attempts before an error code:
@@ -2082,7 +2085,18 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     fill(g, g.dw.p, (long long)g.mpad, 1.0);  // weights.setOnes() (:577)
     while (score > change_th && it < max_iters) {  // :590, strict >
         launch_edge_residual(g);
-        if (g.cg2) {
+        if (g.bcr_B) {
+            // banded operator: assembly of level 0, direct solve, weight and rotation update -- ~14 launches and
+            // ONE host round trip (the score) per iteration
+            rc = ls_solve(g);
+            if (rc != IROTAVG_OK) break;
+            launch_update_weights(g, cost, sigma);
+            score = apply_step(g);
+            if (!std::isfinite(score)) {
+                rc = IROTAVG_ERR_SOLVER;
+                break;
+            }
+        } else if (g.cg2) {
             // The weight update and the rotation update are enqueued BEHIND the PCG before the host has
             // read its done flag, gated on that flag: convergence and score come back in one round trip
             // instead of two (each costs the GPU ~15-30 us of idling). If the solve needs more
