@@ -29,6 +29,8 @@
 namespace irh {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 struct BcrLevel {
     int nb = 0;   // blocks
@@ -72,7 +74,12 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane) {
         const int dl = (kb << 3) | kb;
         const double p = bcr_readlane(t[kt][kt], dl);
         const double ref = bcr_readlane(od[kt], dl);
-        const double pinv = (p > kDeadTol * ref) ? 1.0 / p : 0.0;
+        // reciprocal by v_rcp_f64 + two Newton steps (the IEEE division sequence is three times as long and
+        // sits on the chain from pivot to pivot)
+        double x = __builtin_amdgcn_rcp(p);
+        x = fma(fma(-p, x, 1.0), x, x);
+        x = fma(fma(-p, x, 1.0), x, x);
+        const double pinv = (p > kDeadTol * ref) ? x : 0.0;
         double cr[T], cc[T];
 #pragma unroll
         for (int tr = 0; tr < T; tr++) cr[tr] = __shfl(t[tr][kt], (a << 3) | kb, 64);
@@ -291,25 +298,37 @@ __global__ __launch_bounds__(256, (B <= 24 ? 2 : 1)) void k_bcr_reduce(
             if (row < n) {
                 const int sl = row >> 6, ln = row & 63;
                 const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
-                const int2 *__restrict__ cp = reinterpret_cast<const int2 *>(col) + (size_t)(o0 / 2) * 64 + ln;
-                const double2 *__restrict__ vp = reinterpret_cast<const double2 *>(val) + (size_t)(o0 / 2) * 64 + ln;
-                for (int q = 0; q < w / 2; q++) {
-                    const int2 cc = cp[(size_t)q * 64];
-                    const double2 vv = vp[(size_t)q * 64];
+                const v2i *__restrict__ cp = reinterpret_cast<const v2i *>(col) + (size_t)(o0 / 2) * 64 + ln;
+                const v2d *__restrict__ vp = reinterpret_cast<const v2d *>(val) + (size_t)(o0 / 2) * 64 + ln;
+                // the row's entries in batches of eight pairs: all loads of a batch are issued before the first
+                // value is scattered (a load per scatter was a memory round trip per pair)
+                for (int q0 = 0; q0 < w / 2; q0 += 8) {
+                    v2i cc[8];
+                    v2d vv[8];
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int c = h ? cc.y : cc.x;
-                        const double v = h ? vv.y : vv.x;
-                        if (v == 0.0) continue;
-                        const int gc = c - row0;
-                        if (gc < 0) {
-                            if (blk == 0 && gc >= -B) sG[0][(gc + B) * B + r] += v;
-                        } else if (gc < 8 * B) {
-                            const int cb = gc / B, cj = gc - cb * B;
-                            if (cb == blk)
-                                sD[blk][r * B + cj] += v;
-                            else if (cb == blk + 1)
-                                sG[blk + 1][r * B + cj] += v;
+                    for (int u = 0; u < 8; u++) {
+                        const int q = q0 + u < w / 2 ? q0 + u : w / 2 - 1;
+                        cc[u] = __builtin_nontemporal_load(&cp[(size_t)q * 64]);
+                        vv[u] = __builtin_nontemporal_load(&vp[(size_t)q * 64]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (q0 + u >= w / 2) break;
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int c = h ? cc[u].y : cc[u].x;
+                            const double v = h ? vv[u].y : vv[u].x;
+                            if (v == 0.0) continue;
+                            const int gc = c - row0;
+                            if (gc < 0) {
+                                if (blk == 0 && gc >= -B) sG[0][(gc + B) * B + r] += v;
+                            } else if (gc < 8 * B) {
+                                const int cb = gc / B, cj = gc - cb * B;
+                                if (cb == blk)
+                                    sD[blk][r * B + cj] += v;
+                                else if (cb == blk + 1)
+                                    sG[blk + 1][r * B + cj] += v;
+                            }
                         }
                     }
                 }
@@ -402,16 +421,28 @@ __global__ __launch_bounds__(256, (B <= 24 ? 2 : 1)) void k_bcr_reduce(
     }
 }
 
-// The way back for one chunk: x_7 and the separator before the chunk come from the coarser level.
+// The way back for one chunk: x_7 and the separator before the chunk come from the coarser level. The chunk's
+// W (7 blocks of B x (2B + 3)) is staged in LDS first -- every load of the launch is in flight at once; read row
+// by row behind the three dependent rounds it cost a memory round trip per four rows.
 template <int B, bool L0>
 __global__ __launch_bounds__(256) void k_bcr_back(int nb, int n, const double *__restrict__ W,
                                                    const double *__restrict__ xc, double *__restrict__ xl,
                                                    double4 *__restrict__ X) {
     typedef BcrDim<B> Dm;
+    constexpr int WB = B * Dm::NC;     // doubles of one W block
+    __shared__ double sW[7 * WB];
     __shared__ double sX[9][B * 3];  // slot 0: separator before the chunk; slot j + 1: block j
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = blockIdx.x;
+    int nblk = nb - chunk * 8;  // blocks of this chunk that exist (the separator, block 7, is not staged)
+    nblk = nblk > 7 ? 7 : nblk;
+    {
+        const v2d *__restrict__ src = reinterpret_cast<const v2d *>(W + (size_t)chunk * 7 * WB);
+        v2d *dst = reinterpret_cast<v2d *>(sW);
+        const int cnt = nblk * WB / 2;  // WB is even or odd? B * (2B + 3): B is a multiple of 8 -> even
+        for (int e = tid; e < cnt; e += 256) dst[e] = __builtin_nontemporal_load(&src[e]);
+    }
     for (int e = tid; e < 9 * B * 3; e += 256) (&sX[0][0])[e] = 0.0;
     __syncthreads();
     for (int e = tid; e < B * 3; e += 256) {
@@ -437,26 +468,31 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int n, const double *_
             i = 3;
         }
         if (i >= 0 && chunk * 8 + i < nb) {
-            const double *__restrict__ Wi = W + ((size_t)chunk * 7 + i) * B * Dm::NC;
+            const double *Wi = sW + i * WB;
             const double *xa = sX[a + 1], *xcn = sX[c + 1];
+#pragma unroll 2
             for (int it = 0; it < B / 4; it++) {
                 const int k = 4 * it + lk;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-                for (int cidx = lp; cidx < Dm::NC; cidx += 16) {
-                    const double wv = Wi[k * Dm::NC + cidx];
-                    if (cidx < B) {
-                        s0 -= wv * xa[cidx * 3 + 0];
-                        s1 -= wv * xa[cidx * 3 + 1];
-                        s2 -= wv * xa[cidx * 3 + 2];
-                    } else if (cidx < 2 * B) {
-                        s0 -= wv * xcn[(cidx - B) * 3 + 0];
-                        s1 -= wv * xcn[(cidx - B) * 3 + 1];
-                        s2 -= wv * xcn[(cidx - B) * 3 + 2];
-                    } else {
-                        const int q = cidx - 2 * B;
-                        s0 += q == 0 ? wv : 0.0;
-                        s1 += q == 1 ? wv : 0.0;
-                        s2 += q == 2 ? wv : 0.0;
+#pragma unroll
+                for (int u = 0; u < Dm::NT; u++) {
+                    const int cidx = lp + 16 * u;
+                    if (cidx < Dm::NC) {
+                        const double wv = Wi[k * Dm::NC + cidx];
+                        if (cidx < B) {
+                            s0 -= wv * xa[cidx * 3 + 0];
+                            s1 -= wv * xa[cidx * 3 + 1];
+                            s2 -= wv * xa[cidx * 3 + 2];
+                        } else if (cidx < 2 * B) {
+                            s0 -= wv * xcn[(cidx - B) * 3 + 0];
+                            s1 -= wv * xcn[(cidx - B) * 3 + 1];
+                            s2 -= wv * xcn[(cidx - B) * 3 + 2];
+                        } else {
+                            const int q = cidx - 2 * B;
+                            s0 += q == 0 ? wv : 0.0;
+                            s1 += q == 1 ? wv : 0.0;
+                            s2 += q == 2 ? wv : 0.0;
+                        }
                     }
                 }
 #pragma unroll

@@ -2248,10 +2248,19 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
             hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kRowBlock), 0, g.stream,
                                g.nu, g.f, g.ng, g.X.p, g.Q.p, g.part_score.p, 0, (const int *)nullptr);
             break;
-        default: break;
+        default:
+            // 20 + l: reduction of level l of the banded direct solver, 40 + l: its way back, 19: a whole solve
+            if (which == 19) (void)bcr_solve(g);
+            else if (which >= 20 && which < 40) (void)bcr_solve(g, which - 20);
+            else if (which >= 40 && which < 60) (void)bcr_solve(g, 100 + which - 40);
+            break;
         }
     };
-    if (which < 1 || which > 10) return IROTAVG_ERR_BAD_ARG;
+    if (which >= 19 && which < 60) {
+        if (!g.bcr_B) return IROTAVG_ERR_BAD_ARG;
+        const int nl = bcr_levels(g);
+        if ((which >= 20 && which < 40 && which - 20 >= nl) || (which >= 40 && which - 40 >= nl)) return IROTAVG_ERR_BAD_ARG;
+    } else if (which < 1 || which > 10) return IROTAVG_ERR_BAD_ARG;
     if ((which == 9 || which == 10) && !g.cg2) return IROTAVG_ERR_BAD_ARG;  // not this graph's PCG
     if (which == 8 && !(g.additive_top && g.levels.size() > 1 && g.ng == 0 && g.l0_far_entries == 0 &&
                         g.opt.no_fused_pspmv != 1))

@@ -74,6 +74,14 @@ def big(n, m, reps=10, pbo=0.0):
             t0 = time.time(); r1 = G.l1ra(5, 1e-3); t1 = time.time() - t0
             G.restore_rotations()
             t0 = time.time(); r1 = G.l1ra(5, 1e-3); t1 = time.time() - t0
+            if st["band_block"]:
+                G.restore_rotations(); G.edge_residual(); G.ls_solve()
+                ms = C.c_double(0)
+                parts = []
+                for which in [1, 3, 2, 19] + list(range(20, 30)) + list(range(40, 50)):
+                    if lib.irotavg_graph_time_kernel(G._h, which, 50, C.byref(ms)) == 0:
+                        parts.append("%d:%.1f" % (which, 1e3 * ms.value))
+                print("   kernel us:", " ".join(parts), flush=True)
         res[bd] = Qg
         err = synth.angular_distance(Qg, G0["Qgt"] if False else Qg).max()
         print("n=%d m=%d pbo=%g band_direct=%2d B=%d: irls iters %d, ms/solve min %.3f med %.3f  -> %.3f G edge-updates/s; l1ra(5) %.2f ms (%d iters)" % (

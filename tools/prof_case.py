@@ -27,12 +27,13 @@ ap.add_argument("--agg0", type=int, default=0)
 ap.add_argument("--kc", type=float, default=0.0)
 ap.add_argument("--omega", type=float, default=0.0)
 ap.add_argument("--fixed-every", type=int, default=0)
+ap.add_argument("--band-direct", type=int, default=0)
 a = ap.parse_args()
 S = synth.make_graph(a.views, a.edges, a.p_loop, seed=0)
 Q0 = np.zeros((a.views, 4)); Q0[:, 3] = 1; Q0[0] = S["Qgt"][0]
 ral.init_mst(Q0, S["QQ"], S["I"], 1)
 SIG = 5 * np.pi / 180
-with capi.Graph(S["I"], S["QQ"], a.views, 1, pcg_classic=a.classic, mg_dense_max=a.dense_max, mg_agg=a.agg, mg_agg0=a.agg0, mg_kc=a.kc, mg_omega=a.omega) as G:
+with capi.Graph(S["I"], S["QQ"], a.views, 1, pcg_classic=a.classic, mg_dense_max=a.dense_max, mg_agg=a.agg, mg_agg0=a.agg0, mg_kc=a.kc, mg_omega=a.omega, band_direct=a.band_direct) as G:
     G.set_rotations(Q0)
     G.snapshot_rotations()
     out = {}
