@@ -34,6 +34,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 
 struct BcrLevel {
     int nb = 0;   // blocks
+    int nred = 0; // ... of which the first nred come from the level below (the others: raw level-0 blocks)
     int nch = 0;  // chunks of eight
     DevBuf<double> W;                             // nch * 7 blocks of B x (2B + 3)
     DevBuf<double> sepD, sepR, extD, extR, extG;  // per chunk: what the next level is assembled from
@@ -85,17 +86,27 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane) {
         for (int tr = 0; tr < T; tr++) cr[tr] = __shfl(t[tr][kt], (a << 3) | kb, 64);
 #pragma unroll
         for (int tc = 0; tc < T; tc++) cc[tc] = __shfl(t[tc][kt], (b << 3) | kb, 64);
+        // row k lives in row tile kt of the lanes a == kb, column k in column tile kt of the lanes b == kb: only
+        // those tiles need the selects (a 64-bit select is two VALU operations; with selects on all T x T
+        // elements they, not the arithmetic, set the time per pivot)
+        const bool rowk = a == kb, colk = b == kb;
+        double crp[T];
 #pragma unroll
-        for (int tr = 0; tr < T; tr++) {
-            const bool rk = (a + 8 * tr) == k;
-            const double crp = cr[tr] * pinv;
+        for (int tr = 0; tr < T; tr++) crp[tr] = cr[tr] * pinv;
+#pragma unroll
+        for (int tr = 0; tr < T; tr++)
 #pragma unroll
             for (int tc = 0; tc < T; tc++) {
-                const bool ck = (b + 8 * tc) == k;
-                const double upd = fma(-crp, cc[tc], t[tr][tc]);
-                t[tr][tc] = rk ? (ck ? -pinv : cc[tc] * pinv) : (ck ? crp : upd);
+                const double upd = fma(-crp[tr], cc[tc], t[tr][tc]);
+                if (tr == kt && tc == kt)
+                    t[tr][tc] = rowk ? (colk ? -pinv : cc[tc] * pinv) : (colk ? crp[tr] : upd);
+                else if (tr == kt)
+                    t[tr][tc] = rowk ? cc[tc] * pinv : upd;
+                else if (tc == kt)
+                    t[tr][tc] = colk ? crp[tr] : upd;
+                else
+                    t[tr][tc] = upd;
             }
-        }
     }
 #pragma unroll
     for (int tr = 0; tr < T; tr++)
@@ -148,105 +159,152 @@ __device__ __forceinline__ void bcr_mul_w(const double (&aop)[BcrDim<B>::MT][Bcr
         }
 }
 
-// One block elimination by one wave. sD / sG / sR: the chunk's LDS arrays (see k_bcr_reduce).
-// Phase 1 (PH == 0): D_i^-1, W, W -> global, updates of the right neighbour. Phase 2 (PH == 1): updates of the
-// left neighbour. W stays in the caller's registers between the two (a workgroup barrier lies in between).
-template <int B>
+// The matrix-core part of one block elimination. The 16-column tiles of W are independent of each other in all
+// three products, so they are dealt to the waves of the elimination's group (one wave in the first round of a
+// four-wave workgroup, two in the second, four in the third; four from the start in a sixteen-wave workgroup):
+// this wave owns the tiles nt = part, part + WPE, ... and keeps them in w[][slot] between the phases (workgroup
+// barriers lie in between). NTPW: slots of a wave.
+template <int B, int NTPW>
 struct BcrElim {
     typedef BcrDim<B> Dm;
-    v4d w[Dm::MT][Dm::NT];
+    v4d w[Dm::MT][NTPW];
 
-    __device__ __forceinline__ void phase1(double *Di, const double *P, bool hasP, const double *Q, const double *Ri,
-                                           double *Dc, double *Rc, double *Wg, const double *zero, int lane) {
-        bcr_invert<B>(Di, lane);
-        // W = Di^-1 [P' | Q | R]
+    // W = Di^-1 [P' | Q | R] (Di^-1 in LDS), W -> global (the way back reads it), and the right neighbour:
+    // D_c -= Q' W_Q, R_c -= Q' W_R
+    template <int WPE>
+    __device__ __forceinline__ void phase1(int part, const double *Di, const double *P, bool hasP, const double *Q,
+                                           const double *Ri, double *Dc, double *Rc, double *Wg, const double *zero,
+                                           int lane) {
+        constexpr int NS = (Dm::NT + WPE - 1) / WPE;
+        static_assert(NS <= NTPW, "slots");
         double aop[Dm::MT][Dm::KS];
         bcr_load_a<B, false>(Di, lane, aop);
         const int lj = lane & 15, lk = lane >> 4;
+        const double *base[NS];
+        int stride[NS];
 #pragma unroll
-        for (int mt = 0; mt < Dm::MT; mt++)
-#pragma unroll
-            for (int nt = 0; nt < Dm::NT; nt++) w[mt][nt] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int nt = 0; nt < Dm::NT; nt++) {
+        for (int sl = 0; sl < NS; sl++) {
+            const int nt = part + sl * WPE;
             const int j = 16 * nt + lj;
-            const double *base = zero;
-            int stride = 0;
-            if (j < B) {
-                if (hasP) {
-                    base = P + j * B;  // column j of P' = row j of P
-                    stride = 1;
+            base[sl] = zero;
+            stride[sl] = 0;
+            if (nt < Dm::NT) {
+                if (j < B) {
+                    if (hasP) {
+                        base[sl] = P + j * B;  // column j of P' = row j of P
+                        stride[sl] = 1;
+                    }
+                } else if (j < 2 * B) {
+                    base[sl] = Q + (j - B);
+                    stride[sl] = B;
+                } else if (j < Dm::NC) {
+                    base[sl] = Ri + (j - 2 * B);
+                    stride[sl] = 3;
                 }
-            } else if (j < 2 * B) {
-                base = Q + (j - B);
-                stride = B;
-            } else if (j < Dm::NC) {
-                base = Ri + (j - 2 * B);
-                stride = 3;
             }
 #pragma unroll
-            for (int s = 0; s < Dm::KS; s++) {
-                const double bop = base[(4 * s + lk) * stride];
+            for (int mt = 0; mt < Dm::MT; mt++) w[mt][sl] = v4d{0.0, 0.0, 0.0, 0.0};
+        }
+        // k-steps outermost: the MT x NS accumulator tiles are independent chains, and a chain of dependent
+        // f64 MFMAs issues one instruction per result latency, not per issue slot
+#pragma unroll
+        for (int s = 0; s < Dm::KS; s++) {
+            double bop[NS];
+#pragma unroll
+            for (int sl = 0; sl < NS; sl++) bop[sl] = base[sl][(4 * s + lk) * stride[sl]];
+#pragma unroll
+            for (int sl = 0; sl < NS; sl++)
 #pragma unroll
                 for (int mt = 0; mt < Dm::MT; mt++)
-                    w[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mt][s], bop, w[mt][nt], 0, 0, 0);
-            }
+                    w[mt][sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mt][s], bop[sl], w[mt][sl], 0, 0, 0);
         }
-        // W -> global (the way back reads it)
 #pragma unroll
-        for (int mt = 0; mt < Dm::MT; mt++)
+        for (int sl = 0; sl < NS; sl++) {
+            const int j = 16 * (part + sl * WPE) + lj;
 #pragma unroll
-            for (int nt = 0; nt < Dm::NT; nt++)
+            for (int mt = 0; mt < Dm::MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int row = 16 * mt + 4 * r + lk, c = 16 * nt + lj;
-                    if (row < B && c < Dm::NC) Wg[row * Dm::NC + c] = w[mt][nt][r];
+                    const int row = 16 * mt + 4 * r + lk;
+                    if (row < B && j < Dm::NC) Wg[row * Dm::NC + j] = w[mt][sl][r];
                 }
-        // right neighbour: D_c -= Q' W_Q, R_c -= Q' W_R
+        }
         bcr_load_a<B, true>(Q, lane, aop);
-        v4d out[Dm::MT][Dm::NT];
+        v4d out[Dm::MT][NS];
 #pragma unroll
-        for (int mt = 0; mt < Dm::MT; mt++)
+        for (int sl = 0; sl < NS; sl++)
 #pragma unroll
-            for (int nt = 0; nt < Dm::NT; nt++) out[mt][nt] = v4d{0.0, 0.0, 0.0, 0.0};
-        bcr_mul_w<B, Dm::NT0>(aop, w, out);
+            for (int mt = 0; mt < Dm::MT; mt++) out[mt][sl] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int mt = 0; mt < Dm::MT; mt++)
+        for (int s = 0; s < Dm::KS; s++)
 #pragma unroll
-            for (int nt = Dm::NT0; nt < Dm::NT; nt++)
+            for (int sl = 0; sl < NS; sl++) {
+                const int nt = part + sl * WPE;
+                if (nt >= Dm::NT || nt < Dm::NT0) continue;
+#pragma unroll
+                for (int mt = 0; mt < Dm::MT; mt++)
+                    out[mt][sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mt][s], w[s >> 2][sl][s & 3], out[mt][sl], 0, 0, 0);
+            }
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++) {
+            const int nt = part + sl * WPE;
+            if (nt >= Dm::NT || nt < Dm::NT0) continue;
+            const int c = 16 * nt + lj;
+#pragma unroll
+            for (int mt = 0; mt < Dm::MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int row = 16 * mt + 4 * r + lk, c = 16 * nt + lj;
+                    const int row = 16 * mt + 4 * r + lk;
                     if (row < B) {
                         if (c >= B && c < 2 * B)
-                            Dc[row * B + c - B] -= out[mt][nt][r];
+                            Dc[row * B + c - B] -= out[mt][sl][r];
                         else if (c >= 2 * B && c < Dm::NC)
-                            Rc[row * 3 + c - 2 * B] -= out[mt][nt][r];
+                            Rc[row * 3 + c - 2 * B] -= out[mt][sl][r];
                     }
                 }
+        }
     }
 
-    // left neighbour: D_a -= P W_P (assigned when `assign`: the chunk's first contribution to the separator
-    // before it), A[a, c] = -P W_Q written over P, R_a -= P W_R
-    __device__ __forceinline__ void phase2(double *P, double *Da, bool assign, double *Ra, int lane) {
+    // left neighbour, first half: the products P W (P is read by every wave of the group, and overwritten in
+    // the second half -- a barrier lies in between when the group has more than one wave)
+    template <int WPE>
+    __device__ __forceinline__ void phase2_mul(int part, const double *P, v4d (&out)[Dm::MT][NTPW], int lane) {
+        constexpr int NS = (Dm::NT + WPE - 1) / WPE;
         double aop[Dm::MT][Dm::KS];
         bcr_load_a<B, false>(P, lane, aop);
-        v4d out[Dm::MT][Dm::NT];
 #pragma unroll
-        for (int mt = 0; mt < Dm::MT; mt++)
+        for (int sl = 0; sl < NS; sl++)
 #pragma unroll
-            for (int nt = 0; nt < Dm::NT; nt++) out[mt][nt] = v4d{0.0, 0.0, 0.0, 0.0};
-        bcr_mul_w<B, 0>(aop, w, out);
+            for (int mt = 0; mt < Dm::MT; mt++) out[mt][sl] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < Dm::KS; s++)
+#pragma unroll
+            for (int sl = 0; sl < NS; sl++) {
+                if (part + sl * WPE >= Dm::NT) continue;
+#pragma unroll
+                for (int mt = 0; mt < Dm::MT; mt++)
+                    out[mt][sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mt][s], w[s >> 2][sl][s & 3], out[mt][sl], 0, 0, 0);
+            }
+    }
+    // second half: D_a -= P W_P (assigned when `assign`: the chunk's first contribution to the separator before
+    // it), A[a, c] = -P W_Q written over P, R_a -= P W_R
+    template <int WPE>
+    __device__ __forceinline__ void phase2_put(int part, const v4d (&out)[Dm::MT][NTPW], double *P, double *Da,
+                                               bool assign, double *Ra, int lane) {
+        constexpr int NS = (Dm::NT + WPE - 1) / WPE;
         const int lj = lane & 15, lk = lane >> 4;
 #pragma unroll
-        for (int mt = 0; mt < Dm::MT; mt++)
+        for (int sl = 0; sl < NS; sl++) {
+            const int nt = part + sl * WPE;
+            if (nt >= Dm::NT) continue;
+            const int c = 16 * nt + lj;
 #pragma unroll
-            for (int nt = 0; nt < Dm::NT; nt++)
+            for (int mt = 0; mt < Dm::MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int row = 16 * mt + 4 * r + lk, c = 16 * nt + lj;
+                    const int row = 16 * mt + 4 * r + lk;
                     if (row < B) {
-                        const double v = out[mt][nt][r];
+                        const double v = out[mt][sl][r];
                         if (c < B)
                             Da[row * B + c] = assign ? -v : Da[row * B + c] - v;
                         else if (c < 2 * B)
@@ -255,23 +313,77 @@ struct BcrElim {
                             Ra[row * 3 + c - 2 * B] -= v;
                     }
                 }
+        }
     }
 };
 
-// One chunk of eight blocks per workgroup (256 threads = 4 waves).
+// One row of the level-0 operator into the block arrays of a chunk: `row` lies in block lb (rows lb B ...), r = its
+// row inside the block. Entries in block lb -> Dblk (with the diagonal), entries in block lb + 1 -> Gnext (the
+// coupling lb -> lb + 1; nullptr: not wanted), entries in block lb - 1 -> GprevT, stored transposed (the coupling
+// lb - 1 -> lb as the rows of block lb see it, by symmetry; nullptr: not wanted). The right-hand side -> Rblk.
+// A thread owns its row (and, in GprevT, its column): plain read-modify-writes.
+template <int B>
+__device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int *__restrict__ sl_off,
+                                               const int *__restrict__ col, const double *__restrict__ val,
+                                               const double *__restrict__ diag, const double4 *__restrict__ rhs,
+                                               double *Dblk, double *Gnext, double *GprevT, double *Rblk) {
+    const int sl = row >> 6, ln = row & 63;
+    const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
+    const v2i *__restrict__ cp = reinterpret_cast<const v2i *>(col) + (size_t)(o0 / 2) * 64 + ln;
+    const v2d *__restrict__ vp = reinterpret_cast<const v2d *>(val) + (size_t)(o0 / 2) * 64 + ln;
+    const int c0 = lb * B;
+    // the row's entries in batches of eight pairs: all loads of a batch are issued before the first value is
+    // scattered (a load per scatter was a memory round trip per pair)
+    for (int q0 = 0; q0 < w / 2; q0 += 8) {
+        v2i cc[8];
+        v2d vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + u < w / 2 ? q0 + u : w / 2 - 1;
+            cc[u] = __builtin_nontemporal_load(&cp[(size_t)q * 64]);
+            vv[u] = __builtin_nontemporal_load(&vp[(size_t)q * 64]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (q0 + u >= w / 2) break;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int c = h ? cc[u].y : cc[u].x;
+                const double v = h ? vv[u].y : vv[u].x;
+                if (v == 0.0) continue;  // padding
+                const int gc = c - c0;
+                if (gc >= 0 && gc < B)
+                    Dblk[r * B + gc] += v;
+                else if (gc >= B && gc < 2 * B) {
+                    if (Gnext) Gnext[r * B + gc - B] += v;
+                } else if (gc < 0 && gc >= -B) {
+                    if (GprevT) GprevT[(gc + B) * B + r] += v;
+                }
+            }
+        }
+    }
+    Dblk[r * B + r] += diag[row];
+    const double4 bb = rhs[row];
+    Rblk[r * 3 + 0] = bb.x;
+    Rblk[r * 3 + 1] = bb.y;
+    Rblk[r * 3 + 2] = bb.z;
+}
+
+// One chunk of eight blocks per workgroup of NW waves (4, or 8 when the level has so few chunks that every
+// workgroup has a CU to itself: the column tiles of W are then dealt to two waves in the first round and four afterwards).
 // L0: the blocks are gathered from the level-0 SELL operator (off-diagonals), its diagonal and right-hand side;
 // otherwise from the separator data of the level below (block j of this level = chunk j of that one):
 //   D_j = sepD[j] + extD[j + 1],  R_j = sepR[j] + extR[j + 1],  G_j = extG[j + 1].
 // Output per chunk c: W (seven blocks), sepD / sepR (block 7 after the eliminations), extD / extR (what the
 // chunk's eliminations subtract from the separator of chunk c - 1), extG (coupling of that separator to block 7).
 // TOP (one chunk, nothing before it): block 7 is solved and written to xtop.
-template <int B, bool L0, bool TOP>
-__global__ __launch_bounds__(256, (B <= 24 ? 2 : 1)) void k_bcr_reduce(
-    int nb, int n, const int *__restrict__ sl_off, const int *__restrict__ col, const double *__restrict__ val,
+template <int B, bool L0, bool TOP, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_reduce(
+    int nb, int nred, int n, const int *__restrict__ sl_off, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ diag, const double4 *__restrict__ rhs, const double *__restrict__ inD,
     const double *__restrict__ inR, const double *__restrict__ inXD, const double *__restrict__ inXR,
     const double *__restrict__ inXG, double *__restrict__ W, double *__restrict__ sepD, double *__restrict__ sepR,
-    double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop) {
+    double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop, int dbg) {
     typedef BcrDim<B> Dm;
     constexpr int BB = B * B;
     __shared__ double sD[8][BB];   // sD[0] becomes the chunk's contribution to the separator before it
@@ -282,114 +394,103 @@ __global__ __launch_bounds__(256, (B <= 24 ? 2 : 1)) void k_bcr_reduce(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = blockIdx.x;
     const bool hasExt = chunk > 0;
+    constexpr int NT_ = NW * 64;  // threads
 
     // ---- load ----
-    for (int e = tid; e < 8 * BB; e += 256) {
+    for (int e = tid; e < 8 * BB; e += NT_) {
         (&sD[0][0])[e] = 0.0;
         (&sG[0][0])[e] = 0.0;
     }
-    for (int e = tid; e < 9 * B * 3; e += 256) (&sR[0][0])[e] = 0.0;
+    for (int e = tid; e < 9 * B * 3; e += NT_) (&sR[0][0])[e] = 0.0;
     if (tid < 2) sZ[tid] = 0.0;
     __syncthreads();
     if (L0) {
         const int row0 = chunk * 8 * B;
-        for (int t = tid; t < 8 * B; t += 256) {
+        for (int t = tid; t < 8 * B; t += NT_) {
             const int row = row0 + t, blk = t / B, r = t - blk * B;
-            if (row < n) {
-                const int sl = row >> 6, ln = row & 63;
-                const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
-                const v2i *__restrict__ cp = reinterpret_cast<const v2i *>(col) + (size_t)(o0 / 2) * 64 + ln;
-                const v2d *__restrict__ vp = reinterpret_cast<const v2d *>(val) + (size_t)(o0 / 2) * 64 + ln;
-                // the row's entries in batches of eight pairs: all loads of a batch are issued before the first
-                // value is scattered (a load per scatter was a memory round trip per pair)
-                for (int q0 = 0; q0 < w / 2; q0 += 8) {
-                    v2i cc[8];
-                    v2d vv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int q = q0 + u < w / 2 ? q0 + u : w / 2 - 1;
-                        cc[u] = __builtin_nontemporal_load(&cp[(size_t)q * 64]);
-                        vv[u] = __builtin_nontemporal_load(&vp[(size_t)q * 64]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (q0 + u >= w / 2) break;
-#pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            const int c = h ? cc[u].y : cc[u].x;
-                            const double v = h ? vv[u].y : vv[u].x;
-                            if (v == 0.0) continue;
-                            const int gc = c - row0;
-                            if (gc < 0) {
-                                if (blk == 0 && gc >= -B) sG[0][(gc + B) * B + r] += v;
-                            } else if (gc < 8 * B) {
-                                const int cb = gc / B, cj = gc - cb * B;
-                                if (cb == blk)
-                                    sD[blk][r * B + cj] += v;
-                                else if (cb == blk + 1)
-                                    sG[blk + 1][r * B + cj] += v;
-                            }
-                        }
-                    }
-                }
-                sD[blk][r * B + r] += diag[row];
-                const double4 bb = rhs[row];
-                sR[blk + 1][r * 3 + 0] = bb.x;
-                sR[blk + 1][r * 3 + 1] = bb.y;
-                sR[blk + 1][r * 3 + 2] = bb.z;
-            } else {
+            if (row < n)
+                bcr_gather_row<B>(row, chunk * 8 + blk, r, sl_off, col, val, diag, rhs, sD[blk],
+                                  blk < 7 ? sG[blk + 1] : nullptr, blk == 0 ? sG[0] : nullptr, sR[blk + 1]);
+            else
                 sD[blk][r * B + r] = 1.0;
-            }
         }
     } else {
+        // blocks below nred come from the level below; the others (a mixed level 1, see bcr_alloc) are blocks of
+        // the level-0 operator that no chunk reduced: block gb is level-0 block 8 nred + (gb - nred). Every block
+        // brings the coupling from its predecessor along (slot i; slot 0: from the separator before the chunk).
         for (int i = 0; i < 8; i++) {
             const int gb = chunk * 8 + i;
-            if (gb < nb) {
-                const bool nxt = gb + 1 < nb;
-                for (int e = tid; e < BB; e += 256) {
+            if (gb < nred) {
+                const bool nxt = gb + 1 < nred;
+                for (int e = tid; e < BB; e += NT_) {
                     sD[i][e] = inD[(size_t)gb * BB + e] + (nxt ? inXD[(size_t)(gb + 1) * BB + e] : 0.0);
-                    if (i < 7 && nxt) sG[i + 1][e] = inXG[(size_t)(gb + 1) * BB + e];
+                    if (gb > 0) sG[i][e] = inXG[(size_t)gb * BB + e];
                 }
-                for (int e = tid; e < B * 3; e += 256)
+                for (int e = tid; e < B * 3; e += NT_)
                     sR[i + 1][e] = inR[(size_t)gb * B * 3 + e] + (nxt ? inXR[(size_t)(gb + 1) * B * 3 + e] : 0.0);
-            } else {
-                for (int e = tid; e < B; e += 256) sD[i][e * B + e] = 1.0;
+            } else if (gb >= nb) {
+                for (int e = tid; e < B; e += NT_) sD[i][e * B + e] = 1.0;
             }
         }
-        if (hasExt)
-            for (int e = tid; e < BB; e += 256) sG[0][e] = inXG[(size_t)chunk * 8 * BB + e];
+        if (chunk * 8 + 8 > nred && nred < nb) {
+            for (int t = tid; t < 8 * B; t += NT_) {
+                const int i = t / B, r = t - i * B, gb = chunk * 8 + i;
+                if (gb >= nred && gb < nb) {
+                    const int lb = 8 * nred + (gb - nred), row = lb * B + r;
+                    if (row < n)
+                        bcr_gather_row<B>(row, lb, r, sl_off, col, val, diag, rhs, sD[i], nullptr,
+                                          gb > 0 ? sG[i] : nullptr, sR[i + 1]);
+                    else
+                        sD[i][r * B + r] = 1.0;
+                }
+            }
+        }
     }
     __syncthreads();
 
     // ---- three rounds of eliminations: (0 2 4 6) (1 5) (3) ----
-    BcrElim<B> E;
-#pragma unroll
-    for (int rnd = 0; rnd < 3; rnd++) {
-        int i = -1, a = -1, c = 7;
-        if (rnd == 0) {
-            i = 2 * wave;
-            a = i - 1;
-            c = i + 1;
-        } else if (rnd == 1) {
-            if (wave < 2) {
-                i = 1 + 4 * wave;
-                a = wave == 0 ? -1 : 3;
-                c = wave == 0 ? 3 : 7;
-            }
-        } else if (wave == 0) {
-            i = 3;
-            a = -1;
-            c = 7;
-        }
-        const bool active = i >= 0 && chunk * 8 + i < nb;
-        const bool hasP = a >= 0 || hasExt;
-        if (active)
-            E.phase1(sD[i], sG[a + 1], hasP, sG[i + 1], sR[i + 1], sD[c], sR[c + 1],
-                     W + ((size_t)chunk * 7 + i) * B * Dm::NC, sZ, lane);
-        __syncthreads();
-        if (active && hasP) E.phase2(sG[a + 1], a >= 0 ? sD[a] : sD[0], a < 0 && rnd == 0, sR[a + 1], lane);
-        __syncthreads();
+    constexpr int WPE0 = NW / 4 < Dm::NT ? NW / 4 : Dm::NT;  // waves per elimination in the first round
+    constexpr int NTPW = (Dm::NT + WPE0 - 1) / WPE0;
+    BcrElim<B, NTPW> E;
+    v4d out[Dm::MT][NTPW];
+#define IRH_BCR_ROUND(RND)                                                                                          \
+    {                                                                                                               \
+        constexpr int NE = 4 >> RND;                                                                                \
+        constexpr int WPE = NW / NE < Dm::NT ? NW / NE : Dm::NT;                                                    \
+        const int e = wave / WPE, part = wave - e * WPE;                                                            \
+        int i = -1, a = -1, c = 7;                                                                                  \
+        if (e < NE) {                                                                                               \
+            if (RND == 0) {                                                                                         \
+                i = 2 * e;                                                                                          \
+                a = i - 1;                                                                                          \
+                c = i + 1;                                                                                          \
+            } else if (RND == 1) {                                                                                  \
+                i = 1 + 4 * e;                                                                                      \
+                a = e == 0 ? -1 : 3;                                                                                \
+                c = e == 0 ? 3 : 7;                                                                                 \
+            } else {                                                                                                \
+                i = 3;                                                                                              \
+            }                                                                                                       \
+        }                                                                                                           \
+        const bool active = i >= 0 && chunk * 8 + i < nb;                                                           \
+        const bool hasP = a >= 0 || hasExt;                                                                         \
+        if (active && part == 0 && !(dbg & 1)) bcr_invert<B>(sD[i], lane);                                                        \
+        __syncthreads();                                                                                            \
+        if (active && !(dbg & 2))                                                                                   \
+            E.template phase1<WPE>(part, sD[i], sG[a + 1], hasP, sG[i + 1], sR[i + 1], sD[c], sR[c + 1],            \
+                                   W + ((size_t)chunk * 7 + i) * B * Dm::NC, sZ, lane);                             \
+        __syncthreads();                                                                                            \
+        if (active && hasP && !(dbg & 4)) E.template phase2_mul<WPE>(part, sG[a + 1], out, lane);                             \
+        if (WPE > 1) __syncthreads();                                                                               \
+        if (active && hasP && !(dbg & 4))                                                                           \
+            E.template phase2_put<WPE>(part, out, sG[a + 1], a >= 0 ? sD[a] : sD[0], a < 0 && RND == 0, sR[a + 1],  \
+                                       lane);                                                                       \
+        __syncthreads();                                                                                            \
     }
+    IRH_BCR_ROUND(0)
+    IRH_BCR_ROUND(1)
+    IRH_BCR_ROUND(2)
+#undef IRH_BCR_ROUND
 
     // ---- store ----
     if (TOP) {
@@ -407,14 +508,14 @@ __global__ __launch_bounds__(256, (B <= 24 ? 2 : 1)) void k_bcr_reduce(
             }
         }
     } else {
-        for (int e = tid; e < BB; e += 256) {
+        for (int e = tid; e < BB; e += NT_) {
             sepD[(size_t)chunk * BB + e] = sD[7][e];
             if (hasExt) {
                 extD[(size_t)chunk * BB + e] = sD[0][e];
                 extG[(size_t)chunk * BB + e] = sG[0][e];
             }
         }
-        for (int e = tid; e < B * 3; e += 256) {
+        for (int e = tid; e < B * 3; e += NT_) {
             sepR[(size_t)chunk * B * 3 + e] = sR[8][e];
             if (hasExt) extR[(size_t)chunk * B * 3 + e] = sR[0][e];
         }
@@ -425,7 +526,7 @@ __global__ __launch_bounds__(256, (B <= 24 ? 2 : 1)) void k_bcr_reduce(
 // W (7 blocks of B x (2B + 3)) is staged in LDS first -- every load of the launch is in flight at once; read row
 // by row behind the three dependent rounds it cost a memory round trip per four rows.
 template <int B, bool L0>
-__global__ __launch_bounds__(256) void k_bcr_back(int nb, int n, const double *__restrict__ W,
+__global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const double *__restrict__ W,
                                                    const double *__restrict__ xc, double *__restrict__ xl,
                                                    double4 *__restrict__ X) {
     typedef BcrDim<B> Dm;
@@ -521,6 +622,18 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int n, const double *_
         }
     } else {
         for (int e = tid; e < 8 * B * 3; e += 256) xl[(size_t)chunk * 8 * B * 3 + e] = (&sX[1][0])[e];
+        // blocks of a mixed level that are level-0 blocks themselves: their solution rows
+        if (chunk * 8 + 8 > nred && nred < nb)
+            for (int t = tid; t < 8 * B; t += 256) {
+                const int i = t / B, r = t - i * B, gb = chunk * 8 + i;
+                if (gb >= nred && gb < nb) {
+                    const int row = (8 * nred + (gb - nred)) * B + r;
+                    if (row < n) {
+                        const double *xs = &sX[1][0] + t * 3;
+                        X[row] = double4{xs[0], xs[1], xs[2], 0.0};
+                    }
+                }
+            }
     }
 }
 
@@ -533,21 +646,41 @@ static void bcr_alloc(Graph &g) {
     BcrState &S = *g.bcr;
     S.B = g.bcr_B;
     const int B = S.B, NC = 2 * B + 3;
-    int nb = (g.levels[0].n + B - 1) / B;
-    for (;;) {
+    const int nb0 = (g.levels[0].n + B - 1) / B;
+    int nch0 = (nb0 + 7) / 8;
+    // The level-0 reduction keeps two workgroups per CU resident (one for B = 32: LDS). A chunk count slightly
+    // above a multiple of that capacity would cost a whole extra round of workgroups for a handful of chunks
+    // (100k views, B = 24: 521 chunks on 512 slots): the chunks beyond the multiple are not reduced at all --
+    // their blocks enter level 1 as they are (a MIXED level 1: k_bcr_reduce's loader), where there is room.
+    int nraw = 0;
+    {
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, g.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        const int cap = ncu * (B <= 24 ? 2 : 1);
+        const int full = nch0 / cap * cap, rem = nch0 - full;
+        if (full > 0 && rem > 0 && rem <= cap / 4 && !getenv("IROTAVG_BCR_NO_MIXED")) {
+            nraw = nb0 - 8 * full;
+            nch0 = full;
+        }
+    }
+    int nb = nb0, nch = nch0;
+    for (int l = 0;; l++) {
         S.lev.emplace_back();
         BcrLevel &L = S.lev.back();
         L.nb = nb;
-        L.nch = (nb + 7) / 8;
+        L.nch = nch;
+        L.nred = (l == 1 && nraw > 0) ? nb - nraw : nb;
         L.W.alloc((size_t)L.nch * 7 * B * NC);
-        if (S.lev.size() > 1) L.x.alloc((size_t)L.nch * 8 * B * 3);
+        if (l > 0) L.x.alloc((size_t)L.nch * 8 * B * 3);
         if (nb <= 8) break;
         L.sepD.alloc((size_t)L.nch * B * B);
         L.extD.alloc((size_t)L.nch * B * B);
         L.extG.alloc((size_t)L.nch * B * B);
         L.sepR.alloc((size_t)L.nch * B * 3);
         L.extR.alloc((size_t)L.nch * B * 3);
-        nb = L.nch;
+        nb = L.nch + (l == 0 ? nraw : 0);
+        nch = (nb + 7) / 8;
     }
     S.xtop.alloc((size_t)B * 3);
 }
@@ -558,23 +691,37 @@ static void bcr_run(Graph &g, int only) {
     Level &L0 = g.levels[0];
     hipStream_t st = g.stream;
     const int nl = (int)S.lev.size();
+    const int dbg = getenv("IROTAVG_BCR_DBG") ? atoi(getenv("IROTAVG_BCR_DBG")) : 0;
     for (int l = 0; l < nl; l++) {
         if (only >= 0 && only != l) continue;
         BcrLevel &L = S.lev[l];
         const BcrLevel *F = l > 0 ? &S.lev[l - 1] : nullptr;
         const bool top = l == nl - 1;
 #define IRH_BCR_ARGS                                                                                             \
-    L.nb, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p, L0.b.p, F ? F->sepD.p : nullptr,                      \
+    L.nb, L.nred, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p, L0.b.p, F ? F->sepD.p : nullptr,                      \
         F ? F->sepR.p : nullptr, F ? F->extD.p : nullptr, F ? F->extR.p : nullptr, F ? F->extG.p : nullptr, L.W.p, \
-        L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p
-        if (l == 0 && top)
-            hipLaunchKernelGGL((k_bcr_reduce<B, true, true>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);
-        else if (l == 0)
-            hipLaunchKernelGGL((k_bcr_reduce<B, true, false>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);
-        else if (top)
-            hipLaunchKernelGGL((k_bcr_reduce<B, false, true>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);
-        else
-            hipLaunchKernelGGL((k_bcr_reduce<B, false, false>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);
+        L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p, dbg
+        // eight waves per chunk when every chunk has a CU to itself (see k_bcr_reduce)
+        const bool wide = L.nch <= 256 && !getenv("IROTAVG_BCR_NARROW");
+#define IRH_BCR_LAUNCH(L0_, TOP_)                                                                                   \
+    if constexpr (B <= 24) {                                                                                        \
+        if (wide)                                                                                                   \
+            hipLaunchKernelGGL((k_bcr_reduce<B, L0_, TOP_, 8>), dim3(L.nch), dim3(512), 0, st, IRH_BCR_ARGS);       \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_bcr_reduce<B, L0_, TOP_, 4>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);       \
+    } else {                                                                                                        \
+        hipLaunchKernelGGL((k_bcr_reduce<B, L0_, TOP_, 4>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);           \
+    }
+        if (l == 0 && top) {
+            IRH_BCR_LAUNCH(true, true)
+        } else if (l == 0) {
+            IRH_BCR_LAUNCH(true, false)
+        } else if (top) {
+            IRH_BCR_LAUNCH(false, true)
+        } else {
+            IRH_BCR_LAUNCH(false, false)
+        }
+#undef IRH_BCR_LAUNCH
 #undef IRH_BCR_ARGS
     }
     for (int l = nl - 1; l >= 0; l--) {
@@ -582,11 +729,11 @@ static void bcr_run(Graph &g, int only) {
         BcrLevel &L = S.lev[l];
         const double *xc = l == nl - 1 ? S.xtop.p : S.lev[l + 1].x.p;
         if (l == 0)
-            hipLaunchKernelGGL((k_bcr_back<B, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L0.n, L.W.p, xc,
+            hipLaunchKernelGGL((k_bcr_back<B, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
                                (double *)nullptr, g.X.p + g.ng);
         else
-            hipLaunchKernelGGL((k_bcr_back<B, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L0.n, L.W.p, xc, L.x.p,
-                               (double4 *)nullptr);
+            hipLaunchKernelGGL((k_bcr_back<B, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
+                               L.x.p, g.X.p + g.ng);
     }
 }
 
