@@ -40,7 +40,8 @@ def test_option_and_stats_struct_sizes_match_header():
     o = capi.default_options()
     assert (o.pcg_rtol, o.pcg_max_iters, o.mg_agg, o.mg_dense_max, o.device) == (1e-10, 2000, 0, 0, -1)
     assert o.mg_omega == pytest.approx(0.7) and o.mg_kc == 0.0
-    assert C.sizeof(capi.Options) == 80 and C.sizeof(capi.RotAvgInfo) == 40
+    assert o.band_direct == 0                    # a banded operator above 2048 free views is solved directly
+    assert C.sizeof(capi.Options) == 88 and C.sizeof(capi.RotAvgInfo) == 40
 
 
 def test_init_mst_matches_oracle_and_reports_non_spanning(fixture_graph):

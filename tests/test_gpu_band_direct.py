@@ -1,0 +1,278 @@
+"""GPU parity tests of the banded direct solver (irotavg_amd/csrc/bcr.hip): the HIP path through the C ABI against the
+CPU oracle where the linear systems of `irls` (ral/l1_irls.cpp:536-556, SuiteSparseQR in the reference) and of
+`l1decode_pd` (:131-184, UMFPACK) are solved by block cyclic reduction instead of the PCG.
+
+A graph takes this path when every edge between two free views spans at most 32 views (a sequence without loop
+closures): block sizes 8 / 16 / 24 / 32 by the half-bandwidth. Tolerances: a direct fp64 solve -- linear-solve outputs
+1e-9 relative, final rotations 1e-9 rad with IDENTICAL outer iteration counts, weights 1e-7.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from irotavg_amd import capi, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+SIG = 5 * np.pi / 180
+
+
+def mst_init(G, n, f=1):
+    Q = np.zeros((n, 4)); Q[:, 3] = 1; Q[:f] = G["Qgt"][:f]
+    rc, Qm = O.init_mst(Q, G["QQ"], G["I"], f)
+    assert rc == 0
+    return Qm
+
+
+def direct_stats(st, block):
+    assert st["band_block"] == block, st
+    assert st["direct_solves"] > 0 and st["pcg_solves"] == 0, st
+
+
+# band 5 -> blocks of 8, 16 -> 16, 22 -> 24, 31 -> 32; 2510 / 2999 rows: neither a multiple of the block size
+@pytest.mark.parametrize("n,m,block", [(3000, 12000, 8), (3000, 45000, 16), (3000, 63000, 24), (2511, 75000, 32)])
+def test_direct_solver_matches_oracle(n, m, block):
+    S = synth.make_graph(n, m, 0.0, seed=3, p_band_out=0.02)
+    Qm = mst_init(S, n)
+    rng = np.random.default_rng(0)
+    w = rng.uniform(0.1, 5.0, size=len(S["I"]))
+    w[rng.choice(len(w), len(w) // 40, replace=False)] *= 1e-4   # weights over five decades
+    ro = O.log_map(O.delta_rel(S["I"], S["QQ"], Qm))[:, :3]
+    rc, Xo = O.ls_solve(n, 1, S["I"], w, ro)
+    assert rc == 0
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        G.set_rotations(Qm)
+        G.edge_residual()
+        G.set_weights(w)
+        X = G.ls_solve()
+        direct_stats(G.stats(), block)
+        assert np.abs(X - Xo).max() < 1e-9 * np.abs(Xo).max()
+        G.set_rotations(Qm)
+        a = G.l1ra(2, 1e-3)
+        Qa = G.get_rotations()
+        b = G.irls(4, SIG, 50, 1e-3)
+        Qb = G.get_rotations()
+        wb = G.get_weights()
+        direct_stats(G.stats(), block)
+    ra = O.l1ra(S["QQ"], S["I"], Qm, 1, 2, 1e-3)
+    rb = O.irls(S["QQ"], S["I"], ra["Q"], 1, 4, SIG, 50, 1e-3)
+    assert (a["iters"], b["iters"]) == (ra["iters"], rb["iters"])
+    np.testing.assert_allclose(a["scores"], ra["scores"], rtol=1e-8)
+    np.testing.assert_allclose(b["scores"], rb["scores"], rtol=1e-7)
+    assert synth.angular_distance(Qa, ra["Q"]).max() < 1e-9
+    assert synth.angular_distance(Qb, rb["Q"]).max() < 1e-9
+    np.testing.assert_allclose(wb, rb["weights"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("cost", list(range(14)))
+def test_every_cost_on_the_direct_path(cost):
+    n, m = 2600, 39000
+    S = synth.make_graph(n, m, 0.0, seed=8, p_band_out=0.03)
+    Qm = mst_init(S, n)
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        G.set_rotations(Qm)
+        r = G.irls(cost, SIG, 15, 1e-3)
+        Q = G.get_rotations()
+        w = G.get_weights()
+        direct_stats(G.stats(), 16)
+    ro = O.irls(S["QQ"], S["I"], Qm, 1, cost, SIG, 15, 1e-3)
+    assert r["iters"] == ro["iters"]
+    np.testing.assert_allclose(r["scores"], ro["scores"], rtol=1e-7)
+    assert synth.angular_distance(Q, ro["Q"]).max() < 1e-9
+    np.testing.assert_allclose(w, ro["weights"], rtol=1e-6, atol=1e-12)
+
+
+def test_l1decode_pd_on_the_direct_path():
+    n, m = 3000, 45000
+    S = synth.make_graph(n, m, 0.0, seed=2)
+    Qm = mst_init(S, n)
+    ro = O.log_map(O.delta_rel(S["I"], S["QQ"], Qm))[:, :3]
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        for c in range(3):
+            x, stuck = G.l1decode_pd(np.ascontiguousarray(ro[:, c]), 2)
+            rc, xo, so = O.l1decode_pd(n, 1, S["I"], ro[:, c], 2)
+            assert rc == 0 and stuck == so
+            assert np.abs(x - xo).max() < 1e-9 * max(np.abs(xo).max(), 1e-300)
+        direct_stats(G.stats(), 16)
+
+
+@pytest.mark.parametrize("n", [9, 60, 64, 65, 190, 520, 4100])
+def test_sizes_around_the_chunk_boundaries(n):
+    """One block, one chunk (the top kernel at level 0), one chunk + one block, two and three levels; band 3 -> blocks
+    of 8 rows, chunks of 64."""
+    S = synth.make_graph(n, 3 * n - 6, 0.0, seed=n)
+    Qm = mst_init(S, n)
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        G.set_rotations(Qm)
+        a = G.l1ra(3, 1e-3)
+        b = G.irls(4, SIG, 30, 1e-4)
+        Q = G.get_rotations()
+        direct_stats(G.stats(), 8)
+    ra = O.l1ra(S["QQ"], S["I"], Qm, 1, 3, 1e-3)
+    rb = O.irls(S["QQ"], S["I"], ra["Q"], 1, 4, SIG, 30, 1e-4)
+    assert (a["iters"], b["iters"]) == (ra["iters"], rb["iters"])
+    assert synth.angular_distance(Q, rb["Q"]).max() < 1e-9
+
+
+def test_mixed_level_one():
+    """36000 views in blocks of 8 = 563 chunks on 512 resident slots: the 51 surplus chunks are not reduced at level
+    0 -- their 404 blocks enter level 1 next to the 512 separators (bcr_alloc)."""
+    n, m = 36000, 4 * 36000 - 10
+    S = synth.make_graph(n, m, 0.0, seed=12, p_band_out=0.01)
+    Qm = mst_init(S, n)
+    res = []
+    for env in (None, "1"):
+        import os
+        if env:
+            os.environ["IROTAVG_BCR_NO_MIXED"] = env
+        try:
+            with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+                G.set_rotations(Qm)
+                b = G.irls(4, SIG, 30, 1e-3)
+                res.append((b["iters"], G.get_rotations(), G.get_weights()))
+                direct_stats(G.stats(), 8)
+        finally:
+            os.environ.pop("IROTAVG_BCR_NO_MIXED", None)
+    rb = O.irls(S["QQ"], S["I"], Qm, 1, 4, SIG, 30, 1e-3)
+    for it, Q, w in res:
+        assert it == rb["iters"]
+        assert synth.angular_distance(Q, rb["Q"]).max() < 1e-9
+        np.testing.assert_allclose(w, rb["weights"], rtol=1e-7)
+
+
+def test_fixed_views_flipped_duplicate_and_self_loop_edges():
+    """f = 4 fixed views (rows = views - f; edges to fixed views only reach the diagonal and the right-hand side),
+    30 % of the edges given as (j, i) -- some then have their SECOND endpoint fixed, which make_A drops
+    (ral/l1_irls.cpp:770-771) and make_AtA keeps (:825-835) --, duplicate edges, a self loop."""
+    n, f = 1500, 4
+    S = synth.make_graph(n, 15000, 0.0, seed=13, p_band_out=0.02)
+    rng = np.random.default_rng(5)
+    I, QQ = S["I"].copy(), S["QQ"].copy()
+    flip = rng.random(len(I)) < 0.3
+    I[flip] = I[flip][:, ::-1]
+    QQ[flip] = synth.qconj(QQ[flip])
+    I = np.concatenate([I, I[:80], [[700, 700]]]).astype(np.int32)
+    QQ = np.concatenate([QQ, QQ[:80], [[0, 0, 0, 1.0]]])
+    assert ((I[:, 1] < f) & (I[:, 0] >= f)).sum() > 0
+    Q = np.zeros((n, 4)); Q[:, 3] = 1; Q[:f] = S["Qgt"][:f]
+    rc, Qm = O.init_mst(Q, QQ, I, f)
+    assert rc == 0
+    with capi.Graph(I, QQ, n, f, band_direct=1) as G:
+        G.set_rotations(Qm)
+        a = G.l1ra(3, 1e-3)
+        b = G.irls(4, SIG, 50, 1e-3)
+        Qg = G.get_rotations()
+        w = G.get_weights()
+        direct_stats(G.stats(), 16)
+    ra = O.l1ra(QQ, I, Qm, f, 3, 1e-3)
+    rb = O.irls(QQ, I, ra["Q"], f, 4, SIG, 50, 1e-3)
+    assert (a["iters"], b["iters"]) == (ra["iters"], rb["iters"])
+    assert synth.angular_distance(Qg, rb["Q"]).max() < 1e-9
+    np.testing.assert_allclose(w, rb["weights"], rtol=1e-7)
+    np.testing.assert_array_equal(Qg[:f], Qm[:f])
+
+
+def test_isolated_views_are_dead_pivots():
+    """A free view without any edge has an empty row: its pivot is dead, its unknown solves to 0 and the view stays
+    where it was -- what SPQR's rank detection and the oracle's dead pivot do."""
+    n = 900
+    S = synth.make_graph(n, 9000, 0.0, seed=21)
+    lonely = [17, 400, 401, 899]
+    keep = ~np.isin(S["I"], lonely).any(axis=1)
+    I, QQ = S["I"][keep], S["QQ"][keep]
+    rng = np.random.default_rng(1)
+    Q0 = synth.qmul(synth.qexp(rng.normal(scale=0.03, size=(n, 3))), S["Qgt"]); Q0[0] = S["Qgt"][0]
+    with capi.Graph(I, QQ, n, 1, band_direct=1) as G:
+        G.set_rotations(Q0)
+        r = G.irls(4, SIG, 30, 1e-6)
+        Q = G.get_rotations()
+        w = G.get_weights()
+        direct_stats(G.stats(), 16)
+    ro = O.irls(QQ, I, Q0, 1, 4, SIG, 30, 1e-6)
+    assert r["iters"] == ro["iters"]
+    assert synth.angular_distance(Q, ro["Q"]).max() < 1e-9
+    np.testing.assert_allclose(w, ro["weights"], rtol=1e-7)
+    np.testing.assert_array_equal(Q[lonely], Q0[lonely])
+
+
+def test_direct_path_is_bitwise_reproducible():
+    S = synth.make_graph(5000, 100000, 0.0, seed=4, p_band_out=0.02)
+    Qm = mst_init(S, 5000)
+    outs = []
+    for _ in range(2):
+        with capi.Graph(S["I"], S["QQ"], 5000, 1) as G:
+            G.set_rotations(Qm)
+            G.l1ra(1, 1e-3)
+            G.irls(1, SIG, 10, 1e-3)
+            outs.append((G.get_rotations(), G.get_weights()))
+            direct_stats(G.stats(), 24)   # chosen without the option: more than 2048 free views
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_option_and_environment_switch_the_path(monkeypatch):
+    S = synth.make_graph(3000, 30000, 0.0, seed=5)
+    Qm = mst_init(S, 3000)
+    out = {}
+    for tag, kw, env in [("direct", dict(), None), ("never", dict(band_direct=-1), None), ("env", dict(), "-1")]:
+        if env:
+            monkeypatch.setenv("IROTAVG_BAND_DIRECT", env)
+        else:
+            monkeypatch.delenv("IROTAVG_BAND_DIRECT", raising=False)
+        with capi.Graph(S["I"], S["QQ"], 3000, 1, **kw) as G:
+            G.set_rotations(Qm)
+            r = G.irls(4, SIG, 50, 1e-3)
+            out[tag] = (r["iters"], G.get_rotations(), G.stats())
+    assert out["direct"][2]["band_block"] == 16 and out["direct"][2]["pcg_solves"] == 0
+    for tag in ("never", "env"):
+        assert out[tag][2]["band_block"] == 0 and out[tag][2]["direct_solves"] == 0 and out[tag][2]["pcg_solves"] > 0
+        assert out[tag][0] == out["direct"][0]
+        assert synth.angular_distance(out[tag][1], out["direct"][1]).max() < 1e-8
+    # a loop closure puts the graph back on the iterative path
+    I = np.concatenate([S["I"], [[10, 2900]]]).astype(np.int32)
+    QQ = np.concatenate([S["QQ"], synth.qmul(S["Qgt"][2900:2901], synth.qconj(S["Qgt"][10:11]))])
+    monkeypatch.delenv("IROTAVG_BAND_DIRECT", raising=False)
+    with capi.Graph(I, QQ, 3000, 1, band_direct=1) as G:
+        st = G.stats()
+        assert st["band"] == 2890 and st["band_block"] == 0
+
+
+def test_one_shot_calls_take_the_direct_path_and_match_the_oracle():
+    """irotavg_l1ra / irotavg_irls with host pointers (the reference's signatures, ral/l1_irls.hpp:100-107)."""
+    from irotavg_amd import ral
+    n, m = 5000, 60000
+    S = synth.make_graph(n, m, 0.0, seed=31)
+    Qm = mst_init(S, n)
+    Q = capi.fmat(Qm)
+    wts = np.zeros(len(S["I"]))
+    it1, _ = ral.l1ra(S["QQ"], S["I"], None, Q, 1, 2, 1e-3)
+    it2, _ = ral.irls(S["QQ"], S["I"], None, 4, SIG, Q, 1, 50, 1e-3, wts)
+    ra = O.l1ra(S["QQ"], S["I"], Qm, 1, 2, 1e-3)
+    rb = O.irls(S["QQ"], S["I"], ra["Q"], 1, 4, SIG, 50, 1e-3)
+    assert (it1, it2) == (ra["iters"], rb["iters"])
+    assert synth.angular_distance(Q, rb["Q"]).max() < 1e-9
+    np.testing.assert_allclose(wts, rb["weights"], rtol=1e-7)
+
+
+def test_time_kernel_reports_every_launch_of_a_direct_solve():
+    S = synth.make_graph(20000, 300000, 0.0, seed=1)
+    Qm = mst_init(S, 20000)
+    ms = C.c_double(0)
+    with capi.Graph(S["I"], S["QQ"], 20000, 1) as G:
+        G.set_rotations(Qm)
+        G.edge_residual()
+        X = G.ls_solve()
+        lib = capi.lib()
+        assert lib.irotavg_graph_time_kernel(G._h, 19, 3, C.byref(ms)) == 0 and ms.value > 0
+        total, levels = 0.0, 0
+        for which in list(range(20, 30)) + list(range(40, 50)):
+            if lib.irotavg_graph_time_kernel(G._h, which, 3, C.byref(ms)) == 0:
+                total += ms.value
+                levels += which < 40
+        assert levels >= 3 and total > 0
+        # the timed launches do not disturb the handle: the same solve again
+        G.edge_residual()
+        np.testing.assert_array_equal(G.ls_solve(), X)
+    with capi.Graph(S["I"], S["QQ"], 20000, 1, band_direct=-1) as G:
+        assert capi.lib().irotavg_graph_time_kernel(G._h, 19, 1, C.byref(ms)) == capi.ERR_BAD_ARG

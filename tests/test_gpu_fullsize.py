@@ -14,6 +14,21 @@ pytestmark = pytest.mark.gpu
 SIG = 5 * np.pi / 180
 
 
+@pytest.fixture(autouse=True)
+def iterative_paths(monkeypatch, request):
+    """This module is about the multigrid-PCG paths. Band graphs above 2048 views are solved directly by default
+    (bcr.hip, tests/test_gpu_band_direct.py): switched off here, except where a test asks for both solvers."""
+    if "solver" in getattr(request, "fixturenames", ()) and request.getfixturevalue("solver") == "direct":
+        monkeypatch.delenv("IROTAVG_BAND_DIRECT", raising=False)
+    else:
+        monkeypatch.setenv("IROTAVG_BAND_DIRECT", "-1")
+
+
+@pytest.fixture(params=["direct", "pcg"])
+def solver(request):
+    return request.param
+
+
 def mst(G, n):
     Q = np.zeros((n, 4)); Q[:, 3] = 1; Q[0] = G["Qgt"][0]
     ral.init_mst(Q, G["QQ"], G["I"], 1)
@@ -22,7 +37,9 @@ def mst(G, n):
 
 @pytest.mark.parametrize("n,m,p", [(10000, 150000, 0.0), (10000, 150000, 0.02),
                                    (100000, 2000000, 0.0), (100000, 2000000, 0.02)])
-def test_normal_equation_residual_and_k1(n, m, p):
+def test_normal_equation_residual_and_k1(n, m, p, solver):
+    if p > 0 and solver == "direct":
+        pytest.skip("loop closures: the operator is not banded, the handle has one solver")
     S = synth.make_graph(n, m, p, seed=0)
     Q0 = mst(S, n)
     w = np.random.default_rng(3).uniform(0.2, 3.0, size=m)
@@ -61,9 +78,10 @@ def test_noise_free_exact_recovery_100k(p):
     np.testing.assert_array_equal(Q[0], S["Qgt"][0])
 
 
-def test_band_graph_100k_matches_oracle_irls():
+def test_band_graph_100k_matches_oracle_irls(solver):
     """Band-only 100k/2M: the CPU factorisation is banded and cheap, so the full IRLS run is
-    compared with the oracle: same iteration count, rotations within 1e-6 rad (north star: 1e-4)."""
+    compared with the oracle: same iteration count, rotations within 1e-6 rad (north star: 1e-4).
+    Both solvers of the handle: the banded direct one (the default at this size) and the PCG."""
     n, m = 100000, 2000000
     S = synth.make_graph(n, m, 0.0, seed=0)
     Q0 = mst(S, n)
@@ -72,6 +90,8 @@ def test_band_graph_100k_matches_oracle_irls():
         r = G.irls(4, SIG, 100, 1e-3)
         Q = G.get_rotations()
         w = G.get_weights()
+        st = G.stats()
+        assert (st["direct_solves"] > 0) == (solver == "direct") and (st["pcg_solves"] > 0) == (solver == "pcg")
     ro = O.irls(S["QQ"], S["I"], Q0, 1, 4, SIG, 100, 1e-3)
     assert r["iters"] == ro["iters"]
     np.testing.assert_allclose(r["scores"], ro["scores"], rtol=1e-5)

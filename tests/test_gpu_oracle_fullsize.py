@@ -61,14 +61,16 @@ def test_loop_closure_graph_matches_oracle_irls(n, m):
     assert np.median(w[S["is_outlier"]]) < 0.02 * np.median(w)
 
 
-@pytest.mark.parametrize("n,m,p_loop,f", [(100000, 2000000, 0.0, 1), (20000, 300000, 0.02, 1),
-                                          (131000, 655000, 0.0, 2)])
-def test_l1ra_then_irls_matches_oracle_at_size(n, m, p_loop, f):
+@pytest.mark.parametrize("n,m,p_loop,f,band_direct", [(100000, 2000000, 0.0, 1, 0), (100000, 2000000, 0.0, 1, -1),
+                                                      (20000, 300000, 0.02, 1, 0), (131000, 655000, 0.0, 2, 0),
+                                                      (131000, 655000, 0.0, 2, -1)])
+def test_l1ra_then_irls_matches_oracle_at_size(n, m, p_loop, f, band_direct):
     """`l1ra(2)` then `irls` where `also_l1ra_then_irls` is quoted (100k/2M band), on a 20k graph with
     loop closures, and at 131k views, the largest graph on the two-launch iteration with the BANDED
-    coarse inverse (its only checks were HIP against HIP)."""
+    coarse inverse (its only checks were HIP against HIP). The band graphs with both solvers of the handle:
+    the banded direct solver (band_direct 0: the default at these sizes) and the PCG (-1)."""
     S, Q0 = problem(n, m, p_loop, f)
-    with capi.Graph(S["I"], S["QQ"], n, f) as G:
+    with capi.Graph(S["I"], S["QQ"], n, f, band_direct=band_direct) as G:
         G.set_rotations(Q0)
         a = G.l1ra(2, 1e-3)
         Qa = G.get_rotations()
@@ -83,6 +85,8 @@ def test_l1ra_then_irls_matches_oracle_at_size(n, m, p_loop, f):
     rb = O.irls(S["QQ"], S["I"], ra["Q"], f, 4, SIG, 100, 1e-3)
     compare_irls(b, Qb, w, rb)
     np.testing.assert_array_equal(Qb[:f], Q0[:f])
+    assert (st["direct_solves"] > 0) == (p_loop == 0.0 and band_direct == 0)
+    assert (st["pcg_solves"] > 0) == (p_loop > 0.0 or band_direct == -1)
     if n == 131000:
         assert st["levels"] == 3
 
