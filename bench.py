@@ -55,9 +55,48 @@ def kernel_rooflines(G, S, st, sharded=False):
     }
     which = {"edge_residual": 1, "update_weights": 2, "assemble": 3, "spmv": 4}
     out = {}
+    di = G.direct_info() if not sharded else dict(block=0, levels=[])
+    if di["block"]:
+        # the handle's systems are solved by the banded direct solver (bcr.hip): its launches instead of the PCG's
+        del which["spmv"]
+        alg["assemble"] = m * (8 + 8 + 24) + nu * (8 + 24) + 8 * nnz0   # level 0 only: same formula, no coarse level
     for name, w in which.items():
         ms = G.time_kernel(w, 50)
         out[name] = dict(ms=ms, bytes=alg[name], gbs=alg[name] / (ms * 1e-3) / 1e9)
+    if di["block"]:
+        B = di["block"]
+        NC = 2 * B + 3
+        lev = di["levels"]
+        tot_ms, tot_by, tot_fl = 0.0, 0, 0
+        for l, L in enumerate(lev):
+            top = l == len(lev) - 1
+            elim = sum(min(7, max(0, L["blocks"] - 8 * c)) for c in range(L["chunks"]))   # blocks eliminated
+            wbytes = 8 * elim * B * NC
+            sep = 0 if top else 8 * L["chunks"] * (3 * B * B + 6 * B)
+            if l == 0:
+                rd = nnz0 * (8 + 4) + 4 * (nu // 64 + 2) + nu * (8 + 32)    # SELL entries, slice offsets, diagonal, rhs
+            else:
+                P = lev[l - 1]
+                rd = 8 * P["chunks"] * (3 * B * B + 6 * B)
+                if L["reduced"] < L["blocks"]:   # mixed level 1: the level-0 rows no chunk reduced
+                    raw = (L["blocks"] - L["reduced"]) * B
+                    rd += int(nnz0 * (8 + 4) * raw / max(nu, 1)) + raw * (8 + 32)
+            # flops issued on useful entries: D^-1 (2 B^3), W = D^-1 [P' Q R], P W, Q' W_QR
+            fl = elim * (2 * B ** 3 + 2 * B * B * NC * 2 + 2 * B * B * (B + 3))
+            ms = G.time_kernel(20 + l, 50)
+            out["bcr_reduce_l%d" % l] = dict(ms=ms, bytes=rd + wbytes + sep, gbs=(rd + wbytes + sep) / (ms * 1e-3) / 1e9,
+                                             flops=fl, tflops=fl / (ms * 1e-3) / 1e12, workgroups=L["chunks"])
+            msb = G.time_kernel(40 + l, 50)
+            bb = wbytes + 8 * (L["chunks"] * 8 * B * 3) + (32 * nu if l == 0 else 0)
+            out["bcr_back_l%d" % l] = dict(ms=msb, bytes=bb, gbs=bb / (msb * 1e-3) / 1e9, workgroups=L["chunks"])
+            tot_ms += ms + msb
+            tot_by += rd + wbytes + sep + bb
+            tot_fl += fl
+        ms = G.time_kernel(19, 50)
+        out["bcr_solve"] = dict(ms=ms, bytes=tot_by, gbs=tot_by / (ms * 1e-3) / 1e9, flops=tot_fl,
+                                tflops=tot_fl / (ms * 1e-3) / 1e12, launches=2 * len(lev), sum_of_launches_ms=tot_ms,
+                                block=B, levels=lev)
+        return out
     try:  # band-only graphs on one GPU run the p-update fused into the SpMV (k_pspmv_dot)
         if sharded:   # the sharded PCG exchanges p between its p-update and its SpMV: unfused kernels
             raise capi.IrotavgError(capi.ERR_BAD_ARG, "sharded")
@@ -331,21 +370,30 @@ def main():
                                    "sigma_n=0.01 rad, 5%% outliers among loop edges, seed %d; "
                                    "f=1, init_mst start, Geman-McClure sigma=5deg, change_th=1e-3, "
                                    "max_iters=100" % (S["n"], S["m"], args.p_loop, args.seed),
+                       "linear_solver": ("banded direct solver (block cyclic reduction, blocks of %d; band %d)" % (
+                                             st["band_block"], st["band"]) if st.get("direct_solves", 0) > 0 and dstats is None
+                                         else "multigrid-preconditioned CG"),
+                       "direct_solves": st.get("direct_solves", 0) if dstats is None else 0,
                        "pcg_rtol": args.rtol, "pcg_iters_per_solve": st["pcg_iters"] / max(st["pcg_solves"], 1),
                        "mg_level_rows": st["level_rows"] if dstats is None else dstats["level_rows"],
                        "parallelism": "1 GPU" if world == 1 else
                        "views sharded in %d contiguous ranges, 1 shard/GPU, %s halo + all-reduce" % (world, wire)},
             "final_scores": [float(x) for x in res["scores"]],
             "timing_note": "steady state: %d untimed ramp-up solves precede the --warmup solves (a fresh box starts at "
-                           "idle clocks; the first solves of a process run ~8 %% slower), and every step repeats the "
-                           "identical solve, so the predictive PCG poll schedule and the cached coarse inverse are "
-                           "warm -- a best case, not a first-call figure (that is also_one_shot_host_buffers)" % args.ramp,
+                           "idle clocks; the first solves of a process run ~8 %% slower); every step repeats the "
+                           "identical solve (on the PCG path the predictive poll schedule and the cached coarse inverse "
+                           "are then warm; the direct solver keeps nothing between solves) -- not a first-call figure "
+                           "(that is also_one_shot_host_buffers)" % args.ramp,
         }
         if dstats is not None:
             line["config"]["dist"] = dinfo
         kr = kernel_rooflines(G, S, st, sharded=dstats is not None)
-        dom = "cg_apply" if "cg_apply" in kr else ("pspmv" if "pspmv" in kr else "spmv")
-        dname = {"spmv": "k_spmv_dot (level-0 SELL-64 SpMV + fused dot, dominant PCG kernel)",
+        dom = "bcr_reduce_l0" if "bcr_reduce_l0" in kr else \
+            ("cg_apply" if "cg_apply" in kr else ("pspmv" if "pspmv" in kr else "spmv"))
+        dname = {"bcr_reduce_l0": "k_bcr_reduce, level 0 (banded direct solver: blocks gathered from the SELL-64 operator, "
+                                  "7 of 8 blocks per chunk eliminated on the matrix cores, W written for the way back; the "
+                                  "longest launch of a solve)",
+                 "spmv": "k_spmv_dot (level-0 SELL-64 SpMV + fused dot, dominant PCG kernel)",
                  "pspmv": "k_pspmv_dot (PCG p-update fused into the level-0 SELL-64 SpMV + dot, dominant PCG kernel)",
                  "cg_apply": "k_cg_apply (u = M^-1 r incl. the tile's slice of the dense coarse solve and the level-1 "
                              "up-sweep, then the level-0 SELL-64 SpMV w = L u + dots; dominant PCG kernel)"}[dom]
@@ -353,12 +401,33 @@ def main():
                             "bound": "hbm", "achieved": kr[dom]["gbs"], "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": kr[dom]["gbs"] / HBM_PEAK_GBS,
                             "traffic": pmc_traffic({"pspmv": "k_pspmv_dot", "spmv": "k_spmv_dot",
-                                                    "cg_apply": "k_cg_apply"}[dom], line["config"]["workload"]),
+                                                    "cg_apply": "k_cg_apply", "bcr_reduce_l0": "k_bcr_reduce_l0"}[dom],
+                                                   line["config"]["workload"]),
                             "ms_per_launch": kr[dom]["ms"], "algorithmic_bytes": kr[dom]["bytes"]}
-        kname = {"pspmv": "k_pspmv_dot", "spmv": "k_spmv_dot", "cg_apply": "k_cg_apply"}[dom]
+        kname = {"pspmv": "k_pspmv_dot", "spmv": "k_spmv_dot", "cg_apply": "k_cg_apply",
+                 "bcr_reduce_l0": "k_bcr_reduce_l0"}[dom]
         insitu = in_situ_ms(kname, line["config"]["workload"])
         line["roofline"]["ms_per_launch_in_situ"] = insitu
         line["roofline"]["frac_in_situ"] = (kr[dom]["bytes"] / (insitu * 1e-3) / 1e9 / HBM_PEAK_GBS) if insitu else None
+        if dom == "bcr_reduce_l0":
+            FP64_PEAK_TF = 78.6   # AMD's MI355X data sheet (fp64 vector = matrix); the guide lists no fp64 figure
+            line["roofline"]["note"] = (
+                "a direct solve: its ~14 dependent block eliminations (Gauss-Jordan sweep of a %d x %d block + five "
+                "products on the matrix cores each) set the time, not the bytes -- see roofline_direct_solve for both "
+                "ceilings of the whole solve" % (kr["bcr_solve"]["block"], kr["bcr_solve"]["block"]))
+            line["roofline"]["mfma"] = {"bound": "mfma", "achieved": kr[dom]["tflops"], "peak": FP64_PEAK_TF,
+                                        "unit": "TFLOP/s", "frac": kr[dom]["tflops"] / FP64_PEAK_TF,
+                                        "flops_per_launch": kr[dom]["flops"]}
+            bs = kr["bcr_solve"]
+            line["roofline_direct_solve"] = {
+                "kernel": "all %d launches of one direct solve (k_bcr_reduce x %d, k_bcr_back x %d)" % (
+                    bs["launches"], bs["launches"] // 2, bs["launches"] // 2),
+                "bound": "hbm", "algorithmic_bytes": bs["bytes"], "ms_per_solve": bs["ms"],
+                "achieved": bs["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bs["gbs"] / HBM_PEAK_GBS,
+                "mfma": {"achieved": bs["tflops"], "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": bs["tflops"] / FP64_PEAK_TF, "flops": bs["flops"]},
+                "block": bs["block"], "levels": bs["levels"],
+                "bytes_of_the_pcg_it_replaces": None}
         if "cg_apply" in kr and "cg_update" in kr:
             # the whole PCG iteration (both launches) against SURVEY.md 8(d)'s own K4 + K5 bytes: the dense inverse
             # every tile slice re-reads and the coarse vectors are this design's cost, not algorithmic traffic
@@ -383,13 +452,13 @@ def main():
             "ms_per_launch": kr["edge_residual"]["ms"], "algorithmic_bytes": kr["edge_residual"]["bytes"]}
         ta = [pmc_traffic(k, line["config"]["workload"]) for k in ("k_assemble0w", "k_coarse_level")]
         line["roofline_assembly"] = {
-            "kernel": "K3: k_assemble0w (level 0 + level 1 from the LDS-staged run of the edge list) + "
-                      "k_coarse_level (level 2); the kernel round 1 left furthest below its roofline (0.096)",
+            "kernel": "K3: k_assemble0w (level 0 from the LDS-staged run of the edge list; on the PCG path also level 1 "
+                      "and k_coarse_level for level 2)",
             "bound": "hbm", "achieved": kr["assemble"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": kr["assemble"]["gbs"] / HBM_PEAK_GBS,
             "traffic": (ta[0] + (ta[1] or 0.0)) if ta[0] is not None else None,
             "ms_per_launch": kr["assemble"]["ms"], "algorithmic_bytes": kr["assemble"]["bytes"]}
-        line["kernels"] = {k: {kk: (float(vv) if not isinstance(vv, int) else vv) for kk, vv in v.items()}
+        line["kernels"] = {k: {kk: (vv if isinstance(vv, (int, list, dict, str)) else float(vv)) for kk, vv in v.items()}
                            for k, v in kr.items()}
         if not args.no_extra and world == 1 and args.p_loop == 0.0 and args.views == 100000:
             # the other topology SURVEY.md 8(d) asks for: 2 % random loop-closure edges
@@ -437,10 +506,34 @@ def main():
                 s4 = G4.stats()
             line["also_band_outliers"] = {"value": S4["m"] * r4["iters"] * reps / d4, "unit": "edge-updates/s",
                                           "iters_to_converge": r4["iters"], "ms_per_step": 1e3 * d4 / reps,
+                                          "direct_solves_per_solve_call": s4.get("direct_solves", 0) / reps,
                                           "pcg_iters_per_solve": s4["pcg_iters"] / max(s4["pcg_solves"], 1),
                                           "dense_inversions_per_solve_call": s4["dense_inversions"] / reps,
                                           "note": "p_loop=0, 2 % of ALL edges off by N(0, 0.3^2) rad, init_mst start"}
-        if not args.no_extra and world == 1 and args.rtol == 1e-10:
+        if not args.no_extra and world == 1 and st.get("direct_solves", 0) > 0:
+            # the same workload through the handle's OTHER solver: the multigrid-PCG (what every graph with loop
+            # closures and every shard runs; the headline of rounds 1 and 2)
+            with capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=args.rtol, band_direct=-1) as G5:
+                G5.set_rotations(Q0)
+                G5.snapshot_rotations()
+                for _ in range(10):
+                    G5.restore_rotations()
+                    G5.irls(4, SIG, 100, 1e-3)
+                G5.synchronize()
+                G5.reset_stats()
+                t1 = time.perf_counter()
+                reps = 5
+                for _ in range(reps):
+                    G5.restore_rotations()
+                    r5 = G5.irls(4, SIG, 100, 1e-3)
+                G5.synchronize()
+                d5 = time.perf_counter() - t1
+                s5 = G5.stats()
+            line["also_pcg_path"] = {"value": S["m"] * r5["iters"] * reps / d5, "unit": "edge-updates/s",
+                                     "iters_to_converge": r5["iters"], "ms_per_step": 1e3 * d5 / reps,
+                                     "pcg_iters_per_solve": s5["pcg_iters"] / max(s5["pcg_solves"], 1),
+                                     "note": "band_direct = -1: two-launch multigrid-PCG (cgcg.hip), pcg_rtol %g" % args.rtol}
+        if not args.no_extra and world == 1 and args.rtol == 1e-10 and st.get("direct_solves", 0) == 0:
             # the same workload with the inner tolerance at the accuracy a direct fp64 factorisation of
             # these normal equations reaches itself (kappa*eps ~ 1e-9): fewer PCG iterations, same result
             with capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=1e-8) as G3:
@@ -478,7 +571,7 @@ def main():
                 "irls_iters": rb["iters"], "irls_ms": 1e3 * (t3 - t2),
                 "edge_updates_per_s_whole_pipeline": S["m"] * (ra["iters"] + rb["iters"]) / (t3 - t1),
                 "note": "l1ra(5) then irls(50): the reference demo's defaults; l1ra = 3 coordinate LPs x 2 primal-dual "
-                        "iterations per outer iteration, each a Hessian solve by the same PCG"}
+                        "iterations per outer iteration, each a Hessian solve by the handle's linear solver"}
             G.restore_rotations()
             # what a caller of the drop-in irotavg_irls pays with HOST buffers: graph build (adjacency,
             # hierarchy, SELL) + upload + the same solve + download, per call (the resident

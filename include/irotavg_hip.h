@@ -201,6 +201,14 @@ int irotavg_graph_l1decode_pd(irotavg_graph *g, const double *y, int pdmaxiter, 
  * IROTAVG_ERR_BAD_ARG if this graph's PCG does not use it). */
 int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_per_launch);
 
+/* The banded direct solver of this handle (options.band_direct; irotavg_amd/csrc/bcr.hip): info[0] = block size (0: the
+ * handle's systems run through the PCG -- nothing else is written), info[1] = levels L, then per level l < L three
+ * values: blocks, chunks of eight blocks (= workgroups of its two launches), blocks that come from the level below
+ * (fewer than `blocks` only on a mixed level 1, whose other blocks are level-0 blocks no chunk reduced). which of
+ * irotavg_graph_time_kernel: 19 = a whole solve (2 L launches), 20 + l = the reduction of level l, 40 + l = its way
+ * back. Returns the number of values written (<= cap) or a negative error. */
+int irotavg_graph_direct_info(irotavg_graph *g, int64_t *info, int cap);
+
 /* Testing aid: fingerprint of the handle's static structure -- every index array the build produces (edge
  * streams, boundary slots, per level the SELL-64 pattern and the value-refresh maps) as one 64-bit FNV-1a hash
  * each, followed by the scalars that choose kernels (level shapes, far-entry count, fused-assembly / two-launch

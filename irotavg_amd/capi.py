@@ -34,6 +34,7 @@ SYMBOLS = [
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
     "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_info", "irotavg_dist_plan", "irotavg_dist_plan_host",
     "irotavg_dist_l1ra", "irotavg_dist_create_hosted",
+    "irotavg_graph_direct_info",
     "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_trim_memory", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
 ]
 
@@ -128,6 +129,7 @@ def lib():
     L.irotavg_graph_l1decode_pd.argtypes = [vp, _dp, C.c_int, _dp, C.POINTER(C.c_int)]
     L.irotavg_graph_time_kernel.argtypes = [vp, C.c_int, C.c_int, _dp]
     L.irotavg_graph_fingerprint.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.irotavg_graph_direct_info.argtypes = [vp, _i64p, C.c_int]
     L.irotavg_viewgraph_create.argtypes = [C.POINTER(vp), C.POINTER(Options)]
     L.irotavg_viewgraph_destroy.argtypes = [vp]
     L.irotavg_viewgraph_destroy.restype = None
@@ -343,6 +345,17 @@ class Graph:
         check(lib().irotavg_graph_l1decode_pd(self._h, _d(y), pdmaxiter, _d(x), C.byref(stuck)),
               "l1decode_pd")
         return x, stuck.value
+
+    def direct_info(self):
+        """irotavg_graph_direct_info: dict(block, levels=[dict(blocks, chunks, reduced)]) of the banded direct solver."""
+        out = (C.c_int64 * 64)()
+        k = lib().irotavg_graph_direct_info(self._h, out, 64)
+        if k < 0:
+            raise IrotavgError(k, "direct_info")
+        if out[0] == 0:
+            return dict(block=0, levels=[])
+        return dict(block=int(out[0]), levels=[dict(blocks=int(out[2 + 3 * l]), chunks=int(out[3 + 3 * l]),
+                                                    reduced=int(out[4 + 3 * l])) for l in range(int(out[1]))])
 
     def fingerprint(self):
         """Hashes of every structural array + the kernel-choosing scalars (irotavg_graph_fingerprint)."""

@@ -753,6 +753,23 @@ int bcr_solve(Graph &g, int only) {
     return IROTAVG_OK;
 }
 
+int bcr_info(Graph &g, int64_t *out, int cap) {
+    int k = 0;
+    auto put = [&](int64_t v) {
+        if (k < cap) out[k++] = v;
+    };
+    put(g.bcr_B);
+    if (!g.bcr_B) return k;
+    bcr_alloc(g);
+    put((int64_t)g.bcr->lev.size());
+    for (const BcrLevel &L : g.bcr->lev) {
+        put(L.nb);
+        put(L.nch);
+        put(L.nred);
+    }
+    return k;
+}
+
 int bcr_levels(Graph &g) {
     if (!g.bcr_B) return 0;
     bcr_alloc(g);

@@ -370,6 +370,13 @@ int irotavg_graph_get_stats(irotavg_graph *h, irotavg_stats *out) {
     return IROTAVG_OK;
 }
 
+int irotavg_graph_direct_info(irotavg_graph *h, int64_t *info, int cap) {
+    if (!h || !info || cap < 1) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    return bcr_info(h->g, info, cap);
+    API_CATCH
+}
+
 void irotavg_graph_reset_stats(irotavg_graph *h) {
     if (!h) return;
     irotavg_stats keep = h->g.stats;

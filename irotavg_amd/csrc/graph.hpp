@@ -238,6 +238,7 @@ int window_solve_batch(WindowSolver &ws, int nb, WinBatchItem *items, int l1_max
 void bcr_plan(Graph &g, const int32_t *I);  // sets Graph::bcr_B / band0 (capi.cpp, after the build)
 int bcr_solve(Graph &g, int only = -1);     // levels[0] values / diagonal / right-hand side -> g.X, asynchronous
 int bcr_levels(Graph &g);
+int bcr_info(Graph &g, int64_t *out, int cap);
 // dense.hip
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);
