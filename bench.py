@@ -125,7 +125,7 @@ def kernel_rooflines(G, S, st, sharded=False):
     return out
 
 
-PMC_SUMMARY = "r03_pmc_summary.json"
+PMC_SUMMARY = "r03_pmc_summary.json"   # (the PCG-era profiles of this round: profiles/r03_pcg_*)
 KERNEL_STATS = "r03_bench_kernel_stats.csv"
 
 
@@ -142,11 +142,18 @@ def pmc_traffic(kernel, workload):
         if table.get("_meta", {}).get("workload") != workload:
             return None
         for name, row in table.items():   # template kernels appear as "name<args>"
-            if name == kernel or name.startswith(kernel + "<"):
+            if name == kernel or name.startswith(kernel + "<") or _is_l0_reduce(kernel, name):
                 return float(row["traffic_bytes"])
         return None
     except Exception:
         return None
+
+
+def _is_l0_reduce(kernel, name):
+    """k_bcr_reduce is one template for every level; the level-0 instantiation is k_bcr_reduce<B, true, ...>"""
+    n = name.replace(" ", "")
+    return kernel == "k_bcr_reduce_l0" and n.split("<")[0].endswith("k_bcr_reduce") and "<" in n and \
+        n.split("<")[1].split(",")[1:2] == ["true"]
 
 
 def in_situ_ms(kernel, workload):
@@ -163,7 +170,8 @@ def in_situ_ms(kernel, workload):
         with open(os.path.join(ROOT, "profiles", KERNEL_STATS)) as fh:
             for row in csv.DictReader(fh):
                 name = row.get("Name", "")
-                if name.split("(")[0].split("<")[0].split("::")[-1].strip() == kernel:
+                if name.split("(")[0].split("<")[0].split("::")[-1].strip() == kernel or \
+                        _is_l0_reduce(kernel, name.split("(")[0]):
                     return float(row["AverageNs"]) * 1e-6
     except Exception:
         return None
