@@ -42,8 +42,13 @@ struct BcrLevel {
 };
 struct BcrState {
     int B = 0;
+    int NR = 3;    // right-hand-side columns riding along: 3, or 19 with closures
+    int nfar = 0;  // long-range edges (loop closures) handled by the Woodbury correction
+    int zstride = 0;
     std::vector<BcrLevel> lev;
-    DevBuf<double> xtop;  // B x 3: the last separator
+    DevBuf<double> xtop;  // B x NR: the last separator
+    DevBuf<int> far_i, far_j, far_e;  // rows and edge id of the closures
+    DevBuf<double> Z, lam;            // A_b^-1 V (rows x zstride), lambda (64 x 3)
 };
 
 void BcrDeleter::operator()(BcrState *p) const { delete p; }
@@ -114,9 +119,11 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane) {
         for (int tc = 0; tc < T; tc++) Dm[(a + 8 * tr) * B + b + 8 * tc] = -t[tr][tc];
 }
 
-template <int B>
+// NR: right-hand-side columns riding along (3: the three coordinates; 19: + 16 columns of the closures' incidence
+// vectors, see bcr_solve)
+template <int B, int NR = 3>
 struct BcrDim {
-    static constexpr int NC = 2 * B + 3;        // columns of W: P' | Q | R
+    static constexpr int NC = 2 * B + NR;       // columns of W: P' | Q | R
     static constexpr int MT = (B + 15) / 16;    // 16-row tiles of a block
     static constexpr int NT = (NC + 15) / 16;   // 16-column tiles of W
     static constexpr int KS = B / 4;            // k-steps of a product over a block
@@ -164,9 +171,9 @@ __device__ __forceinline__ void bcr_mul_w(const double (&aop)[BcrDim<B>::MT][Bcr
 // four-wave workgroup, two in the second, four in the third; four from the start in a sixteen-wave workgroup):
 // this wave owns the tiles nt = part, part + WPE, ... and keeps them in w[][slot] between the phases (workgroup
 // barriers lie in between). NTPW: slots of a wave.
-template <int B, int NTPW>
+template <int B, int NR, int NTPW>
 struct BcrElim {
-    typedef BcrDim<B> Dm;
+    typedef BcrDim<B, NR> Dm;
     v4d w[Dm::MT][NTPW];
 
     // W = Di^-1 [P' | Q | R] (Di^-1 in LDS), W -> global (the way back reads it), and the right neighbour:
@@ -199,7 +206,7 @@ struct BcrElim {
                     stride[sl] = B;
                 } else if (j < Dm::NC) {
                     base[sl] = Ri + (j - 2 * B);
-                    stride[sl] = 3;
+                    stride[sl] = NR;
                 }
             }
 #pragma unroll
@@ -259,7 +266,7 @@ struct BcrElim {
                         if (c >= B && c < 2 * B)
                             Dc[row * B + c - B] -= out[mt][sl][r];
                         else if (c >= 2 * B && c < Dm::NC)
-                            Rc[row * 3 + c - 2 * B] -= out[mt][sl][r];
+                            Rc[row * NR + c - 2 * B] -= out[mt][sl][r];
                     }
                 }
         }
@@ -310,7 +317,7 @@ struct BcrElim {
                         else if (c < 2 * B)
                             P[row * B + c - B] = -v;
                         else if (c < Dm::NC)
-                            Ra[row * 3 + c - 2 * B] -= v;
+                            Ra[row * NR + c - 2 * B] -= v;
                     }
                 }
         }
@@ -322,11 +329,16 @@ struct BcrElim {
 // coupling lb -> lb + 1; nullptr: not wanted), entries in block lb - 1 -> GprevT, stored transposed (the coupling
 // lb - 1 -> lb as the rows of block lb see it, by symmetry; nullptr: not wanted). The right-hand side -> Rblk.
 // A thread owns its row (and, in GprevT, its column): plain read-modify-writes.
-template <int B>
+// Entries further away than the neighbouring blocks belong to long-range edges (loop closures): they are not part
+// of the band operator this solver factorises -- their weight is taken back out of the diagonal (the entry is
+// -w, the diagonal holds +w) and the closures re-enter by the Woodbury correction (bcr_solve). nfar > 0: the
+// right-hand-side columns 3 .. 3 + nfar of the row get the incidence vectors of the closures of this pass.
+template <int B, int NR>
 __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int *__restrict__ sl_off,
                                                const int *__restrict__ col, const double *__restrict__ val,
                                                const double *__restrict__ diag, const double4 *__restrict__ rhs,
-                                               double *Dblk, double *Gnext, double *GprevT, double *Rblk) {
+                                               double *Dblk, double *Gnext, double *GprevT, double *Rblk, int nfar,
+                                               const int *__restrict__ far_i, const int *__restrict__ far_j) {
     const int sl = row >> 6, ln = row & 63;
     const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
     const v2i *__restrict__ cp = reinterpret_cast<const v2i *>(col) + (size_t)(o0 / 2) * 64 + ln;
@@ -358,15 +370,22 @@ __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int
                     if (Gnext) Gnext[r * B + gc - B] += v;
                 } else if (gc < 0 && gc >= -B) {
                     if (GprevT) GprevT[(gc + B) * B + r] += v;
+                } else {
+                    Dblk[r * B + r] += v;  // long-range entry
                 }
             }
         }
     }
     Dblk[r * B + r] += diag[row];
     const double4 bb = rhs[row];
-    Rblk[r * 3 + 0] = bb.x;
-    Rblk[r * 3 + 1] = bb.y;
-    Rblk[r * 3 + 2] = bb.z;
+    Rblk[r * NR + 0] = bb.x;
+    Rblk[r * NR + 1] = bb.y;
+    Rblk[r * NR + 2] = bb.z;
+    if (NR > 3)
+        for (int q = 0; q < nfar; q++) {
+            const int fi = far_i[q], fj = far_j[q];
+            if (fi == row || fj == row) Rblk[r * NR + 3 + q] = (fi == row ? 1.0 : 0.0) - (fj == row ? 1.0 : 0.0);
+        }
 }
 
 // One chunk of eight blocks per workgroup of NW waves (4, or 8 when the level has so few chunks that every
@@ -377,18 +396,19 @@ __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int
 // Output per chunk c: W (seven blocks), sepD / sepR (block 7 after the eliminations), extD / extR (what the
 // chunk's eliminations subtract from the separator of chunk c - 1), extG (coupling of that separator to block 7).
 // TOP (one chunk, nothing before it): block 7 is solved and written to xtop.
-template <int B, bool L0, bool TOP, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_reduce(
+template <int B, int NR, bool L0, bool TOP, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) void k_bcr_reduce(
     int nb, int nred, int n, const int *__restrict__ sl_off, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ diag, const double4 *__restrict__ rhs, const double *__restrict__ inD,
     const double *__restrict__ inR, const double *__restrict__ inXD, const double *__restrict__ inXR,
     const double *__restrict__ inXG, double *__restrict__ W, double *__restrict__ sepD, double *__restrict__ sepR,
-    double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop, int dbg) {
-    typedef BcrDim<B> Dm;
+    double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop, int dbg,
+    int nfar, const int *__restrict__ far_i, const int *__restrict__ far_j) {
+    typedef BcrDim<B, NR> Dm;
     constexpr int BB = B * B;
     __shared__ double sD[8][BB];   // sD[0] becomes the chunk's contribution to the separator before it
     __shared__ double sG[8][BB];   // slot 0: coupling (separator before the chunk) -> block 0; slot j + 1: block j -> j + 1
-    __shared__ double sR[9][B * 3];  // slot 0: contribution to the right-hand side of the separator before the chunk
+    __shared__ double sR[9][B * NR];  // slot 0: contribution to the right-hand side of the separator before the chunk
     __shared__ double sZ[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -401,7 +421,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_r
         (&sD[0][0])[e] = 0.0;
         (&sG[0][0])[e] = 0.0;
     }
-    for (int e = tid; e < 9 * B * 3; e += NT_) (&sR[0][0])[e] = 0.0;
+    for (int e = tid; e < 9 * B * NR; e += NT_) (&sR[0][0])[e] = 0.0;
     if (tid < 2) sZ[tid] = 0.0;
     __syncthreads();
     if (L0) {
@@ -409,8 +429,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_r
         for (int t = tid; t < 8 * B; t += NT_) {
             const int row = row0 + t, blk = t / B, r = t - blk * B;
             if (row < n)
-                bcr_gather_row<B>(row, chunk * 8 + blk, r, sl_off, col, val, diag, rhs, sD[blk],
-                                  blk < 7 ? sG[blk + 1] : nullptr, blk == 0 ? sG[0] : nullptr, sR[blk + 1]);
+                bcr_gather_row<B, NR>(row, chunk * 8 + blk, r, sl_off, col, val, diag, rhs, sD[blk],
+                                      blk < 7 ? sG[blk + 1] : nullptr, blk == 0 ? sG[0] : nullptr, sR[blk + 1], nfar,
+                                      far_i, far_j);
             else
                 sD[blk][r * B + r] = 1.0;
         }
@@ -426,8 +447,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_r
                     sD[i][e] = inD[(size_t)gb * BB + e] + (nxt ? inXD[(size_t)(gb + 1) * BB + e] : 0.0);
                     if (gb > 0) sG[i][e] = inXG[(size_t)gb * BB + e];
                 }
-                for (int e = tid; e < B * 3; e += NT_)
-                    sR[i + 1][e] = inR[(size_t)gb * B * 3 + e] + (nxt ? inXR[(size_t)(gb + 1) * B * 3 + e] : 0.0);
+                for (int e = tid; e < B * NR; e += NT_)
+                    sR[i + 1][e] = inR[(size_t)gb * B * NR + e] + (nxt ? inXR[(size_t)(gb + 1) * B * NR + e] : 0.0);
             } else if (gb >= nb) {
                 for (int e = tid; e < B; e += NT_) sD[i][e * B + e] = 1.0;
             }
@@ -438,8 +459,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_r
                 if (gb >= nred && gb < nb) {
                     const int lb = 8 * nred + (gb - nred), row = lb * B + r;
                     if (row < n)
-                        bcr_gather_row<B>(row, lb, r, sl_off, col, val, diag, rhs, sD[i], nullptr,
-                                          gb > 0 ? sG[i] : nullptr, sR[i + 1]);
+                        bcr_gather_row<B, NR>(row, lb, r, sl_off, col, val, diag, rhs, sD[i], nullptr,
+                                              gb > 0 ? sG[i] : nullptr, sR[i + 1], nfar, far_i, far_j);
                     else
                         sD[i][r * B + r] = 1.0;
                 }
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_r
     // ---- three rounds of eliminations: (0 2 4 6) (1 5) (3) ----
     constexpr int WPE0 = NW / 4 < Dm::NT ? NW / 4 : Dm::NT;  // waves per elimination in the first round
     constexpr int NTPW = (Dm::NT + WPE0 - 1) / WPE0;
-    BcrElim<B, NTPW> E;
+    BcrElim<B, NR, NTPW> E;
     v4d out[Dm::MT][NTPW];
 #define IRH_BCR_ROUND(RND)                                                                                          \
     {                                                                                                               \
@@ -497,14 +518,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_r
         if (wave == 0) {
             if (7 < nb) {
                 bcr_invert<B>(sD[7], lane);
-                for (int o = lane; o < B * 3; o += 64) {
-                    const int k = o / 3, q = o - 3 * k;
+                for (int o = lane; o < B * NR; o += 64) {
+                    const int k = o / NR, q = o - NR * k;
                     double s = 0.0;
-                    for (int cidx = 0; cidx < B; cidx++) s += sD[7][k * B + cidx] * sR[8][cidx * 3 + q];
+                    for (int cidx = 0; cidx < B; cidx++) s += sD[7][k * B + cidx] * sR[8][cidx * NR + q];
                     xtop[o] = s;
                 }
             } else {
-                for (int o = lane; o < B * 3; o += 64) xtop[o] = 0.0;
+                for (int o = lane; o < B * NR; o += 64) xtop[o] = 0.0;
             }
         }
     } else {
@@ -515,9 +536,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_r
                 extG[(size_t)chunk * BB + e] = sG[0][e];
             }
         }
-        for (int e = tid; e < B * 3; e += NT_) {
-            sepR[(size_t)chunk * B * 3 + e] = sR[8][e];
-            if (hasExt) extR[(size_t)chunk * B * 3 + e] = sR[0][e];
+        for (int e = tid; e < B * NR; e += NT_) {
+            sepR[(size_t)chunk * B * NR + e] = sR[8][e];
+            if (hasExt) extR[(size_t)chunk * B * NR + e] = sR[0][e];
         }
     }
 }
@@ -525,14 +546,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 ? 2 : 1)) void k_bcr_r
 // The way back for one chunk: x_7 and the separator before the chunk come from the coarser level. The chunk's
 // W (7 blocks of B x (2B + 3)) is staged in LDS first -- every load of the launch is in flight at once; read row
 // by row behind the three dependent rounds it cost a memory round trip per four rows.
-template <int B, bool L0>
+template <int B, int NR, bool L0>
 __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const double *__restrict__ W,
                                                    const double *__restrict__ xc, double *__restrict__ xl,
-                                                   double4 *__restrict__ X) {
-    typedef BcrDim<B> Dm;
+                                                   double4 *__restrict__ X, double *__restrict__ Z, int zstride,
+                                                   int zoff, int nfar) {
+    typedef BcrDim<B, NR> Dm;
     constexpr int WB = B * Dm::NC;     // doubles of one W block
     __shared__ double sW[7 * WB];
-    __shared__ double sX[9][B * 3];  // slot 0: separator before the chunk; slot j + 1: block j
+    __shared__ double sX[9][B * NR];  // slot 0: separator before the chunk; slot j + 1: block j
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = blockIdx.x;
@@ -541,14 +563,14 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
     {
         const v2d *__restrict__ src = reinterpret_cast<const v2d *>(W + (size_t)chunk * 7 * WB);
         v2d *dst = reinterpret_cast<v2d *>(sW);
-        const int cnt = nblk * WB / 2;  // WB is even or odd? B * (2B + 3): B is a multiple of 8 -> even
+        const int cnt = nblk * WB / 2;  // B is a multiple of 8: WB is even
         for (int e = tid; e < cnt; e += 256) dst[e] = __builtin_nontemporal_load(&src[e]);
     }
-    for (int e = tid; e < 9 * B * 3; e += 256) (&sX[0][0])[e] = 0.0;
+    for (int e = tid; e < 9 * B * NR; e += 256) (&sX[0][0])[e] = 0.0;
     __syncthreads();
-    for (int e = tid; e < B * 3; e += 256) {
-        sX[8][e] = xc[(size_t)chunk * B * 3 + e];
-        if (chunk > 0) sX[0][e] = xc[(size_t)(chunk - 1) * B * 3 + e];
+    for (int e = tid; e < B * NR; e += 256) {
+        sX[8][e] = xc[(size_t)chunk * B * NR + e];
+        if (chunk > 0) sX[0][e] = xc[(size_t)(chunk - 1) * B * NR + e];
     }
     __syncthreads();
     const int lk = lane >> 4, lp = lane & 15;
@@ -571,70 +593,166 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
         if (i >= 0 && chunk * 8 + i < nb) {
             const double *Wi = sW + i * WB;
             const double *xa = sX[a + 1], *xcn = sX[c + 1];
+            if (NR == 3) {
+                // sixteen lanes per row of W, three accumulators each
 #pragma unroll 2
-            for (int it = 0; it < B / 4; it++) {
-                const int k = 4 * it + lk;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                for (int it = 0; it < B / 4; it++) {
+                    const int k = 4 * it + lk;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-                for (int u = 0; u < Dm::NT; u++) {
-                    const int cidx = lp + 16 * u;
-                    if (cidx < Dm::NC) {
-                        const double wv = Wi[k * Dm::NC + cidx];
-                        if (cidx < B) {
-                            s0 -= wv * xa[cidx * 3 + 0];
-                            s1 -= wv * xa[cidx * 3 + 1];
-                            s2 -= wv * xa[cidx * 3 + 2];
-                        } else if (cidx < 2 * B) {
-                            s0 -= wv * xcn[(cidx - B) * 3 + 0];
-                            s1 -= wv * xcn[(cidx - B) * 3 + 1];
-                            s2 -= wv * xcn[(cidx - B) * 3 + 2];
-                        } else {
-                            const int q = cidx - 2 * B;
-                            s0 += q == 0 ? wv : 0.0;
-                            s1 += q == 1 ? wv : 0.0;
-                            s2 += q == 2 ? wv : 0.0;
+                    for (int u = 0; u < Dm::NT; u++) {
+                        const int cidx = lp + 16 * u;
+                        if (cidx < Dm::NC) {
+                            const double wv = Wi[k * Dm::NC + cidx];
+                            if (cidx < B) {
+                                s0 -= wv * xa[cidx * 3 + 0];
+                                s1 -= wv * xa[cidx * 3 + 1];
+                                s2 -= wv * xa[cidx * 3 + 2];
+                            } else if (cidx < 2 * B) {
+                                s0 -= wv * xcn[(cidx - B) * 3 + 0];
+                                s1 -= wv * xcn[(cidx - B) * 3 + 1];
+                                s2 -= wv * xcn[(cidx - B) * 3 + 2];
+                            } else {
+                                const int q = cidx - 2 * B;
+                                s0 += q == 0 ? wv : 0.0;
+                                s1 += q == 1 ? wv : 0.0;
+                                s2 += q == 2 ? wv : 0.0;
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s0 += __shfl_xor(s0, o, 64);
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
+                    for (int o = 1; o < 16; o <<= 1) {
+                        s0 += __shfl_xor(s0, o, 64);
+                        s1 += __shfl_xor(s1, o, 64);
+                        s2 += __shfl_xor(s2, o, 64);
+                    }
+                    if (lp == 0) {
+                        sX[i + 1][k * 3 + 0] = s0;
+                        sX[i + 1][k * 3 + 1] = s1;
+                        sX[i + 1][k * 3 + 2] = s2;
+                    }
                 }
-                if (lp == 0) {
-                    sX[i + 1][k * 3 + 0] = s0;
-                    sX[i + 1][k * 3 + 1] = s1;
-                    sX[i + 1][k * 3 + 2] = s2;
+            } else {
+                // a lane per (row, right-hand side)
+                for (int o = lane; o < B * NR; o += 64) {
+                    const int k = o / NR, q = o - NR * k;
+                    const double *wr = Wi + k * Dm::NC;
+                    double sacc = wr[2 * B + q];
+#pragma unroll 4
+                    for (int cidx = 0; cidx < B; cidx++)
+                        sacc -= wr[cidx] * xa[cidx * NR + q] + wr[B + cidx] * xcn[cidx * NR + q];
+                    sX[i + 1][o] = sacc;
                 }
             }
         }
         __syncthreads();
     }
+    auto put_row = [&](int row, int t) {
+        const double *xs = &sX[1][0] + t * NR;
+        X[row] = double4{xs[0], xs[1], xs[2], 0.0};
+        if (NR > 3)
+            for (int q = 0; q < nfar; q++) Z[(size_t)row * zstride + zoff + q] = xs[3 + q];
+    };
     if (L0) {
         const int row0 = chunk * 8 * B;
         for (int t = tid; t < 8 * B; t += 256) {
             const int row = row0 + t;
-            if (row < n) {
-                const double *xs = &sX[1][0] + t * 3;
-                X[row] = double4{xs[0], xs[1], xs[2], 0.0};
-            }
+            if (row < n) put_row(row, t);
         }
     } else {
-        for (int e = tid; e < 8 * B * 3; e += 256) xl[(size_t)chunk * 8 * B * 3 + e] = (&sX[1][0])[e];
+        for (int e = tid; e < 8 * B * NR; e += 256) xl[(size_t)chunk * 8 * B * NR + e] = (&sX[1][0])[e];
         // blocks of a mixed level that are level-0 blocks themselves: their solution rows
         if (chunk * 8 + 8 > nred && nred < nb)
             for (int t = tid; t < 8 * B; t += 256) {
                 const int i = t / B, r = t - i * B, gb = chunk * 8 + i;
                 if (gb >= nred && gb < nb) {
                     const int row = (8 * nred + (gb - nred)) * B + r;
-                    if (row < n) {
-                        const double *xs = &sX[1][0] + t * 3;
-                        X[row] = double4{xs[0], xs[1], xs[2], 0.0};
-                    }
+                    if (row < n) put_row(row, t);
                 }
             }
     }
+}
+
+// The closures' part of a solve. The operator is A = A_b + V C V' (A_b: the band part the reduction factorised,
+// column q of V = e_i - e_j for closure q, C = diag(w_q)). With Y = A_b^-1 b (in X) and Z = A_b^-1 V (n x r, by the
+// 16 extra right-hand sides of each pass):  x = Y - Z (C^-1 + V' Z)^-1 V' Y  (Sherman-Morrison-Woodbury).
+// One workgroup: S = C^-1 + V' Z and T = V' Y gathered, S (r <= 64, SPD) eliminated in LDS, lambda = S^-1 T -> lam.
+// A closure of weight 0 (Talwar, a capped L1 weight never is) is not there: its lambda is 0.
+__global__ __launch_bounds__(256) void k_bcr_woodbury(int r, const int *__restrict__ far_i, const int *__restrict__ far_j,
+                                                      const int *__restrict__ far_e, const double *__restrict__ wsrc,
+                                                      int wsquare, const double *__restrict__ Z, int zstride,
+                                                      const double4 *__restrict__ X, double *__restrict__ lam) {
+    __shared__ double S[64][65];
+    __shared__ double T[64][3];
+    __shared__ int alive[64];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < r * r; e += 256) {
+        const int p = e / r, q = e - p * r;
+        S[p][q] = Z[(size_t)far_i[p] * zstride + q] - Z[(size_t)far_j[p] * zstride + q];
+    }
+    for (int p = tid; p < r; p += 256) {
+        const double4 a = X[far_i[p]], b = X[far_j[p]];
+        T[p][0] = a.x - b.x;
+        T[p][1] = a.y - b.y;
+        T[p][2] = a.z - b.z;
+    }
+    __syncthreads();
+    for (int p = tid; p < r; p += 256) {
+        double w = wsrc[far_e[p]];
+        if (wsquare) w *= w;
+        alive[p] = w > 0.0;
+        if (w > 0.0) S[p][p] += 1.0 / w;
+    }
+    __syncthreads();
+    for (int e = tid; e < r * r; e += 256) {
+        const int p = e / r, q = e - p * r;
+        if (!alive[p] || !alive[q]) S[p][q] = p == q ? 1.0 : 0.0;
+    }
+    for (int p = tid; p < r; p += 256)
+        if (!alive[p]) T[p][0] = T[p][1] = T[p][2] = 0.0;
+    __syncthreads();
+    // Gauss-Jordan without pivoting on [S | T] (SPD); thread (row, column group)
+    for (int k = 0; k < r; k++) {
+        const double pinv = 1.0 / S[k][k];
+        __syncthreads();
+        for (int e = tid; e < r * (r + 3); e += 256) {
+            const int p = e / (r + 3), q = e - p * (r + 3);
+            if (p == k) continue;
+            const double f = S[p][k] * pinv;
+            if (q < r) {
+                if (q != k) S[p][q] -= f * S[k][q];
+            } else {
+                T[p][q - r] -= f * T[k][q - r];
+            }
+        }
+        __syncthreads();
+        for (int p = tid; p < r; p += 256)
+            if (p != k) S[p][k] = 0.0;
+        __syncthreads();
+    }
+    for (int e = tid; e < r * 3; e += 256) {
+        const int p = e / 3, q = e - 3 * p;
+        lam[e] = T[p][q] / S[p][p];
+    }
+}
+
+// x = Y - Z lambda, row by row
+__global__ __launch_bounds__(256) void k_bcr_apply_lambda(int n, int r, const double *__restrict__ Z, int zstride,
+                                                          const double *__restrict__ lam, double4 *__restrict__ X) {
+    __shared__ double sl[64 * 3];
+    for (int e = threadIdx.x; e < r * 3; e += 256) sl[e] = lam[e];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    double4 x = X[row];
+    const double *z = Z + (size_t)row * zstride;
+    for (int q = 0; q < r; q++) {
+        const double zz = z[q];
+        x.x -= zz * sl[3 * q + 0];
+        x.y -= zz * sl[3 * q + 1];
+        x.z -= zz * sl[3 * q + 2];
+    }
+    X[row] = x;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -645,19 +763,22 @@ static void bcr_alloc(Graph &g) {
     g.bcr.reset(new BcrState());
     BcrState &S = *g.bcr;
     S.B = g.bcr_B;
-    const int B = S.B, NC = 2 * B + 3;
+    S.nfar = (int)g.bcr_far_e.size();
+    S.NR = S.nfar > 0 ? 19 : 3;
+    const int B = S.B, NR = S.NR, NC = 2 * B + NR;
     const int nb0 = (g.levels[0].n + B - 1) / B;
     int nch0 = (nb0 + 7) / 8;
-    // The level-0 reduction keeps two workgroups per CU resident (one for B = 32: LDS). A chunk count slightly
-    // above a multiple of that capacity would cost a whole extra round of workgroups for a handful of chunks
-    // (100k views, B = 24: 521 chunks on 512 slots): the chunks beyond the multiple are not reduced at all --
-    // their blocks enter level 1 as they are (a MIXED level 1: k_bcr_reduce's loader), where there is room.
+    // The level-0 reduction keeps two workgroups per CU resident (one for B = 32 or with closure columns: LDS). A
+    // chunk count slightly above a multiple of that capacity would cost a whole extra round of workgroups for a
+    // handful of chunks (100k views, B = 24: 521 chunks on 512 slots): the chunks beyond the multiple are not
+    // reduced at all -- their blocks enter level 1 as they are (a MIXED level 1: k_bcr_reduce's loader), where
+    // there is room.
     int nraw = 0;
     {
         int ncu = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, g.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-        const int cap = ncu * (B <= 24 ? 2 : 1);
+        const int cap = ncu * (B <= 24 && NR == 3 ? 2 : 1);
         const int full = nch0 / cap * cap, rem = nch0 - full;
         if (full > 0 && rem > 0 && rem <= cap / 4 && !getenv("IROTAVG_BCR_NO_MIXED")) {
             nraw = nb0 - 8 * full;
@@ -672,45 +793,56 @@ static void bcr_alloc(Graph &g) {
         L.nch = nch;
         L.nred = (l == 1 && nraw > 0) ? nb - nraw : nb;
         L.W.alloc((size_t)L.nch * 7 * B * NC);
-        if (l > 0) L.x.alloc((size_t)L.nch * 8 * B * 3);
+        if (l > 0) L.x.alloc((size_t)L.nch * 8 * B * NR);
         if (nb <= 8) break;
         L.sepD.alloc((size_t)L.nch * B * B);
         L.extD.alloc((size_t)L.nch * B * B);
         L.extG.alloc((size_t)L.nch * B * B);
-        L.sepR.alloc((size_t)L.nch * B * 3);
-        L.extR.alloc((size_t)L.nch * B * 3);
+        L.sepR.alloc((size_t)L.nch * B * NR);
+        L.extR.alloc((size_t)L.nch * B * NR);
         nb = L.nch + (l == 0 ? nraw : 0);
         nch = (nb + 7) / 8;
     }
-    S.xtop.alloc((size_t)B * 3);
+    S.xtop.alloc((size_t)B * NR);
+    if (S.nfar > 0) {
+        S.zstride = (S.nfar + 15) / 16 * 16;
+        S.far_i.upload(g.bcr_far_i, g.stream);
+        S.far_j.upload(g.bcr_far_j, g.stream);
+        S.far_e.upload(g.bcr_far_e, g.stream);
+        S.Z.alloc((size_t)g.levels[0].n * S.zstride);
+        S.lam.alloc(64 * 3);
+        IRH_CHECK(hipStreamSynchronize(g.stream));  // the host vectors may go away
+    }
 }
 
-template <int B>
-static void bcr_run(Graph &g, int only) {
+template <int B, int NR>
+static void bcr_run(Graph &g, int only, int pass) {
     BcrState &S = *g.bcr;
     Level &L0 = g.levels[0];
     hipStream_t st = g.stream;
     const int nl = (int)S.lev.size();
     const int dbg = getenv("IROTAVG_BCR_DBG") ? atoi(getenv("IROTAVG_BCR_DBG")) : 0;
+    const int nfar = NR > 3 ? std::min(16, S.nfar - 16 * pass) : 0;
+    const int *fi = NR > 3 ? S.far_i.p + 16 * pass : nullptr, *fj = NR > 3 ? S.far_j.p + 16 * pass : nullptr;
     for (int l = 0; l < nl; l++) {
         if (only >= 0 && only != l) continue;
         BcrLevel &L = S.lev[l];
         const BcrLevel *F = l > 0 ? &S.lev[l - 1] : nullptr;
         const bool top = l == nl - 1;
 #define IRH_BCR_ARGS                                                                                             \
-    L.nb, L.nred, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p, L0.b.p, F ? F->sepD.p : nullptr,                      \
+    L.nb, L.nred, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p, L0.b.p, F ? F->sepD.p : nullptr,             \
         F ? F->sepR.p : nullptr, F ? F->extD.p : nullptr, F ? F->extR.p : nullptr, F ? F->extG.p : nullptr, L.W.p, \
-        L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p, dbg
+        L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p, dbg, nfar, fi, fj
         // eight waves per chunk when every chunk has a CU to itself (see k_bcr_reduce)
         const bool wide = L.nch <= 256 && !getenv("IROTAVG_BCR_NARROW");
 #define IRH_BCR_LAUNCH(L0_, TOP_)                                                                                   \
     if constexpr (B <= 24) {                                                                                        \
         if (wide)                                                                                                   \
-            hipLaunchKernelGGL((k_bcr_reduce<B, L0_, TOP_, 8>), dim3(L.nch), dim3(512), 0, st, IRH_BCR_ARGS);       \
+            hipLaunchKernelGGL((k_bcr_reduce<B, NR, L0_, TOP_, 8>), dim3(L.nch), dim3(512), 0, st, IRH_BCR_ARGS);   \
         else                                                                                                        \
-            hipLaunchKernelGGL((k_bcr_reduce<B, L0_, TOP_, 4>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);       \
+            hipLaunchKernelGGL((k_bcr_reduce<B, NR, L0_, TOP_, 4>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);   \
     } else {                                                                                                        \
-        hipLaunchKernelGGL((k_bcr_reduce<B, L0_, TOP_, 4>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);           \
+        hipLaunchKernelGGL((k_bcr_reduce<B, NR, L0_, TOP_, 4>), dim3(L.nch), dim3(256), 0, st, IRH_BCR_ARGS);       \
     }
         if (l == 0 && top) {
             IRH_BCR_LAUNCH(true, true)
@@ -729,11 +861,32 @@ static void bcr_run(Graph &g, int only) {
         BcrLevel &L = S.lev[l];
         const double *xc = l == nl - 1 ? S.xtop.p : S.lev[l + 1].x.p;
         if (l == 0)
-            hipLaunchKernelGGL((k_bcr_back<B, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               (double *)nullptr, g.X.p + g.ng);
+            hipLaunchKernelGGL((k_bcr_back<B, NR, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
+                               (double *)nullptr, g.X.p + g.ng, S.Z.p, S.zstride, 16 * pass, nfar);
         else
-            hipLaunchKernelGGL((k_bcr_back<B, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               L.x.p, g.X.p + g.ng);
+            hipLaunchKernelGGL((k_bcr_back<B, NR, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
+                               L.x.p, g.X.p + g.ng, S.Z.p, S.zstride, 16 * pass, nfar);
+    }
+}
+
+template <int B>
+static void bcr_run_all(Graph &g, int only) {
+    BcrState &S = *g.bcr;
+    if (S.nfar == 0) {
+        bcr_run<B, 3>(g, only, 0);
+        return;
+    }
+    if constexpr (B <= 24) {
+        // closures: every pass factorises the band part again with the incidence vectors of sixteen more closures
+        // as extra right-hand sides (Z = A_b^-1 V), then the Woodbury correction (k_bcr_woodbury)
+        const int npass = only >= 0 ? 1 : (S.nfar + 15) / 16;
+        for (int pass = 0; pass < npass; pass++) bcr_run<B, 19>(g, only, pass);
+        if (only >= 0) return;
+        hipLaunchKernelGGL(k_bcr_woodbury, dim3(1), dim3(256), 0, g.stream, S.nfar, S.far_i.p, S.far_j.p, S.far_e.p,
+                           g.bcr_wsrc, g.bcr_wsquare, S.Z.p, S.zstride, g.X.p + g.ng, S.lam.p);
+        const int n = g.levels[0].n;
+        hipLaunchKernelGGL(k_bcr_apply_lambda, dim3((n + 255) / 256), dim3(256), 0, g.stream, n, S.nfar, S.Z.p,
+                           S.zstride, S.lam.p, g.X.p + g.ng);
     }
 }
 
@@ -743,10 +896,10 @@ int bcr_solve(Graph &g, int only) {
     if (!g.bcr_B) return IROTAVG_ERR_BAD_ARG;
     bcr_alloc(g);
     switch (g.bcr_B) {
-    case 8: bcr_run<8>(g, only); break;
-    case 16: bcr_run<16>(g, only); break;
-    case 24: bcr_run<24>(g, only); break;
-    case 32: bcr_run<32>(g, only); break;
+    case 8: bcr_run_all<8>(g, only); break;
+    case 16: bcr_run_all<16>(g, only); break;
+    case 24: bcr_run_all<24>(g, only); break;
+    case 32: bcr_run_all<32>(g, only); break;
     default: return IROTAVG_ERR_BAD_ARG;
     }
     if (only < 0) g.stats.direct_solves += 1;
@@ -767,6 +920,7 @@ int bcr_info(Graph &g, int64_t *out, int cap) {
         put(L.nch);
         put(L.nred);
     }
+    put(g.bcr->nfar);
     return k;
 }
 
@@ -777,31 +931,67 @@ int bcr_levels(Graph &g) {
 }
 
 // Decides whether the handle's solves run here: one GPU, every edge between two free views within 32 views
-// (ral's I is 0-based; row = view - f), enough rows for the hierarchy of the iterative solver to exist at all
-// (smaller graphs are one dense level = a direct solve already). opt.band_direct: 0 choose, 1 whenever the band
-// allows, -1 never; IROTAVG_BAND_DIRECT overrides the option.
+// (ral's I is 0-based; row = view - f) except for at most kBcrMaxFar long-range edges (loop closures: Woodbury
+// correction, bcr_solve), enough rows for the hierarchy of the iterative solver to exist at all (smaller graphs
+// are one dense level = a direct solve already). opt.band_direct: 0 choose, 1 whenever the band allows, -1 never;
+// IROTAVG_BAND_DIRECT overrides the option.
+constexpr int kBcrMaxFar = 64;
 void bcr_plan(Graph &g, const int32_t *I) {
     g.bcr_B = 0;
     g.band0 = -1;
+    g.bcr_far_i.clear();
+    g.bcr_far_j.clear();
+    g.bcr_far_e.clear();
     int mode = g.opt.band_direct;
     if (const char *e = std::getenv("IROTAVG_BAND_DIRECT")) mode = std::atoi(e);
     if (mode < 0 || g.ng > 0 || g.levels.empty() || g.levels[0].n < 1) return;
     const int f = g.f;
-    std::atomic<int> band(0);
+    std::atomic<int> band(0), bandall(0);
+    std::atomic<long long> nfar(0);
     parallel_for(g.m, 65536, [&](int64_t k0, int64_t k1, int) {
-        int bmax = 0;
+        int bmax = 0, ball = 0;
+        long long far = 0;
         for (int64_t k = k0; k < k1; k++) {
             const int i = I[2 * k], j = I[2 * k + 1];
-            if (i >= f && j >= f) bmax = std::max(bmax, std::abs(i - j));
+            if (i >= f && j >= f) {
+                const int d = std::abs(i - j);
+                ball = std::max(ball, d);
+                if (d <= 32) bmax = std::max(bmax, d);
+                else far++;
+            }
         }
         int cur = band.load();
         while (bmax > cur && !band.compare_exchange_weak(cur, bmax)) {
         }
+        cur = bandall.load();
+        while (ball > cur && !bandall.compare_exchange_weak(cur, ball)) {
+        }
+        nfar += far;
     });
-    g.band0 = band.load();
-    if (g.band0 > 32) return;
+    g.band0 = bandall.load();
+    if (nfar.load() > kBcrMaxFar) return;
     if (mode == 0 && g.levels[0].n <= 2048) return;
-    g.bcr_B = g.band0 <= 8 ? 8 : g.band0 <= 16 ? 16 : g.band0 <= 24 ? 24 : 32;
+    const int b0 = band.load();
+    const int B = b0 <= 8 ? 8 : b0 <= 16 ? 16 : b0 <= 24 ? 24 : 32;
+    if (nfar.load() > 0) {
+        // long-range edges = those whose endpoints lie in blocks that are not neighbours (an edge of more than 32
+        // views between neighbouring blocks is part of the block tridiagonal operator as it is)
+        for (int64_t k = 0; k < g.m; k++) {
+            const int i = I[2 * k], j = I[2 * k + 1];
+            if (i >= f && j >= f && std::abs(i - j) > 32 && std::abs((i - f) / B - (j - f) / B) >= 2) {
+                g.bcr_far_i.push_back(i - f);
+                g.bcr_far_j.push_back(j - f);
+                g.bcr_far_e.push_back((int)k);
+            }
+        }
+        if (!g.bcr_far_e.empty() && (B > 24 || getenv("IROTAVG_BCR_NO_CLOSURES"))) {  // closure columns: LDS of the 32-row blocks
+            g.bcr_far_i.clear();
+            g.bcr_far_j.clear();
+            g.bcr_far_e.clear();
+            return;
+        }
+    }
+    g.bcr_B = B;
 }
 
 }  // namespace irh

@@ -123,6 +123,9 @@ struct Graph {
     // 0 = the solves run through the PCG) and the half-bandwidth found at creation (-1: not looked at)
     int bcr_B = 0, band0 = -1;
     std::unique_ptr<BcrState, BcrDeleter> bcr;
+    std::vector<int> bcr_far_i, bcr_far_j, bcr_far_e;  // long-range edges (rows, edge id): Woodbury correction
+    const double *bcr_wsrc = nullptr;                  // per-edge weights of the last assembly and whether the
+    int bcr_wsquare = 0;                               // operator holds their squares (IRLS) -- assemble_values
 
     double last_score_sum = 0.0;
     double irls_settle = -1.0;  // run_irls: > 0 while the last step was small enough for the weights to have settled (assemble())

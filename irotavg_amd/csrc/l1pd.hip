@@ -630,6 +630,9 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
     q.cg2 = g.cg2;
     q.bcr_B = g.bcr_B;
     q.band0 = g.band0;
+    q.bcr_far_i = g.bcr_far_i;
+    q.bcr_far_j = g.bcr_far_j;
+    q.bcr_far_e = g.bcr_far_e;
     q.dense32 = g.dense32;
     q.b2p.alloc_like(g.b2p, s);
     q.kc_auto = g.kc_auto;

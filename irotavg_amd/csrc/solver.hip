@@ -1671,6 +1671,8 @@ void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense) {
 
 void assemble_values(Graph &g, int mode, const double *wsrc) {
     Level &L0 = g.levels[0];
+    g.bcr_wsrc = wsrc;
+    g.bcr_wsquare = mode == 0;
     const int grid = grid_for_rows(L0);
     size_t first_coarse = 1;
     if (g.asm_windowed) {
