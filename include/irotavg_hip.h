@@ -77,9 +77,10 @@ typedef struct irotavg_options {
                                   <= 64 deviating long-range entries are repaired by a low-rank update) */
     int pcg_classic;           /* 1: the PCG iteration always runs as separate launches (default 0: on one
                                   GPU a graph without loop closures runs it as two launches, cgcg.hip) */
-    int band_direct;           /* a graph whose edges between free views all span <= 32 views (a sequence without
-                                  loop closures) has a banded operator; on one GPU its linear systems are then
-                                  solved DIRECTLY by block cyclic reduction (bcr.hip) instead of the PCG:
+    int band_direct;           /* a graph whose edges between free views all span <= 32 views -- a view sequence --
+                                  except for at most 64 long-range edges (loop closures) has a banded operator plus
+                                  a low-rank part; on one GPU its linear systems are then solved DIRECTLY (block
+                                  cyclic reduction + Woodbury correction, bcr.hip) instead of the PCG:
                                   0 (default) = when it has more than 2048 free views (smaller graphs are one
                                   dense level already), 1 = whenever the band allows, -1 = never */
 } irotavg_options;
@@ -204,7 +205,8 @@ int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_
 /* The banded direct solver of this handle (options.band_direct; irotavg_amd/csrc/bcr.hip): info[0] = block size (0: the
  * handle's systems run through the PCG -- nothing else is written), info[1] = levels L, then per level l < L three
  * values: blocks, chunks of eight blocks (= workgroups of its two launches), blocks that come from the level below
- * (fewer than `blocks` only on a mixed level 1, whose other blocks are level-0 blocks no chunk reduced). which of
+ * (fewer than `blocks` only on a mixed level 1, whose other blocks are level-0 blocks no chunk reduced); after the
+ * levels one more value: the long-range edges (loop closures) the solver handles by its Woodbury correction. which of
  * irotavg_graph_time_kernel: 19 = a whole solve (2 L launches), 20 + l = the reduction of level l, 40 + l = its way
  * back. Returns the number of values written (<= cap) or a negative error. */
 int irotavg_graph_direct_info(irotavg_graph *g, int64_t *info, int cap);

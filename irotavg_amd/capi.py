@@ -353,9 +353,11 @@ class Graph:
         if k < 0:
             raise IrotavgError(k, "direct_info")
         if out[0] == 0:
-            return dict(block=0, levels=[])
+            return dict(block=0, levels=[], closures=0)
+        nl = int(out[1])
         return dict(block=int(out[0]), levels=[dict(blocks=int(out[2 + 3 * l]), chunks=int(out[3 + 3 * l]),
-                                                    reduced=int(out[4 + 3 * l])) for l in range(int(out[1]))])
+                                                    reduced=int(out[4 + 3 * l])) for l in range(nl)],
+                    closures=int(out[2 + 3 * nl]))
 
     def fingerprint(self):
         """Hashes of every structural array + the kernel-choosing scalars (irotavg_graph_fingerprint)."""

@@ -141,6 +141,70 @@ def test_mixed_level_one():
         np.testing.assert_allclose(w, rb["weights"], rtol=1e-7)
 
 
+def closure_graph(n, m, nclose, seed, wrong=0, f=1):
+    """a view sequence (band) + nclose long-range edges, `wrong` of them with a random rotation"""
+    S = synth.make_graph(n, m, 0.0, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    a = rng.integers(f, n - 200, nclose)
+    b = np.minimum(n - 1, a + rng.integers(100, n // 2, nclose))
+    QQc = synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(nclose, 3))), synth.qmul(S["Qgt"][b], synth.qconj(S["Qgt"][a])))
+    if wrong:
+        R = rng.normal(size=(wrong, 4))
+        QQc[:wrong] = R / np.linalg.norm(R, axis=1, keepdims=True)
+    I = np.concatenate([S["I"], np.stack([a, b], 1)]).astype(np.int32)
+    QQ = np.concatenate([S["QQ"], QQc])
+    order = np.lexsort((np.arange(len(I)), I[:, 1]))      # stored under the later view, as the reference does
+    return dict(S, I=I[order], QQ=QQ[order], m=len(I))
+
+
+# 5 closures: one pass of sixteen extra right-hand sides; 20 and 40: two and three passes; 64: the most the direct
+# solver takes (four passes, a 64 x 64 Woodbury system); blocks of 8, 16 and 24
+@pytest.mark.parametrize("n,m,nclose,wrong,block", [(3000, 12000, 5, 1, 8), (3000, 45000, 20, 3, 16),
+                                                    (4000, 80000, 40, 4, 24), (5000, 20000, 64, 6, 8)])
+def test_loop_closures_on_the_direct_path_match_oracle(n, m, nclose, wrong, block):
+    """A sequence with a few loop closures -- the SLAM case (src/IRotAvg.cpp:371-378 re-solves the whole graph on
+    every closure): the band part is factorised, the closures re-enter by the Woodbury correction (bcr_solve).
+    Some closures are wrong: the robust weights must switch them off."""
+    S = closure_graph(n, m, nclose, 7, wrong)
+    Qm = mst_init(S, n)
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        assert G.direct_info()["closures"] == nclose
+        G.set_rotations(Qm)
+        a = G.l1ra(2, 1e-3)
+        Qa = G.get_rotations()
+        b = G.irls(4, SIG, 50, 1e-3)
+        Qb, w = G.get_rotations(), G.get_weights()
+        direct_stats(G.stats(), block)
+    ra = O.l1ra(S["QQ"], S["I"], Qm, 1, 2, 1e-3)
+    rb = O.irls(S["QQ"], S["I"], ra["Q"], 1, 4, SIG, 50, 1e-3)
+    assert (a["iters"], b["iters"]) == (ra["iters"], rb["iters"])
+    np.testing.assert_allclose(a["scores"], ra["scores"], rtol=1e-7)
+    assert synth.angular_distance(Qa, ra["Q"]).max() < 1e-9
+    assert synth.angular_distance(Qb, rb["Q"]).max() < 1e-9
+    np.testing.assert_allclose(w, rb["weights"], rtol=1e-7, atol=1e-12)
+
+
+def test_closure_with_zero_weight_and_too_many_closures():
+    """Talwar sets the weight of a large residual to exactly 0 (ral/l1_irls.cpp:700-707): such a closure is absent
+    from the operator -- its row of the Woodbury system is dead. 65 closures are one too many: the handle solves
+    iteratively."""
+    n = 3000
+    S = closure_graph(n, 30000, 6, 11, wrong=3)
+    Qm = mst_init(S, n)
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        G.set_rotations(Qm)
+        r = G.irls(12, SIG, 30, 1e-3)           # Talwar
+        Q, w = G.get_rotations(), G.get_weights()
+        direct_stats(G.stats(), 16)
+    ro = O.irls(S["QQ"], S["I"], Qm, 1, 12, SIG, 30, 1e-3)
+    assert (w == 0).sum() >= 3 and r["iters"] == ro["iters"]
+    assert synth.angular_distance(Q, ro["Q"]).max() < 1e-9
+    np.testing.assert_array_equal(w == 0, ro["weights"] == 0)
+    S = closure_graph(n, 30000, 65, 11)
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        assert G.stats()["band_block"] == 0 and G.direct_info()["block"] == 0
+
+
 def test_fixed_views_flipped_and_duplicate_edges():
     """f = 4 fixed views (rows = views - f; edges to fixed views only reach the diagonal and the right-hand side),
     30 % of the edges given as (j, i) -- some then have their SECOND endpoint fixed, which make_A drops
@@ -230,13 +294,16 @@ def test_option_and_environment_switch_the_path(monkeypatch):
         assert out[tag][2]["band_block"] == 0 and out[tag][2]["direct_solves"] == 0 and out[tag][2]["pcg_solves"] > 0
         assert out[tag][0] == out["direct"][0]
         assert synth.angular_distance(out[tag][1], out["direct"][1]).max() < 1e-8
-    # a loop closure puts the graph back on the iterative path
+    # a loop closure stays on the direct path (Woodbury) unless the environment says otherwise
     I = np.concatenate([S["I"], [[10, 2900]]]).astype(np.int32)
     QQ = np.concatenate([S["QQ"], synth.qmul(S["Qgt"][2900:2901], synth.qconj(S["Qgt"][10:11]))])
     monkeypatch.delenv("IROTAVG_BAND_DIRECT", raising=False)
     with capi.Graph(I, QQ, 3000, 1, band_direct=1) as G:
         st = G.stats()
-        assert st["band"] == 2890 and st["band_block"] == 0
+        assert st["band"] == 2890 and st["band_block"] == 16 and G.direct_info()["closures"] == 1
+    monkeypatch.setenv("IROTAVG_BCR_NO_CLOSURES", "1")
+    with capi.Graph(I, QQ, 3000, 1, band_direct=1) as G:
+        assert G.stats()["band_block"] == 0
 
 
 def test_one_shot_calls_take_the_direct_path_and_match_the_oracle():
