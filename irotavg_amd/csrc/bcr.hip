@@ -930,6 +930,7 @@ int bcr_levels(Graph &g) {
     return (int)g.bcr->lev.size();
 }
 
+// Called BEFORE the build (capi.cpp): a handle that solves directly gets no multigrid hierarchy at all.
 // Decides whether the handle's solves run here: one GPU, every edge between two free views within 32 views
 // (ral's I is 0-based; row = view - f) except for at most kBcrMaxFar long-range edges (loop closures: Woodbury
 // correction, bcr_solve), enough rows for the hierarchy of the iterative solver to exist at all (smaller graphs
@@ -944,15 +945,21 @@ void bcr_plan(Graph &g, const int32_t *I) {
     g.bcr_far_e.clear();
     int mode = g.opt.band_direct;
     if (const char *e = std::getenv("IROTAVG_BAND_DIRECT")) mode = std::atoi(e);
-    if (mode < 0 || g.ng > 0 || g.levels.empty() || g.levels[0].n < 1) return;
+    if (mode < 0 || g.ng > 0 || g.no < 1) return;
     const int f = g.f;
     std::atomic<int> band(0), bandall(0);
     std::atomic<long long> nfar(0);
+    std::atomic<bool> bad(false);
+    const int64_t nt = g.n_total;
     parallel_for(g.m, 65536, [&](int64_t k0, int64_t k1, int) {
         int bmax = 0, ball = 0;
         long long far = 0;
         for (int64_t k = k0; k < k1; k++) {
             const int i = I[2 * k], j = I[2 * k + 1];
+            if (i < 0 || j < 0 || i >= nt || j >= nt) {
+                bad = true;
+                return;
+            }
             if (i >= f && j >= f) {
                 const int d = std::abs(i - j);
                 ball = std::max(ball, d);
@@ -968,9 +975,10 @@ void bcr_plan(Graph &g, const int32_t *I) {
         }
         nfar += far;
     });
+    if (bad.load()) return;
     g.band0 = bandall.load();
     if (nfar.load() > kBcrMaxFar) return;
-    if (mode == 0 && g.levels[0].n <= 2048) return;
+    if (mode == 0 && g.no <= 2048) return;
     const int b0 = band.load();
     const int B = b0 <= 8 ? 8 : b0 <= 16 ? 16 : b0 <= 24 ? 24 : 32;
     if (nfar.load() > 0) {

@@ -205,12 +205,15 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
     g.ng = 0;
     g.no = g.nu;
     if (const char *e = std::getenv("IROTAVG_STALE_SPREAD")) g.stale_spread = std::max(1.0, std::atof(e));  // experiments
+    // a banded operator (+ a few loop closures) is solved directly (bcr.hip): level 0 is all such a handle needs
+    // (no coarse patterns, no dense level: a third of the build)
+    bcr_plan(g, I);  // (an edge list with an index out of range plans nothing; the build rejects it)
+    if (g.bcr_B) g.opt.mg_levels_max = 1;
     const int rc = build_graph(g, I, QQ, ldqq);
     if (rc != IROTAVG_OK) {
         irotavg_graph_destroy(h);
         return rc;
     }
-    bcr_plan(g, I);  // a banded operator is solved directly (bcr.hip)
     *out = h;
     return IROTAVG_OK;
     }

@@ -11,6 +11,17 @@ pytestmark = pytest.mark.gpu
 SIG = 5 * np.pi / 180
 
 
+@pytest.fixture(autouse=True)
+def full_hierarchy(monkeypatch, request):
+    """A handle whose systems are solved directly (banded operator, bcr.hip) builds level 0 only; this module is about
+    the WHOLE structure -- every level, both builds -- so the direct solver is switched off, except in the test that
+    holds the two builds of a direct handle against each other."""
+    if "direct" in request.node.name:
+        monkeypatch.delenv("IROTAVG_BAND_DIRECT", raising=False)
+    else:
+        monkeypatch.setenv("IROTAVG_BAND_DIRECT", "-1")
+
+
 def start(S, n, f):
     Q = np.zeros((n, 4)); Q[:, 3] = 1; Q[:f] = S["Qgt"][:f]
     ral.init_mst(Q, S["QQ"], S["I"], f)
@@ -132,3 +143,21 @@ def test_one_shot_call_takes_the_device_build_and_matches_the_handle(monkeypatch
     assert res[0][0] == res[1][0]
     np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+def test_direct_handles_build_level_zero_only_and_equally(monkeypatch):
+    """band graph, and band graph + 9 loop closures: solved directly -> one level; host and device build agree"""
+    for n, m, extra in [(30000, 450000, 0), (30000, 120000, 9)]:
+        S = synth.make_graph(n, m, 0.0, seed=2)
+        I, QQ = S["I"], S["QQ"]
+        if extra:
+            rng = np.random.default_rng(3)
+            a = rng.integers(1, n - 5000, extra); b = a + rng.integers(1000, 4000, extra)
+            I = np.concatenate([I, np.stack([a, b], 1)]).astype(np.int32)
+            QQ = np.concatenate([QQ, synth.qmul(S["Qgt"][b], synth.qconj(S["Qgt"][a]))])
+            order = np.lexsort((np.arange(len(I)), I[:, 1]))
+            I, QQ = I[order], QQ[order]
+        out = both(I, QQ, n, 1, start(dict(S, I=I, QQ=QQ), n, 1), monkeypatch, l1=1)
+        same(out)
+        st = out[0][5]
+        assert st["levels"] == 1 and st["direct_solves"] > 0 and st["pcg_solves"] == 0

@@ -87,8 +87,10 @@ def test_l1ra_then_irls_matches_oracle_at_size(n, m, p_loop, f, band_direct):
     np.testing.assert_array_equal(Qb[:f], Q0[:f])
     assert (st["direct_solves"] > 0) == (p_loop == 0.0 and band_direct == 0)
     assert (st["pcg_solves"] > 0) == (p_loop > 0.0 or band_direct == -1)
-    if n == 131000:
+    if n == 131000 and band_direct == -1:
         assert st["levels"] == 3
+    if band_direct == 0 and p_loop == 0.0:
+        assert st["levels"] == 1      # a handle that solves directly builds no hierarchy
 
 
 @pytest.mark.parametrize("p_loop", [0.0, 0.02])
