@@ -150,10 +150,10 @@ def pmc_traffic(kernel, workload):
 
 
 def _is_l0_reduce(kernel, name):
-    """k_bcr_reduce is one template for every level; the level-0 instantiation is k_bcr_reduce<B, true, ...>"""
+    """k_bcr_reduce is one template for every level; the level-0 instantiation is k_bcr_reduce<B, NR, true, ...>"""
     n = name.replace(" ", "")
     return kernel == "k_bcr_reduce_l0" and n.split("<")[0].endswith("k_bcr_reduce") and "<" in n and \
-        n.split("<")[1].split(",")[1:2] == ["true"]
+        n.split("<")[1].split(",")[2:3] == ["true"]
 
 
 def in_situ_ms(kernel, workload):
