@@ -434,8 +434,7 @@ def main():
                 "achieved": bs["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bs["gbs"] / HBM_PEAK_GBS,
                 "mfma": {"achieved": bs["tflops"], "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
                          "frac": bs["tflops"] / FP64_PEAK_TF, "flops": bs["flops"]},
-                "block": bs["block"], "levels": bs["levels"],
-                "bytes_of_the_pcg_it_replaces": None}
+                "block": bs["block"], "levels": bs["levels"]}
         if "cg_apply" in kr and "cg_update" in kr:
             # the whole PCG iteration (both launches) against SURVEY.md 8(d)'s own K4 + K5 bytes: the dense inverse
             # every tile slice re-reads and the coarse vectors are this design's cost, not algorithmic traffic
