@@ -992,7 +992,27 @@ void bcr_plan(Graph &g, const int32_t *I) {
                 g.bcr_far_e.push_back((int)k);
             }
         }
-        if (!g.bcr_far_e.empty() && (B > 24 || getenv("IROTAVG_BCR_NO_CLOSURES"))) {  // closure columns: LDS of the 32-row blocks
+        bool refuse = !g.bcr_far_e.empty() && (B > 24 || getenv("IROTAVG_BCR_NO_CLOSURES"));  // closure columns: LDS of the 32-row blocks
+        if (!g.bcr_far_e.empty() && !refuse) {
+            // The Woodbury correction needs the BAND part alone to be positive definite: every free view must be
+            // tied to a fixed one through band edges. Sufficient and cheap: every view has a band edge to an earlier
+            // view or an edge to a fixed view that the IRLS system keeps (make_A drops an edge whose SECOND endpoint
+            // is fixed, ral/l1_irls.cpp:770-771). A sequence whose band part falls apart (a stretch that only a
+            // closure ties to the rest) is left to the iterative solver.
+            std::vector<uint8_t> ok((size_t)g.no, 0);
+            parallel_for(g.m, 65536, [&](int64_t k0, int64_t k1, int) {
+                for (int64_t k = k0; k < k1; k++) {
+                    const int i = I[2 * k], j = I[2 * k + 1];
+                    if (i >= f && j >= f) {
+                        if (i != j && std::abs(i - j) <= 32) ok[(size_t)(std::max(i, j) - f)] = 1;  // benign race: all write 1
+                    } else if (i < f && j >= f) {
+                        ok[(size_t)(j - f)] = 1;
+                    }
+                }
+            });
+            for (int r = 0; r < g.no && !refuse; r++) refuse = !ok[(size_t)r];
+        }
+        if (refuse) {
             g.bcr_far_i.clear();
             g.bcr_far_j.clear();
             g.bcr_far_e.clear();
