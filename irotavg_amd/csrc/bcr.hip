@@ -49,6 +49,10 @@ struct BcrState {
     DevBuf<double> xtop;  // B x NR: the last separator
     DevBuf<int> far_i, far_j, far_e;  // rows and edge id of the closures
     DevBuf<double> Z, lam;            // A_b^-1 V (rows x zstride), lambda (64 x 3)
+    // a shard of a sharded sequence (dist.hip): the separator before the first chunk is the previous rank's
+    int ext0 = 0;
+    DevBuf<int> ghost_extcol;  // per ghost view: its row in the previous rank's last block, or -1
+    DevBuf<double> remD, remR; // what this shard's eliminations subtract from that separator (sum over its levels)
 };
 
 void BcrDeleter::operator()(BcrState *p) const { delete p; }
@@ -388,6 +392,26 @@ __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int
         }
 }
 
+// Where the k real blocks of a PARTIAL chunk sit among its eight positions. By default the first k (the rest is
+// padding: identity blocks without couplings, whose eliminations are skipped) -- the chunk's separator, position 7, is
+// then padding and its last real block is eliminated like any other: fine when nothing lies to its right. A SHARD's
+// last block is coupled to the next rank and must survive as the separator at every level: its partial chunks place
+// their blocks such that the last one sits at position 7 and every padding position is eliminated (= skipped) before
+// it would be the neighbour of a real elimination in the (0 2 4 6)(1 5)(3) schedule. The coupling of the real block at
+// position p to the next real block lives in slot p + 1, the one to the separator before the chunk in slot 0.
+__constant__ signed char kBcrPlace[9][8] = {{-1, -1, -1, -1, -1, -1, -1, -1}, {7, -1, -1, -1, -1, -1, -1, -1},
+                                             {3, 7, -1, -1, -1, -1, -1, -1},   {3, 5, 7, -1, -1, -1, -1, -1},
+                                             {1, 3, 5, 7, -1, -1, -1, -1},     {1, 3, 5, 6, 7, -1, -1, -1},
+                                             {1, 3, 4, 5, 6, 7, -1, -1},       {1, 2, 3, 4, 5, 6, 7, -1},
+                                             {0, 1, 2, 3, 4, 5, 6, 7}};
+__device__ __forceinline__ int bcr_pos(bool placed, int k, int t) { return placed ? (int)kBcrPlace[k][t] : t; }
+__device__ __forceinline__ int bcr_ridx(bool placed, int k, int i) {
+    if (!placed) return i < k ? i : -1;
+    for (int t = 0; t < k; t++)
+        if (kBcrPlace[k][t] == i) return t;
+    return -1;
+}
+
 // One chunk of eight blocks per workgroup of NW waves (4, or 8 when the level has so few chunks that every
 // workgroup has a CU to itself: the column tiles of W are then dealt to two waves in the first round and four afterwards).
 // L0: the blocks are gathered from the level-0 SELL operator (off-diagonals), its diagonal and right-hand side;
@@ -403,7 +427,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     const double *__restrict__ inR, const double *__restrict__ inXD, const double *__restrict__ inXR,
     const double *__restrict__ inXG, double *__restrict__ W, double *__restrict__ sepD, double *__restrict__ sepR,
     double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop, int dbg,
-    int nfar, const int *__restrict__ far_i, const int *__restrict__ far_j) {
+    int nfar, const int *__restrict__ far_i, const int *__restrict__ far_j, int ext0, const int *__restrict__ bptr,
+    const int *__restrict__ bghost, const double *__restrict__ bval, const int *__restrict__ ghost_extcol, int place) {
     typedef BcrDim<B, NR> Dm;
     constexpr int BB = B * B;
     __shared__ double sD[8][BB];   // sD[0] becomes the chunk's contribution to the separator before it
@@ -413,8 +438,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = blockIdx.x;
-    const bool hasExt = chunk > 0;
+    // ext0: this handle is a SHARD of a sequence (dist.hip) and the separator before its first chunk is the last block
+    // of the rank before it -- same algebra, the coupling comes from the boundary slots of the ghost views
+    const bool hasExt = chunk > 0 || ext0;
     constexpr int NT_ = NW * 64;  // threads
+    const int kreal = nb - chunk * 8 < 8 ? nb - chunk * 8 : 8;  // real blocks of this chunk
+    const bool placed = place && kreal < 8;                      // ... placed so that the last one is the separator
 
     // ---- load ----
     for (int e = tid; e < 8 * BB; e += NT_) {
@@ -426,30 +455,48 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     __syncthreads();
     if (L0) {
         const int row0 = chunk * 8 * B;
-        for (int t = tid; t < 8 * B; t += NT_) {
+        for (int t = tid; t < kreal * B; t += NT_) {
             const int row = row0 + t, blk = t / B, r = t - blk * B;
+            const int ps = bcr_pos(placed, kreal, blk);
             if (row < n)
-                bcr_gather_row<B, NR>(row, chunk * 8 + blk, r, sl_off, col, val, diag, rhs, sD[blk],
-                                      blk < 7 ? sG[blk + 1] : nullptr, blk == 0 ? sG[0] : nullptr, sR[blk + 1], nfar,
+                bcr_gather_row<B, NR>(row, chunk * 8 + blk, r, sl_off, col, val, diag, rhs, sD[ps],
+                                      ps < 7 ? sG[ps + 1] : nullptr, blk == 0 ? sG[0] : nullptr, sR[ps + 1], nfar,
                                       far_i, far_j);
             else
-                sD[blk][r * B + r] = 1.0;
+                sD[ps][r * B + r] = 1.0;
+        }
+        // (position 0 of a placed chunk stays zero: sD[0] collects the chunk's contribution to the separator before it,
+        // and nothing assigns it first when no real block sits there)
+        for (int i = placed ? 1 : 0; i < 8; i++)
+            if (bcr_ridx(placed, kreal, i) < 0)
+                for (int e = tid; e < B; e += NT_) sD[i][e * B + e] = 1.0;
+        if (ext0 && chunk == 0) {
+            // coupling (last block of the previous rank) -> block 0: the ghost entries of block 0's rows, -w each
+            // (k_assemble0w leaves the weight of every boundary slot in bval); a thread owns column r of sG[0]
+            for (int r = tid; r < B && r < n; r += NT_)
+                for (int sl = bptr[r]; sl < bptr[r + 1]; sl++) {
+                    const int gi = bghost[sl];
+                    const int ec = gi >= 0 ? ghost_extcol[gi] : -1;
+                    if (ec >= 0) sG[0][ec * B + r] -= bval[sl];
+                }
         }
     } else {
         // blocks below nred come from the level below; the others (a mixed level 1, see bcr_alloc) are blocks of
         // the level-0 operator that no chunk reduced: block gb is level-0 block 8 nred + (gb - nred). Every block
         // brings the coupling from its predecessor along (slot i; slot 0: from the separator before the chunk).
         for (int i = 0; i < 8; i++) {
-            const int gb = chunk * 8 + i;
-            if (gb < nred) {
+            const int t = bcr_ridx(placed, kreal, i);
+            const int gb = chunk * 8 + t;
+            if (t >= 0 && gb < nred) {
                 const bool nxt = gb + 1 < nred;
+                const int slot = t > 0 ? bcr_pos(placed, kreal, t - 1) + 1 : 0;
                 for (int e = tid; e < BB; e += NT_) {
                     sD[i][e] = inD[(size_t)gb * BB + e] + (nxt ? inXD[(size_t)(gb + 1) * BB + e] : 0.0);
-                    if (gb > 0) sG[i][e] = inXG[(size_t)gb * BB + e];
+                    if (gb > 0 || ext0) sG[slot][e] = inXG[(size_t)gb * BB + e];
                 }
                 for (int e = tid; e < B * NR; e += NT_)
                     sR[i + 1][e] = inR[(size_t)gb * B * NR + e] + (nxt ? inXR[(size_t)(gb + 1) * B * NR + e] : 0.0);
-            } else if (gb >= nb) {
+            } else if (t < 0 && !(placed && i == 0)) {  // (sD[0] of a placed chunk: see the level-0 branch)
                 for (int e = tid; e < B; e += NT_) sD[i][e * B + e] = 1.0;
             }
         }
@@ -493,7 +540,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
                 i = 3;                                                                                              \
             }                                                                                                       \
         }                                                                                                           \
-        const bool active = i >= 0 && chunk * 8 + i < nb;                                                           \
+        const bool active = i >= 0 && bcr_ridx(placed, kreal, i) >= 0;                                              \
         const bool hasP = a >= 0 || hasExt;                                                                         \
         if (active && part == 0 && !(dbg & 1)) bcr_invert<B>(sD[i], lane);                                                        \
         __syncthreads();                                                                                            \
@@ -516,7 +563,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     // ---- store ----
     if (TOP) {
         if (wave == 0) {
-            if (7 < nb) {
+            if (bcr_ridx(placed, kreal, 7) >= 0) {
                 bcr_invert<B>(sD[7], lane);
                 for (int o = lane; o < B * NR; o += 64) {
                     const int k = o / NR, q = o - NR * k;
@@ -550,7 +597,7 @@ template <int B, int NR, bool L0>
 __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const double *__restrict__ W,
                                                    const double *__restrict__ xc, double *__restrict__ xl,
                                                    double4 *__restrict__ X, double *__restrict__ Z, int zstride,
-                                                   int zoff, int nfar) {
+                                                   int zoff, int nfar, const double *__restrict__ xext, int place) {
     typedef BcrDim<B, NR> Dm;
     constexpr int WB = B * Dm::NC;     // doubles of one W block
     __shared__ double sW[7 * WB];
@@ -558,8 +605,9 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = blockIdx.x;
-    int nblk = nb - chunk * 8;  // blocks of this chunk that exist (the separator, block 7, is not staged)
-    nblk = nblk > 7 ? 7 : nblk;
+    const int kreal = nb - chunk * 8 < 8 ? nb - chunk * 8 : 8;
+    const bool placed = place && kreal < 8;  // see kBcrPlace
+    const int nblk = placed || kreal > 7 ? 7 : kreal;  // W blocks to stage (the separator, position 7, has none)
     {
         const v2d *__restrict__ src = reinterpret_cast<const v2d *>(W + (size_t)chunk * 7 * WB);
         v2d *dst = reinterpret_cast<v2d *>(sW);
@@ -571,6 +619,7 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
     for (int e = tid; e < B * NR; e += 256) {
         sX[8][e] = xc[(size_t)chunk * B * NR + e];
         if (chunk > 0) sX[0][e] = xc[(size_t)(chunk - 1) * B * NR + e];
+        else if (xext) sX[0][e] = xext[e];   // a shard: the separator of the rank before it (dist.hip)
     }
     __syncthreads();
     const int lk = lane >> 4, lp = lane & 15;
@@ -590,7 +639,7 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
         } else if (wave == 0) {
             i = 3;
         }
-        if (i >= 0 && chunk * 8 + i < nb) {
+        if (i >= 0 && bcr_ridx(placed, kreal, i) >= 0) {
             const double *Wi = sW + i * WB;
             const double *xa = sX[a + 1], *xcn = sX[c + 1];
             if (NR == 3) {
@@ -655,12 +704,16 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
     };
     if (L0) {
         const int row0 = chunk * 8 * B;
-        for (int t = tid; t < 8 * B; t += 256) {
-            const int row = row0 + t;
-            if (row < n) put_row(row, t);
+        for (int t = tid; t < kreal * B; t += 256) {
+            const int row = row0 + t, blk = t / B;
+            if (row < n) put_row(row, bcr_pos(placed, kreal, blk) * B + (t - blk * B));
         }
     } else {
-        for (int e = tid; e < 8 * B * NR; e += 256) xl[(size_t)chunk * 8 * B * NR + e] = (&sX[1][0])[e];
+        for (int e = tid; e < 8 * B * NR; e += 256) {
+            const int blk = e / (B * NR);
+            xl[(size_t)chunk * 8 * B * NR + e] =
+                blk < kreal ? (&sX[1][0])[bcr_pos(placed, kreal, blk) * B * NR + (e - blk * B * NR)] : 0.0;
+        }
         // blocks of a mixed level that are level-0 blocks themselves: their solution rows
         if (chunk * 8 + 8 > nred && nred < nb)
             for (int t = tid; t < 8 * B; t += 256) {
@@ -776,11 +829,11 @@ static void bcr_alloc(Graph &g) {
     int nraw = 0;
     {
         int ncu = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, g.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g.device);
+        if (ncu <= 0) ncu = 256;
         const int cap = ncu * (B <= 24 && NR == 3 ? 2 : 1);
         const int full = nch0 / cap * cap, rem = nch0 - full;
-        if (full > 0 && rem > 0 && rem <= cap / 4 && !getenv("IROTAVG_BCR_NO_MIXED")) {
+        if (full > 0 && rem > 0 && rem <= cap / 4 && !g.bcr_shard && !getenv("IROTAVG_BCR_NO_MIXED")) {
             nraw = nb0 - 8 * full;
             nch0 = full;
         }
@@ -794,14 +847,22 @@ static void bcr_alloc(Graph &g) {
         L.nred = (l == 1 && nraw > 0) ? nb - nraw : nb;
         L.W.alloc((size_t)L.nch * 7 * B * NC);
         if (l > 0) L.x.alloc((size_t)L.nch * 8 * B * NR);
-        if (nb <= 8) break;
+        if (nb <= 8 && !g.bcr_shard) break;
         L.sepD.alloc((size_t)L.nch * B * B);
         L.extD.alloc((size_t)L.nch * B * B);
         L.extG.alloc((size_t)L.nch * B * B);
         L.sepR.alloc((size_t)L.nch * B * NR);
         L.extR.alloc((size_t)L.nch * B * NR);
+        if (nb <= 8) break;
         nb = L.nch + (l == 0 ? nraw : 0);
         nch = (nb + 7) / 8;
+    }
+    if (g.bcr_shard) {
+        S.ext0 = g.bcr_ext0;
+        S.ghost_extcol.upload(g.bcr_ghost_extcol, g.stream);
+        S.remD.alloc((size_t)B * B);
+        S.remR.alloc((size_t)B * NR);
+        IRH_CHECK(hipStreamSynchronize(g.stream));
     }
     S.xtop.alloc((size_t)B * NR);
     if (S.nfar > 0) {
@@ -815,8 +876,12 @@ static void bcr_alloc(Graph &g) {
     }
 }
 
+// open_top: the last level writes its separator data like every other level instead of solving it (a shard: the
+// separators of all ranks form the top system, bcr_top_solve); xc_top / xext: its solution and the solution of the
+// previous rank's separator for the way back
 template <int B, int NR>
-static void bcr_run(Graph &g, int only, int pass) {
+static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int phase = 0, const double *xc_top = nullptr,
+                    const double *xext = nullptr) {
     BcrState &S = *g.bcr;
     Level &L0 = g.levels[0];
     hipStream_t st = g.stream;
@@ -824,15 +889,16 @@ static void bcr_run(Graph &g, int only, int pass) {
     const int dbg = getenv("IROTAVG_BCR_DBG") ? atoi(getenv("IROTAVG_BCR_DBG")) : 0;
     const int nfar = NR > 3 ? std::min(16, S.nfar - 16 * pass) : 0;
     const int *fi = NR > 3 ? S.far_i.p + 16 * pass : nullptr, *fj = NR > 3 ? S.far_j.p + 16 * pass : nullptr;
-    for (int l = 0; l < nl; l++) {
+    for (int l = 0; l < nl && phase != 2; l++) {
         if (only >= 0 && only != l) continue;
         BcrLevel &L = S.lev[l];
         const BcrLevel *F = l > 0 ? &S.lev[l - 1] : nullptr;
-        const bool top = l == nl - 1;
+        const bool top = l == nl - 1 && !open_top;
 #define IRH_BCR_ARGS                                                                                             \
     L.nb, L.nred, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p, L0.b.p, F ? F->sepD.p : nullptr,             \
         F ? F->sepR.p : nullptr, F ? F->extD.p : nullptr, F ? F->extR.p : nullptr, F ? F->extG.p : nullptr, L.W.p, \
-        L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p, dbg, nfar, fi, fj
+        L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p, dbg, nfar, fi, fj, S.ext0, g.bptr.p, g.bghost.p,  \
+        g.bval.p, S.ghost_extcol.p, (int)g.bcr_shard
         // eight waves per chunk when every chunk has a CU to itself (see k_bcr_reduce)
         const bool wide = L.nch <= 256 && !getenv("IROTAVG_BCR_NARROW");
 #define IRH_BCR_LAUNCH(L0_, TOP_)                                                                                   \
@@ -856,16 +922,16 @@ static void bcr_run(Graph &g, int only, int pass) {
 #undef IRH_BCR_LAUNCH
 #undef IRH_BCR_ARGS
     }
-    for (int l = nl - 1; l >= 0; l--) {
+    for (int l = nl - 1; l >= 0 && phase != 1; l--) {
         if (only >= 0 && only != 100 + l) continue;
         BcrLevel &L = S.lev[l];
-        const double *xc = l == nl - 1 ? S.xtop.p : S.lev[l + 1].x.p;
+        const double *xc = l == nl - 1 ? (open_top ? xc_top : S.xtop.p) : S.lev[l + 1].x.p;
         if (l == 0)
             hipLaunchKernelGGL((k_bcr_back<B, NR, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               (double *)nullptr, g.X.p + g.ng, S.Z.p, S.zstride, 16 * pass, nfar);
+                               (double *)nullptr, g.X.p + g.ng, S.Z.p, S.zstride, 16 * pass, nfar, xext, (int)g.bcr_shard);
         else
             hipLaunchKernelGGL((k_bcr_back<B, NR, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               L.x.p, g.X.p + g.ng, S.Z.p, S.zstride, 16 * pass, nfar);
+                               L.x.p, g.X.p + g.ng, S.Z.p, S.zstride, 16 * pass, nfar, xext, (int)g.bcr_shard);
     }
 }
 
@@ -888,6 +954,101 @@ static void bcr_run_all(Graph &g, int only) {
         hipLaunchKernelGGL(k_bcr_apply_lambda, dim3((n + 255) / 256), dim3(256), 0, g.stream, n, S.nfar, S.Z.p,
                            S.zstride, S.lam.p, g.X.p + g.ng);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the sharded form (dist.hip): a rank's range of the sequence is reduced to its last block; the separators of the
+// `world` <= 8 ranks are one chunk, solved redundantly by every rank after ONE gather
+// ---------------------------------------------------------------------------------------------
+struct BcrPtrs {
+    const double *d[kMaxLevels], *r[kMaxLevels];
+    int n;
+};
+// remote contributions summed over the shard's levels (chunk 0 of each) and, with the top level's separator data,
+// written into this rank's slices of the top buffer
+template <int B>
+__global__ __launch_bounds__(256) void k_bcr_pack_top(BcrPtrs P, int ext0, const double *__restrict__ sepD,
+                                                      const double *__restrict__ sepR, const double *__restrict__ extG,
+                                                      double *__restrict__ buf, int world, int rank) {
+    constexpr int BB = B * B, BR = B * 3;
+    double *oD = buf + (size_t)rank * BB, *oXD = buf + (size_t)world * BB + (size_t)rank * BB,
+           *oXG = buf + (size_t)2 * world * BB + (size_t)rank * BB,
+           *oR = buf + (size_t)3 * world * BB + (size_t)rank * BR,
+           *oXR = buf + (size_t)3 * world * BB + (size_t)world * BR + (size_t)rank * BR;
+    for (int e = threadIdx.x; e < BB; e += 256) {
+        oD[e] = sepD[e];
+        double sacc = 0.0;
+        if (ext0)
+            for (int l = 0; l < P.n; l++) sacc += P.d[l][e];
+        oXD[e] = sacc;
+        oXG[e] = ext0 ? extG[e] : 0.0;
+    }
+    for (int e = threadIdx.x; e < BR; e += 256) {
+        oR[e] = sepR[e];
+        double sacc = 0.0;
+        if (ext0)
+            for (int l = 0; l < P.n; l++) sacc += P.r[l][e];
+        oXR[e] = sacc;
+    }
+}
+
+void bcr_top_alloc(BcrTop &T, int B, int world) {
+    T.B = B;
+    T.world = world;
+    T.buf.alloc(T.n_doubles());
+    T.W.alloc((size_t)7 * B * (2 * B + 3));
+    T.x.alloc((size_t)8 * B * 3);
+    T.xtop.alloc((size_t)B * 3);
+}
+
+template <int B>
+static void bcr_shard_reduce_t(Graph &g, BcrTop &T, int rank) {
+    bcr_run<B, 3>(g, -1, 0, true, 1);
+    BcrState &S = *g.bcr;
+    BcrPtrs P;
+    P.n = (int)S.lev.size();
+    for (int l = 0; l < P.n; l++) {
+        P.d[l] = S.lev[l].extD.p;  // chunk 0 of every level
+        P.r[l] = S.lev[l].extR.p;
+    }
+    BcrLevel &L = S.lev.back();
+    hipLaunchKernelGGL((k_bcr_pack_top<B>), dim3(1), dim3(256), 0, g.stream, P, S.ext0, L.sepD.p, L.sepR.p, L.extG.p,
+                       T.buf.p, T.world, rank);
+}
+template <int B>
+static void bcr_top_solve_t(Graph &g, BcrTop &T) {
+    const int W = T.world;
+    const size_t BB = (size_t)B * B, BR = (size_t)B * 3;
+    double *buf = T.buf.p;
+    const double *nul = nullptr;
+    hipLaunchKernelGGL((k_bcr_reduce<B, 3, false, true, 4>), dim3(1), dim3(256), 0, g.stream, W, W, 0, (const int *)nullptr,
+                       (const int *)nullptr, nul, nul, (const double4 *)nullptr, buf, buf + 3 * W * BB, buf + W * BB,
+                       buf + 3 * W * BB + W * BR, buf + 2 * W * BB, T.W.p, (double *)nullptr, (double *)nullptr,
+                       (double *)nullptr, (double *)nullptr, (double *)nullptr, T.xtop.p, 0, 0, (const int *)nullptr,
+                       (const int *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, nul, (const int *)nullptr, 0);
+    hipLaunchKernelGGL((k_bcr_back<B, 3, false>), dim3(1), dim3(256), 0, g.stream, W, W, 0, T.W.p, T.xtop.p, T.x.p,
+                       (double4 *)nullptr, (double *)nullptr, 0, 0, 0, nul, 0);
+}
+template <int B>
+static void bcr_shard_back_t(Graph &g, BcrTop &T, int rank) {
+    const double *xs = T.x.p + (size_t)rank * B * 3;
+    bcr_run<B, 3>(g, -1, 0, true, 2, xs, rank > 0 ? xs - (size_t)B * 3 : nullptr);
+}
+#define IRH_BCR_DISPATCH(fn, ...)              \
+    switch (g.bcr_B) {                         \
+    case 8: fn<8>(__VA_ARGS__); break;         \
+    case 16: fn<16>(__VA_ARGS__); break;       \
+    case 24: fn<24>(__VA_ARGS__); break;       \
+    default: fn<32>(__VA_ARGS__); break;       \
+    }
+void bcr_shard_reduce(Graph &g, BcrTop &T, int rank) {
+    bcr_alloc(g);
+    IRH_BCR_DISPATCH(bcr_shard_reduce_t, g, T, rank)
+}
+void bcr_top_solve(Graph &g, BcrTop &T) { IRH_BCR_DISPATCH(bcr_top_solve_t, g, T) }
+void bcr_shard_back(Graph &g, BcrTop &T, int rank) {
+    IRH_BCR_DISPATCH(bcr_shard_back_t, g, T, rank)
+    g.stats.direct_solves += 1;
 }
 
 // levels[0] values, diagonal and right-hand side (assemble_values) -> g.X. Asynchronous; only >= 0 launches one

@@ -55,6 +55,12 @@ struct Dist {
     hipStream_t stream = nullptr;
     irotavg_options opt{};
     irotavg_stats stats{};
+    // A view sequence without loop closures is solved DIRECTLY also when it is sharded (bcr.hip): every rank
+    // reduces its range of the banded operator to its last block, ONE gather of the `world` separators replaces
+    // the ~22 halo exchanges + all-reduces of a PCG solve, every rank solves the separator system and walks back.
+    int bcr_B = 0;  // block size; 0: the sharded PCG
+    int band0 = -1;
+    BcrTop top;
 };
 
 #define NCCL_CHECK(expr)                                                                      \
@@ -255,13 +261,18 @@ struct ShardPlan {
     std::vector<int> send_idx;         // owned-local indices to pack, grouped by peer, ascending
 };
 
-static int64_t chunk_of(int64_t nu, int world) { return ((nu + world - 1) / world + 63) / 64 * 64; }
+// shard size: a multiple of 64 views (slices / tiles of the row kernels); for the sharded direct solver a multiple of
+// 192 = of 64 and of every block size (8, 16, 24, 32: a rank's last block must be a full one for its neighbour's
+// coupling to fit it)
+static int64_t chunk_of(int64_t nu, int world, int align = 64) {
+    return ((nu + world - 1) / world + align - 1) / align * align;
+}
 
 static int plan_shard(int world, int rank, int64_t m, int64_t n_total, int f, const int32_t *I,
-                      ShardPlan &P) {
+                      ShardPlan &P, int align = 64) {
     const int64_t nu = n_total - f;
     P.rank = rank;
-    P.chunk = chunk_of(nu, world);
+    P.chunk = chunk_of(nu, world, align);
     if ((int64_t)(world - 1) * P.chunk >= nu) return IROTAVG_ERR_BAD_ARG;  // a shard would be empty
     P.lo = (int64_t)rank * P.chunk;
     P.hi = rank == world - 1 ? nu : (int64_t)(rank + 1) * P.chunk;
@@ -327,7 +338,7 @@ static int plan_shard(int world, int rank, int64_t m, int64_t n_total, int f, co
 static int build_shard(Dist &D, Shard &S, const int32_t *I, const double *QQ, int64_t ldqq) {
     const int f = D.f;
     ShardPlan P;
-    int rc = plan_shard(D.world, S.rank, D.m, D.n_total, f, I, P);
+    int rc = plan_shard(D.world, S.rank, D.m, D.n_total, f, I, P, D.bcr_B ? 192 : 64);
     if (rc != IROTAVG_OK) return rc;
     S.lo = P.lo;
     S.hi = P.hi;
@@ -379,6 +390,24 @@ static int build_shard(Dist &D, Shard &S, const int32_t *I, const double *QQ, in
     g.no = (int)no;
     g.nu = ng + (int)no;
     g.force_np = 1;
+    if (D.bcr_B) {
+        // solved directly: level 0 is all the handle needs; the ghosts owned by the rank before this one are rows of
+        // that rank's LAST block (its range is a multiple of the block size, the band is at most a block)
+        g.opt.mg_levels_max = 1;
+        g.bcr_B = D.bcr_B;
+        g.band0 = D.band0;
+        g.bcr_shard = true;
+        g.bcr_ext0 = S.rank > 0 ? 1 : 0;
+        g.bcr_ghost_extcol.assign((size_t)std::max(ng, 1), -1);
+        const int64_t plo = S.lo - D.chunk;  // the previous rank's range is [plo, S.lo)
+        for (int q = 0; q < ng; q++) {
+            const int64_t gfree = (int64_t)P.ghosts[q] - f;
+            if (S.rank > 0 && gfree >= plo && gfree < S.lo) {
+                const int64_t ec = (gfree - plo) - (D.chunk - D.bcr_B);
+                g.bcr_ghost_extcol[(size_t)q] = ec >= 0 ? (int)ec : -1;
+            }
+        }
+    }
     rc = build_graph(g, Il.data(), QQl.data(), ml);
     if (rc != IROTAVG_OK) return rc;
     S.peers = P.peers;
@@ -629,6 +658,29 @@ static int pcg_dist_any(Dist &D) {
     return ok ? pcg_dist_cg(D) : pcg_dist(D);
 }
 
+// The direct solve of a sharded sequence: local reductions, one gather, the separator system, the ways back.
+static int bcr_dist(Dist &D) {
+    BcrTop &T = D.top;
+    IRH_CHECK(hipMemsetAsync(T.buf.p, 0, sizeof(double) * T.n_doubles(), D.stream));
+    for (auto &sp : D.shards) bcr_shard_reduce(sp->g, T, sp->rank);
+    if (D.hosted) {
+        D.hbuf.assign(T.n_doubles(), 0.0);
+        IRH_CHECK(hipMemcpyAsync(D.hbuf.data(), T.buf.p, sizeof(double) * T.n_doubles(), hipMemcpyDeviceToHost, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+        if (D.tr.allreduce(D.tr.ctx, D.hbuf.data(), (int)T.n_doubles(), 0) != 0) throw HipError{hipErrorUnknown};
+        IRH_CHECK(hipMemcpyAsync(T.buf.p, D.hbuf.data(), sizeof(double) * T.n_doubles(), hipMemcpyHostToDevice, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));  // hbuf is reused
+    } else if (D.use_rccl) {
+        // every rank wrote its own slices into a zeroed buffer: the sum over the ranks is the gather
+        NCCL_CHECK(ncclAllReduce(T.buf.p, T.buf.p, T.n_doubles(), ncclDouble, ncclSum, D.comm, D.stream));
+    }  // loopback: the shards of this process share the buffer
+    bcr_top_solve(D.shards[0]->g, T);
+    for (auto &sp : D.shards) bcr_shard_back(sp->g, T, sp->rank);
+    D.stats.direct_solves += 1;
+    return IROTAVG_OK;
+}
+static int solve_dist(Dist &D) { return D.bcr_B ? bcr_dist(D) : pcg_dist_any(D); }
+
 static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double change_th, int *iters,
                      double *runtime, double *trace) {
     if (cost < IROTAVG_L2 || cost > IROTAVG_WELSCH) return IROTAVG_ERR_UNKNOWN_COST;
@@ -641,7 +693,7 @@ static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double chan
             launch_edge_residual(sp->g);
             assemble(sp->g, 0, sp->g.dw.p, D.opt.dense_always_refresh == 1);
         }
-        rc = pcg_dist_any(D);
+        rc = solve_dist(D);
         if (rc != IROTAVG_OK) break;
         halo_exchange(D, HALO_X);  // ghost views receive their owners' steps
         double local = 0.0;
@@ -691,7 +743,7 @@ static int l1ra_dist(Dist &D, int max_iters, double change_th, int *iters, doubl
             G.m_global = D.m;
             G.combine = [&D](double *v, int n, int op) { combine_host(D, v, n, op); };
             G.halo_x = [&D]() { halo_exchange(D, HALO_X); };
-            G.solve = [&D]() { return pcg_dist_any(D); };
+            G.solve = [&D]() { return solve_dist(D); };
             rc = l1decode_group(G, l1_step, kPdXPlane0 + c, nullptr);
         }
         if (rc != IROTAVG_OK) break;
@@ -780,11 +832,29 @@ static int dist_create_impl(irotavg_dist **out, int world, int rank, const void 
         D.n_total = n_total;
         D.f = f;
         D.nu = n_total - f;
-        D.chunk = chunk_of(D.nu, world);
+        {   // the direct solver for a sharded view sequence? Decided from the GLOBAL graph: every process agrees.
+            int mode = D.opt.band_direct;
+            if (const char *e = std::getenv("IROTAVG_BAND_DIRECT")) mode = std::atoi(e);
+            int band = 0;
+            bool ok = mode >= 0 && world <= 8;
+            for (int64_t k = 0; k < m && ok; k++) {
+                const int i = I[2 * k], j = I[2 * k + 1];
+                if (i < 0 || j < 0 || i >= n_total || j >= n_total) ok = false;
+                else if (i >= f && j >= f) band = std::max(band, std::abs(i - j));
+            }
+            D.band0 = ok ? band : -1;
+            if (ok && band <= 32 && (mode > 0 || D.nu > 2048)) {
+                const int B = band <= 8 ? 8 : band <= 16 ? 16 : band <= 24 ? 24 : 32;
+                const int64_t c192 = chunk_of(D.nu, world, 192);
+                if (c192 >= 2 * B && (int64_t)(world - 1) * c192 < D.nu) D.bcr_B = B;
+            }
+        }
+        D.chunk = chunk_of(D.nu, world, D.bcr_B ? 192 : 64);
         if ((int64_t)(world - 1) * D.chunk >= D.nu) {  // every shard needs at least one view
             irotavg_dist_destroy(h);
             return IROTAVG_ERR_BAD_ARG;
         }
+        if (D.bcr_B) bcr_top_alloc(D.top, D.bcr_B, world);
         D.hosted = tr != nullptr;
         if (D.hosted) D.tr = *tr;
         D.use_rccl = !loopback && !D.hosted;
@@ -928,6 +998,7 @@ int irotavg_dist_info(irotavg_dist *h, int64_t info[8]) {
     info[3] = D.world;
     for (auto &sp : D.shards) info[4] += sp->g.ng;
     info[5] = D.shards.empty() ? 0 : (int64_t)D.shards[0]->peers.size();
+    info[6] = D.bcr_B;  // block size of the sharded direct solver (0: the sharded PCG)
     return IROTAVG_OK;
     API_CATCH
 }

@@ -126,6 +126,10 @@ struct Graph {
     std::vector<int> bcr_far_i, bcr_far_j, bcr_far_e;  // long-range edges (rows, edge id): Woodbury correction
     const double *bcr_wsrc = nullptr;                  // per-edge weights of the last assembly and whether the
     int bcr_wsquare = 0;                               // operator holds their squares (IRLS) -- assemble_values
+    // a shard of a sharded sequence solved directly (dist.hip): bcr_ext0 = a rank lies before this one
+    bool bcr_shard = false;
+    int bcr_ext0 = 0;
+    std::vector<int> bcr_ghost_extcol;                 // per ghost view: row in the previous rank's last block or -1
 
     double last_score_sum = 0.0;
     double irls_settle = -1.0;  // run_irls: > 0 while the last step was small enough for the weights to have settled (assemble())
@@ -242,6 +246,17 @@ void bcr_plan(Graph &g, const int32_t *I);  // sets Graph::bcr_B / band0 (capi.c
 int bcr_solve(Graph &g, int only = -1);     // levels[0] values / diagonal / right-hand side -> g.X, asynchronous
 int bcr_levels(Graph &g);
 int bcr_info(Graph &g, int64_t *out, int cap);
+// the sharded form (dist.hip): every rank reduces its range to its last block; the `world` separators are one chunk
+struct BcrTop {
+    int B = 0, world = 0;
+    DevBuf<double> buf;         // [sepD | extD | extG | sepR | extR], `world` blocks each: filled by the ranks, summed over them
+    DevBuf<double> W, x, xtop;  // factor and solution of the separator system (8 blocks)
+    size_t n_doubles() const { return (size_t)world * (3 * (size_t)B * B + 2 * (size_t)B * 3); }
+};
+void bcr_top_alloc(BcrTop &T, int B, int world);
+void bcr_shard_reduce(Graph &g, BcrTop &T, int rank);  // local reduction; this rank's slices of T.buf
+void bcr_top_solve(Graph &g, BcrTop &T);               // after T.buf holds every rank's slices
+void bcr_shard_back(Graph &g, BcrTop &T, int rank);    // -> g.X (owned rows)
 // dense.hip
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);
