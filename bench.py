@@ -380,12 +380,18 @@ def main():
                                    "max_iters=100" % (S["n"], S["m"], args.p_loop, args.seed),
                        "linear_solver": ("banded direct solver (block cyclic reduction, blocks of %d; band %d)" % (
                                              st["band_block"], st["band"]) if st.get("direct_solves", 0) > 0 and dstats is None
-                                         else "multigrid-preconditioned CG"),
-                       "direct_solves": st.get("direct_solves", 0) if dstats is None else 0,
+                                         else ("sharded banded direct solver (blocks of %d: local reductions, ONE gather of the "
+                                               "%d separators per linear solve, separator system on every rank)" % (
+                                                   dinfo["direct_block"], world)
+                                               if dstats is not None and dinfo.get("direct_block") else
+                                               "multigrid-preconditioned CG")),
+                       "direct_solves": st.get("direct_solves", 0) if dstats is None else dstats.get("direct_solves", 0),
                        "pcg_rtol": args.rtol, "pcg_iters_per_solve": st["pcg_iters"] / max(st["pcg_solves"], 1),
                        "mg_level_rows": st["level_rows"] if dstats is None else dstats["level_rows"],
                        "parallelism": "1 GPU" if world == 1 else
-                       "views sharded in %d contiguous ranges, 1 shard/GPU, %s halo + all-reduce" % (world, wire)},
+                       "views sharded in %d contiguous ranges, 1 shard/GPU, %s %s" % (
+                           world, wire, "gather of the separators (1 per linear solve) + halo of X and score all-reduce "
+                           "(1 per IRLS iteration)" if dstats is not None and dinfo.get("direct_block") else "halo + all-reduce")},
             "final_scores": [float(x) for x in res["scores"]],
             "timing_note": "steady state: %d untimed ramp-up solves precede the --warmup solves (a fresh box starts at "
                            "idle clocks; the first solves of a process run ~8 %% slower); every step repeats the "

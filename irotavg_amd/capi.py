@@ -564,11 +564,13 @@ class DistGraph:
         return dict(rc=rc, iters=iters.value, runtime=rt.value, scores=trace[:iters.value].copy())
 
     def info(self):
-        """wire / RCCL communicator size / local shards / world / ghost views (irotavg_dist_info)."""
+        """wire / RCCL communicator size / local shards / world / ghost views / block size of the sharded direct solver
+        (0: the sharded PCG) (irotavg_dist_info)."""
         v = (C.c_int64 * 8)()
         check(lib().irotavg_dist_info(self._h, v), "dist_info")
         return dict(wire=["loopback", "rccl", "host-staged"][v[0]], rccl_comm_ranks=int(v[1]),
-                    local_shards=int(v[2]), world=int(v[3]), ghost_views=int(v[4]), peers=int(v[5]))
+                    local_shards=int(v[2]), world=int(v[3]), ghost_views=int(v[4]), peers=int(v[5]),
+                    direct_block=int(v[6]))
 
     def stats(self):
         s = Stats()
@@ -576,4 +578,4 @@ class DistGraph:
         return dict(pcg_solves=s.pcg_solves, pcg_iters=s.pcg_iters, pcg_iters_last=s.pcg_iters_last,
                     outer_iters=s.outer_iters, edge_updates=s.edge_updates, seconds_irls=s.seconds_irls,
                     levels=s.levels, level_rows=list(s.level_rows)[:s.levels],
-                    pcg_handed_over=s.pcg_handed_over)
+                    pcg_handed_over=s.pcg_handed_over, direct_solves=s.direct_solves)

@@ -17,26 +17,32 @@ def problem(n, m, p, f=1, seed=0):
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("p_loop", [0.0, 0.02])
-def test_loopback_sharded_equals_unsharded(world, p_loop):
+@pytest.mark.parametrize("p_loop,band_direct", [(0.0, 0), (0.0, -1), (0.02, 0)])
+def test_loopback_sharded_equals_unsharded(world, p_loop, band_direct):
+    """band graph: the sharded DIRECT solver (one gather per linear solve; band_direct 0) and the sharded PCG (-1);
+    with loop closures: the sharded PCG"""
     n, m, f = 20000, 300000, 3
     S, Q0 = problem(n, m, p_loop, f)
-    with capi.Graph(S["I"], S["QQ"], n, f) as G:
+    with capi.Graph(S["I"], S["QQ"], n, f, band_direct=band_direct) as G:
         G.set_rotations(Q0)
         a = G.irls(4, SIG, 50, 1e-3)
         Qa, wa = G.get_rotations(), G.get_weights()
-    with capi.DistGraph(S["I"], S["QQ"], n, f, world) as D:
+    with capi.DistGraph(S["I"], S["QQ"], n, f, world, band_direct=band_direct) as D:
         D.set_rotations(Q0)
         b = D.irls(4, SIG, 50, 1e-3)
         Qb, wb = D.get_rotations(into=Q0), D.get_weights()
         st = D.stats()
+        direct = D.info()["direct_block"]
     assert a["iters"] == b["iters"]
     np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-6, atol=1e-9)  # rad; the last score is ~1e-5
     assert synth.angular_distance(Qa, Qb).max() < 1e-8
     assert not np.isnan(wb).any()                      # every edge belongs to some shard
     np.testing.assert_allclose(wa, wb, rtol=1e-6)
     np.testing.assert_array_equal(Qb[:f], Q0[:f])
-    assert st["pcg_iters"] > 0
+    if p_loop == 0.0 and band_direct == 0:
+        assert direct == 16 and st["direct_solves"] == b["iters"] and st["pcg_iters"] == 0
+    else:
+        assert direct == 0 and st["pcg_iters"] > 0 and st["direct_solves"] == 0
 
 
 def test_loopback_every_cost_family():
@@ -100,6 +106,7 @@ def test_loopback_sharded_l1ra_then_irls_equals_unsharded(world, p_loop):
         b2 = D.irls(4, SIG, 20, 1e-3)
         Qb, wb = D.get_rotations(into=Qw), D.get_weights()
     assert a1["iters"] == b1["iters"] and a2["iters"] == b2["iters"]
+    # p_loop 0: the Hessian solves of the sharded l1ra and the systems of the sharded irls are direct solves
     np.testing.assert_allclose(a1["scores"], b1["scores"], rtol=1e-6)
     assert synth.angular_distance(Q1, Qb1).max() < 1e-8
     assert synth.angular_distance(Qa, Qb).max() < 1e-8
@@ -127,7 +134,7 @@ def test_config4_size_eight_shards_match_the_oracle_checked_handle(p_loop):
     np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-6, atol=1e-9)
     assert synth.angular_distance(Qa, Qb).max() < 1e-7
     np.testing.assert_allclose(wa, wb, rtol=1e-5, atol=1e-9)
-    assert st["pcg_iters"] > 0
+    assert (st["direct_solves"] > 0) == (p_loop == 0.0) and (st["pcg_iters"] > 0) == (p_loop > 0.0)
 
 
 def test_sharded_single_reduction_solve_hands_over_to_the_classic_recurrences(monkeypatch):
@@ -143,7 +150,7 @@ def test_sharded_single_reduction_solve_hands_over_to_the_classic_recurrences(mo
     for limit in (None, "6"):
         if limit:
             monkeypatch.setenv("IROTAVG_CG2_GIVEUP", limit)
-        with capi.DistGraph(S["I"], S["QQ"], n, 1, 4) as D:
+        with capi.DistGraph(S["I"], S["QQ"], n, 1, 4, band_direct=-1) as D:   # the sharded PCG (this is a band graph)
             D.set_rotations(Q0)
             r = D.irls(4, SIG, 50, 1e-3)
             out.append((r, D.get_rotations(into=Q0.copy()), D.get_weights(), D.stats()))
