@@ -162,3 +162,30 @@ def test_sharded_single_reduction_solve_hands_over_to_the_classic_recurrences(mo
         np.testing.assert_allclose(r["scores"], ro["scores"], rtol=1e-5)
         assert synth.angular_distance(Q, ro["Q"]).max() < 1e-7
         np.testing.assert_allclose(w, ro["weights"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("n,m,f,world", [(5000, 20000, 1, 3), (4000, 16000, 4, 6), (9000, 180000, 2, 5),
+                                         (2500, 75000, 1, 2), (30000, 120000, 1, 7)])
+def test_sharded_direct_solver_shapes_match_the_oracle(n, m, f, world):
+    """The sharded direct solver on shapes that stress its bookkeeping: blocks of 8 / 24 / 32, odd world sizes, shards
+    of a few chunks only (the local top level is reached at once; partial chunks place their blocks so that the
+    rank's last block stays the separator), several fixed views, a last shard much smaller than the others. l1ra then
+    irls against the ORACLE."""
+    from oracle import oracle as O
+    S, Q0 = problem(n, m, 0.0, f, seed=5)
+    Qw = Q0.copy()
+    with capi.DistGraph(S["I"], S["QQ"], n, f, world, band_direct=1) as D:
+        assert D.info()["direct_block"] in (8, 24, 32)
+        D.set_rotations(Q0)
+        a = D.l1ra(2, 1e-3)
+        Qa = D.get_rotations(into=Qw).copy()
+        b = D.irls(4, SIG, 30, 1e-3)
+        Qb, wb = D.get_rotations(into=Qw), D.get_weights()
+        st = D.stats()
+    ra = O.l1ra(S["QQ"], S["I"], Q0, f, 2, 1e-3)
+    rb = O.irls(S["QQ"], S["I"], ra["Q"], f, 4, SIG, 30, 1e-3)
+    assert (a["iters"], b["iters"]) == (ra["iters"], rb["iters"])
+    assert synth.angular_distance(Qa, ra["Q"]).max() < 1e-9
+    assert synth.angular_distance(Qb, rb["Q"]).max() < 1e-9
+    np.testing.assert_allclose(wb, rb["weights"], rtol=1e-7)
+    assert st["direct_solves"] > 0 and st["pcg_iters"] == 0
