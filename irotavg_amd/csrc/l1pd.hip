@@ -140,32 +140,54 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_sig(long long m, const double 
 // view-parallel A' y: the lane that owns a view walks its incident-edge entries (SELL layout of
 // level 0; make_A coefficients: +1 for the j endpoint, -1 for the i endpoint; boundary slots
 // only when make_A kept the coefficient).
-__device__ __forceinline__ double at_row(int row, int n, const int *__restrict__ sl_off,
-                                         const uint32_t *__restrict__ slot_eid,
-                                         const int *__restrict__ bptr,
-                                         const uint32_t *__restrict__ beid,
-                                         const uint8_t *__restrict__ bflag,
-                                         const double *__restrict__ t) {
+// The walk is a chain of dependent loads (slot -> edge value); eight entries are in flight per lane (with four the
+// kernels were latency-bound: 90-200 us for 0.4 M rows once the direct solver had removed the PCG around them).
+// TWO: the same walk over two edge planes at once, result c1 * (A' t1)_row + c2 * (A' t2)_row.
+template <bool TWO>
+__device__ __forceinline__ double at_row_t(int row, int n, const int *__restrict__ sl_off,
+                                           const uint32_t *__restrict__ slot_eid,
+                                           const int *__restrict__ bptr,
+                                           const uint32_t *__restrict__ beid,
+                                           const uint8_t *__restrict__ bflag,
+                                           const double *__restrict__ t, const double *__restrict__ tb, double c1,
+                                           double c2) {
     const int sl = row >> 6, lane = row & 63;
-    const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
+    const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;   // a multiple of 8
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u *__restrict__ sp = reinterpret_cast<const v2u *>(slot_eid) + (size_t)(o0 / 2) * 64 + lane;
     double s = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < w; k++) {
-        const uint32_t se = slot_eid[sell_pos(o0, k, lane)];
-        if (se != 0xffffffffu) {
-            const double v = t[se >> 1];
-            s += (se & 1u) ? v : -v;
+    for (int k0 = 0; k0 < w; k0 += 8) {
+        v2u se[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) se[u] = sp[(size_t)(k0 / 2 + u) * 64];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned e = (u & 1) ? se[u >> 1].y : se[u >> 1].x;
+            const bool ok = e != 0xffffffffu;
+            const size_t idx = ok ? (size_t)(e >> 1) : 0;
+            double x = TWO ? c1 * t[idx] + c2 * tb[idx] : t[idx];
+            x = (e & 1u) ? x : -x;
+            v[u] = ok ? x : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
     }
     if (row < n) {
         for (int q = bptr[row]; q < bptr[row + 1]; q++) {
             if (!(bflag[q] & BF_IRLS)) continue;
             const uint32_t se = beid[q];
-            const double v = t[se >> 1];
-            s += (se & 1u) ? v : -v;
+            const double x = TWO ? c1 * t[se >> 1] + c2 * tb[se >> 1] : t[se >> 1];
+            s += (se & 1u) ? x : -x;
         }
     }
     return s;
+}
+__device__ __forceinline__ double at_row(int row, int n, const int *__restrict__ sl_off,
+                                         const uint32_t *__restrict__ slot_eid, const int *__restrict__ bptr,
+                                         const uint32_t *__restrict__ beid, const uint8_t *__restrict__ bflag,
+                                         const double *__restrict__ t) {
+    return at_row_t<false>(row, n, sl_off, slot_eid, bptr, beid, bflag, t, nullptr, 0.0, 0.0);
 }
 
 #define PD_ROW_LOOP(nsl)                                       \
@@ -207,12 +229,9 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_rhs(int n, int nsl, const int 
                                                       double4 *__restrict__ rhs) {
     PD_ROW_LOOP(nsl) {
         const int row = sl_ * 64 + (threadIdx.x & 63);
-        const double a = at_row(row, n, sl_off, slot_eid, bptr, beid, bflag, t1);
-        const double b = at_row(row, n, sl_off, slot_eid, bptr, beid, bflag, t2);
-        if (row < n) {
-            const double w1 = -itau * a;
-            rhs[row] = make_double4(w1 - b, 0.0, 0.0, 0.0);
-        }
+        // -(1/tau) A' t1 - A' t2 in ONE walk of the row
+        const double w1p = at_row_t<true>(row, n, sl_off, slot_eid, bptr, beid, bflag, t1, t2, -itau, -1.0);
+        if (row < n) rhs[row] = make_double4(w1p, 0.0, 0.0, 0.0);
     }
 }
 
