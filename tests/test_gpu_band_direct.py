@@ -205,6 +205,38 @@ def test_closure_with_zero_weight_and_too_many_closures():
         assert G.stats()["band_block"] == 0 and G.direct_info()["block"] == 0
 
 
+def test_blocks_of_32_with_a_mixed_level_match_the_iterative_solver():
+    """70k views, band 29 -> blocks of 32 (one workgroup per CU: LDS), 274 chunks on 256 slots: 18 chunks' blocks enter
+    level 1 unreduced. Too large for the oracle's Cholesky to be quick: both solvers of the handle against each
+    other (each is held against the oracle elsewhere), and the normal equations by the oracle's mat-vec."""
+    n, m = 70000, 2000000
+    S = synth.make_graph(n, m, 0.0, seed=3, p_band_out=0.01)
+    Q0 = np.zeros((n, 4)); Q0[:, 3] = 1; Q0[0] = S["Qgt"][0]
+    from irotavg_amd import ral
+    ral.init_mst(Q0, S["QQ"], S["I"], 1)
+    out = {}
+    for bd in (0, -1):
+        with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=bd) as G:
+            if bd == 0:
+                info = G.direct_info()
+                assert info["block"] == 32 and info["levels"][1]["reduced"] < info["levels"][1]["blocks"], info
+                G.set_rotations(Q0)
+                G.edge_residual()
+                w = np.random.default_rng(1).uniform(0.2, 3.0, size=m)
+                G.set_weights(w)
+                X = G.ls_solve()
+                ro = O.log_map(O.delta_rel(S["I"], S["QQ"], Q0))[:, :3]
+                b = O.make_A(n, 1, S["I"]).T @ ((w * w)[:, None] * ro)
+                rel = np.linalg.norm(O.normal_matvec(n, 1, S["I"], w, X) - b, axis=0) / np.linalg.norm(b, axis=0)
+                assert rel.max() < 5e-10, rel
+            G.set_rotations(Q0)
+            r = G.irls(4, SIG, 50, 1e-3)
+            out[bd] = (r["iters"], G.get_rotations(), G.get_weights())
+    assert out[0][0] == out[-1][0]
+    assert synth.angular_distance(out[0][1], out[-1][1]).max() < 1e-8
+    np.testing.assert_allclose(out[0][2], out[-1][2], rtol=1e-6)
+
+
 def test_fixed_views_flipped_and_duplicate_edges():
     """f = 4 fixed views (rows = views - f; edges to fixed views only reach the diagonal and the right-hand side),
     30 % of the edges given as (j, i) -- some then have their SECOND endpoint fixed, which make_A drops
