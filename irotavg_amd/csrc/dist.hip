@@ -927,6 +927,34 @@ int irotavg_dist_set_rotations(irotavg_dist *h, const double *Q, int64_t ldq) {
     API_CATCH
 }
 
+// device-side snapshot / restore of every local shard's rotations (as irotavg_graph_snapshot_rotations: a bench
+// step restarts from the same rotations without a host-to-device copy inside its timed region)
+int irotavg_dist_snapshot_rotations(irotavg_dist *h) {
+    if (!h) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    for (auto &sp : h->D.shards) {
+        Graph &g = sp->g;
+        if (g.Qsnap.n < (size_t)g.n_total) g.Qsnap.alloc((size_t)g.n_total);
+        IRH_CHECK(hipMemcpyAsync(g.Qsnap.p, g.Q.p, sizeof(double4) * (size_t)g.n_total, hipMemcpyDeviceToDevice,
+                                 h->D.stream));
+    }
+    IRH_CHECK(hipStreamSynchronize(h->D.stream));
+    return IROTAVG_OK;
+    API_CATCH
+}
+int irotavg_dist_restore_rotations(irotavg_dist *h) {
+    if (!h) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    for (auto &sp : h->D.shards) {
+        Graph &g = sp->g;
+        if (g.Qsnap.n < (size_t)g.n_total) return IROTAVG_ERR_BAD_ARG;
+        IRH_CHECK(hipMemcpyAsync(g.Q.p, g.Qsnap.p, sizeof(double4) * (size_t)g.n_total, hipMemcpyDeviceToDevice,
+                                 h->D.stream));
+    }
+    return IROTAVG_OK;
+    API_CATCH
+}
+
 // writes the rows OWNED by this process's shards into the global matrix (other rows untouched)
 int irotavg_dist_get_rotations(irotavg_dist *h, double *Q, int64_t ldq) {
     if (!h || !Q || ldq < h->D.n_total) return IROTAVG_ERR_BAD_ARG;

@@ -29,6 +29,9 @@ def test_loopback_sharded_equals_unsharded(world, p_loop, band_direct):
         Qa, wa = G.get_rotations(), G.get_weights()
     with capi.DistGraph(S["I"], S["QQ"], n, f, world, band_direct=band_direct) as D:
         D.set_rotations(Q0)
+        D.snapshot_rotations()
+        D.irls(4, SIG, 2, 1e-3)          # ... a first run, thrown away: restore brings the start back
+        D.restore_rotations()
         b = D.irls(4, SIG, 50, 1e-3)
         Qb, wb = D.get_rotations(into=Q0), D.get_weights()
         st = D.stats()
@@ -40,7 +43,7 @@ def test_loopback_sharded_equals_unsharded(world, p_loop, band_direct):
     np.testing.assert_allclose(wa, wb, rtol=1e-6)
     np.testing.assert_array_equal(Qb[:f], Q0[:f])
     if p_loop == 0.0 and band_direct == 0:
-        assert direct == 16 and st["direct_solves"] == b["iters"] and st["pcg_iters"] == 0
+        assert direct == 16 and st["direct_solves"] == b["iters"] + 2 and st["pcg_iters"] == 0
     else:
         assert direct == 0 and st["pcg_iters"] > 0 and st["direct_solves"] == 0
 
