@@ -163,3 +163,86 @@ def test_two_rank_gloo_sharded_pcg_matches_unsharded(tmp_path):
         lo, hi = np.load(tmp_path / ("range%d.npy" % rk))
         got[lo:hi] = np.load(tmp_path / ("x%d.npy" % rk))
     assert np.abs(got - X).max() < 1e-9 * np.abs(X).max()
+
+
+def _direct_worker(rank, world, port, n, m, f, B, seed, out):
+    """One rank of the sharded DIRECT solver's protocol (irotavg_amd/csrc/dist.hip, bcr_dist): reduce the own range of
+    the banded normal equations to its last block (dense Schur complements in NumPy stand in for the chunk kernels),
+    ONE sum-all-reduce of a zeroed buffer = the gather of the separators, the separator system solved by every rank,
+    the way back through the own range."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = synth.make_graph(n, m, 0.0, seed=seed)
+    rng = np.random.default_rng(seed)
+    w = rng.uniform(0.3, 2.0, size=len(S["I"]))
+    r = rng.normal(scale=0.02, size=(len(S["I"]), 3))
+    import scipy.sparse as sp
+    A = O.make_A(n, f, S["I"])
+    H = (A.T @ sp.diags(w * w) @ A).toarray()         # every rank holds the graph; it USES its own rows only
+    b = A.T @ ((w * w)[:, None] * r)
+    nu = n - f
+    chunk = ((nu + world - 1) // world + 191) // 192 * 192       # chunk_of(nu, world, 192)
+    lo, hi = rank * chunk, min(nu, (rank + 1) * chunk)
+    sep = np.arange(hi - B, hi) if rank < world - 1 else np.arange(hi - B, hi)   # the range's LAST block
+    inner = np.arange(lo, hi - B)
+    ext = np.arange(lo - B, lo) if rank > 0 else np.arange(0)                   # the previous rank's last block
+    Hii = H[np.ix_(inner, inner)]
+    Yi = np.linalg.solve(Hii, np.concatenate([H[np.ix_(inner, ext)], H[np.ix_(inner, sep)], b[inner]], axis=1))
+    ne = len(ext)
+    Ye, Ys, yb = Yi[:, :ne], Yi[:, ne:ne + B], Yi[:, ne + B:]
+    sepD = H[np.ix_(sep, sep)] - H[np.ix_(sep, inner)] @ Ys
+    sepR = b[sep] - H[np.ix_(sep, inner)] @ yb
+    extD = -H[np.ix_(ext, inner)] @ Ye if ne else np.zeros((B, B))
+    extR = -H[np.ix_(ext, inner)] @ yb if ne else np.zeros((B, 3))
+    extG = (H[np.ix_(ext, sep)] - H[np.ix_(ext, inner)] @ Ys) if ne else np.zeros((B, B))
+    # the gather: every rank writes its slices of a zeroed buffer, one all-reduce (what ncclAllReduce does in dist.hip)
+    buf = np.zeros((world, 3 * B * B + 2 * B * 3))
+    buf[rank] = np.concatenate([sepD.ravel(), extD.ravel(), extG.ravel(), sepR.ravel(), extR.ravel()])
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t)
+    buf = t.numpy()
+    sl = lambda k, a, z, shape: buf[k, a:z].reshape(shape)
+    oD, oXD, oXG, oR, oXR = 0, B * B, 2 * B * B, 3 * B * B, 3 * B * B + 3 * B
+    # separator system: block tridiagonal, `world` blocks; D_k = sepD[k] + extD[k + 1], coupling k-1 -> k = extG[k]
+    T = np.zeros((world * B, world * B)); R = np.zeros((world * B, 3))
+    for k in range(world):
+        Dk = sl(k, oD, oXD, (B, B)).copy(); Rk = sl(k, oR, oXR, (B, 3)).copy()
+        if k + 1 < world:
+            Dk += sl(k + 1, oXD, oXG, (B, B)); Rk += sl(k + 1, oXR, oXR + 3 * B, (B, 3))
+        T[k * B:(k + 1) * B, k * B:(k + 1) * B] = Dk
+        R[k * B:(k + 1) * B] = Rk
+        if k > 0:
+            G = sl(k, oXG, oR, (B, B))
+            T[(k - 1) * B:k * B, k * B:(k + 1) * B] = G
+            T[k * B:(k + 1) * B, (k - 1) * B:k * B] = G.T
+    xs = np.linalg.solve(T, R)                          # every rank solves it (redundantly, identically)
+    x_sep = xs[rank * B:(rank + 1) * B]
+    x_ext = xs[(rank - 1) * B:rank * B] if rank > 0 else np.zeros((0, 3))
+    x_in = yb - Ys @ x_sep - (Ye @ x_ext if ne else 0.0)
+    np.save(os.path.join(out, "dx%d.npy" % rank), np.concatenate([x_in, x_sep]))
+    np.save(os.path.join(out, "drange%d.npy" % rank), np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sharded_direct_solver_protocol_matches_unsharded(tmp_path, world):
+    """the N > 1 form of the banded direct solver: local reduction, ONE collective, separator system, way back"""
+    import torch.multiprocessing as mp
+    n, m, f, B, seed = 1300, 13000, 2, 16, 9        # band 10 <= B; ranges of 768 / 576 views, the last one shorter
+    port = _free_port()
+    mp.spawn(_direct_worker, args=(world, port, n, m, f, B, seed, str(tmp_path)), nprocs=world, join=True)
+    S = synth.make_graph(n, m, 0.0, seed=seed)
+    rng = np.random.default_rng(seed)
+    w = rng.uniform(0.3, 2.0, size=len(S["I"]))
+    r = rng.normal(scale=0.02, size=(len(S["I"]), 3))
+    rc, X = O.ls_solve(n, f, S["I"], w, r)
+    assert rc == 0
+    got = np.zeros_like(X)
+    for rk in range(world):
+        lo, hi = np.load(tmp_path / ("drange%d.npy" % rk))
+        got[lo:hi] = np.load(tmp_path / ("dx%d.npy" % rk))
+    assert np.abs(got - X).max() < 1e-9 * np.abs(X).max()
