@@ -2,7 +2,9 @@
 self-consistent (what A sends to B is exactly B's ghost list owned by A, without a handshake);
 (2) two `gloo` processes run the sharded PCG protocol of irotavg_amd/csrc/dist.hip -- halo exchange
 of the search direction of ghost views + all-reduced dot products -- with NumPy as the local
-compute (the oracle's normal-matrix semantics) and reproduce the unsharded solution."""
+compute (the oracle's normal-matrix semantics) and reproduce the unsharded solution; (3) two and three `gloo`
+processes run the protocol of the sharded DIRECT solver (bcr_dist: every rank reduces its range of a banded system to
+its last block, one all-reduce gathers the separators, every rank solves the separator system and walks back)."""
 import os
 import socket
 
