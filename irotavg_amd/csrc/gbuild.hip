@@ -467,9 +467,46 @@ int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldq
     if (g.mpad > m)
         for (int c = 0; c < 4; c++)
             IRH_CHECK(hipMemsetAsync(g.qq.p + (size_t)c * g.mpad + m, 0, sizeof(double) * (size_t)(g.mpad - m), s));
-    for (int c = 0; c < 4; c++)
-        IRH_CHECK(hipMemcpyAsync(g.qq.p + (size_t)c * g.mpad, QQ + (size_t)c * ldqq, sizeof(double) * (size_t)m,
-                                 hipMemcpyHostToDevice, s));
+    // The relative rotations (4 m doubles: 64 MB at 2M edges, the bulk of the upload) are needed by the first solve
+    // only: helper threads copy them (a plane each, a stream each) while this thread builds the patterns from I (a copy
+    // from pageable memory keeps its caller busy, and one caller reaches ~25 GB/s only).
+    // Joined before the build returns, on every path.
+    struct QQUpload {
+        std::thread th[4];
+        hipError_t err[4] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
+        void join() {
+            for (auto &t : th)
+                if (t.joinable()) t.join();
+        }
+        ~QQUpload() { join(); }
+    } qq_up;
+    const char *upenv = getenv("IROTAVG_UPLOAD_THREADS");
+    const int n_up = m >= 100000 ? (upenv ? std::min(4, std::max(0, atoi(upenv))) : 4) : 0;
+    if (n_up > 0) {
+        double *dst = g.qq.p;
+        const size_t mp = (size_t)g.mpad;
+        const int dev = g.device;
+        for (int t = 0; t < n_up; t++)
+            qq_up.th[t] = std::thread([&qq_up, dst, mp, QQ, ldqq, m, dev, t, n_up]() {
+                hipError_t e = hipSetDevice(dev);
+                hipStream_t s2 = nullptr;
+                try {
+                    if (e == hipSuccess) s2 = StreamPool::get().take();  // (creating a stream costs milliseconds)
+                } catch (...) {
+                    e = hipErrorUnknown;
+                }
+                for (int c = t; c < 4 && e == hipSuccess; c += n_up)
+                    e = hipMemcpyAsync(dst + (size_t)c * mp, QQ + (size_t)c * ldqq, sizeof(double) * (size_t)m,
+                                       hipMemcpyHostToDevice, s2);
+                if (e == hipSuccess) e = hipStreamSynchronize(s2);
+                if (s2 && e == hipSuccess) StreamPool::get().give(s2, dev);
+                qq_up.err[t] = e;
+            });
+    } else {
+        for (int c = 0; c < 4; c++)
+            IRH_CHECK(hipMemcpyAsync(g.qq.p + (size_t)c * g.mpad, QQ + (size_t)c * ldqq, sizeof(double) * (size_t)m,
+                                     hipMemcpyHostToDevice, s));
+    }
     g.ei.alloc((size_t)g.mpad);
     g.ej.alloc((size_t)g.mpad);
     g.eflag.alloc((size_t)g.mpad);
@@ -715,6 +752,11 @@ int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldq
     lap("hierarchy");
     const int rc = finish_build(g, T);
     lap("PCG state");
+    if (n_up > 0) {
+        qq_up.join();
+        for (int t = 0; t < n_up; t++) IRH_CHECK(qq_up.err[t]);
+        lap("join of the rotation upload");
+    }
     return rc;
 }
 
