@@ -7,7 +7,8 @@
 // slots (no atomics), and H11p dx = w1p (UMFPACK in the reference, :308-319) is solved by the
 // same multigrid-PCG as the IRLS step with the matrix values refreshed from sigx under
 // make_AtA's boundary rule (:825-843). Control flow (step length, backtracking, stopping) runs on
-// the host from fixed-order reductions, statement for statement as the reference.
+// the host from fixed-order reductions; the decisions are the reference's, statement for statement, the kernels are
+// grouped so that a primal-dual iteration needs two host round trips.
 #include <thread>
 
 #include "graph.hpp"
@@ -21,8 +22,12 @@ constexpr double kPdSpread = 8.0;  // staleness band of a parked primal-dual inv
 
 enum PdPlane : int {
     P_Y = 0, P_U, P_AX, P_F1, P_F2, P_L1, P_L2, P_SIGX, P_T1, P_T2, P_ADX, P_DU, P_DL1, P_DL2,
+    // the trial point of the back-tracking loop (u, Ax, lamu1, lamu2, fu1, fu2 at step s): accepting it is an exchange
+    // of plane numbers, not another pass over the edges
+    P_U2, P_AX2, P_L12, P_L22, P_F12, P_F22,
     P_COUNT
 };
+constexpr int kPdPartSlots = 3;  // partial arrays of reductions that are fetched with ONE host round trip
 enum PdnPlane : int { N_X = 0, N_ATV, N_ATDV, N_X0, N_X1, N_X2, N_COUNT };
 
 static void pd_prepare(Graph &g) {
@@ -31,7 +36,7 @@ static void pd_prepare(Graph &g) {
     g.pd.zero(g.stream);
     g.pdn.alloc((size_t)N_COUNT * g.nu);
     g.pdn.zero(g.stream);
-    g.pd_part.alloc((size_t)kMaxParts * 4);
+    g.pd_part.alloc((size_t)kMaxParts * 4 * kPdPartSlots);
     g.pd_part.zero(g.stream);
     g.pd_ready = true;
 }
@@ -58,6 +63,38 @@ __device__ __forceinline__ void block_ext_store(double v, double *part) {
         for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = MAX ? fmax(r, sm[i]) : fmin(r, sm[i]);
         part[0] = r;
         part[1] = part[2] = part[3] = 0.0;
+    }
+    __syncthreads();
+}
+
+// workgroup sum of four accumulators -> part[0..3] (fixed order: waves in order)
+__device__ __forceinline__ void block_sum4_store(double a0, double a1, double a2, double a3, double *part) {
+    __shared__ double sm4[4][16];
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    a3 = wave_sum(a3);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        sm4[0][w] = a0;
+        sm4[1][w] = a1;
+        sm4[2][w] = a2;
+        sm4[3][w] = a3;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        const int nw = blockDim.x >> 6;
+        for (int i = 0; i < nw; i++) {
+            s0 += sm4[0][i];
+            s1 += sm4[1][i];
+            s2 += sm4[2][i];
+            s3 += sm4[3][i];
+        }
+        part[0] = s0;
+        part[1] = s1;
+        part[2] = s2;
+        part[3] = s3;
     }
     __syncthreads();
 }
@@ -103,38 +140,32 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_init(long long m, const double
     block_sum3_store(a0, a1, a2, part + 4 * blockIdx.x);
 }
 
-// sum of squares of rcent = [-lamu1.*fu1; -lamu2.*fu2] - 1/tau  (:267-270, 450-453)
-__global__ __launch_bounds__(kRowBlock) void k_pd_rcent(long long m, const double *__restrict__ f1,
-                                                     const double *__restrict__ f2,
-                                                     const double *__restrict__ l1,
-                                                     const double *__restrict__ l2, double itau,
-                                                     double *__restrict__ part,
-                                                     const uint8_t *__restrict__ own) {
-    double a0 = 0;
-    EDGE_LOOP(k) {
-        if (own != nullptr && !own[k]) continue;
-        const double c1 = -l1[k] * f1[k] - itau, c2 = -l2[k] * f2[k] - itau;
-        a0 += c1 * c1 + c2 * c2;
-    }
-    block_sum3_store(a0, 0.0, 0.0, part + 4 * blockIdx.x);
-}
-
-// :292-305 -- sigx and the two operands of A' (t1 for w1, t2 for w1p)
+// :292-305 -- sigx and the two operands of A' (t1 for w1, t2 for w1p); on the way, from the same four loads, the sum
+// of squares of rcent = [-lamu1.*fu1; -lamu2.*fu2] - 1/tau (:267-270, 450-453) that the residual norm of THIS
+// iteration's back-tracking test needs (the reference forms it at the end of the previous iteration, from the same
+// fu, lamu and tau; a pass of its own, with its own host round trip, until round 3)
 __global__ __launch_bounds__(kRowBlock) void k_pd_sig(long long m, const double *__restrict__ f1,
                                                    const double *__restrict__ f2,
                                                    const double *__restrict__ l1,
                                                    const double *__restrict__ l2, double itau,
                                                    double *__restrict__ sigx, double *__restrict__ t1,
-                                                   double *__restrict__ t2) {
+                                                   double *__restrict__ t2, double *__restrict__ part,
+                                                   const uint8_t *__restrict__ own) {
+    double a0 = 0;
     EDGE_LOOP(k) {
-        const double if1 = 1.0 / f1[k], if2 = 1.0 / f2[k];
+        const double g1 = f1[k], g2 = f2[k], m1 = l1[k], m2 = l2[k];
+        const double if1 = 1.0 / g1, if2 = 1.0 / g2;
         const double w2 = -1 - itau * (if1 + if2);
-        const double a = l1[k] / f1[k], b = l2[k] / f2[k];
+        const double a = m1 / g1, b = m2 / g2;
         const double s1 = -a - b, s2 = a - b;
         sigx[k] = s1 - (s2 * s2) / s1;
         t1[k] = -if1 + if2;
         t2[k] = (s2 / s1) * w2;
+        if (own != nullptr && !own[k]) continue;  // sharded: a cross-shard edge is summed by one shard only
+        const double c1 = -m1 * g1 - itau, c2 = -m2 * g2 - itau;
+        a0 += c1 * c1 + c2 * c2;
     }
+    block_sum3_store(a0, 0.0, 0.0, part + 4 * blockIdx.x);
 }
 
 // view-parallel A' y: the lane that owns a view walks its incident-edge entries (SELL layout of
@@ -278,25 +309,37 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_dir(
     block_ext_store<false>(smin, part + 4 * blockIdx.x);
 }
 
-// trial point at step s: sums of squares of the m-tail of rdp (:407-410) and of rcp (:412-416)
+// trial point at step s: sums of squares of the m-tail of rdp (:407-410) and of rcp (:412-416). The point itself is
+// stored (planes u2 ... f22) together with the two sums of the surrogate duality gap (:446) it would have: when the
+// host accepts the step (:432-442) nothing is left to do on the edges.
 __global__ __launch_bounds__(kRowBlock) void k_pd_trial_edge(
     long long m, const double *__restrict__ y, double s, double itau, const double *__restrict__ u,
     const double *__restrict__ du, const double *__restrict__ Ax, const double *__restrict__ Adx,
     const double *__restrict__ l1, const double *__restrict__ dl1, const double *__restrict__ l2,
-    const double *__restrict__ dl2, double *__restrict__ part, const uint8_t *__restrict__ own) {
-    double a0 = 0, a1 = 0;
+    const double *__restrict__ dl2, double *__restrict__ u2, double *__restrict__ Ax2, double *__restrict__ l12,
+    double *__restrict__ l22, double *__restrict__ f12, double *__restrict__ f22, double *__restrict__ part,
+    const uint8_t *__restrict__ own) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     EDGE_LOOP(k) {
-        if (own != nullptr && !own[k]) continue;
         const double up = u[k] + s * du[k];
         const double axp = Ax[k] + s * Adx[k];
         const double m1 = l1[k] + s * dl1[k], m2 = l2[k] + s * dl2[k];
         const double g1 = axp - y[k] - up, g2 = -axp + y[k] - up;
+        u2[k] = up;
+        Ax2[k] = axp;
+        l12[k] = m1;
+        l22[k] = m2;
+        f12[k] = g1;
+        f22[k] = g2;
+        if (own != nullptr && !own[k]) continue;
         const double r = 1.0 + (-m1 - m2);
         a0 += r * r;
         const double c1 = -m1 * g1 - itau, c2 = -m2 * g2 - itau;
         a1 += c1 * c1 + c2 * c2;
+        a2 += g1 * m1;
+        a3 += g2 * m2;
     }
-    block_sum3_store(a0, a1, 0.0, part + 4 * blockIdx.x);
+    block_sum4_store(a0, a1, a2, a3, part + 4 * blockIdx.x);
 }
 
 __global__ __launch_bounds__(kRowBlock) void k_pd_trial_vert(int n, double s,
@@ -311,32 +354,7 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_trial_vert(int n, double s,
     block_sum3_store(a0, 0.0, 0.0, part + 4 * blockIdx.x);
 }
 
-// accept the trial point (:432-442) and produce the new surrogate duality gap sums (:446)
-__global__ __launch_bounds__(kRowBlock) void k_pd_commit_edge(
-    long long m, const double *__restrict__ y, double s, double *__restrict__ u,
-    const double *__restrict__ du, double *__restrict__ Ax, const double *__restrict__ Adx,
-    double *__restrict__ l1, const double *__restrict__ dl1, double *__restrict__ l2,
-    const double *__restrict__ dl2, double *__restrict__ f1, double *__restrict__ f2,
-    double *__restrict__ part, const uint8_t *__restrict__ own) {
-    double a0 = 0, a1 = 0;
-    EDGE_LOOP(k) {
-        const double up = u[k] + s * du[k];
-        const double axp = Ax[k] + s * Adx[k];
-        const double m1 = l1[k] + s * dl1[k], m2 = l2[k] + s * dl2[k];
-        const double g1 = axp - y[k] - up, g2 = -axp + y[k] - up;
-        u[k] = up;
-        Ax[k] = axp;
-        l1[k] = m1;
-        l2[k] = m2;
-        f1[k] = g1;
-        f2[k] = g2;
-        if (own != nullptr && !own[k]) continue;
-        a0 += g1 * m1;
-        a1 += g2 * m2;
-    }
-    block_sum3_store(a0, a1, 0.0, part + 4 * blockIdx.x);
-}
-
+// accept the trial point (:432-442): the views (the edges were stored by the trial kernel)
 __global__ __launch_bounds__(kRowBlock) void k_pd_commit_vert(int n, double s, double *__restrict__ x,
                                                            const double4 *__restrict__ DX,
                                                            double *__restrict__ Atv,
@@ -368,22 +386,28 @@ static int grid_rows(const Level &L) {
     return (int)std::max<long long>(gsz, 1);
 }
 
-// fixed-order host sum of the first `cols` columns of a partial array
-static void fetch_parts(Graph &g, int nparts, double out[3]) {
-    IRH_CHECK(hipMemcpyAsync(g.h_part(), g.pd_part.p, sizeof(double) * 4 * (size_t)nparts,
-                             hipMemcpyDeviceToHost, g.stream));
-    IRH_CHECK(hipStreamSynchronize(g.stream));
-    out[0] = out[1] = out[2] = 0.0;
-    for (int b = 0; b < nparts; b++)
-        for (int c = 0; c < 3; c++) out[c] += g.h_part()[4 * (size_t)b + c];
+// Reductions come back as per-workgroup partials (rows of 4 doubles) and are summed on the host in fixed order. A
+// graph has kPdPartSlots partial arrays, so that kernels whose results are needed at the same decision are fetched with
+// ONE host round trip: pd_fetch enqueues the copies, the caller synchronises once, pd_sum / pd_ext read the staging.
+static double *pd_part_slot(Graph &g, int slot) { return g.pd_part.p + (size_t)slot * 4 * kMaxParts; }
+static double *pd_host_slot(Graph &g, int slot) {  // the pinned block has room behind the PCG's own staging
+    static_assert(4096 + (kPdPartSlots - 1) * 4 * kMaxParts <= (int)(PinPool::kBytes / sizeof(double)), "pinned block");
+    return slot == 0 ? g.h_part() : g.hpin + 4096 + (size_t)(slot - 1) * 4 * kMaxParts;
 }
-static double fetch_ext(Graph &g, int nparts, bool is_max) {
-    IRH_CHECK(hipMemcpyAsync(g.h_part(), g.pd_part.p, sizeof(double) * 4 * (size_t)nparts,
+static void pd_fetch(Graph &g, int slot, int nparts) {
+    IRH_CHECK(hipMemcpyAsync(pd_host_slot(g, slot), pd_part_slot(g, slot), sizeof(double) * 4 * (size_t)nparts,
                              hipMemcpyDeviceToHost, g.stream));
-    IRH_CHECK(hipStreamSynchronize(g.stream));
-    double r = g.h_part()[0];
-    for (int b = 1; b < nparts; b++)
-        r = is_max ? std::max(r, g.h_part()[4 * (size_t)b]) : std::min(r, g.h_part()[4 * (size_t)b]);
+}
+static void pd_sum(Graph &g, int slot, int nparts, double out[4]) {
+    const double *h = pd_host_slot(g, slot);
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    for (int b = 0; b < nparts; b++)
+        for (int c = 0; c < 4; c++) out[c] += h[4 * (size_t)b + c];
+}
+static double pd_ext(Graph &g, int slot, int nparts, bool is_max) {
+    const double *h = pd_host_slot(g, slot);
+    double r = h[0];
+    for (int b = 1; b < nparts; b++) r = is_max ? std::max(r, h[4 * (size_t)b]) : std::min(r, h[4 * (size_t)b]);
     return r;
 }
 
@@ -392,6 +416,12 @@ static double fetch_ext(Graph &g, int nparts, bool is_max) {
 // edges and views; sums over edges count a cross-shard edge once (PdMember::eown), sums over views
 // run over owned views; `combine` adds what other processes hold. y: device pointer per member
 // (plane of er, or P_Y). Result in pdn plane `xplane` of every member (owned views).
+//
+// Host round trips (round 3): the decisions of the reference's loop need, per primal-dual iteration, the step bound
+// (:347-380) and then, per back-tracking trial, the norms of the trial residuals (:407-419). Everything else is a
+// consequence of an accepted trial and is produced by the trial kernels themselves (the trial point and its duality
+// gap) or by the first kernel of the next iteration (rcent): 2 round trips (and, sharded, 2 combines) per iteration
+// with the first trial accepted, where the literal statement order had 5; 2 instead of 4 before the loop.
 void pd_prepare_graph(Graph &g) { pd_prepare(g); }
 
 int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
@@ -403,29 +433,32 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
     } slot_guard{G};
     const double PDTOL = 1e-3, alpha = 0.01, beta = 0.5, mu = 10;  // :231-238
     const double mglob = (double)G.m_global;
-    double s3[3];
     if (stuck) *stuck = 0;
-    auto pl = [](Graph &g, int i) { return g.pd.p + (size_t)i * g.mpad; };
+    int pmap[P_COUNT];  // plane numbers: the accepted trial point becomes the iterate by exchange
+    for (int i = 0; i < P_COUNT; i++) pmap[i] = i;
+    auto pl = [&pmap](Graph &g, int i) { return g.pd.p + (size_t)pmap[i] * g.mpad; };
     auto xv = [&](Graph &g) { return g.pdn.p + (size_t)xplane * g.no; };
     auto atv = [](Graph &g) { return g.pdn.p + (size_t)N_ATV * g.no; };
     auto atdv = [](Graph &g) { return g.pdn.p + (size_t)N_ATDV * g.no; };
     auto ge = [](Graph &g) { return grid_edges(g.m); };
     auto gv = [](Graph &g) { return grid_elems(g.no); };
     auto gr = [](Graph &g) { return grid_rows(g.levels[0]); };
-    // fixed-order sum over the members' partial arrays (members in order), then over processes
-    auto sum_all = [&](auto nparts_of, double out[3]) {
-        out[0] = out[1] = out[2] = 0.0;
-        for (auto &M : G.mem) {
-            double t[3];
-            fetch_parts(*M.g, nparts_of(*M.g), t);
-            for (int c = 0; c < 3; c++) out[c] += t[c];
-        }
-        if (G.combine) G.combine(out, 3, 0);
+    auto sync_all = [&]() {
+        for (auto &M : G.mem) IRH_CHECK(hipStreamSynchronize(M.g->stream));
     };
-    auto ext_all = [&](auto nparts_of, bool is_max) {
+    // fixed-order sum over the members' partial arrays (members in order) -- after pd_fetch + sync_all
+    auto sum_members = [&](int slot, auto nparts_of, double out[4]) {
+        out[0] = out[1] = out[2] = out[3] = 0.0;
+        for (auto &M : G.mem) {
+            double t[4];
+            pd_sum(*M.g, slot, nparts_of(*M.g), t);
+            for (int c = 0; c < 4; c++) out[c] += t[c];
+        }
+    };
+    auto ext_members = [&](int slot, auto nparts_of, bool is_max) {
         double r = is_max ? -HUGE_VAL : HUGE_VAL;
         for (auto &M : G.mem) {
-            const double t = fetch_ext(*M.g, nparts_of(*M.g), is_max);
+            const double t = pd_ext(*M.g, slot, nparts_of(*M.g), is_max);
             r = is_max ? std::max(r, t) : std::min(r, t);
             if (t != t) r = t;  // NaN must surface (breakdown)
         }
@@ -438,41 +471,42 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
         IRH_CHECK(hipMemsetAsync(xv(g), 0, sizeof(double) * (size_t)g.no, st));           // x0 = 0
         IRH_CHECK(hipMemsetAsync(pl(g, P_AX), 0, sizeof(double) * (size_t)g.mpad, st));    // Ax = A*0
         hipLaunchKernelGGL(k_pd_absmax, dim3(ge(g)), dim3(kRowBlock), 0, st, (long long)g.m, M.y, pl(g, P_AX),
-                           g.pd_part.p);
+                           pd_part_slot(g, 0));
+        pd_fetch(g, 0, ge(g));
     }
-    const double maxabs = ext_all(ge, true);
-    for (auto &M : G.mem) {
-        Graph &g = *M.g;
-        hipLaunchKernelGGL(k_pd_init, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, pl(g, P_AX),
-                           maxabs, pl(g, P_U), pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), pl(g, P_T1),
-                           g.pd_part.p, M.eown);
-    }
-    sum_all(ge, s3);
-    double sdg = -(s3[0] + s3[1]);     // :264
-    double tau = mu * 2 * mglob / sdg;  // :265
-    double rd_tail2 = s3[2];
-    auto at_mul = [&](int tplane, bool into_atdv) {
+    sync_all();
+    const double maxabs = ext_members(0, ge, true);
+    auto at_mul = [&](int tplane, bool into_atdv, int slot) {
         for (auto &M : G.mem) {
             Graph &g = *M.g;
             Level &L0 = g.levels[0];
             hipLaunchKernelGGL(k_at_mul, dim3(gr(g)), dim3(kRowBlock), 0, g.stream, g.no, L0.nsl, L0.sl_off.p,
                                g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, tplane),
-                               into_atdv ? atdv(g) : atv(g), g.pd_part.p);
+                               into_atdv ? atdv(g) : atv(g), pd_part_slot(g, slot));
         }
     };
-    at_mul(P_T1, false);
-    sum_all(gr, s3);
-    const double atv2 = s3[0];
-    auto rcent = [&](double itau) {
-        for (auto &M : G.mem) {
-            Graph &g = *M.g;
-            hipLaunchKernelGGL(k_pd_rcent, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, pl(g, P_F1),
-                               pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau, g.pd_part.p, M.eown);
-        }
-        sum_all(ge, s3);
-        return s3[0];
-    };
-    double resnorm = std::sqrt(atv2 + rd_tail2 + rcent(1.0 / tau));  // :278-281
+    for (auto &M : G.mem) {
+        Graph &g = *M.g;
+        hipLaunchKernelGGL(k_pd_init, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, pl(g, P_AX),
+                           maxabs, pl(g, P_U), pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), pl(g, P_T1),
+                           pd_part_slot(g, 0), M.eown);
+    }
+    at_mul(P_T1, false, 1);  // Atv = A'(lamu1 - lamu2) (:262) and its sum of squares
+    for (auto &M : G.mem) {
+        pd_fetch(*M.g, 0, ge(*M.g));
+        pd_fetch(*M.g, 1, gr(*M.g));
+    }
+    sync_all();
+    double s4[4], v4[4];
+    sum_members(0, ge, s4);
+    sum_members(1, gr, v4);
+    s4[3] = v4[0];
+    if (G.combine) G.combine(s4, 4, 0);
+    double sdg = -(s4[0] + s4[1]);      // :264
+    double tau = mu * 2 * mglob / sdg;  // :265
+    // resnorm^2 (:278-281, 455-458) = res2 + |rcent|^2; the rcent part arrives with the first fetch of the iteration
+    // that uses the norm (k_pd_sig)
+    double res2 = s4[3] + s4[2];
 
     int pditer = 0;
     bool done = (sdg < PDTOL) || (pditer >= pdmaxiter);  // :284
@@ -484,7 +518,8 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
             Level &L0 = g.levels[0];
             hipStream_t st = g.stream;
             hipLaunchKernelGGL(k_pd_sig, dim3(ge(g)), dim3(kRowBlock), 0, st, (long long)g.m, pl(g, P_F1),
-                               pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau, pl(g, P_SIGX), pl(g, P_T1), pl(g, P_T2));
+                               pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau, pl(g, P_SIGX), pl(g, P_T1), pl(g, P_T2),
+                               pd_part_slot(g, 1), M.eown);
             // inverse of the same PD iteration of the previous outer iteration, if still close enough
             // (measured at 100k/2M: the entry ratios against (p, t-1) span 2-20x in the first outer
             // iterations and <1.5x from the ~7th on; accepting up to kPdSpread costs ~1 PCG iteration
@@ -524,34 +559,46 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
             Graph &g = *M.g;
             hipLaunchKernelGGL(k_pd_dir, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, g.f, g.ei.p,
                                g.ej.p, g.eflag.p, g.X.p, pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau,
-                               pl(g, P_ADX), pl(g, P_DU), pl(g, P_DL1), pl(g, P_DL2), pl(g, P_T1), g.pd_part.p);
+                               pl(g, P_ADX), pl(g, P_DU), pl(g, P_DL1), pl(g, P_DL2), pl(g, P_T1), pd_part_slot(g, 0));
+            pd_fetch(g, 0, ge(g));
+            pd_fetch(g, 1, ge(g));
         }
-        double s = std::fmin(1.0, ext_all(ge, false));  // :347-380
+        at_mul(P_T1, true, 2);  // Atdv (:383); its sum of squares is not used
+        sync_all();
+        double s = std::fmin(1.0, ext_members(0, ge, false));  // :347-380
         if (!(s == s)) return IROTAVG_ERR_SOLVER;
         s *= 0.99;  // :381
-        at_mul(P_T1, true);
+        double rc4[4];
+        sum_members(1, ge, rc4);  // |rcent|^2 at (fu, lamu, tau) of this iteration; combined with the first trial's sums
         // backtracking (:384-429)
         bool suffdec = false;
         int backiter = 0;
-        double s_acc = s, rdp2 = 0.0;
+        double s_acc = s, rdp2 = 0.0, resnorm = 0.0, sdg_trial = 0.0;
         while (!suffdec) {
             for (auto &M : G.mem) {
                 Graph &g = *M.g;
                 hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv(g)), dim3(kRowBlock), 0, g.stream, g.no, s, atv(g),
-                                   atdv(g), g.pd_part.p);
-            }
-            sum_all(gv, s3);
-            const double rdv = s3[0];
-            for (auto &M : G.mem) {
-                Graph &g = *M.g;
+                                   atdv(g), pd_part_slot(g, 0));
                 hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, s,
                                    itau, pl(g, P_U), pl(g, P_DU), pl(g, P_AX), pl(g, P_ADX), pl(g, P_L1),
-                                   pl(g, P_DL1), pl(g, P_L2), pl(g, P_DL2), g.pd_part.p, M.eown);
+                                   pl(g, P_DL1), pl(g, P_L2), pl(g, P_DL2), pl(g, P_U2), pl(g, P_AX2), pl(g, P_L12),
+                                   pl(g, P_L22), pl(g, P_F12), pl(g, P_F22), pd_part_slot(g, 1), M.eown);
+                pd_fetch(g, 0, gv(g));
+                pd_fetch(g, 1, ge(g));
             }
-            sum_all(ge, s3);
-            rdp2 = rdv + s3[0];
-            suffdec = std::sqrt(rdp2 + s3[1]) <= (1 - alpha * s) * resnorm;  // :419
+            sync_all();
+            double tv[4], te[4], all[6];
+            sum_members(0, gv, tv);
+            sum_members(1, ge, te);
+            all[0] = tv[0];
+            for (int c = 0; c < 4; c++) all[1 + c] = te[c];
+            all[5] = rc4[0];
+            if (G.combine) G.combine(all, backiter == 0 ? 6 : 5, 0);
+            if (backiter == 0) resnorm = std::sqrt(res2 + all[5]);
+            rdp2 = all[0] + all[1];
+            suffdec = std::sqrt(rdp2 + all[2]) <= (1 - alpha * s) * resnorm;  // :419
             s_acc = s;
+            sdg_trial = -(all[3] + all[4]);  // :446 at this trial point
             s *= beta;
             backiter++;
             if (backiter > 32) {  // :423-428 -- return the previous iterate
@@ -559,20 +606,24 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
                 return IROTAVG_OK;
             }
         }
+        // :432-442 -- the trial point is the new iterate
         for (auto &M : G.mem) {
             Graph &g = *M.g;
             hipLaunchKernelGGL(k_pd_commit_vert, dim3(gv(g)), dim3(kRowBlock), 0, g.stream, g.no, s_acc, xv(g),
                                g.X.p + g.ng, atv(g), atdv(g));
-            hipLaunchKernelGGL(k_pd_commit_edge, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y,
-                               s_acc, pl(g, P_U), pl(g, P_DU), pl(g, P_AX), pl(g, P_ADX), pl(g, P_L1), pl(g, P_DL1),
-                               pl(g, P_L2), pl(g, P_DL2), pl(g, P_F1), pl(g, P_F2), g.pd_part.p, M.eown);
         }
-        sum_all(ge, s3);
-        sdg = -(s3[0] + s3[1]);            // :446
-        tau = mu * 2 * mglob / sdg;        // :448
-        resnorm = std::sqrt(rdp2 + rcent(1.0 / tau));  // :455-458
+        std::swap(pmap[P_U], pmap[P_U2]);
+        std::swap(pmap[P_AX], pmap[P_AX2]);
+        std::swap(pmap[P_L1], pmap[P_L12]);
+        std::swap(pmap[P_L2], pmap[P_L22]);
+        std::swap(pmap[P_F1], pmap[P_F12]);
+        std::swap(pmap[P_F2], pmap[P_F22]);
+        sdg = sdg_trial;               // :446
+        tau = mu * 2 * mglob / sdg;    // :448
+        res2 = rdp2;                   // :455-458: resnorm^2 = rdp2 + |rcent(tau)|^2, completed by the next k_pd_sig
         done = (sdg < PDTOL) || (pditer >= pdmaxiter);  // :460
     }
+    for (auto &M : G.mem) IRH_CHECK(hipStreamSynchronize(M.g->stream));  // x is complete when this returns
     return IROTAVG_OK;
 }
 

@@ -16,18 +16,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_worker(wire, nproc=2, port=29611, timeout=420):
+def run_worker(wire, nproc=2, port=29611, timeout=420, extra=()):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MASTER_ADDR"] = "127.0.0.1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tools", "dist_worker.py"),
-           "--wire", wire]
+           "--wire", wire] + list(extra)
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
 
 
 def test_two_processes_host_staged_wire():
     r = run_worker("hosted")
+    assert r.returncode == 0 and "DIST_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_processes_host_staged_wire_sharded_direct_solver(nproc):
+    """a view sequence without loop closures: every rank reduces its range, ONE gather per linear solve, the top
+    levels solved on every rank (bcr_dist); l1ra then irls against the single-GPU handle"""
+    r = run_worker("hosted", nproc=nproc, port=29619 + nproc, extra=["--p-loop", "0", "--views", "9000", "--edges", "90000",
+                                                                     "--expect-direct"])
     assert r.returncode == 0 and "DIST_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--views", type=int, default=6000)
     ap.add_argument("--edges", type=int, default=60000)
     ap.add_argument("--p-loop", type=float, default=0.01)
+    ap.add_argument("--expect-direct", action="store_true", help="fail unless the sharded direct solver ran")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -43,6 +44,10 @@ def main():
     D.set_rotations(Q0)
     b1 = D.l1ra(3, 1e-3)
     b2 = D.irls(4, SIG, 20, 1e-3)
+    st = D.stats()
+    if args.expect_direct and (st["direct_solves"] == 0 or st["pcg_iters"] != 0 or D.info()["direct_block"] == 0):
+        print("DIST_WORKER_FAIL rank %d: the sharded direct solver did not run: %r" % (rank, st), flush=True)
+        sys.exit(1)
     Qmine = D.get_rotations(into=np.zeros_like(Q0))        # rows this rank owns, zeros elsewhere
     wmine = np.nan_to_num(D.get_weights(), nan=-1.0)
     D.close()
