@@ -184,7 +184,7 @@ struct StreamPool {
 // pageable memory goes through the runtime's own staging and left the GPU idle ~30 us per host
 // decision (kernel trace, round 2); into pinned memory it is a plain DMA. Fixed-size blocks, recycled.
 struct PinPool {
-    static constexpr size_t kBytes = 64 * 1024;
+    static constexpr size_t kBytes = 128 * 1024;
     std::mutex mu;
     std::vector<void *> idle;
     static PinPool &get() {
@@ -201,7 +201,9 @@ struct PinPool {
             }
         }
         void *p = nullptr;
-        IRH_CHECK(hipHostMalloc(&p, kBytes, hipHostMallocDefault));
+        // mapped + coherent (fine-grained): a kernel may store into the block and the host may poll it while the
+        // kernel's stream is still busy (publish_parts / wait_published, solver.hip)
+        IRH_CHECK(hipHostMalloc(&p, kBytes, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(p, 0, kBytes);
         return p;
     }

@@ -112,6 +112,10 @@ struct Graph {
     double *h_part() { return hpin; }
     double *h_scal() { return hpin + 4 * kMaxParts; }
     int *h_flags() { return reinterpret_cast<int *>(hpin + 4 * kMaxParts + SC_COUNT); }
+    // [4096, 4096 + 8 kMaxParts): two more partial arrays (l1pd.hip); [8192]: the sequence number a publishing
+    // kernel stores last (publish_parts)
+    int *h_seq() { return reinterpret_cast<int *>(hpin + 8192); }
+    int pub_seq = 0;
     ~Graph() {
         if (hpin) PinPool::get().give(hpin);
     }
@@ -165,6 +169,16 @@ void launch_update_weights(Graph &g, int cost, double sigma, bool gated = false)
 void launch_apply_step(Graph &g, bool gated);
 double finish_apply_step(Graph &g);
 double apply_step(Graph &g);
+// Small read-backs that steer a solve without the runtime's copy + wait (~25 us of idle GPU per decision): ONE tiny
+// kernel behind the producers copies up to three partial arrays into the handle's pinned block and stores a sequence
+// number last (system scope); wait_published polls it (2 ms, then the stream is synchronised: long kernels, faults).
+struct PubPart {
+    const double *src;  // device
+    double *dst;        // inside g.hpin
+    int n;              // doubles
+};
+void publish_parts(Graph &g, const PubPart *parts, int nparts);
+void wait_published(Graph &g);
 int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, int *iters,
              double *runtime, double *trace);
 int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runtime,

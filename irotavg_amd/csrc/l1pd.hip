@@ -388,15 +388,18 @@ static int grid_rows(const Level &L) {
 
 // Reductions come back as per-workgroup partials (rows of 4 doubles) and are summed on the host in fixed order. A
 // graph has kPdPartSlots partial arrays, so that kernels whose results are needed at the same decision are fetched with
-// ONE host round trip: pd_fetch enqueues the copies, the caller synchronises once, pd_sum / pd_ext read the staging.
+// ONE host round trip: pd_publish sends them to the pinned block, the caller waits once, pd_sum / pd_ext read it.
 static double *pd_part_slot(Graph &g, int slot) { return g.pd_part.p + (size_t)slot * 4 * kMaxParts; }
 static double *pd_host_slot(Graph &g, int slot) {  // the pinned block has room behind the PCG's own staging
-    static_assert(4096 + (kPdPartSlots - 1) * 4 * kMaxParts <= (int)(PinPool::kBytes / sizeof(double)), "pinned block");
+    static_assert(4096 + (kPdPartSlots - 1) * 4 * kMaxParts <= 8192, "pinned block: [8192] is the sequence number");
     return slot == 0 ? g.h_part() : g.hpin + 4096 + (size_t)(slot - 1) * 4 * kMaxParts;
 }
-static void pd_fetch(Graph &g, int slot, int nparts) {
-    IRH_CHECK(hipMemcpyAsync(pd_host_slot(g, slot), pd_part_slot(g, slot), sizeof(double) * 4 * (size_t)nparts,
-                             hipMemcpyDeviceToHost, g.stream));
+// the partial arrays of up to three slots go to the pinned block by one publishing kernel (solver.hip)
+static void pd_publish(Graph &g, std::initializer_list<std::pair<int, int>> slot_nparts) {
+    PubPart parts[3];
+    int k = 0;
+    for (const auto &sn : slot_nparts) parts[k++] = PubPart{pd_part_slot(g, sn.first), pd_host_slot(g, sn.first), 4 * sn.second};
+    publish_parts(g, parts, k);
 }
 static void pd_sum(Graph &g, int slot, int nparts, double out[4]) {
     const double *h = pd_host_slot(g, slot);
@@ -443,10 +446,10 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
     auto ge = [](Graph &g) { return grid_edges(g.m); };
     auto gv = [](Graph &g) { return grid_elems(g.no); };
     auto gr = [](Graph &g) { return grid_rows(g.levels[0]); };
-    auto sync_all = [&]() {
-        for (auto &M : G.mem) IRH_CHECK(hipStreamSynchronize(M.g->stream));
+    auto sync_all = [&]() {  // every member's published partials have arrived
+        for (auto &M : G.mem) wait_published(*M.g);
     };
-    // fixed-order sum over the members' partial arrays (members in order) -- after pd_fetch + sync_all
+    // fixed-order sum over the members' partial arrays (members in order) -- after pd_publish + sync_all
     auto sum_members = [&](int slot, auto nparts_of, double out[4]) {
         out[0] = out[1] = out[2] = out[3] = 0.0;
         for (auto &M : G.mem) {
@@ -472,7 +475,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
         IRH_CHECK(hipMemsetAsync(pl(g, P_AX), 0, sizeof(double) * (size_t)g.mpad, st));    // Ax = A*0
         hipLaunchKernelGGL(k_pd_absmax, dim3(ge(g)), dim3(kRowBlock), 0, st, (long long)g.m, M.y, pl(g, P_AX),
                            pd_part_slot(g, 0));
-        pd_fetch(g, 0, ge(g));
+        pd_publish(g, {{0, ge(g)}});
     }
     sync_all();
     const double maxabs = ext_members(0, ge, true);
@@ -492,10 +495,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
                            pd_part_slot(g, 0), M.eown);
     }
     at_mul(P_T1, false, 1);  // Atv = A'(lamu1 - lamu2) (:262) and its sum of squares
-    for (auto &M : G.mem) {
-        pd_fetch(*M.g, 0, ge(*M.g));
-        pd_fetch(*M.g, 1, gr(*M.g));
-    }
+    for (auto &M : G.mem) pd_publish(*M.g, {{0, ge(*M.g)}, {1, gr(*M.g)}});
     sync_all();
     double s4[4], v4[4];
     sum_members(0, ge, s4);
@@ -560,8 +560,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
             hipLaunchKernelGGL(k_pd_dir, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, g.f, g.ei.p,
                                g.ej.p, g.eflag.p, g.X.p, pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau,
                                pl(g, P_ADX), pl(g, P_DU), pl(g, P_DL1), pl(g, P_DL2), pl(g, P_T1), pd_part_slot(g, 0));
-            pd_fetch(g, 0, ge(g));
-            pd_fetch(g, 1, ge(g));
+            pd_publish(g, {{0, ge(g)}, {1, ge(g)}});
         }
         at_mul(P_T1, true, 2);  // Atdv (:383); its sum of squares is not used
         sync_all();
@@ -583,8 +582,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
                                    itau, pl(g, P_U), pl(g, P_DU), pl(g, P_AX), pl(g, P_ADX), pl(g, P_L1),
                                    pl(g, P_DL1), pl(g, P_L2), pl(g, P_DL2), pl(g, P_U2), pl(g, P_AX2), pl(g, P_L12),
                                    pl(g, P_L22), pl(g, P_F12), pl(g, P_F22), pd_part_slot(g, 1), M.eown);
-                pd_fetch(g, 0, gv(g));
-                pd_fetch(g, 1, ge(g));
+                pd_publish(g, {{0, gv(g)}, {1, ge(g)}});
             }
             sync_all();
             double tv[4], te[4], all[6];
@@ -623,7 +621,8 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
         res2 = rdp2;                   // :455-458: resnorm^2 = rdp2 + |rcent(tau)|^2, completed by the next k_pd_sig
         done = (sdg < PDTOL) || (pditer >= pdmaxiter);  // :460
     }
-    for (auto &M : G.mem) IRH_CHECK(hipStreamSynchronize(M.g->stream));  // x is complete when this returns
+    for (auto &M : G.mem) publish_parts(*M.g, nullptr, 0);  // x is complete when this returns
+    sync_all();
     return IROTAVG_OK;
 }
 

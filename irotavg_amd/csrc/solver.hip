@@ -2054,6 +2054,45 @@ int ls_solve(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
     return rc;
 }
 
+__global__ __launch_bounds__(256) void k_publish(const double *__restrict__ s0, double *__restrict__ d0, int n0,
+                                                 const double *__restrict__ s1, double *__restrict__ d1, int n1,
+                                                 const double *__restrict__ s2, double *__restrict__ d2, int n2,
+                                                 int *__restrict__ seqp, int seq) {
+    for (int i = threadIdx.x; i < n0; i += 256) d0[i] = s0[i];
+    for (int i = threadIdx.x; i < n1; i += 256) d1[i] = s1[i];
+    for (int i = threadIdx.x; i < n2; i += 256) d2[i] = s2[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(seqp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void publish_parts(Graph &g, const PubPart *parts, int nparts) {
+    PubPart p[3] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+    for (int i = 0; i < nparts && i < 3; i++) p[i] = parts[i];
+    g.pub_seq = (g.pub_seq + 1 == 0) ? 1 : g.pub_seq + 1;
+    __atomic_store_n(g.h_seq(), 0, __ATOMIC_RELEASE);
+    // (the pinned block is mapped: under unified addressing the device uses the host's pointer)
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, g.stream, p[0].src, p[0].dst, p[0].n, p[1].src, p[1].dst,
+                       p[1].n, p[2].src, p[2].dst, p[2].n, g.h_seq(), g.pub_seq);
+    IRH_CHECK(hipGetLastError());
+}
+
+void wait_published(Graph &g) {
+    static const bool no_poll = std::getenv("IROTAVG_NO_POLL") != nullptr;
+    bool seen = false;
+    if (!no_poll) {
+        const double t0 = now_seconds();
+        int spins = 0;
+        while (!(seen = __atomic_load_n(g.h_seq(), __ATOMIC_ACQUIRE) == g.pub_seq)) {
+            if ((++spins & 255) == 0 && now_seconds() - t0 > 2e-3) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    if (!seen) IRH_CHECK(hipStreamSynchronize(g.stream));
+}
+
 // score, exp map, rotation update: kernel + copy of the score partials into the pinned block (no
 // synchronisation); finish_apply_step sums them once the stream has been synchronised
 void launch_apply_step(Graph &g, bool gated) {
@@ -2072,8 +2111,13 @@ double finish_apply_step(Graph &g) {
     return s / (double)g.no;
 }
 double apply_step(Graph &g) {
-    launch_apply_step(g, false);
-    IRH_CHECK(hipStreamSynchronize(g.stream));
+    const int n = g.nu;
+    const int grid = grid_for_elems(n);
+    hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kRowBlock), 0, g.stream, n, g.f, g.ng, g.X.p, g.Q.p,
+                       g.part_score.p, 1, (const int *)nullptr);
+    const PubPart part{g.part_score.p, g.h_part(), 4 * grid};
+    publish_parts(g, &part, 1);
+    wait_published(g);
     return finish_apply_step(g);
 }
 
