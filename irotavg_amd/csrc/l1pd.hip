@@ -21,7 +21,7 @@ constexpr double kPdSpread = 8.0;  // staleness band of a parked primal-dual inv
 
 
 enum PdPlane : int {
-    P_Y = 0, P_U, P_AX, P_F1, P_F2, P_L1, P_L2, P_SIGX, P_T1, P_T2, P_ADX, P_DU, P_DL1, P_DL2,
+    P_Y = 0, P_U, P_AX, P_F1, P_F2, P_L1, P_L2, P_SIGX, P_T1, P_T2, P_ADX,
     // the trial point of the back-tracking loop (u, Ax, lamu1, lamu2, fu1, fu2 at step s): accepting it is an exchange
     // of plane numbers, not another pass over the edges
     P_U2, P_AX2, P_L12, P_L22, P_F12, P_F22,
@@ -140,18 +140,19 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_init(long long m, const double
     block_sum3_store(a0, a1, a2, part + 4 * blockIdx.x);
 }
 
-// :292-305 -- sigx and the two operands of A' (t1 for w1, t2 for w1p); on the way, from the same four loads, the sum
-// of squares of rcent = [-lamu1.*fu1; -lamu2.*fu2] - 1/tau (:267-270, 450-453) that the residual norm of THIS
-// iteration's back-tracking test needs (the reference forms it at the end of the previous iteration, from the same
-// fu, lamu and tau; a pass of its own, with its own host round trip, until round 3)
+// :292-305 -- sigx and the operand of A' for the right-hand side: w1p = -(1/tau) A' t1 - A' t2 with t1 = -1/fu1 + 1/fu2,
+// t2 = (sig12/sig11) w2 is A'(-(1/tau) t1 - t2), one plane and one gather per entry for k_pd_rhs. On the way, from the
+// same four loads, the sum of squares of rcent = [-lamu1.*fu1; -lamu2.*fu2] - 1/tau (:267-270, 450-453) that the
+// residual norm of THIS iteration's back-tracking test needs (the reference forms it at the end of the previous
+// iteration, from the same fu, lamu and tau; a pass of its own, with its own host round trip, until round 3)
 __global__ __launch_bounds__(kRowBlock) void k_pd_sig(long long m, const double *__restrict__ f1,
                                                    const double *__restrict__ f2,
                                                    const double *__restrict__ l1,
                                                    const double *__restrict__ l2, double itau,
-                                                   double *__restrict__ sigx, double *__restrict__ t1,
-                                                   double *__restrict__ t2, double *__restrict__ part,
-                                                   const uint8_t *__restrict__ own) {
+                                                   double *__restrict__ sigx, double *__restrict__ t12,
+                                                   double *__restrict__ part, const uint8_t *__restrict__ own) {
     double a0 = 0;
+    const double c1 = -itau, c2 = -1.0;
     EDGE_LOOP(k) {
         const double g1 = f1[k], g2 = f2[k], m1 = l1[k], m2 = l2[k];
         const double if1 = 1.0 / g1, if2 = 1.0 / g2;
@@ -159,11 +160,12 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_sig(long long m, const double 
         const double a = m1 / g1, b = m2 / g2;
         const double s1 = -a - b, s2 = a - b;
         sigx[k] = s1 - (s2 * s2) / s1;
-        t1[k] = -if1 + if2;
-        t2[k] = (s2 / s1) * w2;
+        const double t1 = -if1 + if2;
+        const double t2 = (s2 / s1) * w2;
+        t12[k] = c1 * t1 + c2 * t2;
         if (own != nullptr && !own[k]) continue;  // sharded: a cross-shard edge is summed by one shard only
-        const double c1 = -m1 * g1 - itau, c2 = -m2 * g2 - itau;
-        a0 += c1 * c1 + c2 * c2;
+        const double r1 = -m1 * g1 - itau, r2 = -m2 * g2 - itau;
+        a0 += r1 * r1 + r2 * r2;
     }
     block_sum3_store(a0, 0.0, 0.0, part + 4 * blockIdx.x);
 }
@@ -173,15 +175,10 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_sig(long long m, const double 
 // only when make_A kept the coefficient).
 // The walk is a chain of dependent loads (slot -> edge value); eight entries are in flight per lane (with four the
 // kernels were latency-bound: 90-200 us for 0.4 M rows once the direct solver had removed the PCG around them).
-// TWO: the same walk over two edge planes at once, result c1 * (A' t1)_row + c2 * (A' t2)_row.
-template <bool TWO>
-__device__ __forceinline__ double at_row_t(int row, int n, const int *__restrict__ sl_off,
-                                           const uint32_t *__restrict__ slot_eid,
-                                           const int *__restrict__ bptr,
-                                           const uint32_t *__restrict__ beid,
-                                           const uint8_t *__restrict__ bflag,
-                                           const double *__restrict__ t, const double *__restrict__ tb, double c1,
-                                           double c2) {
+__device__ __forceinline__ double at_row(int row, int n, const int *__restrict__ sl_off,
+                                         const uint32_t *__restrict__ slot_eid, const int *__restrict__ bptr,
+                                         const uint32_t *__restrict__ beid, const uint8_t *__restrict__ bflag,
+                                         const double *__restrict__ t) {
     const int sl = row >> 6, lane = row & 63;
     const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;   // a multiple of 8
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -197,7 +194,7 @@ __device__ __forceinline__ double at_row_t(int row, int n, const int *__restrict
             const unsigned e = (u & 1) ? se[u >> 1].y : se[u >> 1].x;
             const bool ok = e != 0xffffffffu;
             const size_t idx = ok ? (size_t)(e >> 1) : 0;
-            double x = TWO ? c1 * t[idx] + c2 * tb[idx] : t[idx];
+            double x = t[idx];
             x = (e & 1u) ? x : -x;
             v[u] = ok ? x : 0.0;
         }
@@ -208,17 +205,11 @@ __device__ __forceinline__ double at_row_t(int row, int n, const int *__restrict
         for (int q = bptr[row]; q < bptr[row + 1]; q++) {
             if (!(bflag[q] & BF_IRLS)) continue;
             const uint32_t se = beid[q];
-            const double x = TWO ? c1 * t[se >> 1] + c2 * tb[se >> 1] : t[se >> 1];
+            const double x = t[se >> 1];
             s += (se & 1u) ? x : -x;
         }
     }
     return s;
-}
-__device__ __forceinline__ double at_row(int row, int n, const int *__restrict__ sl_off,
-                                         const uint32_t *__restrict__ slot_eid, const int *__restrict__ bptr,
-                                         const uint32_t *__restrict__ beid, const uint8_t *__restrict__ bflag,
-                                         const double *__restrict__ t) {
-    return at_row_t<false>(row, n, sl_off, slot_eid, bptr, beid, bflag, t, nullptr, 0.0, 0.0);
 }
 
 #define PD_ROW_LOOP(nsl)                                       \
@@ -249,30 +240,46 @@ __global__ __launch_bounds__(kRowBlock) void k_at_mul(int n, int nsl, const int 
     block_sum3_store(acc, 0.0, 0.0, part + 4 * blockIdx.x);
 }
 
-// rhs = w1p = -(1/tau) A' t1 - A' t2   (:300-306), stored in component 0 of the PCG rhs
+// rhs = w1p = -(1/tau) A' t1 - A' t2 = A' t12  (:300-306; t12 from k_pd_sig), stored in component 0 of the solver's rhs
 __global__ __launch_bounds__(kRowBlock) void k_pd_rhs(int n, int nsl, const int *__restrict__ sl_off,
                                                       const uint32_t *__restrict__ slot_eid,
                                                       const int *__restrict__ bptr,
                                                       const uint32_t *__restrict__ beid,
                                                       const uint8_t *__restrict__ bflag,
-                                                      const double *__restrict__ t1,
-                                                      const double *__restrict__ t2, double itau,
-                                                      double4 *__restrict__ rhs) {
+                                                      const double *__restrict__ t12, double4 *__restrict__ rhs) {
     PD_ROW_LOOP(nsl) {
         const int row = sl_ * 64 + (threadIdx.x & 63);
-        // -(1/tau) A' t1 - A' t2 in ONE walk of the row
-        const double w1p = at_row_t<true>(row, n, sl_off, slot_eid, bptr, beid, bflag, t1, t2, -itau, -1.0);
+        const double w1p = at_row(row, n, sl_off, slot_eid, bptr, beid, bflag, t12);
         if (row < n) rhs[row] = make_double4(w1p, 0.0, 0.0, 0.0);
     }
 }
 
-// :324-381 -- Adx, du, dlamu1, dlamu2, operand of A' (Atdv), and the four guarded step bounds
+// :324-345 -- du, dlamu1, dlamu2 of one edge from A dx and the iterate. k_pd_dir needs them for the step bounds,
+// k_pd_trial_edge for the trial point: both call this (the same statements in the same order), so the three vectors
+// are never stored.
+__device__ __forceinline__ void pd_direction(double adx, double g1, double g2, double m1, double m2, double itau,
+                                             double &d_u, double &d1, double &d2) {
+    const double if1 = 1.0 / g1, if2 = 1.0 / g2;
+    const double w2 = -1 - itau * (if1 + if2);
+    const double a = m1 / g1, b = m2 / g2;
+    const double s1 = -a - b, s2 = a - b;
+    d_u = (w2 - s2 * adx) / s1;
+    d1 = -m1 / g1;
+    d1 *= (adx - d_u);
+    d1 -= m1;
+    d1 -= itau * if1;
+    d2 = m2 / g2;
+    d2 *= (adx + d_u);
+    d2 -= m2;
+    d2 -= itau * if2;
+}
+
+// :324-381 -- Adx, the operand of A' (Atdv), and the four guarded step bounds
 __global__ __launch_bounds__(kRowBlock) void k_pd_dir(
     long long m, int f, const int *__restrict__ ei, const int *__restrict__ ej,
     const uint8_t *__restrict__ eflag, const double4 *__restrict__ DX,
     const double *__restrict__ f1, const double *__restrict__ f2, const double *__restrict__ l1,
-    const double *__restrict__ l2, double itau, double *__restrict__ Adx, double *__restrict__ du,
-    double *__restrict__ dl1, double *__restrict__ dl2, double *__restrict__ t3,
+    const double *__restrict__ l2, double itau, double *__restrict__ Adx, double *__restrict__ t3,
     double *__restrict__ part) {
     double smin = HUGE_VAL;
     EDGE_LOOP(k) {
@@ -281,23 +288,9 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_dir(
         if (fl & EF_CJ) adx += DX[ej[k] - f].x;
         if (fl & EF_CI) adx -= DX[ei[k] - f].x;
         const double g1 = f1[k], g2 = f2[k], m1 = l1[k], m2 = l2[k];
-        const double if1 = 1.0 / g1, if2 = 1.0 / g2;
-        const double w2 = -1 - itau * (if1 + if2);
-        const double a = m1 / g1, b = m2 / g2;
-        const double s1 = -a - b, s2 = a - b;
-        const double d_u = (w2 - s2 * adx) / s1;
-        double d1 = -m1 / g1;
-        d1 *= (adx - d_u);
-        d1 -= m1;
-        d1 -= itau * if1;
-        double d2 = m2 / g2;
-        d2 *= (adx + d_u);
-        d2 -= m2;
-        d2 -= itau * if2;
+        double d_u, d1, d2;
+        pd_direction(adx, g1, g2, m1, m2, itau, d_u, d1, d2);
         Adx[k] = adx;
-        du[k] = d_u;
-        dl1[k] = d1;
-        dl2[k] = d2;
         t3[k] = d1 - d2;
         if (d1 < 0) smin = fmin(smin, -m1 / d1);
         if (d2 < 0) smin = fmin(smin, -m2 / d2);
@@ -311,20 +304,24 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_dir(
 
 // trial point at step s: sums of squares of the m-tail of rdp (:407-410) and of rcp (:412-416). The point itself is
 // stored (planes u2 ... f22) together with the two sums of the surrogate duality gap (:446) it would have: when the
-// host accepts the step (:432-442) nothing is left to do on the edges.
+// host accepts the step (:432-442) nothing is left to do on the edges. fu1, fu2 of the iterate are re-formed from
+// Ax, y, u by the statement that produced the stored ones (bit for bit), the direction by pd_direction.
 __global__ __launch_bounds__(kRowBlock) void k_pd_trial_edge(
     long long m, const double *__restrict__ y, double s, double itau, const double *__restrict__ u,
-    const double *__restrict__ du, const double *__restrict__ Ax, const double *__restrict__ Adx,
-    const double *__restrict__ l1, const double *__restrict__ dl1, const double *__restrict__ l2,
-    const double *__restrict__ dl2, double *__restrict__ u2, double *__restrict__ Ax2, double *__restrict__ l12,
+    const double *__restrict__ Ax, const double *__restrict__ Adx, const double *__restrict__ l1,
+    const double *__restrict__ l2, double *__restrict__ u2, double *__restrict__ Ax2, double *__restrict__ l12,
     double *__restrict__ l22, double *__restrict__ f12, double *__restrict__ f22, double *__restrict__ part,
     const uint8_t *__restrict__ own) {
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     EDGE_LOOP(k) {
-        const double up = u[k] + s * du[k];
-        const double axp = Ax[k] + s * Adx[k];
-        const double m1 = l1[k] + s * dl1[k], m2 = l2[k] + s * dl2[k];
-        const double g1 = axp - y[k] - up, g2 = -axp + y[k] - up;
+        const double yy = y[k], u0 = u[k], ax0 = Ax[k], adx = Adx[k], m10 = l1[k], m20 = l2[k];
+        const double g10 = ax0 - yy - u0, g20 = -ax0 + yy - u0;
+        double d_u, d1, d2;
+        pd_direction(adx, g10, g20, m10, m20, itau, d_u, d1, d2);
+        const double up = u0 + s * d_u;
+        const double axp = ax0 + s * adx;
+        const double m1 = m10 + s * d1, m2 = m20 + s * d2;
+        const double g1 = axp - yy - up, g2 = -axp + yy - up;
         u2[k] = up;
         Ax2[k] = axp;
         l12[k] = m1;
@@ -518,8 +515,8 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
             Level &L0 = g.levels[0];
             hipStream_t st = g.stream;
             hipLaunchKernelGGL(k_pd_sig, dim3(ge(g)), dim3(kRowBlock), 0, st, (long long)g.m, pl(g, P_F1),
-                               pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau, pl(g, P_SIGX), pl(g, P_T1), pl(g, P_T2),
-                               pd_part_slot(g, 1), M.eown);
+                               pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau, pl(g, P_SIGX), pl(g, P_T2), pd_part_slot(g, 1),
+                               M.eown);
             // inverse of the same PD iteration of the previous outer iteration, if still close enough
             // (measured at 100k/2M: the entry ratios against (p, t-1) span 2-20x in the first outer
             // iterations and <1.5x from the ~7th on; accepting up to kPdSpread costs ~1 PCG iteration
@@ -532,8 +529,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
                 g.stale_spread = keep;
             }
             hipLaunchKernelGGL(k_pd_rhs, dim3(gr(g)), dim3(kRowBlock), 0, st, g.no, L0.nsl, L0.sl_off.p,
-                               g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, P_T1), pl(g, P_T2), itau,
-                               L0.b.p);
+                               g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, P_T2), L0.b.p);
         }
         // the primal-dual Hessians (weights 1/f^2 spread over decades) want less over-correction than
         // the IRLS systems of a band graph: 1.6 measured best on both topologies
@@ -559,7 +555,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
             Graph &g = *M.g;
             hipLaunchKernelGGL(k_pd_dir, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, g.f, g.ei.p,
                                g.ej.p, g.eflag.p, g.X.p, pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau,
-                               pl(g, P_ADX), pl(g, P_DU), pl(g, P_DL1), pl(g, P_DL2), pl(g, P_T1), pd_part_slot(g, 0));
+                               pl(g, P_ADX), pl(g, P_T1), pd_part_slot(g, 0));
             pd_publish(g, {{0, ge(g)}, {1, ge(g)}});
         }
         at_mul(P_T1, true, 2);  // Atdv (:383); its sum of squares is not used
@@ -579,9 +575,9 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
                 hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv(g)), dim3(kRowBlock), 0, g.stream, g.no, s, atv(g),
                                    atdv(g), pd_part_slot(g, 0));
                 hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, s,
-                                   itau, pl(g, P_U), pl(g, P_DU), pl(g, P_AX), pl(g, P_ADX), pl(g, P_L1),
-                                   pl(g, P_DL1), pl(g, P_L2), pl(g, P_DL2), pl(g, P_U2), pl(g, P_AX2), pl(g, P_L12),
-                                   pl(g, P_L22), pl(g, P_F12), pl(g, P_F22), pd_part_slot(g, 1), M.eown);
+                                   itau, pl(g, P_U), pl(g, P_AX), pl(g, P_ADX), pl(g, P_L1), pl(g, P_L2), pl(g, P_U2),
+                                   pl(g, P_AX2), pl(g, P_L12), pl(g, P_L22), pl(g, P_F12), pl(g, P_F22),
+                                   pd_part_slot(g, 1), M.eown);
                 pd_publish(g, {{0, gv(g)}, {1, ge(g)}});
             }
             sync_all();
