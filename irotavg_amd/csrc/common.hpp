@@ -203,7 +203,8 @@ struct PinPool {
         void *p = nullptr;
         // mapped + coherent (fine-grained): a kernel may store into the block and the host may poll it while the
         // kernel's stream is still busy (publish_parts / wait_published, solver.hip)
-        IRH_CHECK(hipHostMalloc(&p, kBytes, hipHostMallocMapped | hipHostMallocCoherent));
+        static const bool plain = std::getenv("IROTAVG_PIN_DEFAULT") != nullptr;  // experiments (with IROTAVG_NO_POLL=1)
+        IRH_CHECK(hipHostMalloc(&p, kBytes, plain ? hipHostMallocDefault : (hipHostMallocMapped | hipHostMallocCoherent)));
         std::memset(p, 0, kBytes);
         return p;
     }
