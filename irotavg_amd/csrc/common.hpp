@@ -169,13 +169,50 @@ struct StreamPool {
         }
         (void)hipStreamDestroy(s);
     }
+    // Three streams created back to back and kept together. The runtime multiplexes its streams onto a few hardware
+    // queues (four by default), a new stream going to the least loaded one: three streams created in a row sit on
+    // three different queues, three arbitrary streams of the pool often do not -- and kernels of streams that share
+    // a queue do not overlap (l1ra's three concurrent solver chains: 9.9 ms per call or 13.1 ms, fixed per process,
+    // depending on which streams the pool happened to hand out).
+    struct Trio {
+        hipStream_t s[3];
+    };
+    std::multimap<int, Trio> idle3;
+    Trio take_trio() {
+        int dev = 0;
+        IRH_CHECK(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = idle3.find(dev);
+            if (it != idle3.end()) {
+                Trio t = it->second;
+                idle3.erase(it);
+                return t;
+            }
+        }
+        Trio t{{nullptr, nullptr, nullptr}};
+        for (int c = 0; c < 3; c++) IRH_CHECK(hipStreamCreateWithFlags(&t.s[c], hipStreamNonBlocking));
+        return t;
+    }
+    void give_trio(const Trio &t, int dev) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle3.size() < 16) {
+            idle3.insert({dev, t});
+            return;
+        }
+        for (int c = 0; c < 3; c++) (void)hipStreamDestroy(t.s[c]);
+    }
     void trim() {
         std::multimap<int, hipStream_t> drop;
+        std::multimap<int, Trio> drop3;
         {
             std::lock_guard<std::mutex> lk(mu);
             drop.swap(idle);
+            drop3.swap(idle3);
         }
         for (auto &kv : drop) (void)hipStreamDestroy(kv.second);
+        for (auto &kv : drop3)
+            for (int c = 0; c < 3; c++) (void)hipStreamDestroy(kv.second.s[c]);
     }
 };
 

@@ -657,7 +657,7 @@ int l1decode_pd_dev(Graph &g, int er_plane, const double *y_host, int pdmaxiter,
 // iteration (ral/l1_irls.cpp:889-892, independent by construction) run concurrently on three
 // streams. Every kernel of this latency-bound path leaves most of the chip idle, so the three
 // chains overlap almost perfectly.
-static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
+static std::unique_ptr<Graph> make_solver_clone(Graph &g, hipStream_t stream) {
     std::unique_ptr<Graph> c(new Graph());
     Graph &q = *c;
     q.is_clone = true;
@@ -665,7 +665,7 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
     q.f = g.f; q.nu = g.nu; q.ng = g.ng; q.no = g.no;
     q.opt = g.opt;
     q.device = g.device;
-    q.stream = StreamPool::get().take();
+    q.stream = stream;
     hipStream_t s = q.stream;
     q.ei.alias(g.ei); q.ej.alias(g.ej); q.eflag.alias(g.eflag);
     q.qq.alias(g.qq); q.er.alias(g.er); q.dw.alias(g.dw); q.Q.alias(g.Q);
@@ -714,12 +714,16 @@ static std::unique_ptr<Graph> make_solver_clone(Graph &g) {
 }
 
 static void destroy_clone_streams(Graph &g) {
-    for (auto &c : g.l1_clones)
-        if (c && c->stream) {
-            (void)hipStreamSynchronize(c->stream);
-            StreamPool::get().give(c->stream, g.device);
-            c->stream = nullptr;
-        }
+    if (g.l1_clones.size() != 3) return;
+    StreamPool::Trio t{{nullptr, nullptr, nullptr}};
+    for (int c = 0; c < 3; c++) {
+        Graph *q = g.l1_clones[c].get();
+        if (!q || !q->stream) return;  // (never partially built: see run_l1ra)
+        (void)hipStreamSynchronize(q->stream);
+        t.s[c] = q->stream;
+        q->stream = nullptr;
+    }
+    StreamPool::get().give_trio(t, g.device);
 }
 
 // the three coordinates' solutions (pdn planes N_X0..N_X2, owned views) -> X as double4 rows
@@ -753,8 +757,19 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
         IRH_CHECK(hipStreamSynchronize(g.stream));  // the clones read the residual planes
         // :889-892 -- the three coordinates are independent LPs: one solver clone and one host
         // thread per coordinate, three streams
-        if (g.l1_clones.empty())
-            for (int c = 0; c < 3; c++) g.l1_clones.push_back(make_solver_clone(g));
+        if (g.l1_clones.empty()) {
+            const StreamPool::Trio trio = StreamPool::get().take_trio();  // three hardware queues (common.hpp)
+            std::vector<std::unique_ptr<Graph>> cl;
+            try {
+                for (int c = 0; c < 3; c++) cl.push_back(make_solver_clone(g, trio.s[c]));
+            } catch (...) {
+                for (auto &q : cl) q->stream = nullptr;
+                for (int c = 0; c < 3; c++) (void)hipStreamSynchronize(trio.s[c]);
+                StreamPool::get().give_trio(trio, g.device);
+                throw;
+            }
+            g.l1_clones = std::move(cl);
+        }
         int rcs[3] = {IROTAVG_OK, IROTAVG_OK, IROTAVG_OK};
         std::thread th[3];
         for (int c = 0; c < 3; c++) {
