@@ -1,3 +1,8 @@
+// sweep_mfma.hip -- the blocked symmetric sweep on the matrix cores (built, measured, withdrawn)
+// next to the scalar sweep of irotavg_amd/csrc/bcr.hip (bcr_invert, copied below as it stood), with a stand-alone test:
+// random SPD blocks of 8 / 16 / 24 / 32, with and without a floating pair (dead pivot), both sweeps against each other
+// and against A X = I, and the time per inversion of one wave.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/sweep_mfma.hip -o /tmp/sweep_mfma && /tmp/sweep_mfma
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
