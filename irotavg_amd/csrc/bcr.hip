@@ -608,18 +608,34 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
     const int kreal = nb - chunk * 8 < 8 ? nb - chunk * 8 : 8;
     const bool placed = place && kreal < 8;  // see kBcrPlace
     const int nblk = placed || kreal > 7 ? 7 : kreal;  // W blocks to stage (the separator, position 7, has none)
+    // x of the two separators (from the coarser level) and W are requested together: one memory round trip, not two
+    constexpr int NQ = (B * NR + 255) / 256;
+    double x8[NQ], x0[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int e = tid + 256 * q;
+        x8[q] = 0.0;
+        x0[q] = 0.0;
+        if (e < B * NR) {
+            x8[q] = xc[(size_t)chunk * B * NR + e];
+            if (chunk > 0) x0[q] = xc[(size_t)(chunk - 1) * B * NR + e];
+            else if (xext) x0[q] = xext[e];   // a shard: the separator of the rank before it (dist.hip)
+        }
+    }
     {
         const v2d *__restrict__ src = reinterpret_cast<const v2d *>(W + (size_t)chunk * 7 * WB);
         v2d *dst = reinterpret_cast<v2d *>(sW);
         const int cnt = nblk * WB / 2;  // B is a multiple of 8: WB is even
         for (int e = tid; e < cnt; e += 256) dst[e] = __builtin_nontemporal_load(&src[e]);
     }
-    for (int e = tid; e < 9 * B * NR; e += 256) (&sX[0][0])[e] = 0.0;
-    __syncthreads();
-    for (int e = tid; e < B * NR; e += 256) {
-        sX[8][e] = xc[(size_t)chunk * B * NR + e];
-        if (chunk > 0) sX[0][e] = xc[(size_t)(chunk - 1) * B * NR + e];
-        else if (xext) sX[0][e] = xext[e];   // a shard: the separator of the rank before it (dist.hip)
+    for (int e = tid; e < 7 * B * NR; e += 256) (&sX[1][0])[e] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int e = tid + 256 * q;
+        if (e < B * NR) {
+            sX[8][e] = x8[q];
+            sX[0][e] = x0[q];
+        }
     }
     __syncthreads();
     const int lk = lane >> 4, lp = lane & 15;
