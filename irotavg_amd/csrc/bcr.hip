@@ -20,8 +20,8 @@
 // LDS -- with vector FMAs every value of P, Q and D^-1 would have to reach all 64 lanes, and eight waves
 // per CU saturate the LDS port with that); the accumulator layout of one product IS the B-operand layout
 // of the next (row = 4 reg + lane / 16), so W never leaves the registers between the two. D_i^-1 is
-// formed by a symmetric sweep (Gauss-Jordan without pivoting: SPD) on a register tile per lane, pivot
-// column exchanged by lane permutes. A pivot not above kDeadTol x its original diagonal entry is dead
+// formed by a symmetric sweep (Gauss-Jordan without pivoting: SPD), a column per lane, the pivot row
+// broadcast through LDS (bcr_invert). A pivot not above kDeadTol x its original diagonal entry is dead
 // (an isolated view, a floating component): its unknown solves to 0, as everywhere else in this library.
 #include "graph.hpp"
 #include "kernels.hpp"
@@ -51,6 +51,7 @@ struct BcrState {
     DevBuf<double> Z, lam;            // A_b^-1 V (rows x zstride), lambda (64 x 3)
     // a shard of a sharded sequence (dist.hip): the separator before the first chunk is the previous rank's
     int ext0 = 0;
+    DevBuf<long long> stamps;  // development aid: bcr_stamp
     DevBuf<int> ghost_extcol;  // per ghost view: its row in the previous rank's last block, or -1
     DevBuf<double> remD, remR; // what this shard's eliminations subtract from that separator (sum over its levels)
 };
@@ -64,63 +65,101 @@ __device__ __forceinline__ double bcr_readlane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// In-place inverse of the SPD B x B matrix Dm (LDS, row-major) by one wave. Lane (a, b) = (lane / 8,
-// lane % 8) holds the elements (a + 8 tr, b + 8 tc). Symmetric sweep: after pivot k the tile holds
-// -(inverse) on the swept part; only column k is exchanged (the matrix stays symmetric).
+// In-place inverse of the SPD B x B matrix Dm (LDS, row-major) by one wave; B even, B <= 32. Symmetric sweep: after
+// pivot k the registers hold -(inverse) on the swept part. Lane (c, h) = (lane % 32, lane / 32) holds the rows
+// h HB .. h HB + HB - 1 of column c (HB = B / 2). The sweep stays symmetric, so column k IS row k: per pivot the lanes
+// that hold row k write it to LDS (one store) and every lane reads back its own column's entry (the multiplier of the
+// pivot row) and the HB entries of its rows (the pivot column) -- broadcast reads, no lane permutes, no address
+// arithmetic (round 3 exchanged column k by 12 ds_bpermute on an 8 x 8-lane register tile and needed B % 8 == 0). The
+// pivot and its dead-pivot reference travel through SGPRs (v_readlane), so the reciprocal starts before the LDS round
+// trip of the row has finished. A wave issues in order -- about one instruction per 4.5 clocks, whatever it is -- so the
+// chain of a pivot and the issue time of its updates ADD unless independent work stands between the links: the element
+// of row k + 1 is updated first, written, its reciprocal started and the reads of row k + 1 issued; the other updates
+// of pivot k follow and cover those latencies. (The empty asm statements pin that right-looking order: without them
+// the compiler defers an element's updates until its row is the pivot row -- k dependent FMAs on the critical path.)
+// LDS scratch: the first B doubles of the block itself (it lives in registers during the sweep). One wave alone:
+// 0.85 / 2.3 / 4.2 / 6.9 us for B = 8 / 16 / 24 / 32 (tools/micro/sweep_cols.hip).
 template <int B>
 __device__ __forceinline__ void bcr_invert(double *Dm, int lane) {
-    constexpr int T = B / 8;
-    const int a = lane >> 3, b = lane & 7;
-    double t[T][T], od[T];
+    static_assert(B % 2 == 0 && B <= 32, "block size");
+    constexpr int HB = B / 2;
+    const int c = lane & 31, h = lane >> 5;
+    const bool act = c < B;
+    const int cl = act ? c : B - 1;
+    const v2d *Dh = reinterpret_cast<const v2d *>(Dm + h * HB);
+    double t[HB];
 #pragma unroll
-    for (int tr = 0; tr < T; tr++)
-#pragma unroll
-        for (int tc = 0; tc < T; tc++) t[tr][tc] = Dm[(a + 8 * tr) * B + b + 8 * tc];
-#pragma unroll
-    for (int tr = 0; tr < T; tr++) od[tr] = t[tr][tr];  // the diagonal where a == b
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-        const int kb = k & 7, kt = k >> 3;
-        const int dl = (kb << 3) | kb;
-        const double p = bcr_readlane(t[kt][kt], dl);
-        const double ref = bcr_readlane(od[kt], dl);
-        // reciprocal by v_rcp_f64 + two Newton steps (the IEEE division sequence is three times as long and
-        // sits on the chain from pivot to pivot)
+    for (int i = 0; i < HB; i++) t[i] = Dm[(h * HB + i) * B + cl];
+    const double dg = Dm[cl * B + cl];
+    auto pivot_inverse = [&](double tk, int k, int kh) {
+        // reciprocal by v_rcp_f64 + two Newton steps (the IEEE division sequence is three times as long and sits on
+        // the chain from pivot to pivot)
+        const double p = bcr_readlane(tk, k + 32 * kh), ref = bcr_readlane(dg, k);
         double x = __builtin_amdgcn_rcp(p);
         x = fma(fma(-p, x, 1.0), x, x);
         x = fma(fma(-p, x, 1.0), x, x);
-        const double pinv = (p > kDeadTol * ref) ? x : 0.0;
-        double cr[T], cc[T];
+        return (p > kDeadTol * ref) ? x : 0.0;
+    };
+    if (h == 0 && act) Dm[c] = t[0];
+    asm volatile("" ::: "memory");
+    double pinv = pivot_inverse(t[0], 0, 0);
+    double rowk = Dm[cl], colk[HB];
 #pragma unroll
-        for (int tr = 0; tr < T; tr++) cr[tr] = __shfl(t[tr][kt], (a << 3) | kb, 64);
-#pragma unroll
-        for (int tc = 0; tc < T; tc++) cc[tc] = __shfl(t[tc][kt], (b << 3) | kb, 64);
-        // row k lives in row tile kt of the lanes a == kb, column k in column tile kt of the lanes b == kb: only
-        // those tiles need the selects (a 64-bit select is two VALU operations; with selects on all T x T
-        // elements they, not the arithmetic, set the time per pivot)
-        const bool rowk = a == kb, colk = b == kb;
-        double crp[T];
-#pragma unroll
-        for (int tr = 0; tr < T; tr++) crp[tr] = cr[tr] * pinv;
-#pragma unroll
-        for (int tr = 0; tr < T; tr++)
-#pragma unroll
-            for (int tc = 0; tc < T; tc++) {
-                const double upd = fma(-crp[tr], cc[tc], t[tr][tc]);
-                if (tr == kt && tc == kt)
-                    t[tr][tc] = rowk ? (colk ? -pinv : cc[tc] * pinv) : (colk ? crp[tr] : upd);
-                else if (tr == kt)
-                    t[tr][tc] = rowk ? cc[tc] * pinv : upd;
-                else if (tc == kt)
-                    t[tr][tc] = colk ? crp[tr] : upd;
-                else
-                    t[tr][tc] = upd;
-            }
+    for (int i = 0; i < HB; i += 2) {
+        const v2d v = Dh[i / 2];
+        colk[i] = v.x;
+        colk[i + 1] = v.y;
     }
 #pragma unroll
-    for (int tr = 0; tr < T; tr++)
+    for (int k = 0; k < B; k++) {
+        const int kh = k / HB, ki = k - kh * HB;
+        const int k1 = k + 1, kh1 = k1 / HB, ki1 = k1 - kh1 * HB;  // the next pivot (when k1 < B)
+        const bool isk = c == k;
+        const double f = rowk * pinv;
+        const double g = isk ? -pinv : f;
+        // general element: t -= colk (rowk pinv); column k: colk pinv; row k: rowk pinv; (k, k): -pinv
+        auto upd = [&](int i) {
+            const double a = isk ? 0.0 : t[i];
+            double u = fma(-colk[i], g, a);
+            if (i == ki) u = (h == kh) ? g : u;
+            t[i] = u;
+        };
+        double pinv1 = 0.0, rowk1 = 0.0, colk1[HB];
+        if (k1 < B) {
+            upd(ki1);
+            if (h == kh1 && act) Dm[c] = t[ki1];
+            asm volatile("" ::: "memory");
+            pinv1 = pivot_inverse(t[ki1], k1, kh1);
+            rowk1 = Dm[cl];
 #pragma unroll
-        for (int tc = 0; tc < T; tc++) Dm[(a + 8 * tr) * B + b + 8 * tc] = -t[tr][tc];
+            for (int i = 0; i < HB; i += 2) {
+                const v2d v = Dh[i / 2];
+                colk1[i] = v.x;
+                colk1[i + 1] = v.y;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HB; i++)
+            if (!(k1 < B && i == ki1)) upd(i);
+#pragma unroll
+        for (int i = 0; i < HB; i++) asm volatile("" : "+v"(t[i]));
+        if (k1 < B) {
+            pinv = pinv1;
+            rowk = rowk1;
+#pragma unroll
+            for (int i = 0; i < HB; i++) colk[i] = colk1[i];
+        }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < HB; i++)
+        if (act) Dm[(h * HB + i) * B + c] = -t[i];
+}
+
+// development aid (IROTAVG_BCR_DBG & 64, irotavg_graph_time_kernel 200 + slot): shader-clock stamps of thread 0 of every
+// workgroup of k_bcr_reduce at its phase boundaries, 16 slots per chunk
+__device__ __forceinline__ void bcr_stamp(long long *st, int slot) {
+    if (st && threadIdx.x == 0) st[(size_t)blockIdx.x * 16 + slot] = (long long)__builtin_readcyclecounter();
 }
 
 // NR: right-hand-side columns riding along (3: the three coordinates; 19: + 16 columns of the closures' incidence
@@ -428,7 +467,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     const double *__restrict__ inXG, double *__restrict__ W, double *__restrict__ sepD, double *__restrict__ sepR,
     double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop, int dbg,
     int nfar, const int *__restrict__ far_i, const int *__restrict__ far_j, int ext0, const int *__restrict__ bptr,
-    const int *__restrict__ bghost, const double *__restrict__ bval, const int *__restrict__ ghost_extcol, int place) {
+    const int *__restrict__ bghost, const double *__restrict__ bval, const int *__restrict__ ghost_extcol, int place,
+    long long *__restrict__ stamps) {
     typedef BcrDim<B, NR> Dm;
     constexpr int BB = B * B;
     __shared__ double sD[8][BB];   // sD[0] becomes the chunk's contribution to the separator before it
@@ -452,7 +492,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     }
     for (int e = tid; e < 9 * B * NR; e += NT_) (&sR[0][0])[e] = 0.0;
     if (tid < 2) sZ[tid] = 0.0;
+    bcr_stamp(stamps, 0);
     __syncthreads();
+    bcr_stamp(stamps, 1);
     if (L0) {
         const int row0 = chunk * 8 * B;
         for (int t = tid; t < kreal * B; t += NT_) {
@@ -484,20 +526,53 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
         // blocks below nred come from the level below; the others (a mixed level 1, see bcr_alloc) are blocks of
         // the level-0 operator that no chunk reduced: block gb is level-0 block 8 nred + (gb - nred). Every block
         // brings the coupling from its predecessor along (slot i; slot 0: from the separator before the chunk).
-        for (int i = 0; i < 8; i++) {
+        // every load of the launch is requested before the first value is used (a loop over the eight positions with
+        // its loads inside was a memory round trip per position: 5 of the 8 us a launch costs before its first sweep)
+        auto where = [&](int i, int &gb, int &slot) {
             const int t = bcr_ridx(placed, kreal, i);
-            const int gb = chunk * 8 + t;
-            if (t >= 0 && gb < nred) {
-                const bool nxt = gb + 1 < nred;
-                const int slot = t > 0 ? bcr_pos(placed, kreal, t - 1) + 1 : 0;
-                for (int e = tid; e < BB; e += NT_) {
-                    sD[i][e] = inD[(size_t)gb * BB + e] + (nxt ? inXD[(size_t)(gb + 1) * BB + e] : 0.0);
-                    if (gb > 0 || ext0) sG[slot][e] = inXG[(size_t)gb * BB + e];
+            gb = t >= 0 ? chunk * 8 + t : -1;
+            slot = t > 0 ? bcr_pos(placed, kreal, t - 1) + 1 : 0;
+            return t;
+        };
+        constexpr int NIT = (8 * BB + NT_ - 1) / NT_, U = NIT <= 12 ? NIT : 8;
+        for (int u0 = 0; u0 < NIT; u0 += U) {
+            double vd[U], vx[U], vg[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = tid + NT_ * (u0 + u), i = e / BB, el = e - i * BB;
+                int gb, slot;
+                const int t = e < 8 * BB ? where(i, gb, slot) : -1;
+                const bool ok = t >= 0 && gb < nred;
+                vd[u] = ok ? inD[(size_t)gb * BB + el] : 0.0;
+                vx[u] = ok && gb + 1 < nred ? inXD[(size_t)(gb + 1) * BB + el] : 0.0;
+                vg[u] = ok && (gb > 0 || ext0) ? inXG[(size_t)gb * BB + el] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = tid + NT_ * (u0 + u), i = e / BB, el = e - i * BB;
+                if (e >= 8 * BB) continue;
+                int gb, slot;
+                const int t = where(i, gb, slot);
+                if (t >= 0 && gb < nred) {
+                    sD[i][el] = vd[u] + vx[u];
+                    if (gb > 0 || ext0) sG[slot][el] = vg[u];
+                } else if (t < 0 && !(placed && i == 0) && el / B == el % B) {  // (sD[0] of a placed chunk: see the level-0 branch)
+                    sD[i][el] = 1.0;
                 }
-                for (int e = tid; e < B * NR; e += NT_)
-                    sR[i + 1][e] = inR[(size_t)gb * B * NR + e] + (nxt ? inXR[(size_t)(gb + 1) * B * NR + e] : 0.0);
-            } else if (t < 0 && !(placed && i == 0)) {  // (sD[0] of a placed chunk: see the level-0 branch)
-                for (int e = tid; e < B; e += NT_) sD[i][e * B + e] = 1.0;
+            }
+        }
+        {
+            constexpr int NIR = (8 * B * NR + NT_ - 1) / NT_;
+            double vr[NIR], vy[NIR];
+#pragma unroll
+            for (int u = 0; u < NIR; u++) {
+                const int e = tid + NT_ * u, i = e / (B * NR), el = e - i * (B * NR);
+                int gb, slot;
+                const int t = e < 8 * B * NR ? where(i, gb, slot) : -1;
+                const bool ok = t >= 0 && gb < nred;
+                vr[u] = ok ? inR[(size_t)gb * B * NR + el] : 0.0;
+                vy[u] = ok && gb + 1 < nred ? inXR[(size_t)(gb + 1) * B * NR + el] : 0.0;
+                if (ok) sR[i + 1][el] = vr[u] + vy[u];
             }
         }
         if (chunk * 8 + 8 > nred && nred < nb) {
@@ -515,6 +590,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
         }
     }
     __syncthreads();
+    bcr_stamp(stamps, 2);
 
     // ---- three rounds of eliminations: (0 2 4 6) (1 5) (3) ----
     constexpr int WPE0 = NW / 4 < Dm::NT ? NW / 4 : Dm::NT;  // waves per elimination in the first round
@@ -542,18 +618,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
         }                                                                                                           \
         const bool active = i >= 0 && bcr_ridx(placed, kreal, i) >= 0;                                              \
         const bool hasP = a >= 0 || hasExt;                                                                         \
-        if (active && part == 0 && !(dbg & 1)) bcr_invert<B>(sD[i], lane);                                                        \
+        /* the sweep of elimination e runs on wave e: the first four waves of a workgroup sit on four different */   \
+        /* SIMDs (waves e WPE of an eight-wave workgroup share two, and two sweeps on one SIMD take 7 us, not 4) */  \
+        const int isw = wave < NE ? (RND == 0 ? 2 * wave : RND == 1 ? 1 + 4 * wave : 3) : -1;                       \
+        if (isw >= 0 && bcr_ridx(placed, kreal, isw) >= 0 && !(dbg & 1)) bcr_invert<B>(sD[isw], lane);              \
         __syncthreads();                                                                                            \
+        bcr_stamp(stamps, 3 + 4 * RND);                                                                             \
         if (active && !(dbg & 2))                                                                                   \
             E.template phase1<WPE>(part, sD[i], sG[a + 1], hasP, sG[i + 1], sR[i + 1], sD[c], sR[c + 1],            \
                                    W + ((size_t)chunk * 7 + i) * B * Dm::NC, sZ, lane);                             \
         __syncthreads();                                                                                            \
-        if (active && hasP && !(dbg & 4)) E.template phase2_mul<WPE>(part, sG[a + 1], out, lane);                             \
+        bcr_stamp(stamps, 4 + 4 * RND);                                                                             \
+        if (active && hasP && !(dbg & 4)) E.template phase2_mul<WPE>(part, sG[a + 1], out, lane);                   \
         if (WPE > 1) __syncthreads();                                                                               \
+        bcr_stamp(stamps, 5 + 4 * RND);                                                                             \
         if (active && hasP && !(dbg & 4))                                                                           \
             E.template phase2_put<WPE>(part, out, sG[a + 1], a >= 0 ? sD[a] : sD[0], a < 0 && RND == 0, sR[a + 1],  \
                                        lane);                                                                       \
         __syncthreads();                                                                                            \
+        bcr_stamp(stamps, 6 + 4 * RND);                                                                             \
     }
     IRH_BCR_ROUND(0)
     IRH_BCR_ROUND(1)
@@ -588,6 +671,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
             if (hasExt) extR[(size_t)chunk * B * NR + e] = sR[0][e];
         }
     }
+    bcr_stamp(stamps, 15);
 }
 
 // The way back for one chunk: x_7 and the separator before the chunk come from the coarser level. The chunk's
@@ -903,6 +987,11 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     hipStream_t st = g.stream;
     const int nl = (int)S.lev.size();
     const int dbg = getenv("IROTAVG_BCR_DBG") ? atoi(getenv("IROTAVG_BCR_DBG")) : 0;
+    long long *stamps = nullptr;
+    if (dbg & 64) {
+        if (!S.stamps.p) S.stamps.alloc((size_t)S.lev[0].nch * 16);
+        stamps = S.stamps.p;
+    }
     const int nfar = NR > 3 ? std::min(16, S.nfar - 16 * pass) : 0;
     const int *fi = NR > 3 ? S.far_i.p + 16 * pass : nullptr, *fj = NR > 3 ? S.far_j.p + 16 * pass : nullptr;
     for (int l = 0; l < nl && phase != 2; l++) {
@@ -914,7 +1003,7 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     L.nb, L.nred, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p, L0.b.p, F ? F->sepD.p : nullptr,             \
         F ? F->sepR.p : nullptr, F ? F->extD.p : nullptr, F ? F->extR.p : nullptr, F ? F->extG.p : nullptr, L.W.p, \
         L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p, dbg, nfar, fi, fj, S.ext0, g.bptr.p, g.bghost.p,  \
-        g.bval.p, S.ghost_extcol.p, (int)g.bcr_shard
+        g.bval.p, S.ghost_extcol.p, (int)g.bcr_shard, stamps
         // eight waves per chunk when every chunk has a CU to itself (see k_bcr_reduce)
         const bool wide = L.nch <= 256 && !getenv("IROTAVG_BCR_NARROW");
 #define IRH_BCR_LAUNCH(L0_, TOP_)                                                                                   \
@@ -1041,7 +1130,8 @@ static void bcr_top_solve_t(Graph &g, BcrTop &T) {
                        (const int *)nullptr, nul, nul, (const double4 *)nullptr, buf, buf + 3 * W * BB, buf + W * BB,
                        buf + 3 * W * BB + W * BR, buf + 2 * W * BB, T.W.p, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr, (double *)nullptr, T.xtop.p, 0, 0, (const int *)nullptr,
-                       (const int *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, nul, (const int *)nullptr, 0);
+                       (const int *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, nul, (const int *)nullptr, 0,
+                       (long long *)nullptr);
     hipLaunchKernelGGL((k_bcr_back<B, 3, false>), dim3(1), dim3(256), 0, g.stream, W, W, 0, T.W.p, T.xtop.p, T.x.p,
                        (double4 *)nullptr, (double *)nullptr, 0, 0, 0, nul, 0);
 }
@@ -1074,8 +1164,11 @@ int bcr_solve(Graph &g, int only) {
     bcr_alloc(g);
     switch (g.bcr_B) {
     case 8: bcr_run_all<8>(g, only); break;
+    case 12: bcr_run_all<12>(g, only); break;
     case 16: bcr_run_all<16>(g, only); break;
+    case 20: bcr_run_all<20>(g, only); break;
     case 24: bcr_run_all<24>(g, only); break;
+    case 28: bcr_run_all<28>(g, only); break;
     case 32: bcr_run_all<32>(g, only); break;
     default: return IROTAVG_ERR_BAD_ARG;
     }
@@ -1099,6 +1192,29 @@ int bcr_info(Graph &g, int64_t *out, int cap) {
     }
     put(g.bcr->nfar);
     return k;
+}
+
+// development aid: the reduction of `level` once with stamps on; out[0..16) = shader clocks of chunk `chunk` relative to
+// its first stamp
+int bcr_stamps(Graph &g, int level, int chunk, double *out) {
+    if (!g.bcr_B) return IROTAVG_ERR_BAD_ARG;
+    bcr_alloc(g);
+    BcrState &S = *g.bcr;
+    if (level < 0 || level >= (int)S.lev.size() || chunk < 0 || chunk >= S.lev[level].nch) return IROTAVG_ERR_BAD_ARG;
+    const char *old = getenv("IROTAVG_BCR_DBG");
+    const std::string keep = old ? old : "";
+    setenv("IROTAVG_BCR_DBG", "64", 1);
+    if (!S.stamps.p) S.stamps.alloc((size_t)S.lev[0].nch * 16);
+    IRH_CHECK(hipMemsetAsync(S.stamps.p, 0, sizeof(long long) * (size_t)S.lev[0].nch * 16, g.stream));
+    const int rc = bcr_solve(g, level);
+    if (old) setenv("IROTAVG_BCR_DBG", keep.c_str(), 1);
+    else unsetenv("IROTAVG_BCR_DBG");
+    if (rc != IROTAVG_OK) return rc;
+    long long h[16];
+    IRH_CHECK(hipMemcpyAsync(h, S.stamps.p + (size_t)chunk * 16, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < 16; k++) out[k] = h[k] ? (double)(h[k] - h[0]) : -1.0;
+    return IROTAVG_OK;
 }
 
 int bcr_levels(Graph &g) {
@@ -1157,7 +1273,13 @@ void bcr_plan(Graph &g, const int32_t *I) {
     if (nfar.load() > kBcrMaxFar) return;
     if (mode == 0 && g.no <= 2048) return;
     const int b0 = band.load();
-    const int B = b0 <= 8 ? 8 : b0 <= 16 ? 16 : b0 <= 24 ? 24 : 32;
+    // blocks of 8, 12, ... 32 rows: the smallest multiple of four that holds the band (a shard of a sharded sequence
+    // keeps 8 / 16 / 24 / 32: its range is a multiple of 192 rows, dist.hip); IROTAVG_BCR_BLOCK asks for a larger one
+    int B = b0 <= 8 ? 8 : (b0 + 3) / 4 * 4;
+    if (const char *e = std::getenv("IROTAVG_BCR_BLOCK")) {
+        const int want = std::atoi(e);
+        if (want >= B && want <= 32 && want % 4 == 0) B = want;
+    }
     if (nfar.load() > 0) {
         // long-range edges = those whose endpoints lie in blocks that are not neighbours (an edge of more than 32
         // views between neighbouring blocks is part of the block tridiagonal operator as it is)

@@ -2267,6 +2267,13 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         *ms = st[which - 100];
         return rc;
     }
+    if (which >= 200 && which < 200 + 16 * 16) {  // development aid: phase stamps (shader clocks) of k_bcr_reduce, level
+        double st[16];                             // (which - 200) / 16, chunk IROTAVG_BCR_STAMP_CHUNK, see bcr.hip
+        const char *e = getenv("IROTAVG_BCR_STAMP_CHUNK");
+        const int rc = bcr_stamps(g, (which - 200) / 16, e ? atoi(e) : 0, st);
+        *ms = st[(which - 200) % 16];
+        return rc;
+    }
     hipEvent_t e0, e1;
     IRH_CHECK(hipEventCreate(&e0));
     IRH_CHECK(hipEventCreate(&e1));
