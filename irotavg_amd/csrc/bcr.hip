@@ -674,6 +674,117 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     bcr_stamp(stamps, 15);
 }
 
+// The three rounds of the way back of one chunk: its W in sW, the solutions of the separator before it and of its own
+// separator in sX[0] and sX[8], the other slots zero. Ends with a workgroup barrier. 256 threads. mask: the positions
+// wanted (bit i; closed under what a position depends on, bcr_back_mask) -- the others are not computed.
+// Three right-hand sides: a unit of work is four rows of one block (sixteen lanes per row of W, three accumulators
+// each); the units of a round are dealt to the four waves, so the single block of round 2 and the two of round 1 do not
+// leave three / two waves idle.
+__device__ __forceinline__ int bcr_back_mask(int m) {
+    if (m & 0x05) m |= 0x02;   // 0, 2 need 1
+    if (m & 0x50) m |= 0x20;   // 4, 6 need 5
+    if (m & 0x36) m |= 0x08;   // 1, 2, 4, 5 need 3
+    return m;
+}
+template <int B, int NR>
+__device__ __forceinline__ void bcr_back_rounds(const double *sW, double (*sX)[B * NR], bool placed, int kreal, int wave,
+                                                int lane, int mask = 0x7f) {
+    typedef BcrDim<B, NR> Dm;
+    constexpr int WB = B * Dm::NC;
+    const int lk = lane >> 4, lp = lane & 15;
+#pragma unroll
+    for (int rnd = 2; rnd >= 0; rnd--) {
+        if (NR == 3) {
+            constexpr int UPB = B / 4;                  // units per block
+            const int nbk = 4 >> rnd;                   // blocks of the round: 3 | 1 5 | 0 2 4 6
+            for (int u = wave; u < nbk * UPB; u += 4) {
+                const int e = u / UPB, it = u - e * UPB;
+                int i, a, c;
+                if (rnd == 0) {
+                    i = 2 * e;
+                    a = i - 1;
+                    c = i + 1;
+                } else if (rnd == 1) {
+                    i = 1 + 4 * e;
+                    a = e == 0 ? -1 : 3;
+                    c = e == 0 ? 3 : 7;
+                } else {
+                    i = 3;
+                    a = -1;
+                    c = 7;
+                }
+                if (!((mask >> i) & 1) || bcr_ridx(placed, kreal, i) < 0) continue;
+                const double *Wi = sW + i * WB;
+                const double *xa = sX[a + 1], *xcn = sX[c + 1];
+                const int k = 4 * it + lk;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int t = 0; t < Dm::NT; t++) {
+                    const int cidx = lp + 16 * t;
+                    if (cidx < Dm::NC) {
+                        const double wv = Wi[k * Dm::NC + cidx];
+                        if (cidx < B) {
+                            s0 -= wv * xa[cidx * 3 + 0];
+                            s1 -= wv * xa[cidx * 3 + 1];
+                            s2 -= wv * xa[cidx * 3 + 2];
+                        } else if (cidx < 2 * B) {
+                            s0 -= wv * xcn[(cidx - B) * 3 + 0];
+                            s1 -= wv * xcn[(cidx - B) * 3 + 1];
+                            s2 -= wv * xcn[(cidx - B) * 3 + 2];
+                        } else {
+                            const int q = cidx - 2 * B;
+                            s0 += q == 0 ? wv : 0.0;
+                            s1 += q == 1 ? wv : 0.0;
+                            s2 += q == 2 ? wv : 0.0;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s0 += __shfl_xor(s0, o, 64);
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (lp == 0) {
+                    sX[i + 1][k * 3 + 0] = s0;
+                    sX[i + 1][k * 3 + 1] = s1;
+                    sX[i + 1][k * 3 + 2] = s2;
+                }
+            }
+        } else {
+            int i = -1, a = -1, c = 7;
+            if (rnd == 0) {
+                i = 2 * wave;
+                a = i - 1;
+                c = i + 1;
+            } else if (rnd == 1) {
+                if (wave < 2) {
+                    i = 1 + 4 * wave;
+                    a = wave == 0 ? -1 : 3;
+                    c = wave == 0 ? 3 : 7;
+                }
+            } else if (wave == 0) {
+                i = 3;
+            }
+            if (i >= 0 && bcr_ridx(placed, kreal, i) >= 0) {
+                const double *Wi = sW + i * WB;
+                const double *xa = sX[a + 1], *xcn = sX[c + 1];
+                // a lane per (row, right-hand side)
+                for (int o = lane; o < B * NR; o += 64) {
+                    const int k = o / NR, q = o - NR * k;
+                    const double *wr = Wi + k * Dm::NC;
+                    double sacc = wr[2 * B + q];
+#pragma unroll 4
+                    for (int cidx = 0; cidx < B; cidx++)
+                        sacc -= wr[cidx] * xa[cidx * NR + q] + wr[B + cidx] * xcn[cidx * NR + q];
+                    sX[i + 1][o] = sacc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // The way back for one chunk: x_7 and the separator before the chunk come from the coarser level. The chunk's
 // W (7 blocks of B x (2B + 3)) is staged in LDS first -- every load of the launch is in flight at once; read row
 // by row behind the three dependent rounds it cost a memory round trip per four rows.
@@ -722,80 +833,7 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
         }
     }
     __syncthreads();
-    const int lk = lane >> 4, lp = lane & 15;
-#pragma unroll
-    for (int rnd = 2; rnd >= 0; rnd--) {
-        int i = -1, a = -1, c = 7;
-        if (rnd == 0) {
-            i = 2 * wave;
-            a = i - 1;
-            c = i + 1;
-        } else if (rnd == 1) {
-            if (wave < 2) {
-                i = 1 + 4 * wave;
-                a = wave == 0 ? -1 : 3;
-                c = wave == 0 ? 3 : 7;
-            }
-        } else if (wave == 0) {
-            i = 3;
-        }
-        if (i >= 0 && bcr_ridx(placed, kreal, i) >= 0) {
-            const double *Wi = sW + i * WB;
-            const double *xa = sX[a + 1], *xcn = sX[c + 1];
-            if (NR == 3) {
-                // sixteen lanes per row of W, three accumulators each
-#pragma unroll 2
-                for (int it = 0; it < B / 4; it++) {
-                    const int k = 4 * it + lk;
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                    for (int u = 0; u < Dm::NT; u++) {
-                        const int cidx = lp + 16 * u;
-                        if (cidx < Dm::NC) {
-                            const double wv = Wi[k * Dm::NC + cidx];
-                            if (cidx < B) {
-                                s0 -= wv * xa[cidx * 3 + 0];
-                                s1 -= wv * xa[cidx * 3 + 1];
-                                s2 -= wv * xa[cidx * 3 + 2];
-                            } else if (cidx < 2 * B) {
-                                s0 -= wv * xcn[(cidx - B) * 3 + 0];
-                                s1 -= wv * xcn[(cidx - B) * 3 + 1];
-                                s2 -= wv * xcn[(cidx - B) * 3 + 2];
-                            } else {
-                                const int q = cidx - 2 * B;
-                                s0 += q == 0 ? wv : 0.0;
-                                s1 += q == 1 ? wv : 0.0;
-                                s2 += q == 2 ? wv : 0.0;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-                        s0 += __shfl_xor(s0, o, 64);
-                        s1 += __shfl_xor(s1, o, 64);
-                        s2 += __shfl_xor(s2, o, 64);
-                    }
-                    if (lp == 0) {
-                        sX[i + 1][k * 3 + 0] = s0;
-                        sX[i + 1][k * 3 + 1] = s1;
-                        sX[i + 1][k * 3 + 2] = s2;
-                    }
-                }
-            } else {
-                // a lane per (row, right-hand side)
-                for (int o = lane; o < B * NR; o += 64) {
-                    const int k = o / NR, q = o - NR * k;
-                    const double *wr = Wi + k * Dm::NC;
-                    double sacc = wr[2 * B + q];
-#pragma unroll 4
-                    for (int cidx = 0; cidx < B; cidx++)
-                        sacc -= wr[cidx] * xa[cidx * NR + q] + wr[B + cidx] * xcn[cidx * NR + q];
-                    sX[i + 1][o] = sacc;
-                }
-            }
-        }
-        __syncthreads();
-    }
+    bcr_back_rounds<B, NR>(sW, sX, placed, kreal, wave, lane);
     auto put_row = [&](int row, int t) {
         const double *xs = &sX[1][0] + t * NR;
         X[row] = double4{xs[0], xs[1], xs[2], 0.0};
@@ -823,6 +861,129 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
                     if (row < n) put_row(row, t);
                 }
             }
+    }
+}
+
+// The ways back of ALL levels above level 0 in one launch (round 4; they were a launch per level, 11 - 16 us each for
+// a handful of workgroups). A workgroup = a chunk of level `base`. What it needs from the level above are the solutions
+// of two neighbouring blocks, i.e. the way back of the one or two chunks of that level that hold them, which in turn
+// need at most two chunks of the level above them, ... up to the single chunk of the top level: at most two ways back
+// per level, computed REDUNDANTLY by every workgroup that needs them -- no workgroup waits for another, nothing is
+// exchanged through memory. The solutions of the (<= 16) blocks solved at a level stay in LDS for the level below.
+struct BcrBackPlan {
+    const double *W[kMaxLevels];
+    int nb[kMaxLevels];
+    int top, base;
+};
+template <int B>
+__global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const double *__restrict__ xtop, double *__restrict__ xl,
+                                                       double4 *__restrict__ X, int n, int nred) {
+    constexpr int NR = 3;
+    typedef BcrDim<B, NR> Dm;
+    constexpr int WB = B * Dm::NC, XB = B * NR;
+    constexpr int NV = (7 * WB / 2 + 255) / 256;   // 16-byte pieces of a chunk's W per thread
+    __shared__ double sW[7 * WB];
+    __shared__ double sX[9][XB];
+    __shared__ double sWin[2][16][XB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cbase = blockIdx.x;
+    // the chunks [lo, hi] of level L this workgroup solves (hi - lo <= 1)
+    auto range = [&](int L, int &lo, int &hi) {
+        lo = hi = cbase;
+        for (int l = P.base; l < L; l++) {
+            lo = (lo > 0 ? lo - 1 : 0) >> 3;
+            hi >>= 3;
+        }
+    };
+    // the positions of chunk q of level L whose solutions are wanted: all at the base level; above it the blocks the
+    // chunks of the level below need (the separators of those chunks and the one before the first), plus what they
+    // depend on inside the chunk
+    auto wanted = [&](int L, int q) {
+        if (L == P.base) return 0x7f;
+        int lo, hi, m = 0;
+        range(L - 1, lo, hi);
+        for (int j = (lo > 0 ? lo - 1 : 0); j <= hi; j++)
+            if ((j >> 3) == q && (j & 7) < 7) m |= 1 << (j & 7);
+        return bcr_back_mask(m);
+    };
+    // W of the next chunk is requested while this one is solved: pieces of 16 bytes in registers
+    v2d wreg[NV];
+    auto request = [&](int L, int q) {
+        const int kreal = P.nb[L] - q * 8 < 8 ? P.nb[L] - q * 8 : 8;
+        const int nblk = kreal > 7 ? 7 : kreal;
+        const int mask = wanted(L, q);
+        const v2d *__restrict__ src = reinterpret_cast<const v2d *>(P.W[L] + (size_t)q * 7 * WB);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const int e = tid + 256 * v, blk = e / (WB / 2);
+            wreg[v] = (blk < nblk && ((mask >> blk) & 1)) ? __builtin_nontemporal_load(&src[e]) : v2d{0.0, 0.0};
+        }
+    };
+    auto deposit = [&]() {
+        v2d *dst = reinterpret_cast<v2d *>(sW);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const int e = tid + 256 * v;
+            if (e < 7 * WB / 2) dst[e] = wreg[v];
+        }
+    };
+    int L = P.top, lo, hi;
+    range(L, lo, hi);
+    int q = lo;
+    request(L, q);
+    while (true) {
+        int plo = 0, phi = 0;
+        if (L < P.top) range(L + 1, plo, phi);
+        const double(*winP)[XB] = sWin[(L + 1) & 1];
+        double(*winC)[XB] = sWin[L & 1];
+        const int kreal = P.nb[L] - q * 8 < 8 ? P.nb[L] - q * 8 : 8;
+        const int mask = wanted(L, q);
+        deposit();
+        for (int e = tid; e < 7 * XB; e += 256) (&sX[1][0])[e] = 0.0;
+        for (int e = tid; e < XB; e += 256) {
+            sX[8][e] = L == P.top ? xtop[e] : winP[q - 8 * plo][e];
+            sX[0][e] = (L == P.top || q == 0) ? 0.0 : winP[q - 1 - 8 * plo][e];
+        }
+        // the next chunk: the same level's second chunk, else the first of the level below
+        int Ln = L, qn = q + 1;
+        if (qn > hi) {
+            Ln = L - 1;
+            if (Ln >= P.base) {
+                range(Ln, lo, hi);
+                qn = lo;
+            }
+        }
+        if (Ln >= P.base) request(Ln, qn);
+        __syncthreads();
+        bcr_back_rounds<B, NR>(sW, sX, false, kreal, wave, lane, mask);
+        if (L > P.base) {
+            int clo, chi;
+            range(L, clo, chi);
+            for (int e = tid; e < 8 * XB; e += 256) {
+                const int blk = e / XB;
+                winC[(q - clo) * 8 + blk][e - blk * XB] = blk < kreal ? (&sX[1][0])[e] : 0.0;
+            }
+        } else {
+            for (int e = tid; e < 8 * XB; e += 256) {
+                const int blk = e / XB;
+                xl[(size_t)q * 8 * XB + e] = blk < kreal ? (&sX[1][0])[e] : 0.0;
+            }
+            // blocks of a mixed level that are level-0 blocks themselves: their solution rows
+            if (q * 8 + 8 > nred && nred < P.nb[L])
+                for (int t = tid; t < 8 * B; t += 256) {
+                    const int i = t / B, r = t - i * B, gb = q * 8 + i;
+                    if (gb >= nred && gb < P.nb[L]) {
+                        const int row = (8 * nred + (gb - nred)) * B + r;
+                        const double *xs = &sX[1][0] + t * NR;
+                        if (row < n) X[row] = double4{xs[0], xs[1], xs[2], 0.0};
+                    }
+                }
+        }
+        if (Ln < P.base) break;
+        __syncthreads();
+        L = Ln;
+        q = qn;
     }
 }
 
@@ -1027,9 +1188,28 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
 #undef IRH_BCR_LAUNCH
 #undef IRH_BCR_ARGS
     }
+    // the ways back of the levels above level 0 in one launch (k_bcr_back_top) unless this is a shard, the closures'
+    // columns ride along or IROTAVG_BCR_NO_FUSED_BACK is set
+    bool fused_back = false;
+    if constexpr (NR == 3) fused_back = nl >= 2 && !g.bcr_shard && !open_top && !getenv("IROTAVG_BCR_NO_FUSED_BACK");
     for (int l = nl - 1; l >= 0 && phase != 1; l--) {
         if (only >= 0 && only != 100 + l) continue;
         BcrLevel &L = S.lev[l];
+        if constexpr (NR == 3) {
+            if (fused_back && l >= 1) {
+                if (l > 1) continue;
+                BcrBackPlan P;
+                for (int k = 0; k < nl; k++) {
+                    P.W[k] = S.lev[k].W.p;
+                    P.nb[k] = S.lev[k].nb;
+                }
+                P.top = nl - 1;
+                P.base = 1;
+                hipLaunchKernelGGL((k_bcr_back_top<B>), dim3(L.nch), dim3(256), 0, st, P, S.xtop.p, L.x.p, g.X.p + g.ng, L0.n,
+                                   L.nred);
+                continue;
+            }
+        }
         const double *xc = l == nl - 1 ? (open_top ? xc_top : S.xtop.p) : S.lev[l + 1].x.p;
         if (l == 0)
             hipLaunchKernelGGL((k_bcr_back<B, NR, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,

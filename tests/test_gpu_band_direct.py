@@ -334,7 +334,7 @@ def test_option_and_environment_switch_the_path(monkeypatch):
     monkeypatch.delenv("IROTAVG_BAND_DIRECT", raising=False)
     with capi.Graph(I, QQ, 3000, 1, band_direct=1) as G:
         st = G.stats()
-        assert st["band"] == 2890 and st["band_block"] == 16 and G.direct_info()["closures"] == 1
+        assert st["band"] == 2890 and st["band_block"] == 12 and G.direct_info()["closures"] == 1
     monkeypatch.setenv("IROTAVG_BCR_NO_CLOSURES", "1")
     with capi.Graph(I, QQ, 3000, 1, band_direct=1) as G:
         assert G.stats()["band_block"] == 0
