@@ -380,8 +380,10 @@ template <int B, int NR>
 __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int *__restrict__ sl_off,
                                                const int *__restrict__ col, const double *__restrict__ val,
                                                const double *__restrict__ diag, const double4 *__restrict__ rhs,
-                                               double *Dblk, double *Gnext, double *GprevT, double *Rblk, int nfar,
+                                               double *blocks, int oD, int oGnext, int oGprevT, double *Rblk, int nfar,
                                                const int *__restrict__ far_i, const int *__restrict__ far_j) {
+    // (Dblk, Gnext, GprevT = blocks + oD, + oGnext, + oGprevT; a negative offset: not wanted)
+    double *Dblk = blocks + oD;
     const int sl = row >> 6, ln = row & 63;
     const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
     const v2i *__restrict__ cp = reinterpret_cast<const v2i *>(col) + (size_t)(o0 / 2) * 64 + ln;
@@ -398,24 +400,25 @@ __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int
             cc[u] = __builtin_nontemporal_load(&cp[(size_t)q * 64]);
             vv[u] = __builtin_nontemporal_load(&vp[(size_t)q * 64]);
         }
+        // branch-free scatter by LDS adds without return (ds_add_f64: issued back to back, executed in program order, so
+        // the sum of a row's duplicates keeps its order; a read-modify-write per entry was an LDS round trip and four
+        // divergent branches each: a third of the load phase)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            if (q0 + u >= w / 2) break;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int c = h ? cc[u].y : cc[u].x;
                 const double v = h ? vv[u].y : vv[u].x;
-                if (v == 0.0) continue;  // padding
                 const int gc = c - c0;
-                if (gc >= 0 && gc < B)
-                    Dblk[r * B + gc] += v;
-                else if (gc >= B && gc < 2 * B) {
-                    if (Gnext) Gnext[r * B + gc - B] += v;
-                } else if (gc < 0 && gc >= -B) {
-                    if (GprevT) GprevT[(gc + B) * B + r] += v;
-                } else {
-                    Dblk[r * B + r] += v;  // long-range entry
-                }
+                // the target as an index: selects, no branches
+                const bool inD = gc >= 0 && gc < B, inN = gc >= B && gc < 2 * B, inP = gc < 0 && gc >= -B;
+                int idx = oD + r * B + r;  // long-range entry: its weight back out of the diagonal
+                idx = inD ? oD + r * B + gc : idx;
+                idx = inN ? oGnext + r * B + gc - B : idx;
+                idx = inP ? oGprevT + (gc + B) * B + r : idx;
+                const bool keep = q0 + u < w / 2 && v != 0.0 && !(inN && oGnext < 0) && !(inP && oGprevT < 0);  // (zero: padding)
+                double *dst = blocks + idx;
+                if (keep) atomicAdd(dst, v);
             }
         }
     }
@@ -471,8 +474,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     long long *__restrict__ stamps) {
     typedef BcrDim<B, NR> Dm;
     constexpr int BB = B * B;
-    __shared__ double sD[8][BB];   // sD[0] becomes the chunk's contribution to the separator before it
-    __shared__ double sG[8][BB];   // slot 0: coupling (separator before the chunk) -> block 0; slot j + 1: block j -> j + 1
+    __shared__ double sDG[16][BB];
+    double(*sD)[BB] = sDG;       // sD[0] becomes the chunk's contribution to the separator before it
+    double(*sG)[BB] = sDG + 8;   // slot 0: coupling (separator before the chunk) -> block 0; slot j + 1: block j -> j + 1
     __shared__ double sR[9][B * NR];  // slot 0: contribution to the right-hand side of the separator before the chunk
     __shared__ double sZ[2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -501,9 +505,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
             const int row = row0 + t, blk = t / B, r = t - blk * B;
             const int ps = bcr_pos(placed, kreal, blk);
             if (row < n)
-                bcr_gather_row<B, NR>(row, chunk * 8 + blk, r, sl_off, col, val, diag, rhs, sD[ps],
-                                      ps < 7 ? sG[ps + 1] : nullptr, blk == 0 ? sG[0] : nullptr, sR[ps + 1], nfar,
-                                      far_i, far_j);
+                bcr_gather_row<B, NR>(row, chunk * 8 + blk, r, sl_off, col, val, diag, rhs, &sDG[0][0], ps * BB,
+                                      ps < 7 ? (8 + ps + 1) * BB : -1, blk == 0 ? 8 * BB : -1, sR[ps + 1], nfar, far_i,
+                                      far_j);
             else
                 sD[ps][r * B + r] = 1.0;
         }
@@ -581,8 +585,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
                 if (gb >= nred && gb < nb) {
                     const int lb = 8 * nred + (gb - nred), row = lb * B + r;
                     if (row < n)
-                        bcr_gather_row<B, NR>(row, lb, r, sl_off, col, val, diag, rhs, sD[i], nullptr,
-                                              gb > 0 ? sG[i] : nullptr, sR[i + 1], nfar, far_i, far_j);
+                        bcr_gather_row<B, NR>(row, lb, r, sl_off, col, val, diag, rhs, &sDG[0][0], i * BB, -1,
+                                              gb > 0 ? (8 + i) * BB : -1, sR[i + 1], nfar, far_i, far_j);
                     else
                         sD[i][r * B + r] = 1.0;
                 }
