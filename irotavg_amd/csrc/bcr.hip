@@ -44,11 +44,23 @@ struct BcrState {
     int B = 0;
     int NR = 3;    // right-hand-side columns riding along: 3, or 19 with closures
     int nfar = 0;  // long-range edges (loop closures) handled by the Woodbury correction
-    int zstride = 0;
     std::vector<BcrLevel> lev;
     DevBuf<double> xtop;  // B x NR: the last separator
     DevBuf<int> far_i, far_j, far_e;  // rows and edge id of the closures
-    DevBuf<double> Z, lam;            // A_b^-1 V (rows x zstride), lambda (64 x 3)
+    // the closures' part of a solve (bcr_closures): per level the inverse of every eliminated block, the step programs
+    // of the closures' forward eliminations and what they record, the Woodbury system
+    std::vector<DevBuf<double>> Dinv;
+    DevBuf<double> topDinv;
+    DevBuf<int> cl_off;          // nfar + 1: first step of a closure
+    DevBuf<int4> cl_step;        // {level (-1: the top block), elimination inside the level, slots src | dstA << 8 | dstC << 16, sort key}
+    DevBuf<int4> cl_init;        // {slot, row inside the block} of the two endpoints
+    DevBuf<int> cl_owner;        // the closure of a step
+    DevBuf<double> cl_R, cl_W;   // per step: the block's right-hand side when it was eliminated, and D^-1 times it
+    DevBuf<double> cl_S, cl_T, lam;  // Woodbury system (npad x npad, npad x 3), its solution (nfar x 3)
+    DevBuf<int> cl_alive;
+    DevBuf<int> co_off, co_rec;  // per touched elimination: the steps that touch it ...
+    DevBuf<int2> co_elim;        // ... and {level, elimination}
+    int cl_nslots = 0, cl_nsteps = 0, cl_nelim = 0, cl_npad = 0;
     // a shard of a sharded sequence (dist.hip): the separator before the first chunk is the previous rank's
     int ext0 = 0;
     DevBuf<long long> stamps;  // development aid: bcr_stamp
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop, int dbg,
     int nfar, const int *__restrict__ far_i, const int *__restrict__ far_j, int ext0, const int *__restrict__ bptr,
     const int *__restrict__ bghost, const double *__restrict__ bval, const int *__restrict__ ghost_extcol, int place,
-    long long *__restrict__ stamps) {
+    long long *__restrict__ stamps, double *__restrict__ Dinvg, double *__restrict__ topDinv) {
     typedef BcrDim<B, NR> Dm;
     constexpr int BB = B * B;
     __shared__ double sDG[16][BB];
@@ -627,6 +639,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
         const int isw = wave < NE ? (RND == 0 ? 2 * wave : RND == 1 ? 1 + 4 * wave : 3) : -1;                       \
         if (isw >= 0 && bcr_ridx(placed, kreal, isw) >= 0 && !(dbg & 1)) bcr_invert<B>(sD[isw], lane);              \
         __syncthreads();                                                                                            \
+        /* closures: the inverse of every eliminated block is kept (bcr_closures) */                                \
+        if (Dinvg && active && part == 0)                                                                           \
+            for (int o = lane; o < BB; o += 64) Dinvg[((size_t)chunk * 7 + i) * BB + o] = sD[i][o];                 \
         bcr_stamp(stamps, 3 + 4 * RND);                                                                             \
         if (active && !(dbg & 2))                                                                                   \
             E.template phase1<WPE>(part, sD[i], sG[a + 1], hasP, sG[i + 1], sR[i + 1], sD[c], sR[c + 1],            \
@@ -652,6 +667,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
         if (wave == 0) {
             if (bcr_ridx(placed, kreal, 7) >= 0) {
                 bcr_invert<B>(sD[7], lane);
+                if (topDinv)
+                    for (int o = lane; o < BB; o += 64) topDinv[o] = sD[7][o];
                 for (int o = lane; o < B * NR; o += 64) {
                     const int k = o / NR, q = o - NR * k;
                     double s = 0.0;
@@ -991,45 +1008,181 @@ __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const doubl
     }
 }
 
-// The closures' part of a solve. The operator is A = A_b + V C V' (A_b: the band part the reduction factorised,
-// column q of V = e_i - e_j for closure q, C = diag(w_q)). With Y = A_b^-1 b (in X) and Z = A_b^-1 V (n x r, by the
-// 16 extra right-hand sides of each pass):  x = Y - Z (C^-1 + V' Z)^-1 V' Y  (Sherman-Morrison-Woodbury).
-// One workgroup: S = C^-1 + V' Z and T = V' Y gathered, S (r <= 64, SPD) eliminated in LDS, lambda = S^-1 T -> lam.
-// A closure of weight 0 (Talwar, a capped L1 weight never is) is not there: its lambda is 0.
-__global__ __launch_bounds__(256) void k_bcr_woodbury(int r, const int *__restrict__ far_i, const int *__restrict__ far_j,
-                                                      const int *__restrict__ far_e, const double *__restrict__ wsrc,
-                                                      int wsquare, const double *__restrict__ Z, int zstride,
-                                                      const double4 *__restrict__ X, double *__restrict__ lam) {
+// ---------------------------------------------------------------------------------------------
+// The closures' part of a solve (round 4). The operator is A = A_b + V C V' (A_b: the band part the reduction
+// factorised, column q of V = e_i - e_j for closure q, C = diag(w_q)), so with Y = A_b^-1 b
+//     x = Y - A_b^-1 V lambda,    (C^-1 + V' A_b^-1 V) lambda = V' Y        (Sherman-Morrison-Woodbury).
+// Round 3 got A_b^-1 V by riding sixteen incidence vectors at a time through a whole re-factorisation (0.3 ms per
+// sixteen closures, at most 64). But a column of V has TWO non-zeros, and the block elimination is a nested dissection:
+// the forward elimination of e_i only ever touches the blocks on the path from i's block up the elimination tree -- three
+// eliminations per level and endpoint, plus what spills into the separator before the chunk. And nothing but the
+// forward elimination is needed: with R_g(v) = the right-hand side of block g when it is eliminated,
+//     u' A_b^-1 v = sum over the eliminated blocks g of R_g(u)' D_g^-1 R_g(v),
+// so S = C^-1 + V' A_b^-1 V and T = V' Y are sums over the blocks two closures' paths share (Y's forward elimination
+// is what the reduction stored as W_R), and x = A_b^-1 (b - V lambda) is the ordinary way back from right-hand
+// sides corrected by sum_q lambda_q D_g^-1 R_g(v_q) on the blocks of the paths. Which blocks a closure touches
+// depends on the positions of its endpoints only: the host writes a STEP PROGRAM per closure once (bcr_closure_plan),
+// a wave executes it per solve (k_bcr_closure_forward), pairs of closures are joined on the blocks they share
+// (k_bcr_closure_S), the Woodbury system is solved in LDS (<= 64 closures) or by the blocked Gauss-Jordan sweep of
+// dense.hip, and one launch corrects the stored right-hand sides (k_bcr_closure_correct) before the ways back.
+// No second pass over the matrix, no n x r array: 2048 closures instead of 64.
+// ---------------------------------------------------------------------------------------------
+struct BcrClPlan {
+    const double *W[kMaxLevels], *Dinv[kMaxLevels];
+    double *Wrw[kMaxLevels];  // the same W, writable (k_bcr_closure_correct)
+    const double *topDinv;
+    double *xtop;
+};
+
+// One wave per closure: its step program. A step eliminates one block g of the path: R = slot[src];
+// slot[dstA] -= W_P' R, slot[dstC] -= W_Q' R (the block's W = D^-1 [P' | Q | R_main]), T += R' W_R(main),
+// and R and D^-1 R are recorded. Every lane owns one column of [W_P | W_Q | W_R | D^-1] per pass.
+template <int B>
+__global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r, int nslots, const int *__restrict__ off,
+                                                              const int4 *__restrict__ steps,
+                                                              const int4 *__restrict__ init, double *__restrict__ recR,
+                                                              double *__restrict__ recW, double *__restrict__ T) {
+    constexpr int NR = 3, NC = 2 * B + NR, BB = B * B, NCOL = NC + B;
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (q >= r) return;  // (no workgroup barrier below)
+    double *slots = smem + (size_t)wave * nslots * B;
+    for (int e = lane; e < nslots * B; e += 64) slots[e] = 0.0;
+    const int4 in = init[q];
+    if (lane == 0) {
+        slots[in.x * B + in.y] += 1.0;
+        slots[in.z * B + in.w] -= 1.0;
+    }
+    double tacc = 0.0;  // lanes 2B .. 2B + 2 of the first pass: a coordinate of T each
+    for (int st = off[q]; st < off[q + 1]; st++) {
+        const int4 sp = steps[st];
+        const int lvl = sp.x, src = sp.z & 255, dA = (sp.z >> 8) & 255, dC = (sp.z >> 16) & 255;
+        const double *Wb = lvl >= 0 ? P.W[lvl] + (size_t)sp.y * B * NC : nullptr;
+        const double *Db = lvl >= 0 ? P.Dinv[lvl] + (size_t)sp.y * BB : P.topDinv;
+        double R[B];
+        {
+            const v2d *rs = reinterpret_cast<const v2d *>(slots + src * B);
+#pragma unroll
+            for (int k = 0; k < B / 2; k++) {
+                const v2d v = rs[k];
+                R[2 * k] = v.x;
+                R[2 * k + 1] = v.y;
+            }
+        }
+        if (lane < B) recR[(size_t)st * B + lane] = slots[src * B + lane];
+#pragma unroll
+        for (int pass = 0; pass * 64 < NCOL; pass++) {
+            const int col = pass * 64 + lane;
+            if (col >= NCOL) continue;
+            const double *base;
+            int stride;
+            bool have = true;
+            if (col < NC) {
+                if (lvl >= 0) {
+                    base = Wb + col;
+                    stride = NC;
+                } else {  // the top block: nothing beside it; its part of Y is xtop
+                    base = P.xtop + (col - 2 * B);
+                    stride = NR;
+                    have = col >= 2 * B;
+                }
+            } else {
+                base = Db + (col - NC);
+                stride = B;
+            }
+            double acc = 0.0;
+            if (have) {
+                double m[B];
+#pragma unroll
+                for (int k = 0; k < B; k++) m[k] = base[(size_t)k * stride];
+#pragma unroll
+                for (int k = 0; k < B; k++) acc = fma(m[k], R[k], acc);
+            }
+            if (col < B) {
+                if (dA != 255) slots[dA * B + col] -= acc;
+            } else if (col < 2 * B) {
+                if (dC != 255) slots[dC * B + col - B] -= acc;
+            } else if (col < NC) {
+                tacc += acc;
+            } else {
+                recW[(size_t)st * B + col - NC] = acc;
+            }
+        }
+    }
+    // the T lanes: column 2B + c sits in pass (2B + c) / 64, lane (2B + c) % 64 -- the same lane in every step
+    {
+        const int c0 = 2 * B;
+        for (int c = 0; c < 3; c++)
+            if (((c0 + c) & 63) == lane) T[(size_t)q * 3 + c] = tacc;
+    }
+}
+
+// S = C^-1 + V' A_b^-1 V: entry (p, q) = sum over the steps of p and q on the same block of R_p . (D^-1 R_q); the
+// step lists are sorted by block. A thread per pair of the upper triangle; a closure of weight 0 (Talwar) is not
+// there: its row and column are the identity's, its T is 0.
+template <int B>
+__global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, const int *__restrict__ off,
+                                                        const int4 *__restrict__ steps, const double *__restrict__ recR,
+                                                        const double *__restrict__ recW, const int *__restrict__ far_e,
+                                                        const double *__restrict__ wsrc, int wsquare,
+                                                        double *__restrict__ S, double *__restrict__ T,
+                                                        int *__restrict__ alive) {
+    const int p = blockIdx.y * 16 + (threadIdx.x >> 4), q = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (blockIdx.x < blockIdx.y || p >= npad || q >= npad || q < p) return;
+    if (p >= r || q >= r) {  // padding of the inversion
+        S[(size_t)p * npad + q] = S[(size_t)q * npad + p] = p == q ? 1.0 : 0.0;
+        return;
+    }
+    double wp = wsrc[far_e[p]], wq = wsrc[far_e[q]];
+    if (wsquare) {
+        wp *= wp;
+        wq *= wq;
+    }
+    double sum = 0.0;
+    if (wp > 0.0 && wq > 0.0) {
+        int a = off[p], b = off[q];
+        const int ae = off[p + 1], be = off[q + 1];
+        while (a < ae && b < be) {
+            const int ka = steps[a].w, kb = steps[b].w;
+            if (ka == kb) {
+                const double *x = recR + (size_t)a * B, *y = recW + (size_t)b * B;
+                double d = 0.0;
+#pragma unroll
+                for (int k = 0; k < B; k++) d = fma(x[k], y[k], d);
+                sum += d;
+                a++;
+                b++;
+            } else if (ka < kb) {
+                a++;
+            } else {
+                b++;
+            }
+        }
+        if (p == q) sum += 1.0 / wp;
+    } else {
+        sum = p == q ? 1.0 : 0.0;
+    }
+    S[(size_t)p * npad + q] = sum;
+    S[(size_t)q * npad + p] = sum;
+    if (p == q) {
+        alive[p] = wp > 0.0;
+        if (!(wp > 0.0)) T[3 * p] = T[3 * p + 1] = T[3 * p + 2] = 0.0;
+    }
+}
+
+// lambda = S^-1 T for at most 64 closures: one workgroup, S in LDS, Gauss-Jordan without pivoting on [S | T] (SPD)
+__global__ __launch_bounds__(256) void k_bcr_closure_solve64(int r, int npad, const double *__restrict__ Sg,
+                                                              const double *__restrict__ Tg, double *__restrict__ lam) {
     __shared__ double S[64][65];
     __shared__ double T[64][3];
-    __shared__ int alive[64];
     const int tid = threadIdx.x;
     for (int e = tid; e < r * r; e += 256) {
         const int p = e / r, q = e - p * r;
-        S[p][q] = Z[(size_t)far_i[p] * zstride + q] - Z[(size_t)far_j[p] * zstride + q];
+        S[p][q] = Sg[(size_t)p * npad + q];
     }
-    for (int p = tid; p < r; p += 256) {
-        const double4 a = X[far_i[p]], b = X[far_j[p]];
-        T[p][0] = a.x - b.x;
-        T[p][1] = a.y - b.y;
-        T[p][2] = a.z - b.z;
-    }
+    for (int e = tid; e < r * 3; e += 256) T[e / 3][e % 3] = Tg[e];
     __syncthreads();
-    for (int p = tid; p < r; p += 256) {
-        double w = wsrc[far_e[p]];
-        if (wsquare) w *= w;
-        alive[p] = w > 0.0;
-        if (w > 0.0) S[p][p] += 1.0 / w;
-    }
-    __syncthreads();
-    for (int e = tid; e < r * r; e += 256) {
-        const int p = e / r, q = e - p * r;
-        if (!alive[p] || !alive[q]) S[p][q] = p == q ? 1.0 : 0.0;
-    }
-    for (int p = tid; p < r; p += 256)
-        if (!alive[p]) T[p][0] = T[p][1] = T[p][2] = 0.0;
-    __syncthreads();
-    // Gauss-Jordan without pivoting on [S | T] (SPD); thread (row, column group)
     for (int k = 0; k < r; k++) {
         const double pinv = 1.0 / S[k][k];
         __syncthreads();
@@ -1054,35 +1207,238 @@ __global__ __launch_bounds__(256) void k_bcr_woodbury(int r, const int *__restri
     }
 }
 
-// x = Y - Z lambda, row by row
-__global__ __launch_bounds__(256) void k_bcr_apply_lambda(int n, int r, const double *__restrict__ Z, int zstride,
-                                                          const double *__restrict__ lam, double4 *__restrict__ X) {
-    __shared__ double sl[64 * 3];
-    for (int e = threadIdx.x; e < r * 3; e += 256) sl[e] = lam[e];
-    __syncthreads();
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= n) return;
-    double4 x = X[row];
-    const double *z = Z + (size_t)row * zstride;
-    for (int q = 0; q < r; q++) {
-        const double zz = z[q];
-        x.x -= zz * sl[3 * q + 0];
-        x.y -= zz * sl[3 * q + 1];
-        x.z -= zz * sl[3 * q + 2];
+// lambda = Sinv T (more than 64 closures: Sinv from the blocked Gauss-Jordan sweep); a wave per row
+__global__ __launch_bounds__(256) void k_bcr_closure_lambda(int r, int npad, const double *__restrict__ Sinv,
+                                                             const double *__restrict__ T, double *__restrict__ lam) {
+    const int lane = threadIdx.x & 63, p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= r) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int q = lane; q < r; q += 64) {
+        const double v = Sinv[(size_t)p * npad + q];
+        s0 = fma(v, T[3 * q], s0);
+        s1 = fma(v, T[3 * q + 1], s1);
+        s2 = fma(v, T[3 * q + 2], s2);
     }
-    X[row] = x;
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        lam[3 * p] = s0;
+        lam[3 * p + 1] = s1;
+        lam[3 * p + 2] = s2;
+    }
+}
+
+// W_R of every block a closure touches -= sum over the steps on it of (D^-1 R_q) lambda_q' (the top block: xtop):
+// a workgroup per block, the steps in a fixed order
+template <int B>
+__global__ __launch_bounds__(128) void k_bcr_closure_correct(BcrClPlan P, const int *__restrict__ eoff,
+                                                              const int *__restrict__ erec, const int2 *__restrict__ elim,
+                                                              const int *__restrict__ owner,
+                                                              const double *__restrict__ recW,
+                                                              const double *__restrict__ lam) {
+    constexpr int NR = 3, NC = 2 * B + NR;
+    const int g = blockIdx.x, t = threadIdx.x;
+    if (t >= B * 3) return;
+    const int row = t / 3, c = t - 3 * row;
+    double acc = 0.0;
+    for (int k = eoff[g]; k < eoff[g + 1]; k++) {
+        const int st = erec[k];
+        acc = fma(recW[(size_t)st * B + row], lam[3 * owner[st] + c], acc);
+    }
+    const int2 el = elim[g];
+    if (el.x >= 0)
+        P.Wrw[el.x][(size_t)el.y * B * NC + (size_t)row * NC + 2 * B + c] -= acc;
+    else
+        P.xtop[row * NR + c] -= acc;
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// The step programs of the closures (see "The closures' part of a solve"): a symbolic forward elimination of
+// e_i - e_j per closure. Blocks are tracked as (level, block of that level) -> slot; a chunk's eliminations run in the
+// kernel's order (0 2 4 6)(1 5)(3); what an elimination subtracts from the separator before its chunk is kept in the
+// slot of that separator's block of the NEXT level (the reduction adds sepR[j] + extR[j + 1] there as well).
+static void bcr_closure_plan(Graph &g) {
+    BcrState &S = *g.bcr;
+    const int B = S.B, nl = (int)S.lev.size(), r = S.nfar;
+    const int nch0 = S.lev[0].nch;
+    const bool mixed = nl > 1 && S.lev[1].nred < S.lev[1].nb;
+    std::vector<int> off(1, 0), owner;
+    std::vector<int4> steps, init((size_t)r);
+    std::vector<long long> koff((size_t)nl + 1, 0);  // sort keys: (level, chunk, rank in the schedule)
+    for (int l = 0; l < nl; l++) koff[(size_t)l + 1] = koff[(size_t)l] + (long long)S.lev[l].nch * 8;
+    static const int rank_of[7] = {0, 4, 1, 6, 2, 5, 3}, sched[7] = {0, 2, 4, 6, 1, 5, 3};
+    int nslots = 2;
+    for (int q = 0; q < r; q++) {
+        std::vector<std::map<int, int>> nz((size_t)nl + 1);  // per level: block -> slot
+        std::vector<int> freelist;
+        int next = 0;
+        auto take = [&]() {
+            if (!freelist.empty()) {
+                const int t = freelist.back();
+                freelist.pop_back();
+                return t;
+            }
+            return next++;
+        };
+        auto slot_of = [&](int l, int blk) {
+            auto it = nz[(size_t)l].find(blk);
+            if (it != nz[(size_t)l].end()) return it->second;
+            const int t = take();
+            nz[(size_t)l][blk] = t;
+            return t;
+        };
+        int4 in;
+        for (int e = 0; e < 2; e++) {
+            const int row = e ? g.bcr_far_j[(size_t)q] : g.bcr_far_i[(size_t)q];
+            const int b = row / B;
+            int l = 0, blk = b;
+            if (nl > 1 && b >= 8 * nch0) {  // a block no chunk of level 0 reduces: a block of the mixed level 1
+                l = 1;
+                blk = S.lev[1].nred + (b - 8 * nch0);
+            }
+            const int t = slot_of(l, blk);
+            if (e == 0) {
+                in.x = t;
+                in.y = row - b * B;
+            } else {
+                in.z = t;
+                in.w = row - b * B;
+            }
+        }
+        init[(size_t)q] = in;
+        (void)mixed;
+        for (int l = 0; l < nl; l++) {
+            const bool top = l == nl - 1;
+            // chunks with non-zero blocks, ascending (std::map is ordered)
+            while (!nz[(size_t)l].empty()) {
+                const int chunk = nz[(size_t)l].begin()->first / 8;
+                const int kreal = std::min(8, S.lev[l].nb - chunk * 8);
+                int slot[9];  // positions 0..7, [8] = the separator before the chunk
+                for (int i = 0; i < 9; i++) slot[i] = -1;
+                for (int i = 0; i < 8; i++) {
+                    auto it = nz[(size_t)l].find(chunk * 8 + i);
+                    if (it != nz[(size_t)l].end()) {
+                        slot[i] = it->second;
+                        nz[(size_t)l].erase(it);
+                    }
+                }
+                const bool has_ext = chunk > 0;
+                for (int k = 0; k < 7; k++) {
+                    const int i = sched[k];
+                    if (i >= kreal || slot[i] < 0) continue;
+                    int a, c;
+                    if (k < 4) {
+                        a = i - 1;
+                        c = i + 1;
+                    } else if (k < 6) {
+                        a = i == 1 ? -1 : 3;
+                        c = i == 1 ? 3 : 7;
+                    } else {
+                        a = -1;
+                        c = 7;
+                    }
+                    int dA = 255, dC = 255;
+                    if (a >= 0) {
+                        if (slot[a] < 0) slot[a] = take();
+                        dA = slot[a];
+                    } else if (has_ext) {
+                        if (slot[8] < 0) {
+                            // the separator before the chunk = block chunk - 1 of the next level (it may hold a value)
+                            slot[8] = slot_of(l + 1, chunk - 1);
+                        }
+                        dA = slot[8];
+                    }
+                    if (c < kreal) {
+                        if (slot[c] < 0) slot[c] = take();
+                        dC = slot[c];
+                    }
+                    int4 sp;
+                    sp.x = l;
+                    sp.y = chunk * 7 + i;
+                    sp.z = slot[i] | (dA << 8) | (dC << 16);
+                    sp.w = (int)(koff[(size_t)l] + (long long)chunk * 8 + rank_of[i]);
+                    steps.push_back(sp);
+                    owner.push_back(q);
+                    slot[i] = -1;  // (its slot is not reused: a new slot must start from zero)
+                }
+                // what is left: the separator (position 7 when the chunk is full)
+                if (kreal == 8 && slot[7] >= 0) {
+                    if (top) {  // solved on the spot
+                        int4 sp;
+                        sp.x = -1;
+                        sp.y = 0;
+                        sp.z = slot[7] | (255 << 8) | (255 << 16);
+                        sp.w = (int)(koff[(size_t)l] + (long long)chunk * 8 + 7);
+                        steps.push_back(sp);
+                        owner.push_back(q);
+                    } else {
+                        auto it = nz[(size_t)l + 1].find(chunk);
+                        if (it == nz[(size_t)l + 1].end()) {
+                            nz[(size_t)l + 1][chunk] = slot[7];
+                        } else {
+                            // the block of the next level already has a slot (the chunk after this one subtracted from
+                            // it first): cannot happen -- chunks run in ascending order and only chunk + 1 writes there
+                            throw HipError{hipErrorUnknown};
+                        }
+                    }
+                }
+            }
+        }
+        nslots = std::max(nslots, next);
+        off.push_back((int)steps.size());
+    }
+    if (nslots > 250) throw HipError{hipErrorUnknown};
+    // the steps of every touched elimination, in step order
+    std::map<int, std::vector<int>> by_key;
+    for (size_t k = 0; k < steps.size(); k++) by_key[steps[k].w].push_back((int)k);
+    std::vector<int> eoff(1, 0), erec;
+    std::vector<int2> elim;
+    for (auto &kv : by_key) {
+        const int4 sp = steps[(size_t)kv.second[0]];
+        int2 el;
+        el.x = sp.x;
+        el.y = sp.y;
+        elim.push_back(el);
+        for (int k : kv.second) erec.push_back(k);
+        eoff.push_back((int)erec.size());
+    }
+    S.cl_nslots = nslots;
+    S.cl_nsteps = (int)steps.size();
+    S.cl_nelim = (int)elim.size();
+    S.cl_npad = r <= 64 ? r : (r + 63) / 64 * 64;
+    S.far_i.upload(g.bcr_far_i, g.stream);
+    S.far_j.upload(g.bcr_far_j, g.stream);
+    S.far_e.upload(g.bcr_far_e, g.stream);
+    S.cl_off.upload(off, g.stream);
+    S.cl_step.upload(steps, g.stream);
+    S.cl_init.upload(init, g.stream);
+    S.cl_owner.upload(owner, g.stream);
+    S.co_off.upload(eoff, g.stream);
+    S.co_rec.upload(erec, g.stream);
+    S.co_elim.upload(elim, g.stream);
+    S.cl_R.alloc(steps.size() * (size_t)B);
+    S.cl_W.alloc(steps.size() * (size_t)B);
+    S.cl_S.alloc((size_t)S.cl_npad * S.cl_npad);
+    S.cl_T.alloc((size_t)S.cl_npad * 3);
+    S.lam.alloc((size_t)S.cl_npad * 3);
+    S.cl_alive.alloc((size_t)S.cl_npad);
+    S.Dinv.resize((size_t)nl);
+    for (int l = 0; l < nl; l++) S.Dinv[(size_t)l].alloc((size_t)S.lev[l].nch * 7 * B * B);
+    S.topDinv.alloc((size_t)B * B);
+    IRH_CHECK(hipMemsetAsync(S.topDinv.p, 0, sizeof(double) * (size_t)B * B, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));  // the host vectors go away
+}
+
 static void bcr_alloc(Graph &g) {
     if (g.bcr) return;
     g.bcr.reset(new BcrState());
     BcrState &S = *g.bcr;
     S.B = g.bcr_B;
     S.nfar = (int)g.bcr_far_e.size();
-    S.NR = S.nfar > 0 ? 19 : 3;
+    S.NR = 3;
     const int B = S.B, NR = S.NR, NC = 2 * B + NR;
     const int nb0 = (g.levels[0].n + B - 1) / B;
     int nch0 = (nb0 + 7) / 8;
@@ -1130,15 +1486,7 @@ static void bcr_alloc(Graph &g) {
         IRH_CHECK(hipStreamSynchronize(g.stream));
     }
     S.xtop.alloc((size_t)B * NR);
-    if (S.nfar > 0) {
-        S.zstride = (S.nfar + 15) / 16 * 16;
-        S.far_i.upload(g.bcr_far_i, g.stream);
-        S.far_j.upload(g.bcr_far_j, g.stream);
-        S.far_e.upload(g.bcr_far_e, g.stream);
-        S.Z.alloc((size_t)g.levels[0].n * S.zstride);
-        S.lam.alloc(64 * 3);
-        IRH_CHECK(hipStreamSynchronize(g.stream));  // the host vectors may go away
-    }
+    if (S.nfar > 0) bcr_closure_plan(g);
 }
 
 // open_top: the last level writes its separator data like every other level instead of solving it (a shard: the
@@ -1157,8 +1505,9 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
         if (!S.stamps.p) S.stamps.alloc((size_t)S.lev[0].nch * 16);
         stamps = S.stamps.p;
     }
-    const int nfar = NR > 3 ? std::min(16, S.nfar - 16 * pass) : 0;
-    const int *fi = NR > 3 ? S.far_i.p + 16 * pass : nullptr, *fj = NR > 3 ? S.far_j.p + 16 * pass : nullptr;
+    const int nfar = 0;
+    const int *fi = nullptr, *fj = nullptr;
+    (void)pass;
     for (int l = 0; l < nl && phase != 2; l++) {
         if (only >= 0 && only != l) continue;
         BcrLevel &L = S.lev[l];
@@ -1168,7 +1517,8 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     L.nb, L.nred, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p, L0.b.p, F ? F->sepD.p : nullptr,             \
         F ? F->sepR.p : nullptr, F ? F->extD.p : nullptr, F ? F->extR.p : nullptr, F ? F->extG.p : nullptr, L.W.p, \
         L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p, dbg, nfar, fi, fj, S.ext0, g.bptr.p, g.bghost.p,  \
-        g.bval.p, S.ghost_extcol.p, (int)g.bcr_shard, stamps
+        g.bval.p, S.ghost_extcol.p, (int)g.bcr_shard, stamps, S.nfar > 0 ? S.Dinv[(size_t)l].p : (double *)nullptr,         \
+        S.nfar > 0 ? S.topDinv.p : (double *)nullptr
         // eight waves per chunk when every chunk has a CU to itself (see k_bcr_reduce)
         const bool wide = L.nch <= 256 && !getenv("IROTAVG_BCR_NARROW");
 #define IRH_BCR_LAUNCH(L0_, TOP_)                                                                                   \
@@ -1217,32 +1567,54 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
         const double *xc = l == nl - 1 ? (open_top ? xc_top : S.xtop.p) : S.lev[l + 1].x.p;
         if (l == 0)
             hipLaunchKernelGGL((k_bcr_back<B, NR, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               (double *)nullptr, g.X.p + g.ng, S.Z.p, S.zstride, 16 * pass, nfar, xext, (int)g.bcr_shard);
+                               (double *)nullptr, g.X.p + g.ng, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard);
         else
             hipLaunchKernelGGL((k_bcr_back<B, NR, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               L.x.p, g.X.p + g.ng, S.Z.p, S.zstride, 16 * pass, nfar, xext, (int)g.bcr_shard);
+                               L.x.p, g.X.p + g.ng, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard);
     }
 }
 
 template <int B>
 static void bcr_run_all(Graph &g, int only) {
     BcrState &S = *g.bcr;
-    if (S.nfar == 0) {
+    if (S.nfar == 0 || only >= 0) {
         bcr_run<B, 3>(g, only, 0);
         return;
     }
-    if constexpr (B <= 24) {
-        // closures: every pass factorises the band part again with the incidence vectors of sixteen more closures
-        // as extra right-hand sides (Z = A_b^-1 V), then the Woodbury correction (k_bcr_woodbury)
-        const int npass = only >= 0 ? 1 : (S.nfar + 15) / 16;
-        for (int pass = 0; pass < npass; pass++) bcr_run<B, 19>(g, only, pass);
-        if (only >= 0) return;
-        hipLaunchKernelGGL(k_bcr_woodbury, dim3(1), dim3(256), 0, g.stream, S.nfar, S.far_i.p, S.far_j.p, S.far_e.p,
-                           g.bcr_wsrc, g.bcr_wsquare, S.Z.p, S.zstride, g.X.p + g.ng, S.lam.p);
-        const int n = g.levels[0].n;
-        hipLaunchKernelGGL(k_bcr_apply_lambda, dim3((n + 255) / 256), dim3(256), 0, g.stream, n, S.nfar, S.Z.p,
-                           S.zstride, S.lam.p, g.X.p + g.ng);
+    // closures: the reduction (which keeps the inverses of the eliminated blocks), the closures' forward eliminations,
+    // the Woodbury system, the corrected right-hand sides, the ways back
+    hipStream_t st = g.stream;
+    const int r = S.nfar, npad = S.cl_npad, nl = (int)S.lev.size();
+    bcr_run<B, 3>(g, -1, 0, false, 1);
+    BcrClPlan P;
+    for (int l = 0; l < nl; l++) {
+        P.W[l] = S.lev[l].W.p;
+        P.Wrw[l] = S.lev[l].W.p;
+        P.Dinv[l] = S.Dinv[(size_t)l].p;
     }
+    P.topDinv = S.topDinv.p;
+    P.xtop = S.xtop.p;
+    int wpb = 4;
+    while (wpb > 1 && (size_t)wpb * S.cl_nslots * B * sizeof(double) > 60 * 1024) wpb >>= 1;
+    const size_t lds = (size_t)wpb * S.cl_nslots * B * sizeof(double);
+    if (lds > 64 * 1024)
+        IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_forward<B>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_bcr_closure_forward<B>), dim3((r + wpb - 1) / wpb), dim3(64 * wpb), lds, st, P, r, S.cl_nslots,
+                       S.cl_off.p, S.cl_step.p, S.cl_init.p, S.cl_R.p, S.cl_W.p, S.cl_T.p);
+    const int nt = (npad + 15) / 16;
+    hipLaunchKernelGGL((k_bcr_closure_S<B>), dim3(nt, nt), dim3(256), 0, st, r, npad, S.cl_off.p, S.cl_step.p, S.cl_R.p,
+                       S.cl_W.p, S.far_e.p, g.bcr_wsrc, g.bcr_wsquare, S.cl_S.p, S.cl_T.p, S.cl_alive.p);
+    if (r <= 64) {
+        hipLaunchKernelGGL(k_bcr_closure_solve64, dim3(1), dim3(256), 0, st, r, npad, S.cl_S.p, S.cl_T.p, S.lam.p);
+    } else {
+        dense_invert_spd(g, S.cl_S.p, npad);
+        hipLaunchKernelGGL(k_bcr_closure_lambda, dim3((r + 3) / 4), dim3(256), 0, st, r, npad, S.cl_S.p, S.cl_T.p,
+                           S.lam.p);
+    }
+    hipLaunchKernelGGL((k_bcr_closure_correct<B>), dim3(S.cl_nelim), dim3(128), 0, st, P, S.co_off.p, S.co_rec.p,
+                       S.co_elim.p, S.cl_owner.p, S.cl_W.p, S.lam.p);
+    bcr_run<B, 3>(g, -1, 0, false, 2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1315,7 +1687,7 @@ static void bcr_top_solve_t(Graph &g, BcrTop &T) {
                        buf + 3 * W * BB + W * BR, buf + 2 * W * BB, T.W.p, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr, (double *)nullptr, T.xtop.p, 0, 0, (const int *)nullptr,
                        (const int *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, nul, (const int *)nullptr, 0,
-                       (long long *)nullptr);
+                       (long long *)nullptr, (double *)nullptr, (double *)nullptr);
     hipLaunchKernelGGL((k_bcr_back<B, 3, false>), dim3(1), dim3(256), 0, g.stream, W, W, 0, T.W.p, T.xtop.p, T.x.p,
                        (double4 *)nullptr, (double *)nullptr, 0, 0, 0, nul, 0);
 }
@@ -1413,7 +1785,7 @@ int bcr_levels(Graph &g) {
 // correction, bcr_solve), enough rows for the hierarchy of the iterative solver to exist at all (smaller graphs
 // are one dense level = a direct solve already). opt.band_direct: 0 choose, 1 whenever the band allows, -1 never;
 // IROTAVG_BAND_DIRECT overrides the option.
-constexpr int kBcrMaxFar = 64;
+constexpr int kBcrMaxFar = 2048;
 void bcr_plan(Graph &g, const int32_t *I) {
     g.bcr_B = 0;
     g.band0 = -1;
@@ -1475,7 +1847,7 @@ void bcr_plan(Graph &g, const int32_t *I) {
                 g.bcr_far_e.push_back((int)k);
             }
         }
-        bool refuse = !g.bcr_far_e.empty() && (B > 24 || getenv("IROTAVG_BCR_NO_CLOSURES"));  // closure columns: LDS of the 32-row blocks
+        bool refuse = !g.bcr_far_e.empty() && getenv("IROTAVG_BCR_NO_CLOSURES");
         if (!g.bcr_far_e.empty() && !refuse) {
             // The Woodbury correction needs the BAND part alone to be positive definite: every free view must be
             // tied to a fixed one through band edges. Sufficient and cheap: every view has a band edge to an earlier

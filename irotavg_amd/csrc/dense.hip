@@ -1299,6 +1299,52 @@ void dense_refresh(Graph &g) {
     }
 }
 
+// In-place inverse of a dense symmetric positive definite matrix that is not a handle's coarse operator (the Woodbury
+// system of the banded direct solver's closures, bcr.hip): the same blocked Gauss-Jordan sweep with look-ahead. npad: a
+// multiple of 64, padding rows / columns = the identity's. Dead-pivot scale: the largest diagonal entry.
+__global__ __launch_bounds__(256) void k_diag_max(int n, int npad, const double *__restrict__ A, double *__restrict__ maxdiag) {
+    double dm = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dm = fmax(dm, A[(size_t)i * npad + i]);
+    for (int o = 32; o > 0; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+    if ((threadIdx.x & 63) == 0 && dm > 0.0)
+        atomicMax(reinterpret_cast<unsigned long long *>(maxdiag), (unsigned long long)__double_as_longlong(dm));
+}
+void dense_invert_spd(Graph &g, double *A, int npad) {
+    const size_t pan = (size_t)32 * npad;
+    if (g.dense_wr.n < 2 * pan) g.dense_wr.alloc(2 * pan);
+    if (g.dense_wc.n < 2 * pan) g.dense_wc.alloc(2 * pan);
+    if (g.dense_la.n < (size_t)2 * GJB * GJB) g.dense_la.alloc((size_t)2 * GJB * GJB);
+    if (g.dense_maxdiag.n < 1) g.dense_maxdiag.alloc(1);
+    IRH_CHECK(hipMemsetAsync(g.dense_maxdiag.p, 0, sizeof(double), g.stream));
+    hipLaunchKernelGGL(k_diag_max, dim3(4), dim3(256), 0, g.stream, npad, npad, A, g.dense_maxdiag.p);
+    const int nchunk = npad / GJT;
+    if (nchunk < 2) {
+        for (int k0 = 0; k0 < npad; k0 += GJB) {
+            hipLaunchKernelGGL(k_gj_panel, dim3(2 * nchunk), dim3(256), 0, g.stream, npad, k0, A, g.dense_wr.p,
+                               g.dense_wc.p, g.dense_maxdiag.p);
+            hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0, A, g.dense_wr.p,
+                               g.dense_wc.p);
+        }
+        return;
+    }
+    hipLaunchKernelGGL(k_gj_panel, dim3(2 * nchunk), dim3(256), 0, g.stream, npad, 0, A, g.dense_wr.p, g.dense_wc.p,
+                       g.dense_maxdiag.p);
+    hipLaunchKernelGGL(k_gj_snapshot, dim3(1), dim3(256), 0, g.stream, npad, GJB, A, g.dense_la.p + GJB * GJB);
+    int cur = 0;
+    for (int k0 = 0; k0 < npad; k0 += GJB) {
+        double *wr = g.dense_wr.p + cur * pan, *wc = g.dense_wc.p + cur * pan;
+        double *wrn = g.dense_wr.p + (cur ^ 1) * pan, *wcn = g.dense_wc.p + (cur ^ 1) * pan;
+        const int step = k0 / GJB;
+        double *sr = g.dense_la.p + ((step + 1) & 1) * GJB * GJB, *sw = g.dense_la.p + (step & 1) * GJB * GJB;
+        if (k0 + GJB < npad)
+            hipLaunchKernelGGL(k_gj_update_la, dim3(nchunk * nchunk), dim3(GJ_LA_THREADS), 0, g.stream, npad, k0, A, wr,
+                               wc, wrn, wcn, sr, sw, g.dense_maxdiag.p);
+        else
+            hipLaunchKernelGGL(k_gj_update, dim3(nchunk * nchunk), dim3(256), 0, g.stream, npad, k0, A, wr, wc);
+        cur ^= 1;
+    }
+}
+
 // y = E^-1 b on the dense level (3 columns). One wave per row, 16 rows per workgroup; b lives in
 // LDS (one wave per row, 4 rows per workgroup so that ~n/4 workgroups spread over the chip). CHECK: PCG convergence prologue (when this is the first kernel after the PCG update).
 // DOT: partial sums of b.y (the coarse part of r.z in the additive variant / the whole r.z when

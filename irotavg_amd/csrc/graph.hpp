@@ -260,6 +260,7 @@ void bcr_plan(Graph &g, const int32_t *I);  // sets Graph::bcr_B / band0 (capi.c
 int bcr_solve(Graph &g, int only = -1);     // levels[0] values / diagonal / right-hand side -> g.X, asynchronous
 int bcr_levels(Graph &g);
 int bcr_info(Graph &g, int64_t *out, int cap);
+void dense_invert_spd(Graph &g, double *A, int npad);  // in place, npad a multiple of 64 (dense.hip)
 int bcr_stamps(Graph &g, int level, int chunk, double *out);  // development aid
 // the sharded form (dist.hip): every rank reduces its range to its last block; the `world` separators are one chunk
 struct BcrTop {

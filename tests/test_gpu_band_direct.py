@@ -159,10 +159,13 @@ def closure_graph(n, m, nclose, seed, wrong=0, f=1):
     return dict(S, I=I[order], QQ=QQ[order], m=len(I))
 
 
-# 5 closures: one pass of sixteen extra right-hand sides; 20 and 40: two and three passes; 64: the most the direct
-# solver takes (four passes, a 64 x 64 Woodbury system); blocks of 8, 16 and 24
+# 5 ... 64 closures: the Woodbury system is solved in LDS; 65, 300, 1000: by the blocked Gauss-Jordan sweep (round 4:
+# the closures' forward eliminations follow their paths up the elimination tree, bcr.hip; round 3 took at most 64,
+# sixteen per re-factorisation); blocks of 8, 12, 16, 24 and 32
 @pytest.mark.parametrize("n,m,nclose,wrong,block", [(3000, 12000, 5, 1, 8), (3000, 45000, 20, 3, 16),
-                                                    (4000, 80000, 40, 4, 24), (5000, 20000, 64, 6, 8)])
+                                                    (4000, 80000, 40, 4, 24), (5000, 20000, 64, 6, 8),
+                                                    (5000, 20000, 65, 6, 8), (6000, 60000, 300, 20, 12),
+                                                    (2511, 74830, 100, 8, 32), (20000, 300000, 1000, 40, 16)])
 def test_loop_closures_on_the_direct_path_match_oracle(n, m, nclose, wrong, block):
     """A sequence with a few loop closures -- the SLAM case (src/IRotAvg.cpp:371-378 re-solves the whole graph on
     every closure): the band part is factorised, the closures re-enter by the Woodbury correction (bcr_solve).
@@ -188,7 +191,7 @@ def test_loop_closures_on_the_direct_path_match_oracle(n, m, nclose, wrong, bloc
 
 def test_closure_with_zero_weight_and_too_many_closures():
     """Talwar sets the weight of a large residual to exactly 0 (ral/l1_irls.cpp:700-707): such a closure is absent
-    from the operator -- its row of the Woodbury system is dead. 65 closures are one too many: the handle solves
+    from the operator -- its row of the Woodbury system is dead. 2049 closures are one too many: the handle solves
     iteratively."""
     n = 3000
     S = closure_graph(n, 30000, 6, 11, wrong=3)
@@ -202,8 +205,8 @@ def test_closure_with_zero_weight_and_too_many_closures():
     assert (w == 0).sum() >= 3 and r["iters"] == ro["iters"]
     assert synth.angular_distance(Q, ro["Q"]).max() < 1e-9
     np.testing.assert_array_equal(w == 0, ro["weights"] == 0)
-    S = closure_graph(n, 30000, 65, 11)
-    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+    S = closure_graph(12000, 48000, 2049, 11)
+    with capi.Graph(S["I"], S["QQ"], 12000, 1, band_direct=1) as G:
         assert G.stats()["band_block"] == 0 and G.direct_info()["block"] == 0
 
 

@@ -50,6 +50,13 @@ def run(n, m, nclose, oracle=True, wrong=0, reps=3):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "many":   # round 4: hundreds of closures (the oracle up to 20k views)
+        run(3000, 45000, 100, wrong=5)
+        run(20000, 300000, 300, wrong=10)
+        run(20000, 300000, 1000, wrong=30)
+        run(100000, 2000000, 100, oracle=False, wrong=5)
+        run(100000, 2000000, 1000, oracle=False, wrong=30)
+        sys.exit(0)
     run(3000, 12000, 5)
     run(3000, 45000, 20, wrong=3)
     run(4000, 80000, 40, wrong=4)
