@@ -108,6 +108,10 @@ typedef struct irotavg_stats {
     int64_t direct_solves;    /* linear systems solved by the banded direct solver (options.band_direct) */
     int64_t band;             /* half-bandwidth of the operator found at creation (-1: not looked at), and ... */
     int64_t band_block;       /* ... the block size of the direct solver (0: the solves run through the PCG) */
+    int64_t direct_guarded;   /* direct solves with loop closures whose BAND part lost a pivot (a cost with exact-zero
+                                 weights cut a view off its band neighbours while a closure may still hold it): repeated as a
+                                 conjugate-gradient solve of the full operator preconditioned by the regularised direct solve */
+    int64_t direct_dead_pivots; /* dead pivots of the band factor seen by the last such solve */
 } irotavg_stats;
 
 /* ---------------------------------------------------------------------------------------------

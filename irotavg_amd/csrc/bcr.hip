@@ -58,9 +58,11 @@ struct BcrState {
     DevBuf<double> cl_R, cl_W;   // per step: the block's right-hand side when it was eliminated, and D^-1 times it
     DevBuf<double> cl_S, cl_T, lam;  // Woodbury system (npad x npad, npad x 3), its solution (nfar x 3)
     DevBuf<int> cl_alive;
+    DevBuf<int> dead;            // dead pivots of the band factor of the last solve
     DevBuf<int> co_off, co_rec;  // per touched elimination: the steps that touch it ...
     DevBuf<int2> co_elim;        // ... and {level, elimination}
-    int cl_nslots = 0, cl_nsteps = 0, cl_nelim = 0, cl_npad = 0;
+    int cl_nslots = 0, cl_nsteps = 0, cl_nelim = 0, cl_npad = 0, cl_maxsteps = 1, cl_ndense = 0;
+    DevBuf<int> cl_dense;        // cl_ndense x nfar: the step of closure q on dense elimination d, or -1
     // a shard of a sharded sequence (dist.hip): the separator before the first chunk is the previous rank's
     int ext0 = 0;
     DevBuf<long long> stamps;  // development aid: bcr_stamp
@@ -91,8 +93,11 @@ __device__ __forceinline__ double bcr_readlane(double v, int lane) {
 // the compiler defers an element's updates until its row is the pivot row -- k dependent FMAs on the critical path.)
 // LDS scratch: the first B doubles of the block itself (it lives in registers during the sweep). One wave alone:
 // 0.85 / 2.3 / 4.2 / 6.9 us for B = 8 / 16 / 24 / 32 (tools/micro/sweep_cols.hip).
+// dead: a counter of dead pivots (nullptr: not wanted); reg: a dead pivot is replaced by the row's own original
+// diagonal entry (1 if that is not positive) instead of zeroing the unknown -- the regularised factorisation the guard of
+// the closure path preconditions with (Graph::bcr_guard).
 template <int B>
-__device__ __forceinline__ void bcr_invert(double *Dm, int lane) {
+__device__ __forceinline__ void bcr_invert(double *Dm, int lane, int *dead = nullptr, bool reg = false) {
     static_assert(B % 2 == 0 && B <= 32, "block size");
     constexpr int HB = B / 2;
     const int c = lane & 31, h = lane >> 5;
@@ -103,14 +108,18 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane) {
 #pragma unroll
     for (int i = 0; i < HB; i++) t[i] = Dm[(h * HB + i) * B + cl];
     const double dg = Dm[cl * B + cl];
+    int ndead = 0;
     auto pivot_inverse = [&](double tk, int k, int kh) {
         // reciprocal by v_rcp_f64 + two Newton steps (the IEEE division sequence is three times as long and sits on
         // the chain from pivot to pivot)
-        const double p = bcr_readlane(tk, k + 32 * kh), ref = bcr_readlane(dg, k);
+        const double p0 = bcr_readlane(tk, k + 32 * kh), ref = bcr_readlane(dg, k);
+        const bool alive = p0 > kDeadTol * ref;
+        ndead += alive ? 0 : 1;
+        const double p = (alive || !reg) ? p0 : (ref > 0.0 ? ref : 1.0);
         double x = __builtin_amdgcn_rcp(p);
         x = fma(fma(-p, x, 1.0), x, x);
         x = fma(fma(-p, x, 1.0), x, x);
-        return (p > kDeadTol * ref) ? x : 0.0;
+        return (alive || reg) ? x : 0.0;
     };
     if (h == 0 && act) Dm[c] = t[0];
     asm volatile("" ::: "memory");
@@ -166,6 +175,7 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane) {
 #pragma unroll
     for (int i = 0; i < HB; i++)
         if (act) Dm[(h * HB + i) * B + c] = -t[i];
+    if (dead && ndead && lane == 0) atomicAdd(dead, ndead);
 }
 
 // development aid (IROTAVG_BCR_DBG & 64, irotavg_graph_time_kernel 200 + slot): shader-clock stamps of thread 0 of every
@@ -483,7 +493,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop, int dbg,
     int nfar, const int *__restrict__ far_i, const int *__restrict__ far_j, int ext0, const int *__restrict__ bptr,
     const int *__restrict__ bghost, const double *__restrict__ bval, const int *__restrict__ ghost_extcol, int place,
-    long long *__restrict__ stamps, double *__restrict__ Dinvg, double *__restrict__ topDinv) {
+    long long *__restrict__ stamps, double *__restrict__ Dinvg, double *__restrict__ topDinv, int *__restrict__ deadctr,
+    int reg) {
     typedef BcrDim<B, NR> Dm;
     constexpr int BB = B * B;
     __shared__ double sDG[16][BB];
@@ -637,7 +648,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
         /* the sweep of elimination e runs on wave e: the first four waves of a workgroup sit on four different */   \
         /* SIMDs (waves e WPE of an eight-wave workgroup share two, and two sweeps on one SIMD take 7 us, not 4) */  \
         const int isw = wave < NE ? (RND == 0 ? 2 * wave : RND == 1 ? 1 + 4 * wave : 3) : -1;                       \
-        if (isw >= 0 && bcr_ridx(placed, kreal, isw) >= 0 && !(dbg & 1)) bcr_invert<B>(sD[isw], lane);              \
+        if (isw >= 0 && bcr_ridx(placed, kreal, isw) >= 0 && !(dbg & 1))                                            \
+            bcr_invert<B>(sD[isw], lane, deadctr, reg != 0);                                                        \
         __syncthreads();                                                                                            \
         /* closures: the inverse of every eliminated block is kept (bcr_closures) */                                \
         if (Dinvg && active && part == 0)                                                                           \
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     if (TOP) {
         if (wave == 0) {
             if (bcr_ridx(placed, kreal, 7) >= 0) {
-                bcr_invert<B>(sD[7], lane);
+                bcr_invert<B>(sD[7], lane, deadctr, reg != 0);
                 if (topDinv)
                     for (int o = lane; o < BB; o += 64) topDinv[o] = sD[7][o];
                 for (int o = lane; o < B * NR; o += 64) {
@@ -1071,13 +1083,16 @@ __global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r,
             }
         }
         if (lane < B) recR[(size_t)st * B + lane] = slots[src * B + lane];
+        // the columns of both passes are requested before the first is used: one memory round trip per step
+        constexpr int NPASS = (NCOL + 63) / 64;
+        double m[NPASS][B];
+        bool have[NPASS];
 #pragma unroll
-        for (int pass = 0; pass * 64 < NCOL; pass++) {
+        for (int pass = 0; pass < NPASS; pass++) {
             const int col = pass * 64 + lane;
-            if (col >= NCOL) continue;
-            const double *base;
-            int stride;
-            bool have = true;
+            const double *base = Db;
+            int stride = B;
+            have[pass] = col < NCOL;
             if (col < NC) {
                 if (lvl >= 0) {
                     base = Wb + col;
@@ -1085,20 +1100,21 @@ __global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r,
                 } else {  // the top block: nothing beside it; its part of Y is xtop
                     base = P.xtop + (col - 2 * B);
                     stride = NR;
-                    have = col >= 2 * B;
+                    have[pass] = col >= 2 * B;
                 }
             } else {
                 base = Db + (col - NC);
-                stride = B;
             }
+#pragma unroll
+            for (int k = 0; k < B; k++) m[pass][k] = have[pass] ? base[(size_t)k * stride] : 0.0;
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
+            const int col = pass * 64 + lane;
+            if (col >= NCOL) continue;
             double acc = 0.0;
-            if (have) {
-                double m[B];
 #pragma unroll
-                for (int k = 0; k < B; k++) m[k] = base[(size_t)k * stride];
-#pragma unroll
-                for (int k = 0; k < B; k++) acc = fma(m[k], R[k], acc);
-            }
+            for (int k = 0; k < B; k++) acc = fma(m[pass][k], R[k], acc);
             if (col < B) {
                 if (dA != 255) slots[dA * B + col] -= acc;
             } else if (col < 2 * B) {
@@ -1119,17 +1135,62 @@ __global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r,
 }
 
 // S = C^-1 + V' A_b^-1 V: entry (p, q) = sum over the steps of p and q on the same block of R_p . (D^-1 R_q); the
-// step lists are sorted by block. A thread per pair of the upper triangle; a closure of weight 0 (Talwar) is not
-// there: its row and column are the identity's, its T is 0.
+// step lists are sorted by block. A workgroup per 16 x 16 tile of the upper triangle, the keys of its 32 closures in
+// LDS (a merge that fetched every key from memory was a dependent load per step: 270 us at a thousand closures); a
+// closure of weight 0 (Talwar) is not there: its row and column are the identity's, its T is 0.
 template <int B>
-__global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, const int *__restrict__ off,
+__global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, int maxsteps, int ndense,
+                                                        const int *__restrict__ dense, const int *__restrict__ off,
                                                         const int4 *__restrict__ steps, const double *__restrict__ recR,
                                                         const double *__restrict__ recW, const int *__restrict__ far_e,
                                                         const double *__restrict__ wsrc, int wsquare,
                                                         double *__restrict__ S, double *__restrict__ T,
                                                         int *__restrict__ alive) {
-    const int p = blockIdx.y * 16 + (threadIdx.x >> 4), q = blockIdx.x * 16 + (threadIdx.x & 15);
-    if (blockIdx.x < blockIdx.y || p >= npad || q >= npad || q < p) return;
+    extern __shared__ int skey[];  // [32][maxsteps]: rows 0..15 the tile's p, 16..31 its q
+    __shared__ double sx[2][16][B + 1], sy[2][16][B + 1];
+    if (blockIdx.x < blockIdx.y) return;
+    const int tp = threadIdx.x >> 4, tq = threadIdx.x & 15;
+    const int p = blockIdx.y * 16 + tp, q = blockIdx.x * 16 + tq;
+    for (int e = threadIdx.x; e < 32 * maxsteps; e += 256) {
+        const int who = e / maxsteps, k = e - who * maxsteps;
+        const int cl = who < 16 ? blockIdx.y * 16 + who : blockIdx.x * 16 + who - 16;
+        int key = 0x7fffffff;
+        if (cl < r && k < off[cl + 1] - off[cl]) key = steps[off[cl] + k].w;
+        skey[e] = key;
+    }
+    // the dense eliminations (the blocks of the top levels, on almost every closure's path): the records of the tile's
+    // sixteen p and sixteen q through LDS, double buffered -- each is used sixteen times
+    double sum = 0.0;
+    {
+        // thread -> (which of the 32 closures, a pair of entries): 32 x B / 2 pairs of doubles
+        auto fetch = [&](int d, int buf) {
+            for (int e = threadIdx.x; e < 32 * (B / 2); e += 256) {
+                const int who = e / (B / 2), k2 = e - who * (B / 2);
+                const int cl = who < 16 ? blockIdx.y * 16 + who : blockIdx.x * 16 + who - 16;
+                const int st = cl < r ? dense[(size_t)d * r + cl] : -1;
+                v2d v = v2d{0.0, 0.0};
+                if (st >= 0) v = *reinterpret_cast<const v2d *>((who < 16 ? recR : recW) + (size_t)st * B + 2 * k2);
+                double *dst = who < 16 ? &sx[buf][who][2 * k2] : &sy[buf][who - 16][2 * k2];
+                dst[0] = v.x;
+                dst[1] = v.y;
+            }
+        };
+        if (ndense > 0) fetch(0, 0);
+        __syncthreads();
+        for (int d = 0; d < ndense; d++) {
+            if (d + 1 < ndense) fetch(d + 1, (d + 1) & 1);
+            const double *x = sx[d & 1][tp], *y = sy[d & 1][tq];
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < B; k += 2) {
+                d0 = fma(x[k], y[k], d0);
+                d1 = fma(x[k + 1], y[k + 1], d1);
+            }
+            sum += d0 + d1;
+            __syncthreads();
+        }
+    }
+    if (p >= npad || q >= npad || q < p) return;
     if (p >= r || q >= r) {  // padding of the inversion
         S[(size_t)p * npad + q] = S[(size_t)q * npad + p] = p == q ? 1.0 : 0.0;
         return;
@@ -1139,21 +1200,27 @@ __global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, const in
         wp *= wp;
         wq *= wq;
     }
-    double sum = 0.0;
     if (wp > 0.0 && wq > 0.0) {
-        int a = off[p], b = off[q];
-        const int ae = off[p + 1], be = off[q + 1];
-        while (a < ae && b < be) {
-            const int ka = steps[a].w, kb = steps[b].w;
-            if (ka == kb) {
-                const double *x = recR + (size_t)a * B, *y = recW + (size_t)b * B;
-                double d = 0.0;
+        const int *ka = skey + tp * maxsteps, *kb = skey + (16 + tq) * maxsteps;
+        const int na = off[p + 1] - off[p], nb = off[q + 1] - off[q];
+        const double *x0 = recR + (size_t)off[p] * B, *y0 = recW + (size_t)off[q] * B;
+        int a = 0, b = 0;
+        while (a < na && b < nb) {
+            const int va = ka[a], vb = kb[b];
+            if (va == vb) {
+                if (!(va & 1)) {  // (a dense elimination: summed above)
+                    const double *x = x0 + (size_t)a * B, *y = y0 + (size_t)b * B;
+                    double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-                for (int k = 0; k < B; k++) d = fma(x[k], y[k], d);
-                sum += d;
+                    for (int k = 0; k < B; k += 2) {
+                        d0 = fma(x[k], y[k], d0);
+                        d1 = fma(x[k + 1], y[k + 1], d1);
+                    }
+                    sum += d0 + d1;
+                }
                 a++;
                 b++;
-            } else if (ka < kb) {
+            } else if (va < vb) {
                 a++;
             } else {
                 b++;
@@ -1230,22 +1297,36 @@ __global__ __launch_bounds__(256) void k_bcr_closure_lambda(int r, int npad, con
 }
 
 // W_R of every block a closure touches -= sum over the steps on it of (D^-1 R_q) lambda_q' (the top block: xtop):
-// a workgroup per block, the steps in a fixed order
+// a workgroup per block. The top blocks lie on every closure's path (a thousand steps each): the list is dealt to
+// PARTS groups of threads whose partial sums are added in a fixed order.
 template <int B>
-__global__ __launch_bounds__(128) void k_bcr_closure_correct(BcrClPlan P, const int *__restrict__ eoff,
-                                                              const int *__restrict__ erec, const int2 *__restrict__ elim,
-                                                              const int *__restrict__ owner,
-                                                              const double *__restrict__ recW,
-                                                              const double *__restrict__ lam) {
-    constexpr int NR = 3, NC = 2 * B + NR;
+__global__ __launch_bounds__(1024) void k_bcr_closure_correct(BcrClPlan P, const int *__restrict__ eoff,
+                                                               const int *__restrict__ erec, const int2 *__restrict__ elim,
+                                                               const int *__restrict__ owner,
+                                                               const double *__restrict__ recW,
+                                                               const double *__restrict__ lam) {
+    constexpr int NR = 3, NC = 2 * B + NR, NO = B * 3, PARTS = 1024 / NO;
+    __shared__ double part[PARTS][NO];
     const int g = blockIdx.x, t = threadIdx.x;
-    if (t >= B * 3) return;
-    const int row = t / 3, c = t - 3 * row;
-    double acc = 0.0;
-    for (int k = eoff[g]; k < eoff[g + 1]; k++) {
-        const int st = erec[k];
-        acc = fma(recW[(size_t)st * B + row], lam[3 * owner[st] + c], acc);
+    const int pt = t / NO, o = t - pt * NO;
+    const int row = o / 3, c = o - 3 * row;
+    const int k0 = eoff[g], k1 = eoff[g + 1];
+    if (pt < PARTS) {
+        double acc = 0.0;
+        if (k1 - k0 > pt) {
+#pragma unroll 4
+            for (int k = k0 + pt; k < k1; k += PARTS) {
+                const int st = erec[k];
+                acc = fma(recW[(size_t)st * B + row], lam[3 * owner[st] + c], acc);
+            }
+        }
+        part[pt][o] = acc;
     }
+    __syncthreads();
+    if (t >= NO) return;
+    double acc = 0.0;
+    const int np = k1 - k0 < PARTS ? k1 - k0 : PARTS;
+    for (int q = 0; q < np; q++) acc += part[q][o];
     const int2 el = elim[g];
     if (el.x >= 0)
         P.Wrw[el.x][(size_t)el.y * B * NC + (size_t)row * NC + 2 * B + c] -= acc;
@@ -1388,6 +1469,7 @@ static void bcr_closure_plan(Graph &g) {
             }
         }
         nslots = std::max(nslots, next);
+        S.cl_maxsteps = std::max(S.cl_maxsteps, (int)steps.size() - off.back());
         off.push_back((int)steps.size());
     }
     if (nslots > 250) throw HipError{hipErrorUnknown};
@@ -1405,6 +1487,25 @@ static void bcr_closure_plan(Graph &g) {
         for (int k : kv.second) erec.push_back(k);
         eoff.push_back((int)erec.size());
     }
+    // eliminations on (almost) every closure's path -- the blocks of the top levels: their part of S is a dense
+    // product, done tile-wise from LDS (k_bcr_closure_S); the key of a step carries the mark in its lowest bit
+    std::vector<int> dense;
+    for (size_t k = 0; k < steps.size(); k++) steps[k].w *= 2;
+    if (r > 64) {
+        int d = 0;
+        for (auto &kv : by_key)
+            if ((long long)kv.second.size() * 4 >= r) {
+                dense.resize((size_t)(d + 1) * r, -1);
+                for (int k : kv.second) {
+                    dense[(size_t)d * r + owner[(size_t)k]] = k;
+                    steps[(size_t)k].w |= 1;
+                }
+                d++;
+            }
+        S.cl_ndense = d;
+    }
+    if (dense.empty()) dense.push_back(-1);
+    S.cl_dense.upload(dense, g.stream);
     S.cl_nslots = nslots;
     S.cl_nsteps = (int)steps.size();
     S.cl_nelim = (int)elim.size();
@@ -1428,6 +1529,7 @@ static void bcr_closure_plan(Graph &g) {
     S.Dinv.resize((size_t)nl);
     for (int l = 0; l < nl; l++) S.Dinv[(size_t)l].alloc((size_t)S.lev[l].nch * 7 * B * B);
     S.topDinv.alloc((size_t)B * B);
+    S.dead.alloc(1);
     IRH_CHECK(hipMemsetAsync(S.topDinv.p, 0, sizeof(double) * (size_t)B * B, g.stream));
     IRH_CHECK(hipStreamSynchronize(g.stream));  // the host vectors go away
 }
@@ -1518,7 +1620,7 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
         F ? F->sepR.p : nullptr, F ? F->extD.p : nullptr, F ? F->extR.p : nullptr, F ? F->extG.p : nullptr, L.W.p, \
         L.sepD.p, L.sepR.p, L.extD.p, L.extR.p, L.extG.p, S.xtop.p, dbg, nfar, fi, fj, S.ext0, g.bptr.p, g.bghost.p,  \
         g.bval.p, S.ghost_extcol.p, (int)g.bcr_shard, stamps, S.nfar > 0 ? S.Dinv[(size_t)l].p : (double *)nullptr,         \
-        S.nfar > 0 ? S.topDinv.p : (double *)nullptr
+        S.nfar > 0 ? S.topDinv.p : (double *)nullptr, S.nfar > 0 ? S.dead.p : (int *)nullptr, (int)g.bcr_guard
         // eight waves per chunk when every chunk has a CU to itself (see k_bcr_reduce)
         const bool wide = L.nch <= 256 && !getenv("IROTAVG_BCR_NARROW");
 #define IRH_BCR_LAUNCH(L0_, TOP_)                                                                                   \
@@ -1544,6 +1646,7 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     }
     // the ways back of the levels above level 0 in one launch (k_bcr_back_top) unless this is a shard, the closures'
     // columns ride along or IROTAVG_BCR_NO_FUSED_BACK is set
+    double4 *Xout = g.bcr_out ? g.bcr_out : g.X.p + g.ng;
     bool fused_back = false;
     if constexpr (NR == 3) fused_back = nl >= 2 && !g.bcr_shard && !open_top && !getenv("IROTAVG_BCR_NO_FUSED_BACK");
     for (int l = nl - 1; l >= 0 && phase != 1; l--) {
@@ -1559,7 +1662,7 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
                 }
                 P.top = nl - 1;
                 P.base = 1;
-                hipLaunchKernelGGL((k_bcr_back_top<B>), dim3(L.nch), dim3(256), 0, st, P, S.xtop.p, L.x.p, g.X.p + g.ng, L0.n,
+                hipLaunchKernelGGL((k_bcr_back_top<B>), dim3(L.nch), dim3(256), 0, st, P, S.xtop.p, L.x.p, Xout, L0.n,
                                    L.nred);
                 continue;
             }
@@ -1567,10 +1670,10 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
         const double *xc = l == nl - 1 ? (open_top ? xc_top : S.xtop.p) : S.lev[l + 1].x.p;
         if (l == 0)
             hipLaunchKernelGGL((k_bcr_back<B, NR, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               (double *)nullptr, g.X.p + g.ng, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard);
+                               (double *)nullptr, Xout, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard);
         else
             hipLaunchKernelGGL((k_bcr_back<B, NR, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               L.x.p, g.X.p + g.ng, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard);
+                               L.x.p, Xout, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard);
     }
 }
 
@@ -1585,6 +1688,7 @@ static void bcr_run_all(Graph &g, int only) {
     // the Woodbury system, the corrected right-hand sides, the ways back
     hipStream_t st = g.stream;
     const int r = S.nfar, npad = S.cl_npad, nl = (int)S.lev.size();
+    IRH_CHECK(hipMemsetAsync(S.dead.p, 0, sizeof(int), st));
     bcr_run<B, 3>(g, -1, 0, false, 1);
     BcrClPlan P;
     for (int l = 0; l < nl; l++) {
@@ -1603,7 +1707,8 @@ static void bcr_run_all(Graph &g, int only) {
     hipLaunchKernelGGL((k_bcr_closure_forward<B>), dim3((r + wpb - 1) / wpb), dim3(64 * wpb), lds, st, P, r, S.cl_nslots,
                        S.cl_off.p, S.cl_step.p, S.cl_init.p, S.cl_R.p, S.cl_W.p, S.cl_T.p);
     const int nt = (npad + 15) / 16;
-    hipLaunchKernelGGL((k_bcr_closure_S<B>), dim3(nt, nt), dim3(256), 0, st, r, npad, S.cl_off.p, S.cl_step.p, S.cl_R.p,
+    hipLaunchKernelGGL((k_bcr_closure_S<B>), dim3(nt, nt), dim3(256), (size_t)32 * S.cl_maxsteps * sizeof(int), st, r, npad,
+                       S.cl_maxsteps, S.cl_ndense, S.cl_dense.p, S.cl_off.p, S.cl_step.p, S.cl_R.p,
                        S.cl_W.p, S.far_e.p, g.bcr_wsrc, g.bcr_wsquare, S.cl_S.p, S.cl_T.p, S.cl_alive.p);
     if (r <= 64) {
         hipLaunchKernelGGL(k_bcr_closure_solve64, dim3(1), dim3(256), 0, st, r, npad, S.cl_S.p, S.cl_T.p, S.lam.p);
@@ -1612,7 +1717,7 @@ static void bcr_run_all(Graph &g, int only) {
         hipLaunchKernelGGL(k_bcr_closure_lambda, dim3((r + 3) / 4), dim3(256), 0, st, r, npad, S.cl_S.p, S.cl_T.p,
                            S.lam.p);
     }
-    hipLaunchKernelGGL((k_bcr_closure_correct<B>), dim3(S.cl_nelim), dim3(128), 0, st, P, S.co_off.p, S.co_rec.p,
+    hipLaunchKernelGGL((k_bcr_closure_correct<B>), dim3(S.cl_nelim), dim3(1024), 0, st, P, S.co_off.p, S.co_rec.p,
                        S.co_elim.p, S.cl_owner.p, S.cl_W.p, S.lam.p);
     bcr_run<B, 3>(g, -1, 0, false, 2);
 }
@@ -1687,7 +1792,7 @@ static void bcr_top_solve_t(Graph &g, BcrTop &T) {
                        buf + 3 * W * BB + W * BR, buf + 2 * W * BB, T.W.p, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr, (double *)nullptr, T.xtop.p, 0, 0, (const int *)nullptr,
                        (const int *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, nul, (const int *)nullptr, 0,
-                       (long long *)nullptr, (double *)nullptr, (double *)nullptr);
+                       (long long *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr, 0);
     hipLaunchKernelGGL((k_bcr_back<B, 3, false>), dim3(1), dim3(256), 0, g.stream, W, W, 0, T.W.p, T.xtop.p, T.x.p,
                        (double4 *)nullptr, (double *)nullptr, 0, 0, 0, nul, 0);
 }
@@ -1772,6 +1877,18 @@ int bcr_stamps(Graph &g, int level, int chunk, double *out) {
     for (int k = 0; k < 16; k++) out[k] = h[k] ? (double)(h[k] - h[0]) : -1.0;
     return IROTAVG_OK;
 }
+
+__global__ void k_bcr_gate(const int *__restrict__ dead, int *__restrict__ flags) {
+    const int d = dead ? dead[0] : 0;
+    flags[FL_DONE] = d == 0 ? 1 : 0;
+    flags[3] = d;
+}
+void bcr_gate(Graph &g) {
+    const int *dead = g.bcr && g.bcr->nfar > 0 ? g.bcr->dead.p : nullptr;
+    hipLaunchKernelGGL(k_bcr_gate, dim3(1), dim3(1), 0, g.stream, dead, g.flags.p);
+}
+
+int bcr_closures(Graph &g) { return g.bcr_B ? (int)g.bcr_far_e.size() : 0; }
 
 int bcr_levels(Graph &g) {
     if (!g.bcr_B) return 0;

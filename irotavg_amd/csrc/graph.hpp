@@ -130,6 +130,11 @@ struct Graph {
     std::vector<int> bcr_far_i, bcr_far_j, bcr_far_e;  // long-range edges (rows, edge id): Woodbury correction
     const double *bcr_wsrc = nullptr;                  // per-edge weights of the last assembly and whether the
     int bcr_wsquare = 0;                               // operator holds their squares (IRLS) -- assemble_values
+    // the guard of the closure path (run_irls, precondition): a direct solve whose BAND part lost a pivot is repeated as
+    // a CG solve of the full operator with the regularised direct solve (dead pivot -> the row's own diagonal entry) as
+    // its preconditioner: bcr_guard switches bcr_solve to that mode, bcr_out redirects its result (nullptr: X)
+    bool bcr_guard = false;
+    double4 *bcr_out = nullptr;
     // a shard of a sharded sequence solved directly (dist.hip): bcr_ext0 = a rank lies before this one
     bool bcr_shard = false;
     int bcr_ext0 = 0;
@@ -168,7 +173,7 @@ int ls_solve(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_r
 void launch_update_weights(Graph &g, int cost, double sigma, bool gated = false);
 void launch_apply_step(Graph &g, bool gated);
 double finish_apply_step(Graph &g);
-double apply_step(Graph &g);
+double apply_step(Graph &g, bool gated = false);
 // Small read-backs that steer a solve without the runtime's copy + wait (~25 us of idle GPU per decision): ONE tiny
 // kernel behind the producers copies up to three partial arrays into the handle's pinned block and stores a sequence
 // number last (system scope); wait_published polls it (2 ms, then the stream is synchronised: long kernels, faults).
@@ -260,6 +265,8 @@ void bcr_plan(Graph &g, const int32_t *I);  // sets Graph::bcr_B / band0 (capi.c
 int bcr_solve(Graph &g, int only = -1);     // levels[0] values / diagonal / right-hand side -> g.X, asynchronous
 int bcr_levels(Graph &g);
 int bcr_info(Graph &g, int64_t *out, int cap);
+int bcr_closures(Graph &g);  // loop closures the direct solver of this handle carries
+void bcr_gate(Graph &g);  // flags[FL_DONE] = 1 unless the last direct solve with closures saw a dead pivot (flags[3] = their number)
 void dense_invert_spd(Graph &g, double *A, int npad);  // in place, npad a multiple of 64 (dense.hip)
 int bcr_stamps(Graph &g, int level, int chunk, double *out);  // development aid
 // the sharded form (dist.hip): every rank reduces its range to its last block; the `world` separators are one chunk

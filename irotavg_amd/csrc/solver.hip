@@ -985,6 +985,27 @@ __global__ __launch_bounds__(kRowBlock) void k_jacobi_z(int n, const double *__r
     block_sum3_store(a0, a1, a2, part_rz + 4 * blockIdx.x);
 }
 
+// The guard of the banded direct solver's closure path (Graph::bcr_guard): the preconditioner IS a direct solve
+// (regularised: bcr.hip), so the convergence prologue and the r.z partials are kernels of their own around it.
+__global__ void k_pcg_check_only(const double *__restrict__ part_rr, int nparts, int first, double rtol2,
+                                 double *__restrict__ scal, int *__restrict__ flags) {
+    if (flags[FL_DONE]) return;
+    (void)pcg_check(part_rr, nparts, first, rtol2, scal, flags);
+}
+__global__ __launch_bounds__(kRowBlock) void k_rz_parts(int n, const double4 *__restrict__ r,
+                                                        const double4 *__restrict__ z, double *__restrict__ part_rz,
+                                                        const int *__restrict__ flags) {
+    if (flags[FL_DONE]) return;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double4 ri = r[i], zi = z[i];
+        a0 += ri.x * zi.x;
+        a1 += ri.y * zi.y;
+        a2 += ri.z * zi.z;
+    }
+    block_sum3_store(a0, a1, a2, part_rz + 4 * blockIdx.x);
+}
+
 // =============================================================================================
 // K5 -- PCG vector kernels (three independent columns share the matrix and the preconditioner)
 // =============================================================================================
@@ -1805,6 +1826,20 @@ PrecInfo precondition(Graph &g, int first, double rtol2, bool check) {
     Level &L0 = g.levels[0];
     int np_rr = g.additive_top && nl > 1 ? grid_for_rows(L0) : grid_for_elems(L0.n);
     if (g.force_np) np_rr = g.force_np;  // sharded run: partials were reduced across shards into row 0
+    if (nl == 1 && g.bcr_B && g.bcr_guard) {
+        // z = (A_b + E + V C V')^-1 r: the regularised direct solve (every dead pivot of the band part replaced by the
+        // row's own diagonal entry: E); the operator of the iteration is the true one, so the iteration ends after about
+        // as many steps as there are dead pivots
+        hipLaunchKernelGGL(k_pcg_check_only, dim3(1), dim3(kRowBlock), 0, g.stream, g.part_rr.p, np_rr, first, rtol2,
+                           g.scal.p, g.flags.p);
+        g.bcr_out = L0.y.p;
+        (void)bcr_solve(g);
+        g.bcr_out = nullptr;
+        pi.np_rz = grid_for_elems(L0.n);
+        hipLaunchKernelGGL(k_rz_parts, dim3(pi.np_rz), dim3(kRowBlock), 0, g.stream, L0.n, L0.b.p, L0.y.p, g.part_rz.p,
+                           g.flags.p);
+        return pi;
+    }
     if (nl == 1) {
         if (g.ndense > 0) {  // the whole system is the dense level: z = L^-1 r exactly
             dense_apply(g, L0.b.p, L0.y.p, true, true, g.part_rz.p, np_rr, first, rtol2);
@@ -1973,6 +2008,7 @@ int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ra
     // so the first poll is placed where the previous solve converged and later ones every few
     // iterations (each poll drains the stream; iterations enqueued past convergence are no-ops).
     int chunk = g.stats.pcg_iters_last > 2 ? (int)std::min<int64_t>(g.stats.pcg_iters_last, maxit) : check;
+    if (g.bcr_guard) chunk = 2;  // (every iteration is a direct solve: poll often)
     // Stagnation: an ill-conditioned system (weights spread over many decades, e.g. a sub-tree held
     // by one down-weighted edge) can have an attainable residual above pcg_rtol. If the residual
     // has not halved over kStallIters iterations and is at most `accept`, the iterate is taken as
@@ -1991,7 +2027,7 @@ int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ra
             PrecInfo pi = precondition(g, it == 0, rtol2);
             iteration_tail(pi);
         }
-        chunk = std::max(2, check / 2);
+        chunk = g.bcr_guard ? 1 : std::max(2, check / 2);
         // the convergence test of the last update runs in the next preconditioner prologue
         PrecInfo pi = precondition(g, it == 0, rtol2);
         const bool with_tail = tail != nullptr && first_poll;
@@ -2110,13 +2146,15 @@ double finish_apply_step(Graph &g) {
     g.last_score_sum = s;
     return s / (double)g.no;
 }
-double apply_step(Graph &g) {
+// gated: the step is applied only if flags[FL_DONE] == 1, and the flags come back with the score (h_flags())
+double apply_step(Graph &g, bool gated) {
     const int n = g.nu;
     const int grid = grid_for_elems(n);
     hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kRowBlock), 0, g.stream, n, g.f, g.ng, g.X.p, g.Q.p,
-                       g.part_score.p, 1, (const int *)nullptr);
-    const PubPart part{g.part_score.p, g.h_part(), 4 * grid};
-    publish_parts(g, &part, 1);
+                       g.part_score.p, 1, gated ? (const int *)g.flags.p : (const int *)nullptr);
+    PubPart part[2] = {{g.part_score.p, g.h_part(), 4 * grid},
+                       {reinterpret_cast<const double *>(g.flags.p), reinterpret_cast<double *>(g.h_flags()), FL_COUNT / 2}};
+    publish_parts(g, part, gated ? 2 : 1);
     wait_published(g);
     return finish_apply_step(g);
 }
@@ -2136,8 +2174,31 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
             // ONE host round trip (the score) per iteration
             rc = ls_solve(g);
             if (rc != IROTAVG_OK) break;
-            launch_update_weights(g, cost, sigma);
-            score = apply_step(g);
+            if (bcr_closures(g) > 0) {
+                // The Woodbury correction of the closures needs the BAND part alone to be positive definite. A cost whose
+                // weights reach exactly 0 (Talwar, bisquare, Andrews) can cut a view off all its band neighbours while a
+                // closure still holds it: the band factor then has a dead pivot and the step would be wrong. The
+                // reduction counts dead pivots; weight and rotation update are gated on "none", and the verdict comes
+                // back with the score. One or more: the system is solved again by conjugate gradients on the true operator
+                // (closures included), preconditioned by the regularised direct solve -- about one iteration per dead
+                // pivot -- and the tail runs ungated. (ral/l1_irls.cpp:536-556 always solves the full system.)
+                bcr_gate(g);
+                launch_update_weights(g, cost, sigma, true);
+                score = apply_step(g, true);
+                if (g.h_flags()[FL_DONE] != 1) {
+                    g.stats.direct_guarded += 1;
+                    g.stats.direct_dead_pivots = g.h_flags()[3];
+                    g.bcr_guard = true;
+                    rc = pcg_solve_classic(g);
+                    g.bcr_guard = false;
+                    if (rc != IROTAVG_OK) break;
+                    launch_update_weights(g, cost, sigma);
+                    score = apply_step(g);
+                }
+            } else {
+                launch_update_weights(g, cost, sigma);
+                score = apply_step(g);
+            }
             if (!std::isfinite(score)) {
                 rc = IROTAVG_ERR_SOLVER;
                 break;

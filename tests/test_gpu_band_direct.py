@@ -210,6 +210,50 @@ def test_closure_with_zero_weight_and_too_many_closures():
         assert G.stats()["band_block"] == 0 and G.direct_info()["block"] == 0
 
 
+@pytest.mark.parametrize("stretch", [1, 3])
+def test_views_held_only_by_a_closure_match_oracle(stretch):
+    """The known limit of round 3, guarded in round 4: Talwar's exact-zero weights (ral/l1_irls.cpp:700-707) cut a view
+    (or a stretch of views) off ALL its band neighbours while a loop closure still holds it. The band part of the operator
+    is then singular and its factor has a dead pivot, but the full system -- which the reference always solves,
+    ral/l1_irls.cpp:536-556 -- is not: the handle notices (dead pivots are counted on the device), repeats that solve by
+    conjugate gradients on the full operator preconditioned with the regularised direct solve, and says so in its stats."""
+    n = 3000
+    S = closure_graph(n, 12000, 6, 5)
+    I, QQ = S["I"].copy(), S["QQ"].copy()
+    v0 = 1500
+    cut = np.arange(v0, v0 + stretch)
+    rng = np.random.default_rng(9)
+    inside = np.isin(I[:, 0], cut) & np.isin(I[:, 1], cut)
+    touching = (np.isin(I[:, 0], cut) | np.isin(I[:, 1], cut)) & ~inside & (np.abs(I[:, 0] - I[:, 1]) <= 32)
+    assert touching.sum() >= 4
+    R = rng.normal(size=(int(touching.sum()), 4))
+    QQ[touching] = R / np.linalg.norm(R, axis=1, keepdims=True)        # every band edge out of the stretch is wrong ...
+    far = np.array([[200, v0]], dtype=np.int32)                        # ... and one correct closure holds it
+    QQf = synth.qmul(S["Qgt"][v0:v0 + 1], synth.qconj(S["Qgt"][200:201]))
+    I = np.concatenate([I, far]).astype(np.int32)
+    QQ = np.concatenate([QQ, QQf])
+    order = np.lexsort((np.arange(len(I)), I[:, 1]))
+    I, QQ = I[order], QQ[order]
+    Q = np.zeros((n, 4)); Q[:, 3] = 1; Q[0] = S["Qgt"][0]
+    rc, Qm = O.init_mst(Q, QQ, I, 1)
+    assert rc == 0
+    with capi.Graph(I, QQ, n, 1, band_direct=1) as G:
+        assert G.direct_info()["closures"] == 7
+        G.set_rotations(Qm)
+        r = G.irls(12, SIG, 30, 1e-3)           # Talwar
+        Qg, w = G.get_rotations(), G.get_weights()
+        st = G.stats()
+    ro = O.irls(QQ, I, Qm, 1, 12, SIG, 30, 1e-3)
+    assert st["direct_guarded"] >= 1 and st["direct_dead_pivots"] >= 1, st
+    assert st["band_block"] == 8 and st["direct_solves"] > 0
+    assert r["iters"] == ro["iters"], (r["iters"], ro["iters"], r["scores"], ro["scores"])
+    np.testing.assert_array_equal(w == 0, ro["weights"] == 0)
+    assert synth.angular_distance(Qg, ro["Q"]).max() < 1e-8
+    # the stretch really hangs on the closure alone: all its band edges to the outside ended at weight 0
+    out = (np.isin(I[:, 0], cut) ^ np.isin(I[:, 1], cut)) & (np.abs(I[:, 0] - I[:, 1]) <= 32)
+    assert (w[out] == 0).all() and w[(I[:, 0] == 200) & (I[:, 1] == v0)][0] > 0
+
+
 def test_blocks_of_32_with_a_mixed_level_match_the_iterative_solver():
     """70k views, band 29 -> blocks of 32 (one workgroup per CU: LDS), 274 chunks on 256 slots: 18 chunks' blocks enter
     level 1 unreduced. Too large for the oracle's Cholesky to be quick: both solvers of the handle against each
