@@ -260,6 +260,15 @@ int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]
  * Sub-problems with <= 64 free views / <= 640 edges (every rotAvg(10) call) run as ONE kernel
  * launch (irotavg_amd/csrc/window.hip); larger ones through the graph handle path. */
 int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotavg_info *info);
+/* Global re-solves (win_size >= the number of views: rotAvg(5000000) after a loop closure, src/IRotAvg.cpp:371-378) of a
+ * graph with >= 20000 connections run on a DEVICE-RESIDENT, growing copy of the graph (irotavg_amd/csrc/resident.hip):
+ * edge records, poses and the fixed mask stay in HBM between calls and a call sends only what changed since the last one
+ * (views admitted, poses moved by sliding windows, new connections); results are bit-identical to extracting and
+ * rebuilding the whole problem (IROTAVG_NO_RESIDENT=1 in the environment forces that).
+ * irotavg_viewgraph_prepare runs that pipeline once on the graph as it is and drops the result (no pose changes): the
+ * one-time costs of a process (device allocations, kernel code loads, streams) are then paid before the first loop
+ * closure instead of inside it. Optional; IROTAVG_OK also when there is nothing to prepare. */
+int irotavg_viewgraph_prepare(irotavg_viewgraph *vg);
 /* The same for n DIFFERENT view-graphs at once (a server that tracks many sequences; the reference has one graph
  * per process, src/IRotAvg.cpp). The windows of different graphs are independent: those that fit the wave-resident
  * kernel (every rotAvg(10) of a sequence linked to <= 4 predecessors) are solved by ONE launch with a workgroup per

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 CLI = os.path.join(HERE, "bin", "l1_irls")
 LIB = os.path.join(HERE, "libirotavg_hip.so")
-SOURCES = ["build.cpp", "gbuild.hip", "solver.hip", "cgcg.hip", "dense.hip", "bcr.hip", "l1pd.hip", "capi.cpp", "viewgraph.cpp", "dist.hip", "window.hip"]
+SOURCES = ["build.cpp", "gbuild.hip", "solver.hip", "cgcg.hip", "dense.hip", "bcr.hip", "l1pd.hip", "capi.cpp", "viewgraph.cpp", "dist.hip", "window.hip", "resident.hip"]
 HEADERS = ["common.hpp", "graph.hpp", "kernels.hpp", "../../include/irotavg_hip.h"]
 
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "irotavg_viewgraph_num_views", "irotavg_viewgraph_connect", "irotavg_viewgraph_fix_pose",
     "irotavg_viewgraph_is_pose_fixed", "irotavg_viewgraph_count_fixed_poses",
     "irotavg_viewgraph_get_pose", "irotavg_viewgraph_set_pose", "irotavg_viewgraph_rot_avg",
-    "irotavg_viewgraph_rot_avg_batch",
+    "irotavg_viewgraph_rot_avg_batch", "irotavg_viewgraph_prepare",
     "irotavg_dist_unique_id", "irotavg_dist_create", "irotavg_dist_destroy",
     "irotavg_dist_set_rotations", "irotavg_dist_get_rotations", "irotavg_dist_get_weights",
     "irotavg_dist_snapshot_rotations", "irotavg_dist_restore_rotations",

@@ -1997,4 +1997,152 @@ void bcr_plan(Graph &g, const int32_t *I) {
     g.bcr_B = B;
 }
 
+// ---- the same plan from an edge list that lives on the device (a resident view-graph, resident.hip) --------------
+namespace {
+// out: [0] widest span <= 32, [1] widest span, [2] index out of range; nfar: spans > 32 between free views
+__global__ __launch_bounds__(256) void k_plan_stats(long long m, int f, int nt, const int2 *__restrict__ I,
+                                                    const int *__restrict__ relabel, int *__restrict__ out,
+                                                    unsigned long long *__restrict__ nfar) {
+    __shared__ int sb[3][4];
+    __shared__ unsigned long long sf[4];
+    int band = 0, ball = 0, bad = 0;
+    unsigned long long far = 0;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < m; k += (long long)gridDim.x * 256) {
+        const int2 e = I[k];
+        int i = e.x, j = e.y;
+        if (i < 0 || j < 0 || i >= nt || j >= nt) {
+            bad = 1;
+            continue;
+        }
+        if (relabel) {
+            i = relabel[i];
+            j = relabel[j];
+        }
+        if (i >= f && j >= f) {
+            const int d = abs(i - j);
+            ball = max(ball, d);
+            if (d <= 32) band = max(band, d);
+            else far++;
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        band = max(band, __shfl_xor(band, o));
+        ball = max(ball, __shfl_xor(ball, o));
+        bad |= __shfl_xor(bad, o);
+        far += __shfl_xor(far, o);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sb[0][w] = band;
+        sb[1][w] = ball;
+        sb[2][w] = bad;
+        sf[w] = far;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(out, max(max(sb[0][0], sb[0][1]), max(sb[0][2], sb[0][3])));
+        atomicMax(out + 1, max(max(sb[1][0], sb[1][1]), max(sb[1][2], sb[1][3])));
+        if (sb[2][0] | sb[2][1] | sb[2][2] | sb[2][3]) atomicOr(out + 2, 1);
+        const unsigned long long t = sf[0] + sf[1] + sf[2] + sf[3];
+        if (t) atomicAdd(nfar, t);
+    }
+}
+// the long-range edges (rows, edge id; any order: the host sorts them by edge id) and the coverage of the band part:
+// ok[r] = 1 when row r has a band edge to an earlier view or an edge to a fixed view that the IRLS system keeps
+__global__ __launch_bounds__(256) void k_plan_far(long long m, int f, int B, const int2 *__restrict__ I,
+                                                  const int *__restrict__ relabel, int cap, int *__restrict__ cnt,
+                                                  int *__restrict__ fi, int *__restrict__ fj, int *__restrict__ fe,
+                                                  uint8_t *__restrict__ ok) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= m) return;
+    const int2 e = I[k];
+    const int i = relabel ? relabel[e.x] : e.x, j = relabel ? relabel[e.y] : e.y;
+    if (i >= f && j >= f) {
+        const int d = abs(i - j);
+        if (d > 32 && abs((i - f) / B - (j - f) / B) >= 2) {
+            const int q = atomicAdd(cnt, 1);
+            if (q < cap) {
+                fi[q] = i - f;
+                fj[q] = j - f;
+                fe[q] = (int)k;
+            }
+        }
+        if (i != j && d <= 32) ok[max(i, j) - f] = 1;
+    } else if (i < f && j >= f) {
+        ok[j - f] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_plan_uncovered(int no, const uint8_t *__restrict__ ok, int *__restrict__ cnt) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < no && !ok[r]) atomicAdd(cnt, 1);
+}
+}  // namespace
+
+void bcr_plan_dev(Graph &g, const DevEdgeSrc &src) {
+    g.bcr_B = 0;
+    g.band0 = -1;
+    g.bcr_far_i.clear();
+    g.bcr_far_j.clear();
+    g.bcr_far_e.clear();
+    int mode = g.opt.band_direct;
+    if (const char *e = std::getenv("IROTAVG_BAND_DIRECT")) mode = std::atoi(e);
+    if (mode < 0 || g.ng > 0 || g.no < 1) return;
+    const int f = g.f;
+    hipStream_t s = g.stream;
+    int *h = reinterpret_cast<int *>(PinPool::get().take());
+    struct PinGuard {
+        int *p;
+        ~PinGuard() { PinPool::get().give(p); }
+    } pin_guard{h};
+    DevBuf<int> out;  // [0..2] the statistics, [4..5] the far count (64 bit), [6] far-list length, [7] uncovered rows
+    out.alloc(8);
+    out.zero(s);
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(1024, (g.m + 255) / 256));
+    hipLaunchKernelGGL(k_plan_stats, dim3(grid), dim3(256), 0, s, (long long)g.m, f, (int)g.n_total, src.I, src.relabel, out.p,
+                       reinterpret_cast<unsigned long long *>(out.p + 4));
+    IRH_CHECK(hipMemcpyAsync(h, out.p, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    IRH_CHECK(hipStreamSynchronize(s));
+    if (h[2]) return;
+    g.band0 = h[1];
+    const long long nfar = (long long)*reinterpret_cast<unsigned long long *>(h + 4);
+    if (nfar > (g.no < 8192 ? kBcrMaxFar / 2 : kBcrMaxFar)) return;
+    if (mode == 0 && g.no <= 2048) return;
+    const int b0 = h[0];
+    int B = b0 <= 8 ? 8 : (b0 + 3) / 4 * 4;
+    if (const char *e = std::getenv("IROTAVG_BCR_BLOCK")) {
+        const int want = std::atoi(e);
+        if (want >= B && want <= 32 && want % 4 == 0) B = want;
+    }
+    if (nfar > 0) {
+        DevBuf<int> fl;
+        DevBuf<uint8_t> ok;
+        fl.alloc((size_t)3 * kBcrMaxFar);
+        ok.alloc((size_t)g.no);
+        ok.zero(s);
+        hipLaunchKernelGGL(k_plan_far, dim3((unsigned)((g.m + 255) / 256)), dim3(256), 0, s, (long long)g.m, f, B, src.I,
+                           src.relabel, kBcrMaxFar, out.p + 6, fl.p, fl.p + kBcrMaxFar, fl.p + 2 * kBcrMaxFar, ok.p);
+        hipLaunchKernelGGL(k_plan_uncovered, dim3((unsigned)((g.no + 255) / 256)), dim3(256), 0, s, g.no, ok.p, out.p + 7);
+        IRH_CHECK(hipMemcpyAsync(h, out.p + 6, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        IRH_CHECK(hipStreamSynchronize(s));
+        const int nl = h[0], uncovered = h[1];
+        if (nl > kBcrMaxFar) return;  // (cannot happen: nl <= nfar)
+        if (nl > 0) {
+            if (uncovered > 0 || getenv("IROTAVG_BCR_NO_CLOSURES")) return;  // see bcr_plan: the band part must be SPD alone
+            std::vector<int> hl((size_t)3 * kBcrMaxFar);
+            IRH_CHECK(hipMemcpyAsync(hl.data(), fl.p, sizeof(int) * hl.size(), hipMemcpyDeviceToHost, s));
+            IRH_CHECK(hipStreamSynchronize(s));
+            std::vector<int> order((size_t)nl);
+            for (int q = 0; q < nl; q++) order[(size_t)q] = q;
+            std::sort(order.begin(), order.end(),
+                      [&](int a, int b) { return hl[(size_t)2 * kBcrMaxFar + a] < hl[(size_t)2 * kBcrMaxFar + b]; });
+            for (int q : order) {  // edge order, as the host plan lists them
+                g.bcr_far_i.push_back(hl[(size_t)q]);
+                g.bcr_far_j.push_back(hl[(size_t)kBcrMaxFar + q]);
+                g.bcr_far_e.push_back(hl[(size_t)2 * kBcrMaxFar + q]);
+            }
+        }
+    }
+    g.bcr_B = B;
+}
+
 }  // namespace irh

@@ -175,9 +175,12 @@ int64_t irotavg_make_A(int n, int f, int64_t m, const int32_t *I, int64_t *colpt
 // ---------------------------------------------------------------------------------------------
 // handle API
 // ---------------------------------------------------------------------------------------------
-int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f, const int32_t *I,
-                         const double *QQ, int64_t ldqq, const irotavg_options *opt) {
-    if (!out || !I || !QQ || m <= 0 || n_total <= 0 || f < 0 || n_total - f < 1 || ldqq < m ||
+}  // extern "C"
+
+// the handle behind irotavg_graph_create; src != nullptr: the edge list lives on the device already (resident.hip)
+static int graph_create_impl(irotavg_graph **out, int64_t m, int64_t n_total, int f, const int32_t *I,
+                             const double *QQ, int64_t ldqq, const irotavg_options *opt, const DevEdgeSrc *src) {
+    if (!out || (!src && (!I || !QQ || ldqq < m)) || m <= 0 || n_total <= 0 || f < 0 || n_total - f < 1 ||
         n_total > 0x7fffffffLL)
         return IROTAVG_ERR_BAD_ARG;
     *out = nullptr;
@@ -207,9 +210,12 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
     if (const char *e = std::getenv("IROTAVG_STALE_SPREAD")) g.stale_spread = std::max(1.0, std::atof(e));  // experiments
     // a banded operator (+ a few loop closures) is solved directly (bcr.hip): level 0 is all such a handle needs
     // (no coarse patterns, no dense level: a third of the build)
-    bcr_plan(g, I);  // (an edge list with an index out of range plans nothing; the build rejects it)
+    if (src)
+        bcr_plan_dev(g, *src);
+    else
+        bcr_plan(g, I);  // (an edge list with an index out of range plans nothing; the build rejects it)
     if (g.bcr_B) g.opt.mg_levels_max = 1;
-    const int rc = build_graph(g, I, QQ, ldqq);
+    const int rc = src ? build_graph_device(g, nullptr, nullptr, 0, src) : build_graph(g, I, QQ, ldqq);
     if (rc != IROTAVG_OK) {
         irotavg_graph_destroy(h);
         return rc;
@@ -229,6 +235,22 @@ int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f,
         if (h) irotavg_graph_destroy(h);
         return IROTAVG_ERR_HIP;
     }
+}
+
+namespace irh {
+int graph_create_dev(irotavg_graph **out, int64_t m, int64_t n_total, int f, const DevEdgeSrc &src,
+                     const irotavg_options *opt) {
+    if (!src.I || !src.QQ) return IROTAVG_ERR_BAD_ARG;
+    return graph_create_impl(out, m, n_total, f, nullptr, nullptr, 0, opt, &src);
+}
+Graph &graph_of(irotavg_graph *h) { return h->g; }
+}  // namespace irh
+
+extern "C" {
+
+int irotavg_graph_create(irotavg_graph **out, int64_t m, int64_t n_total, int f, const int32_t *I,
+                         const double *QQ, int64_t ldqq, const irotavg_options *opt) {
+    return graph_create_impl(out, m, n_total, f, I, QQ, ldqq, opt, nullptr);
 }
 
 // Device buffers of destroyed handles are cached for reuse (common.hpp, DevPool): hand them back.

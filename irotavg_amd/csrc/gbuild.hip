@@ -44,10 +44,12 @@ inline int bits_for(unsigned long long v) {  // bits needed to represent values 
 
 // ---- edges ---------------------------------------------------------------------------------------
 // I (m pairs) -> ei, ej, eflag over [0, mpad); range check -> info[0]
+// relabel (a resident view-graph's edge list, resident.hip): the pairs hold the caller's view ids, the rows of this
+// problem are relabel[id]
 __global__ __launch_bounds__(kT) void k_gb_edges(long long m, long long mpad, int n_total, int f,
-                                                 const int2 *__restrict__ I, int *__restrict__ ei,
-                                                 int *__restrict__ ej, uint8_t *__restrict__ eflag,
-                                                 int *__restrict__ info) {
+                                                 const int2 *__restrict__ I, const int *__restrict__ relabel,
+                                                 int *__restrict__ ei, int *__restrict__ ej,
+                                                 uint8_t *__restrict__ eflag, int *__restrict__ info) {
     const long long k = (long long)blockIdx.x * kT + threadIdx.x;
     if (k >= mpad) return;
     int i = 0, j = 0;
@@ -56,6 +58,10 @@ __global__ __launch_bounds__(kT) void k_gb_edges(long long m, long long mpad, in
         const int2 e = I[k];
         i = e.x;
         j = e.y;
+        if (relabel && i >= 0 && j >= 0 && i < n_total && j < n_total) {
+            i = relabel[i];
+            j = relabel[j];
+        }
         if (i < 0 || j < 0 || i >= n_total || j >= n_total) {
             atomicOr(info, 1);
             i = j = 0;
@@ -71,6 +77,18 @@ __global__ __launch_bounds__(kT) void k_gb_edges(long long m, long long mpad, in
     ei[k] = i;
     ej[k] = j;
     eflag[k] = fl;
+}
+
+// relative rotations held on the device as one double4 per edge -> the four planes of the edge kernels
+__global__ __launch_bounds__(kT) void k_gb_qq_planes(long long m, long long mpad, const double4 *__restrict__ q,
+                                                     double *__restrict__ planes) {
+    const long long k = (long long)blockIdx.x * kT + threadIdx.x;
+    if (k >= mpad) return;
+    const double4 v = k < m ? q[k] : make_double4(0, 0, 0, 0);
+    planes[k] = v.x;
+    planes[mpad + k] = v.y;
+    planes[2 * mpad + k] = v.z;
+    planes[3 * mpad + k] = v.w;
 }
 
 // level-0 matrix entries and boundary slots, generated in EDGE order: edge k yields the entries 2k (row j:
@@ -436,7 +454,7 @@ void sell_map_device(Graph &g, Scratch &S, const DevCsr &A, DevSell &M, int *h_i
 
 }  // namespace
 
-int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq) {
+int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq, const DevEdgeSrc *src) {
     const bool timing = getenv("IROTAVG_BUILD_TIMING") != nullptr;
     double tlast = now_seconds();
     auto lap = [&](const char *what) {
@@ -461,10 +479,15 @@ int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldq
     // ---- edge streams ----------------------------------------------------------------------------------
     g.mpad = (m + 63) / 64 * 64;
     DevBuf<int> dI;
-    dI.alloc((size_t)2 * m);
-    IRH_CHECK(hipMemcpyAsync(dI.p, I, sizeof(int) * 2 * (size_t)m, hipMemcpyHostToDevice, s));
+    if (!src) {
+        dI.alloc((size_t)2 * m);
+        IRH_CHECK(hipMemcpyAsync(dI.p, I, sizeof(int) * 2 * (size_t)m, hipMemcpyHostToDevice, s));
+    }
     g.qq.alloc((size_t)4 * g.mpad);
-    if (g.mpad > m)
+    if (src)  // the edge list is resident on the device already (resident.hip): planes from its records, no upload
+        hipLaunchKernelGGL(k_gb_qq_planes, dim3(grid_of(g.mpad)), dim3(kT), 0, s, (long long)m, (long long)g.mpad, src->QQ,
+                           g.qq.p);
+    else if (g.mpad > m)
         for (int c = 0; c < 4; c++)
             IRH_CHECK(hipMemsetAsync(g.qq.p + (size_t)c * g.mpad + m, 0, sizeof(double) * (size_t)(g.mpad - m), s));
     // The relative rotations (4 m doubles: 64 MB at 2M edges, the bulk of the upload) are needed by the first solve
@@ -481,8 +504,9 @@ int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldq
         ~QQUpload() { join(); }
     } qq_up;
     const char *upenv = getenv("IROTAVG_UPLOAD_THREADS");
-    const int n_up = m >= 100000 ? (upenv ? std::min(4, std::max(0, atoi(upenv))) : 4) : 0;
-    if (n_up > 0) {
+    const int n_up = (m >= 100000 && !src) ? (upenv ? std::min(4, std::max(0, atoi(upenv))) : 4) : 0;
+    if (src) {
+    } else if (n_up > 0) {
         double *dst = g.qq.p;
         const size_t mp = (size_t)g.mpad;
         const int dev = g.device;
@@ -514,7 +538,8 @@ int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldq
     info.alloc(16);
     info.zero(s);
     hipLaunchKernelGGL(k_gb_edges, dim3(grid_of(g.mpad)), dim3(kT), 0, s, (long long)m, (long long)g.mpad,
-                       (int)g.n_total, f, reinterpret_cast<const int2 *>(dI.p), g.ei.p, g.ej.p, g.eflag.p, info.p);
+                       (int)g.n_total, f, src ? src->I : reinterpret_cast<const int2 *>(dI.p), src ? src->relabel : nullptr,
+                       g.ei.p, g.ej.p, g.eflag.p, info.p);
     g.er.alloc((size_t)3 * g.mpad);
     g.er.zero(s);
     g.dw.alloc((size_t)g.mpad);

@@ -162,9 +162,16 @@ struct HierPlan {
     std::vector<int> n, agg;  // rows and aggregation factor per level (agg of the coarsest level: 0)
 };
 HierPlan plan_hierarchy(Graph &g, int n0, int64_t nnz0, bool far0);
+// a build whose edge list lives on the device already (a resident view-graph, resident.hip): m pairs in the caller's
+// view ids, one double4 [x y z w] per edge, and the caller id -> row map of this problem (nullptr: identity)
+struct DevEdgeSrc {
+    const int2 *I = nullptr;
+    const double4 *QQ = nullptr;
+    const int *relabel = nullptr;
+};
 int build_graph(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
 int build_graph_host(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
-int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq);
+int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldqq, const DevEdgeSrc *src = nullptr);
 int finish_build(Graph &g, const BuildTail &T);
 
 // solver entry points (solver.hip)
@@ -261,7 +268,8 @@ struct WinBatchItem {  // one problem of a batched launch: inputs as window_solv
 int window_solve_batch(WindowSolver &ws, int nb, WinBatchItem *items, int l1_max, int irls_max, int cost, double sigma,
                        double change_th);
 // bcr.hip
-void bcr_plan(Graph &g, const int32_t *I);  // sets Graph::bcr_B / band0 (capi.cpp, after the build)
+void bcr_plan(Graph &g, const int32_t *I);  // sets Graph::bcr_B / band0 (capi.cpp, ahead of the build)
+void bcr_plan_dev(Graph &g, const DevEdgeSrc &src);  // the same from an edge list on the device (needs g.stream)
 int bcr_solve(Graph &g, int only = -1);     // levels[0] values / diagonal / right-hand side -> g.X, asynchronous
 int bcr_levels(Graph &g);
 int bcr_info(Graph &g, int64_t *out, int cap);
@@ -290,6 +298,32 @@ void dense_check_async(Graph &g);  // same test, decision on the device (scal[SC
 int dense_apply_grid(const Graph &g);
 void dense_apply(Graph &g, const double4 *b, double4 *y, bool check, bool dot, double *part_dot,
                  int np_rr, int first, double rtol2);
+
+}  // namespace irh
+struct irotavg_graph;
+namespace irh {
+// capi.cpp: a handle built from an edge list on the device; the Graph behind a handle
+int graph_create_dev(irotavg_graph **out, int64_t m, int64_t n_total, int f, const DevEdgeSrc &src,
+                     const irotavg_options *opt);
+Graph &graph_of(irotavg_graph *h);
+
+// resident.hip: the device-resident, growing copy of a view-graph behind rot_avg's global re-solves
+struct Resident;
+struct ResidentStage {  // pinned host blocks the caller fills before resident_rot_avg
+    double *R;          // 9 per view of [view_lo, n_views): row-major poses
+    uint8_t *fixed;     // their fixed flags
+    int32_t *I;         // pairs (view ids) of the edges [edge_lo, n_edges)
+    double *qq;         // their relative rotations, 4 per edge [x y z w]
+    double *Q;          // OUT: n_views x 4 (AoS), the solved quaternion of every free view
+};
+Resident *resident_new();
+void resident_delete(Resident *r);
+void resident_invalidate(Resident &r);
+long resident_views(const Resident &r);  // views / edges the device holds
+long resident_edges(const Resident &r);
+ResidentStage resident_stage(Resident &r, long n_views, long view_lo, long n_edges, long edge_lo);
+int resident_rot_avg(Resident &r, long n_views, long view_lo, long n_edges, long edge_lo, int f,
+                     const irotavg_options &opt, irotavg_rotavg_info &loc, bool timing, bool dry = false);
 
 inline double now_seconds() {
     using namespace std::chrono;

@@ -96,6 +96,16 @@ struct irotavg_viewgraph {
     irotavg_options opt;
     irotavg_rotavg_info last{};
     irh::WindowSolver *win = nullptr;  // persistent staging of the single-kernel window solve
+    // The device-resident growing copy of the graph that the global re-solves run on (resident.hip) and what the
+    // host has changed since the device last saw it: poses / fixed flags of views >= res_pose_lo, edge records of
+    // views >= res_edge_view (a connection is filed under its HIGHER view); eoff[t] = edges of the views below t,
+    // valid up to res_edge_view. Counters that decide rot_avg's early-outs without walking the graph.
+    irh::Resident *res = nullptr;
+    long res_pose_lo = 0, res_edge_view = 0;
+    std::vector<long> eoff;
+    std::vector<char> touched;  // view has at least one connection
+    long n_touched = 0, n_fixed = 0, n_conn = 0;
+    void pose_changed(long idx) { res_pose_lo = std::min(res_pose_lo, idx); }
     // a window extracted by rot_avg whose solve was deferred to a batched launch (irotavg_viewgraph_rot_avg_batch)
     struct Pending {
         bool on = false;
@@ -105,6 +115,7 @@ struct irotavg_viewgraph {
     } pending;
     ~irotavg_viewgraph() {
         if (win) irh::window_solver_delete(win);
+        if (res) irh::resident_delete(res);
     }
 };
 
@@ -116,10 +127,14 @@ thread_local bool tl_defer_windows = false;  // set by irotavg_viewgraph_rot_avg
 void rotavg_writeback(irotavg_viewgraph *vg, int f, long nv) {
     const std::vector<double> &Q = vg->scratch.Q;
     const std::vector<int> &i2v = vg->scratch.i2v;
-    for (long r = f; r < nv; r++) {
-        const double q[4] = {Q[(size_t)r], Q[(size_t)(nv + r)], Q[(size_t)(2 * nv + r)], Q[(size_t)(3 * nv + r)]};
-        quat2rmat(q, vg->pose[(size_t)i2v[(size_t)r]].m);
-    }
+    irh::parallel_for((int64_t)(nv - f), 4096, [&](int64_t a, int64_t b, int) {
+        for (int64_t r = f + a; r < f + b; r++) {
+            const double q[4] = {Q[(size_t)r], Q[(size_t)(nv + r)], Q[(size_t)(2 * nv + r)], Q[(size_t)(3 * nv + r)]};
+            quat2rmat(q, vg->pose[(size_t)i2v[(size_t)r]].m);
+        }
+    });
+    // free views are relabelled in ascending id: the lowest one is row f
+    if (nv > f) vg->pose_changed(i2v[(size_t)f]);
 }
 }  // namespace
 
@@ -154,6 +169,7 @@ int irotavg_viewgraph_add_view(irotavg_viewgraph *vg, const double R[9]) {
     vg->fixed.push_back(0);
     vg->mark.push_back(-1);
     vg->conn.emplace_back();
+    vg->touched.push_back(0);
     return (int)vg->pose.size() - 1;
 }
 
@@ -181,14 +197,23 @@ int irotavg_viewgraph_connect(irotavg_viewgraph *vg, int a, int b, const double 
     }
     rmat2quat(c.R.m, c.q);
     list.insert(it, c);
+    vg->n_conn++;
+    for (int x : {lo, hi})
+        if (!vg->touched[(size_t)x]) {
+            vg->touched[(size_t)x] = 1;
+            vg->n_touched++;
+        }
+    vg->res_edge_view = std::min<long>(vg->res_edge_view, hi);
     return 1;
 }
 
 // ViewGraph::fixPose / isPoseFixed / countFixedPoses (src/ViewGraph.cpp:1234-1260)
 int irotavg_viewgraph_fix_pose(irotavg_viewgraph *vg, int idx, const double R[9]) {
     if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
+    if (!vg->fixed[idx]) vg->n_fixed++;
     vg->fixed[idx] = 1;
     std::copy(R, R + 9, vg->pose[idx].m);
+    vg->pose_changed(idx);
     return IROTAVG_OK;
 }
 int irotavg_viewgraph_is_pose_fixed(const irotavg_viewgraph *vg, int idx) {
@@ -209,8 +234,97 @@ int irotavg_viewgraph_get_pose(const irotavg_viewgraph *vg, int idx, double R[9]
 int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]) {
     if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
     std::copy(R, R + 9, vg->pose[idx].m);
+    vg->pose_changed(idx);
     return IROTAVG_OK;
 }
+
+namespace {
+// A GLOBAL re-solve (the window holds every view: rotAvg(5000000) after a loop closure, src/IRotAvg.cpp:371-378) on
+// the device-resident copy of the graph (resident.hip). With every view in the window the quantities of
+// src/ViewGraph.cpp:1282-1363 are counters: the edges are all connections, the vertices all views that have one
+// (fewer than the window -> early-out 3, so a call that goes on has ALL views), f = the fixed views, relabelled
+// fixed-first in ascending id. Returns false when the call is not of that kind (the caller takes the general path:
+// windows, graphs of fewer than 20000 connections, f == 0, no device); true with *rc set otherwise.
+bool rotavg_resident(irotavg_viewgraph *vg, irotavg_rotavg_info &loc, bool timing, int *rc, bool dry = false) {
+    const long m = (long)vg->pose.size();
+    if (std::getenv("IROTAVG_NO_RESIDENT")) return false;
+    long min_edges = 20000;  // below: the host build of the general path (build.cpp) is the faster one
+    if (const char *e = std::getenv("IROTAVG_RESIDENT_MIN_EDGES")) min_edges = std::atol(e);
+    if (vg->n_conn < min_edges || vg->n_conn < m || vg->n_touched < m || vg->n_fixed < 1 || m - vg->n_fixed < 1) return false;
+    if (vg->n_conn > 0x3fffffffL) return false;
+    if (irotavg_device_count() <= 0) return false;
+    const double t0 = irh::now_seconds();
+    try {
+        if (!vg->res) vg->res = irh::resident_new();
+        irh::Resident &R = *vg->res;
+        // what the device holds is valid below these marks
+        long view_lo = std::min({vg->res_pose_lo, irh::resident_views(R), m});
+        long ev = std::min({vg->res_edge_view, m});
+        if (irh::resident_views(R) == 0 || irh::resident_edges(R) == 0) {
+            view_lo = 0;
+            ev = 0;
+        }
+        std::vector<long> &eoff = vg->eoff;
+        if ((long)eoff.size() < m + 1) eoff.resize((size_t)m + 1 + (size_t)m / 2, 0);
+        for (long t = ev; t < m; t++) eoff[(size_t)t + 1] = eoff[(size_t)t] + (long)vg->conn[(size_t)t].size();
+        const long ne = eoff[(size_t)m], edge_lo = eoff[(size_t)ev];
+        if (edge_lo > irh::resident_edges(R)) {  // (cannot happen: the marks only move down between calls)
+            irh::resident_invalidate(R);
+            vg->res_pose_lo = 0;
+            vg->res_edge_view = 0;
+            return false;
+        }
+        irh::ResidentStage st = irh::resident_stage(R, m, view_lo, ne, edge_lo);
+        irh::parallel_for((int64_t)(m - ev), 2048, [&](int64_t a, int64_t b, int) {
+            for (int64_t t = ev + a; t < ev + b; t++) {
+                size_t e = (size_t)(eoff[(size_t)t] - edge_lo);
+                for (const auto &c : vg->conn[(size_t)t]) {
+                    st.I[2 * e] = c.i;
+                    st.I[2 * e + 1] = (int32_t)t;
+                    for (int q = 0; q < 4; q++) st.qq[4 * e + q] = c.q[q];
+                    e++;
+                }
+            }
+        });
+        irh::parallel_for((int64_t)(m - view_lo), 4096, [&](int64_t a, int64_t b, int) {
+            for (int64_t x = view_lo + a; x < view_lo + b; x++) {
+                std::copy(vg->pose[(size_t)x].m, vg->pose[(size_t)x].m + 9, st.R + 9 * (size_t)(x - view_lo));
+                st.fixed[(size_t)(x - view_lo)] = (uint8_t)(vg->fixed[(size_t)x] ? 1 : 0);
+            }
+        });
+        if (timing) std::fprintf(stderr, "[rot_avg resident] %-24s %8.3f ms (%ld views, %ld edges sent)\n", "delta packing",
+                                 1e3 * (irh::now_seconds() - t0), m - view_lo, ne - edge_lo);
+        const int f = (int)vg->n_fixed;
+        // the marks move up BEFORE the call: whatever fails inside invalidates the resident copy as a whole
+        vg->res_pose_lo = m;
+        vg->res_edge_view = m;
+        *rc = irh::resident_rot_avg(R, m, view_lo, ne, edge_lo, f, vg->opt, loc, timing, dry);
+        loc.n_views = (int)m;
+        loc.n_edges = (int)ne;
+        loc.n_fixed = f;
+        if (*rc != IROTAVG_OK) {
+            vg->res_pose_lo = 0;
+            vg->res_edge_view = 0;
+            irh::resident_invalidate(R);
+            return true;
+        }
+        if (dry) return true;
+        const double t1 = irh::now_seconds();
+        irh::parallel_for((int64_t)m, 4096, [&](int64_t a, int64_t b, int) {
+            for (int64_t x = a; x < b; x++)
+                if (!vg->fixed[(size_t)x]) quat2rmat(st.Q + 4 * (size_t)x, vg->pose[(size_t)x].m);
+        });
+        if (timing) std::fprintf(stderr, "[rot_avg resident] %-24s %8.3f ms\n", "poses (host)", 1e3 * (irh::now_seconds() - t1));
+        return true;
+    } catch (...) {
+        if (vg->res) irh::resident_invalidate(*vg->res);
+        vg->res_pose_lo = 0;
+        vg->res_edge_view = 0;
+        *rc = IROTAVG_ERR_HIP;
+        return true;
+    }
+}
+}  // namespace
 
 // ViewGraph::rotAvg(winSize), src/ViewGraph.cpp:1263-1435. Returns IROTAVG_OK also for the
 // reference's silent early-outs (info->skipped tells which).
@@ -238,6 +352,14 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
         loc.skipped = 1;
         if (info) *info = loc;
         return IROTAVG_OK;  // :1270-1273
+    }
+    if (win == m) {  // a global re-solve: on the device-resident copy of the graph when it is of that kind
+        int rrc = IROTAVG_OK;
+        if (rotavg_resident(vg, loc, timing, &rrc)) {
+            if (rrc == IROTAVG_OK) vg->last = loc;
+            if (info) *info = loc;
+            return rrc;
+        }
     }
     // ---- local connections (:1282-1307): for the last `win` views, edges with i < j.
     // `vertices` of the reference is a std::set<int> (ascending ids); here: a mark array + sort.
@@ -424,6 +546,20 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
     vg->last = loc;
     if (info) *info = loc;
     return IROTAVG_OK;
+}
+
+// Takes what a process pays ONCE for its first global re-solve -- the resident copy of the graph on the device,
+// the device allocations of a solver handle of this size, kernel code loads, the streams and pinned blocks of
+// l1ra's three solver chains -- out of that call's latency: the pipeline of a global rotAvg runs on the graph as it
+// is and its result is dropped (no pose changes). For callers that load a graph and then stream onto it
+// (BASELINE.json config 5); never needed for correctness. Returns IROTAVG_OK also when there was nothing to do.
+int irotavg_viewgraph_prepare(irotavg_viewgraph *vg) {
+    if (!vg) return IROTAVG_ERR_BAD_ARG;
+    irotavg_rotavg_info loc{};
+    int rc = IROTAVG_OK;
+    const bool timing = std::getenv("IROTAVG_ROTAVG_TIMING") != nullptr;
+    if (!rotavg_resident(vg, loc, timing, &rc, true)) return IROTAVG_OK;
+    return rc;
 }
 
 // rotAvg for SEVERAL independent view-graphs at once (a server tracking many sequences): each graph's window is

@@ -80,6 +80,11 @@ class ViewGraph:
         capi.check(capi.lib().irotavg_viewgraph_rot_avg(self._h, int(winSize), C.byref(info)), "rotAvg")
         return {k: getattr(info, k) for k, _ in capi.RotAvgInfo._fields_}
 
+    def prepare(self):
+        """irotavg_viewgraph_prepare: a dry run of the global re-solve (no pose changes) that takes the one-time
+        costs of a process out of the first loop closure's latency."""
+        capi.check(capi.lib().irotavg_viewgraph_prepare(self._h), "prepare")
+
     def savePoses(self, filename, t=None):
         """ViewGraph::savePoses (src/ViewGraph.cpp:1206-1231); t: optional (n, 3) translations."""
         tp = None

@@ -168,12 +168,22 @@ def test_connect_with_swapped_arguments_stores_the_transpose():
         np.testing.assert_allclose(a.R(v), b.R(v), atol=1e-12)
 
 
+_STREAM_POSES = {}
+
+
 @pytest.mark.gpu
-def test_incremental_stream_with_loop_closures_at_scale_matches_oracle():
+@pytest.mark.parametrize("path", ["resident", "rebuild"])
+def test_incremental_stream_with_loop_closures_at_scale_matches_oracle(path, monkeypatch):
     """Config 5's call pattern at a size the oracle still covers: 2000 warm views, 1200 streamed one by
     one (rotAvg(10) each -- the single-launch window kernel), 3 loop closures (global re-solves through
     the multi-level handle path), a ground-truth fix every 20 frames. Every call's bookkeeping and
-    iteration counts equal the oracle's, and so do the final poses."""
+    iteration counts equal the oracle's, and so do the final poses. Both forms of the global re-solve: on the
+    device-resident growing copy of the graph (resident.hip; its size threshold lowered to reach it here) and by
+    extracting and rebuilding the whole problem per call -- with bit-identical poses."""
+    if path == "resident":
+        monkeypatch.setenv("IROTAVG_RESIDENT_MIN_EDGES", "1000")
+    else:
+        monkeypatch.setenv("IROTAVG_NO_RESIDENT", "1")
     warm, stream, n_loops = 2000, 1200, 3
     n = warm + stream
     rng = np.random.default_rng(21)
@@ -218,6 +228,80 @@ def test_incremental_stream_with_loop_closures_at_scale_matches_oracle():
     assert worst < 1e-6, worst
     err = [synth.angular_distance(O.rmat2quat(vg.R(v)), Qgt[v]) for v in range(warm, n, 13)]
     assert max(err) < 0.05
+    _STREAM_POSES[path] = np.stack([vg.R(v) for v in range(n)])
+    if len(_STREAM_POSES) == 2:
+        np.testing.assert_array_equal(_STREAM_POSES["resident"], _STREAM_POSES["rebuild"])
+
+
+@pytest.mark.gpu
+def test_resident_global_resolves_equal_rebuilt_ones_bit_for_bit(monkeypatch):
+    """The device-resident growing graph (resident.hip) at its default size threshold: a 6000-view
+    sequence with global re-solves between which the graph changes in every way the API allows -- views appended
+    with their links (the append-only case), sliding windows moving the newest poses, a view fixed long after it
+    was admitted, a pose overwritten by the caller, a loop closure between two OLD views (its record lands in the
+    middle of the resident edge list) -- gives bit-identical poses and identical bookkeeping to the path that
+    extracts, relabels and rebuilds the whole problem on every call."""
+    n0, extra = 6000, 260
+    rng = np.random.default_rng(5)
+    Qgt = rng.normal(size=(n0 + extra, 4)); Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+    noise = rng.normal(scale=0.01, size=(8 * (n0 + extra), 3))
+    script = []      # (op, args) replayed on both graphs
+
+    def rel(i, j, k):
+        return rot(synth.qmul(synth.qexp(noise[k:k + 1])[0], synth.qmul(Qgt[j], synth.qconj(Qgt[i]))))
+    k = 0
+    for v in range(n0 + extra):
+        script.append(("add", v, rot(synth.qmul(synth.qexp(noise[k:k + 1] * 2)[0], Qgt[v])))); k += 1
+        for d in range(1, min(4, v) + 1):
+            script.append(("connect", v - d, v, rel(v - d, v, k))); k += 1
+        if v % 20 == 0:
+            script.append(("fix", v, rot(Qgt[v])))
+        if v >= n0:
+            script.append(("avg", 10))
+        if v == n0 - 1:
+            script.append(("prepare",))                            # dry run: nothing may change
+            script.append(("avg", 5000000))                        # first global solve: everything goes up
+        if v == n0 + 40:
+            script.append(("connect", 100, v, rel(100, v, k))); k += 1  # loop closure at the newest view
+            script.append(("avg", 5000000))
+        if v == n0 + 90:
+            script.append(("fix", 3001, rot(Qgt[3001])))          # an old view becomes fixed: every row behind it moves
+            script.append(("avg", 5000000))
+        if v == n0 + 150:
+            script.append(("set", 4000, rot(Qgt[4000])))           # the caller overwrites an old pose
+            script.append(("connect", 700, 5200, rel(700, 5200, k))); k += 1   # closure between two old views
+            script.append(("avg", 5000000))
+        if v == n0 + 151:
+            script.append(("avg", 5000000))                        # nothing but one view changed
+    out = {}
+    for path in ("resident", "rebuild"):
+        if path == "rebuild":
+            monkeypatch.setenv("IROTAVG_NO_RESIDENT", "1")
+        vg = ViewGraph()
+        infos = []
+        for op in script:
+            if op[0] == "add":
+                vg.addView(op[2])
+            elif op[0] == "connect":
+                vg.connect(op[1], op[2], op[3])
+            elif op[0] == "fix":
+                vg.fixPose(op[1], op[2])
+            elif op[0] == "set":
+                vg.setR(op[1], op[2])
+            elif op[0] == "prepare":
+                before = np.stack([vg.R(v) for v in range(0, n0, 7)])
+                vg.prepare()
+                np.testing.assert_array_equal(before, np.stack([vg.R(v) for v in range(0, n0, 7)]))
+            else:
+                a = vg.rotAvg(op[1])
+                if op[1] > 10:
+                    infos.append((a["skipped"], a["n_views"], a["n_edges"], a["n_fixed"], a["l1_iters"], a["irls_iters"]))
+        out[path] = (infos, np.stack([vg.R(v) for v in range(n0 + extra)]))
+    assert len(out["resident"][0]) == 5 and all(i[0] == 0 for i in out["resident"][0])
+    assert out["resident"][0] == out["rebuild"][0]
+    np.testing.assert_array_equal(out["resident"][1], out["rebuild"][1])
+    err = synth.angular_distance(np.stack([O.rmat2quat(R) for R in out["resident"][1][::17]]), Qgt[::17])
+    assert err.max() < 0.05
 
 
 @pytest.mark.gpu
