@@ -67,9 +67,11 @@ def kernel_rooflines(G, S, st, sharded=False):
         B = di["block"]
         NC = 2 * B + 3
         lev = di["levels"]
+        nl = len(lev)
         tot_ms, tot_by, tot_fl = 0.0, 0, 0
+        back_upper = 0   # the ways back of the levels >= 1 are ONE launch (k_bcr_back_top), timed as 40 + 1
         for l, L in enumerate(lev):
-            top = l == len(lev) - 1
+            top = l == nl - 1
             elim = sum(min(7, max(0, L["blocks"] - 8 * c)) for c in range(L["chunks"]))   # blocks eliminated
             wbytes = 8 * elim * B * NC
             sep = 0 if top else 8 * L["chunks"] * (3 * B * B + 6 * B)
@@ -86,16 +88,25 @@ def kernel_rooflines(G, S, st, sharded=False):
             ms = G.time_kernel(20 + l, 50)
             out["bcr_reduce_l%d" % l] = dict(ms=ms, bytes=rd + wbytes + sep, gbs=(rd + wbytes + sep) / (ms * 1e-3) / 1e9,
                                              flops=fl, tflops=fl / (ms * 1e-3) / 1e12, workgroups=L["chunks"])
-            msb = G.time_kernel(40 + l, 50)
             bb = wbytes + 8 * (L["chunks"] * 8 * B * 3) + (32 * nu if l == 0 else 0)
-            out["bcr_back_l%d" % l] = dict(ms=msb, bytes=bb, gbs=bb / (msb * 1e-3) / 1e9, workgroups=L["chunks"])
-            tot_ms += ms + msb
+            tot_ms += ms
             tot_by += rd + wbytes + sep + bb
             tot_fl += fl
+            if l == 0 or nl < 2:
+                msb = G.time_kernel(40 + l, 50)
+                out["bcr_back_l%d" % l] = dict(ms=msb, bytes=bb, gbs=bb / (msb * 1e-3) / 1e9, workgroups=L["chunks"])
+                tot_ms += msb
+            else:
+                back_upper += bb
+        if nl >= 2:
+            msb = G.time_kernel(41, 50)
+            out["bcr_back_upper"] = dict(ms=msb, bytes=back_upper, gbs=back_upper / (msb * 1e-3) / 1e9,
+                                         workgroups=lev[1]["chunks"], levels="1..%d in one launch (k_bcr_back_top)" % (nl - 1))
+            tot_ms += msb
         ms = G.time_kernel(19, 50)
         out["bcr_solve"] = dict(ms=ms, bytes=tot_by, gbs=tot_by / (ms * 1e-3) / 1e9, flops=tot_fl,
-                                tflops=tot_fl / (ms * 1e-3) / 1e12, launches=2 * len(lev), sum_of_launches_ms=tot_ms,
-                                block=B, levels=lev)
+                                tflops=tot_fl / (ms * 1e-3) / 1e12, launches=nl + (2 if nl >= 2 else 1),
+                                sum_of_launches_ms=tot_ms, block=B, levels=lev)
         return out
     try:  # band-only graphs on one GPU run the p-update fused into the SpMV (k_pspmv_dot)
         if sharded:   # the sharded PCG exchanges p between its p-update and its SpMV: unfused kernels
@@ -125,57 +136,72 @@ def kernel_rooflines(G, S, st, sharded=False):
     return out
 
 
-PMC_SUMMARY = "r03_pmc_summary.json"   # (the PCG-era profiles of this round: profiles/r03_pcg_*)
-KERNEL_STATS = "r03_bench_kernel_stats.csv"
-
-
-def pmc_traffic(kernel, workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload
-    (tools/profile_counters.sh + tools/summarize_pmc.py -> profiles/r02_pmc_summary.json). The counters
-    need their own rocprofv3 passes, so they cannot be collected inside a plain bench run; the summary
-    carries the workload string of the bench line it was taken on, and a run on any other workload
-    reports null instead of a number that belongs to another size or topology."""
-    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+def live_profile(args, note):
+    """rocprofv3 passes of THIS command (same workload, short run, no extras) launched from inside the bench run:
+    kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own passes (they do not fit one pass), exactly as
+    tools/profile_counters.sh runs them by hand; counters summarised as /opt/skills/guides/MI355X_MICROARCH.md's HBM
+    section prescribes (tools/summarize_pmc.py: KiB units, the gfx950 read side doubled). Returns (table, where) --
+    table: per kernel {calls, avg_us, traffic_bytes, ...} measured in this run, or None with the reason in `where`.
+    The CSVs are kept under gpurun_out/bench_profile/ (the copies the judged profiles/ files are made from)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out = os.path.join(ROOT, "gpurun_out", "bench_profile")
     try:
-        with open(path) as fh:
-            table = json.load(fh)
-        if table.get("_meta", {}).get("workload") != workload:
-            return None
-        for name, row in table.items():   # template kernels appear as "name<args>"
-            if name == kernel or name.startswith(kernel + "<") or _is_l0_reduce(kernel, name):
-                return float(row["traffic_bytes"])
-        return None
-    except Exception:
-        return None
-
-
-def _is_l0_reduce(kernel, name):
-    """k_bcr_reduce is one template for every level; the level-0 instantiation is k_bcr_reduce<B, NR, true, ...>"""
-    n = name.replace(" ", "")
-    return kernel == "k_bcr_reduce_l0" and n.split("<")[0].endswith("k_bcr_reduce") and "<" in n and \
-        n.split("<")[1].split(",")[2:3] == ["true"]
-
-
-def in_situ_ms(kernel, workload):
-    """Average duration (ms) of `kernel` inside real solves, from the committed `rocprofv3 --kernel-trace --stats`
-    summary of this bench command (profiles/r03_bench_kernel_stats.csv, stamped with the workload string by
-    tools/summarize_pmc.py in the PMC summary next to it). The HIP-event figure of `roofline.ms_per_launch` is a
-    back-to-back loop of one kernel; inside a solve the same kernel runs 2-7 % slower (dependent launches, cold
-    L2 after other kernels). None when no profile of THIS workload is committed."""
-    import csv
+        os.makedirs(out, exist_ok=True)
+    except OSError:
+        out = tempfile.mkdtemp(prefix="irotavg_bench_profile_")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--views", str(args.views), "--edges", str(args.edges),
+            "--p-loop", str(args.p_loop), "--seed", str(args.seed), "--rtol", str(args.rtol), "--ramp", "3", "--warmup", "1",
+            "--no-cpu", "--no-extra", "--no-pmc", "--no-kernels"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for tag, flags, steps in (("trace", ["--kernel-trace", "--stats"], "5"), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"], "2"),
+                              ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"], "2")):
+        d = os.path.join(out, tag)
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = ["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "-o", tag[0], "--"] + base + ["--steps", steps]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        except Exception as e:   # a hung rocprofv3 (seen after "tool finalization") must not take the bench line with it
+            return None, "rocprofv3 %s pass: %s" % (tag, e)
+        with open(os.path.join(out, tag + ".log"), "w") as fh:
+            fh.write(r.stdout[-20000:] + "\n" + r.stderr[-20000:])
+        if r.returncode != 0:
+            return None, "rocprofv3 %s pass exited with %d" % (tag, r.returncode)
     try:
-        with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as fh:
-            if json.load(fh).get("_meta", {}).get("workload") != workload:
-                return None
-        with open(os.path.join(ROOT, "profiles", KERNEL_STATS)) as fh:
-            for row in csv.DictReader(fh):
-                name = row.get("Name", "")
-                if name.split("(")[0].split("<")[0].split("::")[-1].strip() == kernel or \
-                        _is_l0_reduce(kernel, name.split("(")[0]):
-                    return float(row["AverageNs"]) * 1e-6
-    except Exception:
+        from tools.summarize_pmc import summarize
+        table = summarize(out)
+    except Exception as e:
+        return None, "summary failed: %s" % e
+    with open(os.path.join(out, "pmc_summary.json"), "w") as fh:
+        json.dump(dict(table, _meta=dict(workload=note)), fh, indent=1)
+    return table, out
+
+
+def prof_rows(table, kernel, targs=None):
+    """rows of the live profile whose kernel is `kernel`; targs: {position: value} on its template arguments"""
+    rows = []
+    for name, row in (table or {}).items():
+        n = name.replace(" ", "")
+        base = n.split("<")[0].split("::")[-1]
+        if base != kernel:
+            continue
+        if targs:
+            ta = n.split("<", 1)[1].rstrip(">").split(",") if "<" in n else []
+            if any(pos >= len(ta) or ta[pos] != val for pos, val in targs.items()):
+                continue
+        rows.append(row)
+    return rows
+
+
+def prof_value(table, kernel, key, targs=None):
+    rows = [r for r in prof_rows(table, kernel, targs) if key in r]
+    if not rows:
         return None
-    return None
+    calls = sum(r["calls"] for r in rows)
+    return sum(r[key] * r["calls"] for r in rows) / max(calls, 1)   # per launch, averaged over the instantiations
 
 
 def suitesparse_baseline(S, Q0, budget_s=20.0):
@@ -246,11 +272,119 @@ def cpu_baseline(S, Q0, p_loop, budget_s=25.0):
                 note="oracle = C restatement + own sparse Cholesky; NOT Eigen+SuiteSparse")
 
 
+def cpu_baselines_main(spec):
+    """`python bench.py --cpu-only '<json>'`: every CPU-oracle baseline of the bench line, in a process of its own (started
+    by the bench run behind its timed region: the oracle's Python glue would otherwise take the interpreter lock away
+    from the GPU legs, and the GPU stays busy while the host cores are timed). Prints ONE JSON object."""
+    from oracle import oracle as O
+    from irotavg_amd import synth
+    out = {}
+    n, m, p_loop, seed = spec["views"], spec["edges"], spec["p_loop"], spec["seed"]
+    S, Q0 = build_problem(n, m, p_loop, seed)
+    out["cpu_baseline"] = cpu_baseline(S, Q0, p_loop)
+    ss = suitesparse_baseline(S, Q0)
+    if isinstance(ss, dict):
+        out["cpu_baseline_suitesparse"] = ss
+    else:
+        out["cpu_baseline"]["suitesparse_probe"] = ss
+    if spec.get("extras"):
+        # the loop-closure topology at FULL size: one IRLS iteration (the oracle's fill test hands such a graph to its
+        # Gauss-Seidel-preconditioned CG, true relative residual 1e-13)
+        S2, Q2 = build_problem(n, m, 0.02, seed)
+        t = time.time()
+        r = O.irls(S2["QQ"], S2["I"], Q2, 1, 4, SIG, 1, 1e-3)
+        dt = time.time() - t
+        out["also_p_loop_0.02"] = dict(value=S2["m"] * r["iters"] / dt, unit="edge-updates/s", cores=1, kind="port",
+                                       sample="1 IRLS iteration (of the 5 a solve takes) of the same %d-view/%d-edge graph with "
+                                              "2 %% loop edges, %.1f s" % (S2["n"], S2["m"], dt),
+                                       solver_stats=str(O.solver_stats()))
+        # config 2
+        S3, Q3 = build_problem(10000, 150000, 0.0, seed)
+        t, updates, runs, iters = time.time(), 0, 0, 0
+        while time.time() - t < 4.0 and runs < 50:
+            r = O.irls(S3["QQ"], S3["I"], Q3, 1, 4, SIG, 100, 1e-3)
+            updates += S3["m"] * r["iters"]
+            iters = r["iters"]
+            runs += 1
+        dt = time.time() - t
+        out["also_config2_10k150k"] = dict(value=updates / dt, unit="edge-updates/s", cores=1, kind="port",
+                                           sample="%d complete IRLS solves (%d iterations each) of the same 10000-view/150000-edge "
+                                                  "graph, %.1f s" % (runs, iters, dt), iters_to_converge=iters)
+        # config 5: the oracle's literal ViewGraph::rotAvg driven through the same call pattern on a bounded stream
+        out["also_config5_stream"] = oracle_stream(20000, 3000, 2, seed)
+    print(json.dumps(out), flush=True)
+
+
+def oracle_stream(warm, stream, loops, seed):
+    """BASELINE.json config 5 on the CPU oracle (oracle/viewgraph_oracle.py: a literal restatement of ViewGraph::rotAvg
+    over the C oracle), bounded: `warm` views as a converged run left them, `stream` views admitted one by one with
+    rotAvg(10) each, `loops` loop closures with a global rotAvg, a fix every 20 frames (src/IRotAvg.cpp:360-378)."""
+    from oracle import oracle as O
+    from oracle.viewgraph_oracle import ViewGraphOracle
+    from irotavg_amd import synth
+    n = warm + stream
+    rng = np.random.default_rng(seed)
+    Qgt = rng.normal(size=(n, 4))
+    Qgt /= np.linalg.norm(Qgt, axis=1, keepdims=True)
+
+    def rel(i, j):
+        e = synth.qexp(rng.normal(scale=0.01, size=(1, 3)))[0]
+        return O.quat2rmat(synth.qmul(e, synth.qmul(Qgt[j], synth.qconj(Qgt[i]))))
+    vo = ViewGraphOracle()
+    for v in range(warm):
+        vo.addView(O.quat2rmat(synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(1, 3)))[0], Qgt[v])))
+        for d in range(1, min(4, v) + 1):
+            vo.connect(v - d, v, rel(v - d, v))
+        if v % 20 == 0:
+            vo.fixPose(v, O.quat2rmat(Qgt[v]))
+    loop_at = set(rng.choice(np.arange(warm + 50, n), size=loops, replace=False).tolist()) if loops else set()
+    meas = {v: [rel(v - d, v) for d in range(1, 5)] for v in range(warm, n)}
+    lm = {v: (int(rng.integers(0, v - 500)),) for v in loop_at}
+    lm = {v: (u[0], rel(u[0], v)) for v, u in lm.items()}
+    t0, tg, ng = time.time(), 0.0, 0
+    for v in range(warm, n):
+        vo.addView(meas[v][0] @ vo.R[v - 1])
+        for d in range(1, 5):
+            vo.connect(v - d, v, meas[v][d - 1])
+        if v in lm:
+            vo.connect(lm[v][0], v, lm[v][1])
+        if v % 20 == 0:
+            vo.fixPose(v, O.quat2rmat(Qgt[v]))
+        t1 = time.time()
+        vo.rotAvg(5000000 if v in lm else 10)
+        if v in lm:
+            tg += time.time() - t1
+            ng += 1
+    dt = time.time() - t0
+    return dict(value=stream / dt, unit="views/s", cores=1, kind="port",
+                sample="%d views streamed onto a warm %d-view sequence (4 links per view, %d loop closure(s) with a global "
+                       "re-solve, a fix every 20 frames), %.1f s; Python-driven: the oracle's window extraction is "
+                       "interpreter code, the solves are the C oracle" % (stream, warm, loops, dt),
+                local_rotavg_ms_mean=1e3 * (dt - tg) / max(stream - ng, 1), global_rotavg_ms_mean=1e3 * tg / max(ng, 1))
+
+
+def pcg_iteration_roofline(S, st, kr, ia=None, iu=None):
+    """the whole two-launch PCG iteration against SURVEY.md 8(d)'s own K4 + K5 bytes: the dense inverse every tile slice
+    re-reads and the coarse vectors are this design's cost, not algorithmic traffic"""
+    nu_ = S["n"] - 1
+    nnz0_ = st["level_nnz"][0]
+    k45 = nnz0_ * 12 + 4 * (nu_ + 1) + 2 * 24 * nu_ + 10 * 24 * nu_
+    ms_it = kr["cg_apply"]["ms"] + kr["cg_update"]["ms"]
+    return {"kernel": "k_cg_apply + k_cg_update (one PCG iteration)", "bound": "hbm",
+            "algorithmic_bytes": k45, "formula": "K4 + K5 of SURVEY.md 8(d): nnz0*(8+4) + 4(n+1) + 2*24n + 10*24n",
+            "ms_per_iteration": ms_it, "achieved": k45 / (ms_it * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": k45 / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "ms_per_iteration_in_situ": (ia + iu) if ia and iu else None,
+            "frac_in_situ": (k45 / ((ia + iu) * 1e-3) / 1e9 / HBM_PEAK_GBS) if ia and iu else None,
+            "own_bytes_both_kernels": kr["cg_apply"]["bytes"] + kr["cg_update"]["bytes"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=300,
+                    help="timed steps (default 300: ~0.6 s of GPU work at 100k/2M, long enough for an outside GPU-busy sampler)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ramp", type=int, default=40, help="untimed ramp-up steps ahead of --warmup")
     ap.add_argument("--views", type=int, default=100000)
     ap.add_argument("--edges", type=int, default=2000000)
@@ -259,11 +393,18 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true",
+                    help="no per-kernel HIP-event loops and no extra legs: the timed solves only (what the profiling passes run)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the rocprofv3 passes this run launches for HBM traffic and in-solve kernel durations")
     ap.add_argument("--classic", action="store_true",
                     help="A/B: the classic PCG recurrences (separate launches) instead of the two-launch iteration")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the sharded (RCCL) path even with one rank (exercises it on a 1-GPU box)")
+    ap.add_argument("--cpu-only", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_only:
+        return cpu_baselines_main(json.loads(args.cpu_only))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -404,76 +545,120 @@ def main():
         }
         if dstats is not None:
             line["config"]["dist"] = dinfo
+        if args.no_kernels:
+            G.close()
+            print(json.dumps(line), flush=True)
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
+        extras = (not args.no_extra) and world == 1 and args.p_loop == 0.0 and args.views == 100000
+        cpu_proc = None
+        if not args.no_cpu and world == 1:
+            # every CPU-oracle baseline runs in a process of its own while the GPU legs below go on (cpu_baselines_main)
+            import subprocess
+            spec = dict(views=args.views, edges=args.edges, p_loop=args.p_loop, seed=args.seed, extras=extras)
+            cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-only", json.dumps(spec)],
+                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         kr = kernel_rooflines(G, S, st, sharded=dstats is not None)
-        dom = "bcr_reduce_l0" if "bcr_reduce_l0" in kr else \
+        FP64_PEAK_TF = 78.6   # AMD's MI355X data sheet (fp64 vector = matrix); the guide lists no fp64 figure
+        # HBM traffic and in-solve kernel durations: measured NOW, by rocprofv3 passes of this command (live_profile)
+        prof, prof_where = (None, "--no-pmc") if (args.no_pmc or dstats is not None) else live_profile(args, line["config"]["workload"])
+        line["profile_source"] = ("rocprofv3 passes launched by this run (kernel trace, FETCH_SIZE, WRITE_SIZE): " + prof_where
+                                  ) if prof else "no in-run profile (%s): traffic and in-situ fields are null" % prof_where
+
+        def traffic(kernel, targs=None):
+            return prof_value(prof, kernel, "traffic_bytes", targs)
+
+        def insitu_ms(kernel, targs=None):
+            v = prof_value(prof, kernel, "avg_us", targs)
+            return v * 1e-3 if v is not None else None
+        dom = "bcr_solve" if "bcr_solve" in kr else \
             ("cg_apply" if "cg_apply" in kr else ("pspmv" if "pspmv" in kr else "spmv"))
-        dname = {"bcr_reduce_l0": "k_bcr_reduce, level 0 (banded direct solver: blocks gathered from the SELL-64 operator, "
-                                  "7 of 8 blocks per chunk eliminated on the matrix cores, W written for the way back; the "
-                                  "longest launch of a solve)",
-                 "spmv": "k_spmv_dot (level-0 SELL-64 SpMV + fused dot, dominant PCG kernel)",
-                 "pspmv": "k_pspmv_dot (PCG p-update fused into the level-0 SELL-64 SpMV + dot, dominant PCG kernel)",
-                 "cg_apply": "k_cg_apply (u = M^-1 r incl. the tile's slice of the dense coarse solve and the level-1 "
-                             "up-sweep, then the level-0 SELL-64 SpMV w = L u + dots; dominant PCG kernel)"}[dom]
-        line["roofline"] = {"kernel": dname,
-                            "bound": "hbm", "achieved": kr[dom]["gbs"], "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": kr[dom]["gbs"] / HBM_PEAK_GBS,
-                            "traffic": pmc_traffic({"pspmv": "k_pspmv_dot", "spmv": "k_spmv_dot",
-                                                    "cg_apply": "k_cg_apply", "bcr_reduce_l0": "k_bcr_reduce_l0"}[dom],
-                                                   line["config"]["workload"]),
-                            "ms_per_launch": kr[dom]["ms"], "algorithmic_bytes": kr[dom]["bytes"]}
-        kname = {"pspmv": "k_pspmv_dot", "spmv": "k_spmv_dot", "cg_apply": "k_cg_apply",
-                 "bcr_reduce_l0": "k_bcr_reduce_l0"}[dom]
-        insitu = in_situ_ms(kname, line["config"]["workload"])
-        line["roofline"]["ms_per_launch_in_situ"] = insitu
-        line["roofline"]["frac_in_situ"] = (kr[dom]["bytes"] / (insitu * 1e-3) / 1e9 / HBM_PEAK_GBS) if insitu else None
-        if dom == "bcr_reduce_l0":
-            FP64_PEAK_TF = 78.6   # AMD's MI355X data sheet (fp64 vector = matrix); the guide lists no fp64 figure
-            line["roofline"]["note"] = (
-                "a direct solve: its ~14 dependent block eliminations (Gauss-Jordan sweep of a %d x %d block + five "
-                "products on the matrix cores each) set the time, not the bytes -- see roofline_direct_solve for both "
-                "ceilings of the whole solve" % (kr["bcr_solve"]["block"], kr["bcr_solve"]["block"]))
-            line["roofline"]["mfma"] = {"bound": "mfma", "achieved": kr[dom]["tflops"], "peak": FP64_PEAK_TF,
-                                        "unit": "TFLOP/s", "frac": kr[dom]["tflops"] / FP64_PEAK_TF,
-                                        "flops_per_launch": kr[dom]["flops"]}
+        if dom == "bcr_solve":
+            # the dominant "kernel" of a direct solve is the solve itself: 77 % of an IRLS iteration, one template
+            # (k_bcr_reduce) launched once per level + two launches for the ways back. Quoted as a whole -- all
+            # launches, all levels -- and launch by launch below it (round 3 quoted level 0 only: the best third)
             bs = kr["bcr_solve"]
-            line["roofline_direct_solve"] = {
-                "kernel": "all %d launches of one direct solve (k_bcr_reduce x %d, k_bcr_back x %d)" % (
-                    bs["launches"], bs["launches"] // 2, bs["launches"] // 2),
-                "bound": "hbm", "algorithmic_bytes": bs["bytes"], "ms_per_solve": bs["ms"],
-                "achieved": bs["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bs["gbs"] / HBM_PEAK_GBS,
-                "mfma": {"achieved": bs["tflops"], "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": bs["tflops"] / FP64_PEAK_TF, "flops": bs["flops"]},
+            nl = len(bs["levels"])
+            # (kernel, template arguments that pick the instantiation, launches per solve)
+            parts = [("bcr_reduce_l0", "k_bcr_reduce", {2: "true"}, 1)]
+            if nl >= 3:
+                parts.append(("bcr_reduce_mid", "k_bcr_reduce", {2: "false", 3: "false"}, nl - 2))
+            if nl >= 2:
+                parts.append(("bcr_reduce_top", "k_bcr_reduce", {2: "false", 3: "true"}, 1))
+                parts.append(("bcr_back_upper", "k_bcr_back_top", None, 1))
+            parts.append(("bcr_back_l0", "k_bcr_back", {2: "true"}, 1))
+            tr = [traffic(k, ta) for _, k, ta, _ in parts]
+            du = [insitu_ms(k, ta) for _, k, ta, _ in parts]
+            tr_solve = sum(t * c for t, (_, _, _, c) in zip(tr, parts)) if all(t is not None for t in tr) else None
+            ms_insitu = sum(d * c for d, (_, _, _, c) in zip(du, parts)) if all(d is not None for d in du) else None
+            line["roofline"] = {
+                "kernel": "one banded direct solve = %d launches: k_bcr_reduce x %d (level 0 gathers the blocks from the SELL-64 "
+                          "operator; every level eliminates 7 of 8 blocks per chunk on the matrix cores and writes W), "
+                          "k_bcr_back_top (ways back of the levels >= 1), k_bcr_back (level 0 -> X)" % (bs["launches"], nl),
+                "bound": "hbm", "achieved": bs["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bs["gbs"] / HBM_PEAK_GBS,
+                "algorithmic_bytes": bs["bytes"], "ms_per_launch": bs["ms"], "launches_per_solve": bs["launches"],
+                "traffic": tr_solve, "ms_per_launch_in_situ": ms_insitu,
+                "frac_in_situ": (bs["bytes"] / (ms_insitu * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_insitu else None,
+                "note": "HIP-event time of the whole solve (all launches back to back on the handle's stream) against the "
+                        "algorithmic bytes of all its launches (DESIGN.md 5d). Not bandwidth-bound: ~14 dependent rounds of "
+                        "block eliminations (sweep of a %d x %d block, five products on the matrix cores) set the time; "
+                        "1.6 %% of the rows (levels >= 1) take half of it" % (bs["block"], bs["block"]),
+                "mfma": {"bound": "mfma", "achieved": bs["tflops"], "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": bs["tflops"] / FP64_PEAK_TF, "flops_per_solve": bs["flops"]},
+                "by_launch": {name: dict(launches=c, ms=(kr[name]["ms"] if name in kr else None),
+                                         algorithmic_bytes=(kr[name]["bytes"] if name in kr else None),
+                                         frac=(kr[name]["gbs"] / HBM_PEAK_GBS if name in kr else None),
+                                         ms_in_situ=d, traffic=t)
+                              for (name, _, _, c), t, d in zip(parts, tr, du)},
                 "block": bs["block"], "levels": bs["levels"]}
+            if nl >= 3:   # levels 1 .. nl-2 share one instantiation: HIP-event figures per level
+                line["roofline"]["by_launch"]["bcr_reduce_mid"].update(
+                    ms=[kr["bcr_reduce_l%d" % l]["ms"] for l in range(1, nl - 1)],
+                    algorithmic_bytes=[kr["bcr_reduce_l%d" % l]["bytes"] for l in range(1, nl - 1)],
+                    frac=[kr["bcr_reduce_l%d" % l]["gbs"] / HBM_PEAK_GBS for l in range(1, nl - 1)])
+                line["roofline"]["by_launch"]["bcr_reduce_top"].update(
+                    ms=kr["bcr_reduce_l%d" % (nl - 1)]["ms"], algorithmic_bytes=kr["bcr_reduce_l%d" % (nl - 1)]["bytes"],
+                    frac=kr["bcr_reduce_l%d" % (nl - 1)]["gbs"] / HBM_PEAK_GBS)
+            line["roofline_direct_solve"] = {k: line["roofline"][k] for k in ("kernel", "bound", "algorithmic_bytes", "achieved",
+                                                                            "peak", "unit", "frac", "mfma", "block", "levels")}
+            line["roofline_direct_solve"]["ms_per_solve"] = bs["ms"]
+        else:
+            dname = {"spmv": "k_spmv_dot (level-0 SELL-64 SpMV + fused dot, dominant PCG kernel)",
+                     "pspmv": "k_pspmv_dot (PCG p-update fused into the level-0 SELL-64 SpMV + dot, dominant PCG kernel)",
+                     "cg_apply": "k_cg_apply (u = M^-1 r incl. the tile's slice of the dense coarse solve and the level-1 "
+                                 "up-sweep, then the level-0 SELL-64 SpMV w = L u + dots; dominant PCG kernel)"}[dom]
+            kname = {"pspmv": "k_pspmv_dot", "spmv": "k_spmv_dot", "cg_apply": "k_cg_apply"}[dom]
+            insitu = insitu_ms(kname)
+            line["roofline"] = {"kernel": dname,
+                                "bound": "hbm", "achieved": kr[dom]["gbs"], "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": kr[dom]["gbs"] / HBM_PEAK_GBS, "traffic": traffic(kname),
+                                "ms_per_launch": kr[dom]["ms"], "algorithmic_bytes": kr[dom]["bytes"],
+                                "ms_per_launch_in_situ": insitu,
+                                "frac_in_situ": (kr[dom]["bytes"] / (insitu * 1e-3) / 1e9 / HBM_PEAK_GBS) if insitu else None}
         if "cg_apply" in kr and "cg_update" in kr:
-            # the whole PCG iteration (both launches) against SURVEY.md 8(d)'s own K4 + K5 bytes: the dense inverse
-            # every tile slice re-reads and the coarse vectors are this design's cost, not algorithmic traffic
-            nu_ = S["n"] - 1
-            nnz0_ = st["level_nnz"][0]
-            k45 = nnz0_ * 12 + 4 * (nu_ + 1) + 2 * 24 * nu_ + 10 * 24 * nu_
-            ms_it = kr["cg_apply"]["ms"] + kr["cg_update"]["ms"]
-            ia, iu = in_situ_ms("k_cg_apply", line["config"]["workload"]), in_situ_ms("k_cg_update", line["config"]["workload"])
-            line["roofline_pcg_iteration"] = {
-                "kernel": "k_cg_apply + k_cg_update (one PCG iteration)", "bound": "hbm",
-                "algorithmic_bytes": k45, "formula": "K4 + K5 of SURVEY.md 8(d): nnz0*(8+4) + 4(n+1) + 2*24n + 10*24n",
-                "ms_per_iteration": ms_it, "achieved": k45 / (ms_it * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": k45 / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "ms_per_iteration_in_situ": (ia + iu) if ia and iu else None,
-                "frac_in_situ": (k45 / ((ia + iu) * 1e-3) / 1e9 / HBM_PEAK_GBS) if ia and iu else None,
-                "own_bytes_both_kernels": kr["cg_apply"]["bytes"] + kr["cg_update"]["bytes"]}
-        line["roofline_edge_residual"] = {
-            "kernel": "k_edge_residual (K1, the kernel north_star names)", "bound": "hbm",
-            "achieved": kr["edge_residual"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kr["edge_residual"]["gbs"] / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("k_edge_residual", line["config"]["workload"]),
-            "ms_per_launch": kr["edge_residual"]["ms"], "algorithmic_bytes": kr["edge_residual"]["bytes"]}
-        ta = [pmc_traffic(k, line["config"]["workload"]) for k in ("k_assemble0w", "k_coarse_level")]
+            line["roofline_pcg_iteration"] = pcg_iteration_roofline(S, st, kr, insitu_ms("k_cg_apply"), insitu_ms("k_cg_update"))
+        for key, kn, label, targs in (
+                ("update_weights", "k_update_weights", "K2: k_update_weights (residual of the step + the robust weight, "
+                                                       "ral/l1_irls.cpp:614-727)", None),
+                ("edge_residual", "k_edge_residual", "k_edge_residual (K1, the kernel north_star names)", None)):
+            ins = insitu_ms(kn, targs)
+            line["roofline_" + key] = {
+                "kernel": label, "bound": "hbm", "achieved": kr[key]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kr[key]["gbs"] / HBM_PEAK_GBS, "traffic": traffic(kn, targs), "ms_per_launch": kr[key]["ms"],
+                "algorithmic_bytes": kr[key]["bytes"], "ms_per_launch_in_situ": ins,
+                "frac_in_situ": (kr[key]["bytes"] / (ins * 1e-3) / 1e9 / HBM_PEAK_GBS) if ins else None}
+        ta = [traffic(k) for k in ("k_assemble0w", "k_coarse_level")]
+        ins = insitu_ms("k_assemble0w")
         line["roofline_assembly"] = {
             "kernel": "K3: k_assemble0w (level 0 from the LDS-staged run of the edge list; on the PCG path also level 1 "
                       "and k_coarse_level for level 2)",
             "bound": "hbm", "achieved": kr["assemble"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": kr["assemble"]["gbs"] / HBM_PEAK_GBS,
             "traffic": (ta[0] + (ta[1] or 0.0)) if ta[0] is not None else None,
-            "ms_per_launch": kr["assemble"]["ms"], "algorithmic_bytes": kr["assemble"]["bytes"]}
+            "ms_per_launch": kr["assemble"]["ms"], "algorithmic_bytes": kr["assemble"]["bytes"],
+            "ms_per_launch_in_situ": ins}
         line["kernels"] = {k: {kk: (vv if isinstance(vv, (int, list, dict, str)) else float(vv)) for kk, vv in v.items()}
                            for k, v in kr.items()}
         if not args.no_extra and world == 1 and args.p_loop == 0.0 and args.views == 100000:
@@ -491,11 +676,23 @@ def main():
                 G2.synchronize()
                 d2 = time.perf_counter() - t1
                 s2 = G2.stats()
+                kr2 = {}
+                try:   # the six-launch iteration of a graph with far entries: its SpMV and one preconditioner application
+                    by = s2["level_nnz"][0] * 12 + 4 * S2["n"] + 2 * 24 * (S2["n"] - 1)
+                    ms = G2.time_kernel(4, 50)
+                    kr2["spmv"] = dict(ms=ms, bytes=by, gbs=by / (ms * 1e-3) / 1e9, frac=by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                    kr2["precondition"] = dict(ms=G2.time_kernel(5, 50))
+                    kr2["dense_inversion"] = dict(ms=G2.time_kernel(7, 5), rows=int(s2["level_rows"][s2["levels"] - 1]))
+                except capi.IrotavgError:
+                    pass
             line["also_p_loop_0.02"] = {"value": S2["m"] * r2["iters"] * reps / d2, "unit": "edge-updates/s",
                                         "iters_to_converge": r2["iters"], "ms_per_step": 1e3 * d2 / reps,
                                         "pcg_iters_per_solve": s2["pcg_iters"] / max(s2["pcg_solves"], 1),
                                         "dense_inversions_per_solve_call": s2["dense_inversions"] / (reps + 1),
-                                        "dense_repairs_per_solve_call": s2["dense_repairs"] / (reps + 1)}
+                                        "dense_repairs_per_solve_call": s2["dense_repairs"] / (reps + 1),
+                                        "linear_solver": "multigrid-preconditioned CG (40 000 loop closures: beyond the "
+                                                         "2048 the direct solver carries)",
+                                        "kernels": kr2}
         if not args.no_extra and world == 1 and args.p_loop == 0.0 and args.views == 100000:
             # the headline topology with a NON-uniform re-weighting: 2 % of the band edges carry a 0.3 rad
             # error (the workload of test_every_cost_on_the_two_launch_path_matches_oracle at full size); the
@@ -526,6 +723,77 @@ def main():
                                           "pcg_iters_per_solve": s4["pcg_iters"] / max(s4["pcg_solves"], 1),
                                           "dense_inversions_per_solve_call": s4["dense_inversions"] / reps,
                                           "note": "p_loop=0, 2 % of ALL edges off by N(0, 0.3^2) rad, init_mst start"}
+        if extras:
+            # a view sequence WITH loop closures (what a SLAM run produces, src/IRotAvg.cpp:371-378): the banded direct
+            # solver carries up to 2048 of them (forward eliminations along the elimination tree + Woodbury system,
+            # bcr.hip), beyond that -- and for comparison here -- the multigrid-PCG
+            from irotavg_amd import ral, synth
+            for nclose in (100, 1000):
+                Sc = synth.add_closures(S, nclose, seed=7, wrong=max(1, nclose // 33))
+                Qc = np.zeros((Sc["n"], 4)); Qc[:, 3] = 1; Qc[0] = Sc["Qgt"][0]
+                ral.init_mst(Qc, Sc["QQ"], Sc["I"], 1)
+                leg = {}
+                for bd, tag in ((0, "direct"), (-1, "pcg")):
+                    with capi.Graph(Sc["I"], Sc["QQ"], Sc["n"], 1, pcg_rtol=args.rtol, band_direct=bd) as Gc:
+                        Gc.set_rotations(Qc)
+                        Gc.snapshot_rotations()
+                        Gc.irls(4, SIG, 100, 1e-3)
+                        Gc.synchronize()
+                        Gc.reset_stats()
+                        reps = 5 if bd == 0 else 2
+                        t1 = time.perf_counter()
+                        for _ in range(reps):
+                            Gc.restore_rotations()
+                            rc_ = Gc.irls(4, SIG, 100, 1e-3)
+                        Gc.synchronize()
+                        dc = time.perf_counter() - t1
+                        sc = Gc.stats()
+                    leg[tag] = dict(ms_per_step=1e3 * dc / reps, iters_to_converge=rc_["iters"],
+                                    value=Sc["m"] * rc_["iters"] * reps / dc, direct_solves_per_solve_call=sc.get("direct_solves", 0) / reps,
+                                    direct_guarded=sc.get("direct_guarded", 0),
+                                    pcg_iters_per_solve=sc["pcg_iters"] / max(sc["pcg_solves"], 1))
+                line["also_closures_%d" % nclose] = dict(
+                    leg["direct"], unit="edge-updates/s", pcg_path=leg["pcg"],
+                    note="the headline sequence + %d loop closures 100 ... n/2 views long, %d of them wrong (random rotation); "
+                         "irls to convergence; pcg_path: the same through band_direct = -1" % (nclose, max(1, nclose // 33)))
+            # BASELINE.json config 2
+            S3, Q3 = build_problem(10000, 150000, 0.0, args.seed)
+            with capi.Graph(S3["I"], S3["QQ"], S3["n"], 1, pcg_rtol=args.rtol) as G3:
+                G3.set_rotations(Q3)
+                G3.snapshot_rotations()
+                for _ in range(20):
+                    G3.restore_rotations()
+                    G3.irls(4, SIG, 100, 1e-3)
+                G3.synchronize()
+                reps = 50
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    G3.restore_rotations()
+                    r3 = G3.irls(4, SIG, 100, 1e-3)
+                G3.synchronize()
+                d3 = time.perf_counter() - t1
+                s3 = G3.stats()
+            line["also_config2_10k150k"] = {"value": S3["m"] * r3["iters"] * reps / d3, "unit": "edge-updates/s",
+                                            "iters_to_converge": r3["iters"], "ms_per_step": 1e3 * d3 / reps,
+                                            "linear_solver": "banded direct solver, blocks of %d" % s3["band_block"]
+                                            if s3.get("direct_solves", 0) else "multigrid-preconditioned CG",
+                                            "note": "BASELINE.json config 2: synthetic 10k views / 150k edges, same protocol as the headline"}
+            # BASELINE.json config 5: the native stream driver (tools/stream_bench.cpp over the C ABI)
+            import subprocess
+            exe = os.path.join(ROOT, "irotavg_amd", "bin", "stream_bench")
+            try:
+                r5 = subprocess.run([exe, "50000", "50000", "10", str(args.seed), "1", "1"], capture_output=True, text=True, timeout=300)
+                d5 = json.loads([ln for ln in r5.stdout.splitlines() if ln.startswith("{")][-1])
+                line["also_config5_stream"] = dict(
+                    value=d5["views_per_s"], unit="views/s", seconds=d5["seconds"], local_rotavg_ms_mean=d5["local_rotavg_ms_mean"],
+                    local_rotavg_ms_p99=d5["local_rotavg_ms_p99"], global_rotavg_ms_mean=d5["global_rotavg_ms_mean"],
+                    global_rotavg_ms=d5.get("global_rotavg_ms"), prepare_seconds=d5.get("prepare_seconds"),
+                    loop_closures=d5["loop_closures"], mean_angular_error_rad=d5["mean_angular_error_rad"],
+                    note="BASELINE.json config 5: 50k views streamed one by one (rotAvg(10) each: one kernel launch) onto a warm "
+                         "50k-view sequence, 10 loop closures (rotAvg(5000000) each, on the device-resident growing graph, "
+                         "resident.hip), a fix every 20 frames; irotavg_viewgraph_prepare after loading, outside the timed loop")
+            except Exception as e:
+                line["also_config5_stream"] = dict(value=None, unit="views/s", note="stream_bench failed: %s" % e)
         if not args.no_extra and world == 1 and st.get("direct_solves", 0) > 0:
             # the same workload through the handle's OTHER solver: the multigrid-PCG (what every graph with loop
             # closures and every shard runs; the headline of rounds 1 and 2)
@@ -624,13 +892,22 @@ def main():
                 "iters_to_converge": it1, "irls_ms_inside": 1e3 * rt_c.value,
                 "note": "irotavg_irls from host pointers (pageable memory): handle creation by the device build "
                         "(gbuild.hip) + PCIe both ways + the solve inside the timed region; one untimed call first"}
-        if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(S, Q0, args.p_loop)
-            ss = suitesparse_baseline(S, Q0)
-            if isinstance(ss, dict):
-                line["cpu_baseline_suitesparse"] = ss
-            else:
-                line["cpu_baseline"]["suitesparse_probe"] = ss
+        if cpu_proc is not None:
+            try:
+                so, se = cpu_proc.communicate(timeout=600)
+                cb = json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1])
+                line["cpu_baseline"] = cb.pop("cpu_baseline")
+                if "cpu_baseline_suitesparse" in cb:
+                    line["cpu_baseline_suitesparse"] = cb.pop("cpu_baseline_suitesparse")
+                for k, v in cb.items():   # the baselines of the other legs sit next to their GPU figures
+                    if k in line:
+                        line[k]["cpu_baseline"] = v
+                        if v.get("unit") == line[k].get("unit") and v.get("value"):
+                            line[k]["gpu_over_cpu"] = line[k]["value"] / v["value"]
+            except Exception as e:
+                cpu_proc.kill()
+                line["cpu_baseline"] = dict(value=None, unit="edge-updates/s", cores=1, kind="port",
+                                            sample="the baseline process failed: %s" % e)
         G.close()
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -123,3 +123,23 @@ def make_graph(n, m, p_loop=0.0, sigma_n=0.01, p_out=0.05, seed=0, p_band_out=0.
         is_out[bad] = True
     return dict(I=I, QQ=QQ, Qgt=Qgt, is_loop=is_loop, is_outlier=is_out, w=w, n=n, m=mm,
                 p_loop=p_loop, seed=seed)
+
+
+def add_closures(S, nclose, seed=7, wrong=0):
+    """A view sequence (make_graph with p_loop 0) plus `nclose` loop closures between views 100 ... n/2 apart,
+    `wrong` of them with a random relative rotation (a false loop detection); edges stay grouped by the newer view,
+    as ViewGraph::rotAvg lists them (src/ViewGraph.cpp:1290-1300)."""
+    n = S["n"]
+    rng = np.random.default_rng(seed + 100)
+    a = rng.integers(0, n - 200, nclose)
+    b = np.minimum(n - 1, a + rng.integers(100, n // 2, nclose))
+    eps = rng.normal(scale=0.01, size=(nclose, 3))
+    QQc = qmul(qexp(eps), qmul(S["Qgt"][b], qconj(S["Qgt"][a])))
+    if wrong:
+        R = rng.normal(size=(wrong, 4))
+        R /= np.linalg.norm(R, axis=1, keepdims=True)
+        QQc[:wrong] = R
+    I = np.concatenate([S["I"], np.stack([a, b], 1)]).astype(np.int32)
+    QQ = np.concatenate([S["QQ"], QQc])
+    order = np.lexsort((np.arange(len(I)), I[:, 1]))
+    return dict(S, I=I[order], QQ=QQ[order], m=len(I))

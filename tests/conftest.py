@@ -21,8 +21,16 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
-    # -m gpu on a box without a GPU must fail loudly rather than skip: the product has no CPU path.
-    pass
+    # -m gpu on a box without a usable GPU (or without the built HIP library) must fail loudly rather than skip or
+    # pass on some other path: the product has no CPU path. The check runs once, before the first selected gpu test.
+    if not any(it.get_closest_marker("gpu") for it in items):
+        return
+    sel = config.getoption("-m") or ""
+    if "gpu" not in sel or "not gpu" in sel:
+        return
+    if not _has_gpu():
+        raise pytest.UsageError("-m gpu was asked for, but irotavg_amd/libirotavg_hip.so does not load or reports no HIP "
+                                "device: the product has no CPU path, the gpu tests cannot pass here")
 
 
 @pytest.fixture(scope="session")

@@ -8,18 +8,7 @@ SIG = 5 * np.pi / 180
 
 
 def graph(n, m, nclose, seed, wrong=0):
-    S = synth.make_graph(n, m, 0.0, seed=seed)
-    rng = np.random.default_rng(seed + 100)
-    a = rng.integers(0, n - 200, nclose); b = np.minimum(n - 1, a + rng.integers(100, n // 2, nclose))
-    eps = rng.normal(scale=0.01, size=(nclose, 3))
-    QQc = synth.qmul(synth.qexp(eps), synth.qmul(S["Qgt"][b], synth.qconj(S["Qgt"][a])))
-    if wrong:
-        R = rng.normal(size=(wrong, 4)); R /= np.linalg.norm(R, axis=1, keepdims=True)
-        QQc[:wrong] = R
-    I = np.concatenate([S["I"], np.stack([a, b], 1)]).astype(np.int32)
-    QQ = np.concatenate([S["QQ"], QQc])
-    order = np.lexsort((np.arange(len(I)), I[:, 1]))
-    return dict(S, I=I[order], QQ=QQ[order], m=len(I))
+    return synth.add_closures(synth.make_graph(n, m, 0.0, seed=seed), nclose, seed, wrong)
 
 
 def run(n, m, nclose, oracle=True, wrong=0, reps=3):

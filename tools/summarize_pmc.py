@@ -21,7 +21,8 @@ def short(name):
     return n
 
 
-def main(d, out):
+def summarize(d):
+    """d: directory with trace/t_kernel_stats.csv, fetch/f_counter_collection.csv, write/w_counter_collection.csv"""
     stats = {}
     for r in csv.DictReader(open(d + "/trace/t_kernel_stats.csv")):
         stats[short(r["Name"])] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
@@ -39,6 +40,11 @@ def main(d, out):
     for k, s in stats.items():
         if "fetch_kib" in s and "write_kib" in s:
             s["traffic_bytes"] = 2 * s["fetch_kib"] * 1024 + s["write_kib"] * 1024
+    return stats
+
+
+def main(d, out):
+    stats = summarize(d)
     meta = {}
     try:  # the bench line of the trace pass (tools/profile_counters.sh redirects stdout into trace.log)
         for line in open(d + "/trace.log"):
