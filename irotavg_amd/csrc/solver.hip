@@ -68,7 +68,7 @@ void launch_edge_residual(Graph &g) {
 }
 
 // =============================================================================================
-// K2 -- residual of the linearised system and robust weight update (one edge per thread).
+// K2 -- residual of the linearised system and robust weight update (two edges per thread).
 // =============================================================================================
 __device__ __forceinline__ double robust_weight(int cost, double sigma, double e2, double prev) {
     switch (cost) {
@@ -131,10 +131,35 @@ __device__ __forceinline__ double robust_weight(int cost, double sigma, double e
     }
 }
 
+// Two edges per thread, as K1: index pairs, residual planes and weights move as 8 / 16 B per lane. What the kernel does
+// NOT read: the per-edge flag byte (EF_CJ / EF_CI follow from the endpoints and f -- the rule of the builds, build.cpp /
+// gbuild.hip: j free -> +X_j; i free as well -> -X_i; a self loop keeps the -1 only) and, unless the cost keeps previous
+// values (L2, Huber: PREV), the old weight. Algorithmic traffic: 8 B indices + 24 B residual + 8 B weight per edge.
+__device__ __forceinline__ double step_residual2(int i, int j, int f, double r0, double r1, double r2,
+                                                 const double4 *__restrict__ X) {
+    double e0 = 0.0, e1 = 0.0, e2c = 0.0;
+    if (j >= f && !(i == j)) {  // EF_CJ
+        const double4 xj = X[j - f];
+        e0 += xj.x;
+        e1 += xj.y;
+        e2c += xj.z;
+    }
+    if (j >= f && i >= f) {  // EF_CI
+        const double4 xi = X[i - f];
+        e0 -= xi.x;
+        e1 -= xi.y;
+        e2c -= xi.z;
+    }
+    e0 -= r0;
+    e1 -= r1;
+    e2c -= r2;
+    return e0 * e0 + e1 * e1 + e2c * e2c;
+}
+
+template <bool PREV, int EPT>
 __global__ __launch_bounds__(256) void k_update_weights(long long m, long long mpad, int f,
                                                         const int *__restrict__ ei,
                                                         const int *__restrict__ ej,
-                                                        const uint8_t *__restrict__ eflag,
                                                         const double *__restrict__ er,
                                                         const double4 *__restrict__ X, int cost,
                                                         double sigma, double *__restrict__ dw,
@@ -142,34 +167,49 @@ __global__ __launch_bounds__(256) void k_update_weights(long long m, long long m
     // gate: launched speculatively behind a PCG whose convergence the host has not read yet -- runs
     // only if that solve is done (run_irls reads the flag and the score in ONE round trip afterwards)
     if (gate != nullptr && gate[FL_DONE] != 1) return;
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
-    const uint8_t fl = eflag[k];
-    double e0 = 0.0, e1 = 0.0, e2c = 0.0;
-    if (fl & EF_CJ) {
-        const double4 xj = X[ej[k] - f];
-        e0 += xj.x;
-        e1 += xj.y;
-        e2c += xj.z;
+    // EPT edges per thread in EPT / 2 pairs; a wave's pairs of one load lie next to each other (16 B per lane)
+    const long long base = (long long)blockIdx.x * (256 * EPT) + 2 * threadIdx.x;
+    int2 ii[EPT / 2], jj[EPT / 2];
+    double2 r0[EPT / 2], r1[EPT / 2], r2[EPT / 2], prev[EPT / 2];
+#pragma unroll
+    for (int u = 0; u < EPT / 2; u++) {
+        const long long k = base + 512 * u;
+        ii[u] = jj[u] = make_int2(0, 0);
+        r0[u] = r1[u] = r2[u] = prev[u] = make_double2(0.0, 0.0);
+        if (k < m) {
+            ii[u] = *reinterpret_cast<const int2 *>(ei + k);
+            jj[u] = *reinterpret_cast<const int2 *>(ej + k);
+            r0[u] = *reinterpret_cast<const double2 *>(er + k);
+            r1[u] = *reinterpret_cast<const double2 *>(er + mpad + k);
+            r2[u] = *reinterpret_cast<const double2 *>(er + 2 * mpad + k);
+            if (PREV) prev[u] = *reinterpret_cast<const double2 *>(dw + k);
+        }
     }
-    if (fl & EF_CI) {
-        const double4 xi = X[ei[k] - f];
-        e0 -= xi.x;
-        e1 -= xi.y;
-        e2c -= xi.z;
+#pragma unroll
+    for (int u = 0; u < EPT / 2; u++) {
+        const long long k = base + 512 * u;
+        if (k >= m) continue;
+        const double ea = step_residual2(ii[u].x, jj[u].x, f, r0[u].x, r1[u].x, r2[u].x, X);
+        const double wa = robust_weight(cost, sigma, ea, prev[u].x);
+        if (k + 1 < m) {
+            const double eb = step_residual2(ii[u].y, jj[u].y, f, r0[u].y, r1[u].y, r2[u].y, X);
+            *reinterpret_cast<double2 *>(dw + k) = make_double2(wa, robust_weight(cost, sigma, eb, prev[u].y));
+        } else {
+            dw[k] = wa;  // the pad entry behind an odd m keeps its value
+        }
     }
-    e0 -= er[k];
-    e1 -= er[mpad + k];
-    e2c -= er[2 * mpad + k];
-    const double e2 = e0 * e0 + e1 * e1 + e2c * e2c;
-    dw[k] = robust_weight(cost, sigma, e2, dw[k]);
 }
 
 void launch_update_weights(Graph &g, int cost, double sigma, bool gated) {
-    const int grid = (int)((g.m + 255) / 256);
-    hipLaunchKernelGGL(k_update_weights, dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
-                       (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.eflag.p, g.er.p, g.X.p, cost,
-                       sigma, g.dw.p, gated ? (const int *)g.flags.p : (const int *)nullptr);
+    // (four and eight edges per thread were measured: 17.6 -> 18.3 / 18.9 us at 2M edges; two it is)
+    const int *gate = gated ? (const int *)g.flags.p : (const int *)nullptr;
+    const int grid = (int)((g.m + 511) / 512);
+    if (cost == IROTAVG_L2 || cost == IROTAVG_HUBER)
+        hipLaunchKernelGGL((k_update_weights<true, 2>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m, (long long)g.mpad, g.f,
+                           g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, gate);
+    else
+        hipLaunchKernelGGL((k_update_weights<false, 2>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m, (long long)g.mpad, g.f,
+                           g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, gate);
 }
 
 // =============================================================================================
