@@ -27,6 +27,7 @@ struct WinParams {
 struct WinResult {
     int l1_iters, irls_iters, status, seq;
     double l1_score, irls_score;
+    long long stamp[8];  // development aid (IROTAVG_WINDOW_STAMPS=1 prints them): s_memtime at the phase boundaries of k_window_wave
 };
 
 #define W_PI 3.141592653589793238462643383279502884
@@ -851,6 +852,8 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
     __shared__ int sStatus[3];
     const int nv = P.nv, ne = P.ne, f = P.f, nu = nv - f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long stamp[6];
+    stamp[0] = (long long)__builtin_amdgcn_s_memtime();
     for (int i = tid; i < nv; i += SM_THREADS) sQ[i] = Qg[i];
     SmLane E;
     E.m = ne;
@@ -877,20 +880,49 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
         }
     }
     const bool ek = lane < ne, vk = lane < nu;
-    if (wave == 0) {  // incidence lists of the free views, ascending edge id
-        int da = 0, dh = 0;
+    if (wave == 0) {
+        // Incidence lists of the free views, ascending edge id. The edges that touch view v are the set bits of wave
+        // ballots (lane k = edge k), taken for all views in turn and kept by lane v; lane v then walks ITS bits in
+        // ascending order -- a handful of steps -- and fetches the other endpoint of each edge from the edge's lane.
+        // (Until round 4 every lane walked all ne edges through readlanes: 40 serial steps, a fifth of the kernel.)
+        const bool self = ek && ai >= 0 && ai == aj;
+        unsigned long long mAj = 0, mAi = 0, mHs = 0, mHi = 0, mHj = 0;
+        for (int v = 0; v < nu; v++) {
+            const unsigned long long bj = __ballot(ek && E.cj == v), bi = __ballot(ek && E.ci == v);
+            const unsigned long long hs = __ballot(self && ai == v), hi = __ballot(ek && !self && ai == v),
+                                     hj = __ballot(ek && !self && aj == v);
+            if (lane == v) {
+                mAj = bj;
+                mAi = bi;
+                mHs = hs;
+                mHi = hi;
+                mHj = hj;
+            }
+        }
         const int row = vk ? lane : 0;
-        for (int k = 0; k < ne; k++) {
-            const int kj = rl_i(E.cj, k), ki = rl_i(E.ci, k), i = rl_i(ai, k), j = rl_i(aj, k);
-            if (vk) {
-                if (kj == lane) sAdjA[row][da++] = (unsigned)k | ((unsigned)(ki + 1) << 8);
-                if (ki == lane) sAdjA[row][da++] = (unsigned)k | ((unsigned)(kj + 1) << 8) | ADJ_NEG;
-                if (i >= 0 && i == j) {
-                    if (i == lane) sAdjH[row][dh++] = (unsigned)k | ADJ_SELF;
-                } else {
-                    if (i == lane) sAdjH[row][dh++] = (unsigned)k | ((unsigned)(j >= 0 ? j + 1 : 0) << 8);
-                    if (j == lane) sAdjH[row][dh++] = (unsigned)k | ((unsigned)(i >= 0 ? i + 1 : 0) << 8);
-                }
+        int da = 0, dh = 0;
+        unsigned long long ma = mAj | mAi, mh = mHs | mHi | mHj;
+        while (__ballot(ma != 0ull || mh != 0ull) != 0ull) {  // wave-uniform trip count: the shuffles need every lane
+            const int ka = ma ? (int)__builtin_ctzll(ma) : 0, kh = mh ? (int)__builtin_ctzll(mh) : 0;
+            const int kj = __shfl(E.cj, ka, 64), ki = __shfl(E.ci, ka, 64);
+            const int hi_ = __shfl(ai, kh, 64), hj_ = __shfl(aj, kh, 64);
+            if (ma) {  // (an edge is in at most one of the two make_A lists of a view: cj == ci only for a self loop, whose cj is -1)
+                const unsigned long long bit = 1ull << ka;
+                if (mAj & bit)
+                    sAdjA[row][da++] = (unsigned)ka | ((unsigned)(ki + 1) << 8);
+                else
+                    sAdjA[row][da++] = (unsigned)ka | ((unsigned)(kj + 1) << 8) | ADJ_NEG;
+                ma &= ma - 1;
+            }
+            if (mh) {
+                const unsigned long long bit = 1ull << kh;
+                if (mHs & bit)
+                    sAdjH[row][dh++] = (unsigned)kh | ADJ_SELF;
+                else if (mHi & bit)
+                    sAdjH[row][dh++] = (unsigned)kh | ((unsigned)(hj_ >= 0 ? hj_ + 1 : 0) << 8);
+                else
+                    sAdjH[row][dh++] = (unsigned)kh | ((unsigned)(hi_ >= 0 ? hi_ + 1 : 0) << 8);
+                mh &= mh - 1;
             }
         }
         if (vk) {
@@ -900,6 +932,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
     }
     if (tid < 3) sStatus[tid] = 0;
     __syncthreads();
+    stamp[1] = (long long)__builtin_amdgcn_s_memtime();
     E.adjA = sAdjA[vk ? lane : 0];
     E.adjH = sAdjH[vk ? lane : 0];
     E.degA = vk ? sDeg[0][lane] : 0;
@@ -970,6 +1003,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
     }
     const int l1_iters = iter;
     const double l1_score = score;
+    stamp[2] = (long long)__builtin_amdgcn_s_memtime();
     // ---------------- irls (ral/l1_irls.cpp:559-752): wave c solves right-hand side c ------------
     double d = 1.0;
     score = HUGE_VAL;
@@ -1030,6 +1064,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
     }
     if (status) status = IROTAVG_ERR_SOLVER;
     __syncthreads();
+    stamp[3] = (long long)__builtin_amdgcn_s_memtime();
     for (int i = tid; i < nv; i += SM_THREADS) Qg[i] = sQ[i];
     if (wave == 0 && ek) weights[lane] = d;
     // The outputs live in pinned host memory; the sequence number goes out last, after a system-scope fence
@@ -1038,6 +1073,8 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {
+        stamp[4] = (long long)__builtin_amdgcn_s_memtime();
+        for (int q = 0; q < 5; q++) out->stamp[q] = stamp[q];
         out->l1_iters = l1_iters;
         out->irls_iters = iter;
         out->status = status;
@@ -1146,6 +1183,11 @@ int window_solve(WindowSolver &ws, int nv, int f, int ne, const int32_t *I, cons
     }
     WinResult R;
     std::memcpy(&R, ws.host + oR, sizeof(R));
+    static const bool stamps = getenv("IROTAVG_WINDOW_STAMPS") != nullptr;
+    if (stamps && wave)  // s_memtime counts at 100 MHz
+        std::fprintf(stderr, "[window] nv %d f %d ne %d l1 %d irls %d: load+lists %.2f us, l1ra %.2f us, irls %.2f us, store %.2f us\n", nv,
+                     f, ne, R.l1_iters, R.irls_iters, (R.stamp[1] - R.stamp[0]) * 1e-2, (R.stamp[2] - R.stamp[1]) * 1e-2,
+                     (R.stamp[3] - R.stamp[2]) * 1e-2, (R.stamp[4] - R.stamp[3]) * 1e-2);
     std::memcpy(Q_aos, ws.host + oQ, sizeof(double) * 4 * (size_t)nv);
     if (weights) std::memcpy(weights, ws.host + oW, sizeof(double) * (size_t)ne);
     if (l1_iters) *l1_iters = R.l1_iters;

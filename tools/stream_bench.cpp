@@ -132,7 +132,7 @@ int main(int argc, char **argv) {
     }
     std::vector<double> lat_local, lat_global;
     lat_local.reserve((size_t)stream);
-    long long edges_solved = 0;
+    long long edges_solved = 0, l1_sum = 0, irls_sum = 0, win_solved = 0;
     std::vector<irotavg_viewgraph *> batch((size_t)sessions);
     std::vector<irotavg_rotavg_info> infos((size_t)sessions);
     const double t0 = now();
@@ -163,6 +163,11 @@ int main(int argc, char **argv) {
                     return 4;
                 }
                 if (!info.skipped) edges_solved += (long long)info.n_edges * std::max(info.irls_iters, 1);
+                if (!info.skipped && !loop) {
+                    l1_sum += info.l1_iters;
+                    irls_sum += info.irls_iters;
+                    win_solved++;
+                }
             } else {
                 batch[(size_t)nb++] = Z.vg;
             }
@@ -206,9 +211,10 @@ int main(int argc, char **argv) {
                 "\"streamed_views\": %d, \"loop_closures\": %d, \"views_per_s\": %.1f, \"seconds\": %.4f, "
                 "\"warm_build_seconds\": %.3f, \"prepare_seconds\": %.3f, \"local_rotavg_ms_mean\": %.5f, \"local_rotavg_ms_p99\": %.5f, "
                 "\"global_rotavg_ms_mean\": %.3f, \"irls_edge_updates_per_s\": %.1f, \"mean_angular_error_rad\": %.6f, "
-                "\"max_angular_error_rad\": %.6f, \"global_rotavg_ms\": [",
+                "\"max_angular_error_rad\": %.6f, \"window_l1_iters_mean\": %.3f, \"window_irls_iters_mean\": %.3f, \"global_rotavg_ms\": [",
                 sessions, warm, stream, (int)lat_global.size(), (double)stream * sessions / dt, dt, warm_s, prepare_s, 1e3 * mean(lat_local),
-                1e3 * p99, 1e3 * mean(lat_global), (double)edges_solved / dt, err_sum / std::max(err_n, 1), err_max);
+                1e3 * p99, 1e3 * mean(lat_global), (double)edges_solved / dt, err_sum / std::max(err_n, 1), err_max,
+                (double)l1_sum / std::max(win_solved, 1LL), (double)irls_sum / std::max(win_solved, 1LL));
     for (size_t k = 0; k < lat_global.size(); k++) std::printf("%s%.3f", k ? ", " : "", 1e3 * lat_global[k]);
     std::printf("]}\n");
     for (auto &Z : S) irotavg_viewgraph_destroy(Z.vg);
