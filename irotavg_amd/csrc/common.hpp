@@ -64,7 +64,16 @@ struct DevPool {
     // time (every array scales with the views / edges seen so far), and a request one step up would miss every block
     // the previous re-solve released (rot_avg inside the stream: 22 ms against 8 ms at a steady size; hipMalloc of
     // the handle's few hundred buffers). At most 19 % of head-room, on a 288 GB device.
+    // headroom() > 1: requests of this thread are enlarged by that factor first (the handles of a GROWING view-graph,
+    // resident.hip: every global re-solve is a few per cent larger than the last one; with half as much again the
+    // blocks of one solve serve the following ones until the graph has grown by 50 %)
+    static std::atomic<int> &headroom_users() {  // process-wide: l1ra's solver clones allocate on their own threads
+        static std::atomic<int> n{0};
+        return n;
+    }
+    static double headroom() { return headroom_users().load(std::memory_order_relaxed) > 0 ? 1.5 : 1.0; }
     static size_t round_up(size_t bytes) {
+        if (headroom() > 1.0 && bytes >= (64u << 10)) bytes = (size_t)((double)bytes * headroom());
         if (bytes < (64u << 10)) return (bytes + 511) & ~(size_t)511;
         size_t p2 = (size_t)64 << 10;
         while (p2 * 2 <= bytes) p2 *= 2;
@@ -81,7 +90,8 @@ struct DevPool {
         {
             std::lock_guard<std::mutex> lk(mu);
             auto it = cache.lower_bound({dev, bytes});
-            if (it == cache.end() || it->first.first != dev || it->first.second > bytes + bytes / 8 + 4096)
+            if (it == cache.end() || it->first.first != dev ||
+                it->first.second > (headroom() > 1.0 ? 2 * bytes : bytes + bytes / 8 + 4096))
                 return nullptr;
             p = it->second.p;
             *got = it->second.bytes;

@@ -323,7 +323,8 @@ long resident_views(const Resident &r);  // views / edges the device holds
 long resident_edges(const Resident &r);
 ResidentStage resident_stage(Resident &r, long n_views, long view_lo, long n_edges, long edge_lo);
 int resident_rot_avg(Resident &r, long n_views, long view_lo, long n_edges, long edge_lo, int f,
-                     const irotavg_options &opt, irotavg_rotavg_info &loc, bool timing, bool dry = false);
+                     const irotavg_options &opt, irotavg_rotavg_info &loc, bool timing, bool dry = false, int dry_a = -1,
+                     int dry_b = -1);
 
 inline double now_seconds() {
     using namespace std::chrono;

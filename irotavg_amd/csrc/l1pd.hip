@@ -103,11 +103,13 @@ __device__ __forceinline__ void block_sum4_store(double a0, double a1, double a2
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += (long long)gridDim.x * blockDim.x)
 
 // max_k |y - Ax|   (ral/l1_irls.cpp:250-253)
+// (Ax == nullptr: x0 = 0, so Ax = A x0 is the zero vector -- l1ra always starts there, ral/l1_irls.cpp:889-892 -- and the
+// plane is neither cleared nor read: y - 0.0 and the other statements below give the same bits as with a stored zero)
 __global__ __launch_bounds__(kRowBlock) void k_pd_absmax(long long m, const double *__restrict__ y,
                                                       const double *__restrict__ Ax,
                                                       double *__restrict__ part) {
     double v = -HUGE_VAL;
-    EDGE_LOOP(k) v = fmax(v, fabs(y[k] - Ax[k]));
+    EDGE_LOOP(k) v = fmax(v, fabs(y[k] - (Ax ? Ax[k] : 0.0)));
     block_ext_store<true>(v, part + 4 * blockIdx.x);
 }
 
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_init(long long m, const double
                                                     const uint8_t *__restrict__ own) {
     double a0 = 0, a1 = 0, a2 = 0;
     EDGE_LOOP(k) {
-        const double ax = Ax[k], yy = y[k];
+        const double ax = Ax ? Ax[k] : 0.0, yy = y[k];
         const double uu = fabs(yy - ax) * 0.95 + maxabs * 0.10;
         const double g1 = ax - yy - uu, g2 = -ax + yy - uu;
         const double m1 = -(1.0 / g1), m2 = -(1.0 / g2);
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_trial_edge(
     const uint8_t *__restrict__ own) {
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     EDGE_LOOP(k) {
-        const double yy = y[k], u0 = u[k], ax0 = Ax[k], adx = Adx[k], m10 = l1[k], m20 = l2[k];
+        const double yy = y[k], u0 = u[k], ax0 = Ax ? Ax[k] : 0.0, adx = Adx[k], m10 = l1[k], m20 = l2[k];
         const double g10 = ax0 - yy - u0, g20 = -ax0 + yy - u0;
         double d_u, d1, d2;
         pd_direction(adx, g10, g20, m10, m20, itau, d_u, d1, d2);
@@ -469,8 +471,8 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
         Graph &g = *M.g;
         hipStream_t st = g.stream;
         IRH_CHECK(hipMemsetAsync(xv(g), 0, sizeof(double) * (size_t)g.no, st));           // x0 = 0
-        IRH_CHECK(hipMemsetAsync(pl(g, P_AX), 0, sizeof(double) * (size_t)g.mpad, st));    // Ax = A*0
-        hipLaunchKernelGGL(k_pd_absmax, dim3(ge(g)), dim3(kRowBlock), 0, st, (long long)g.m, M.y, pl(g, P_AX),
+        // Ax = A x0 = 0: never stored (the kernels of the first iteration take a null plane for it)
+        hipLaunchKernelGGL(k_pd_absmax, dim3(ge(g)), dim3(kRowBlock), 0, st, (long long)g.m, M.y, (const double *)nullptr,
                            pd_part_slot(g, 0));
         pd_publish(g, {{0, ge(g)}});
     }
@@ -487,7 +489,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
     };
     for (auto &M : G.mem) {
         Graph &g = *M.g;
-        hipLaunchKernelGGL(k_pd_init, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, pl(g, P_AX),
+        hipLaunchKernelGGL(k_pd_init, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, (const double *)nullptr,
                            maxabs, pl(g, P_U), pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), pl(g, P_T1),
                            pd_part_slot(g, 0), M.eown);
     }
@@ -506,6 +508,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
     double res2 = s4[3] + s4[2];
 
     int pditer = 0;
+    bool ax_zero = true;  // Ax of the iterate is still A x0 = 0 (no plane holds it)
     bool done = (sdg < PDTOL) || (pditer >= pdmaxiter);  // :284
     while (!done) {
         pditer++;
@@ -575,7 +578,8 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
                 hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv(g)), dim3(kRowBlock), 0, g.stream, g.no, s, atv(g),
                                    atdv(g), pd_part_slot(g, 0));
                 hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, s,
-                                   itau, pl(g, P_U), pl(g, P_AX), pl(g, P_ADX), pl(g, P_L1), pl(g, P_L2), pl(g, P_U2),
+                                   itau, pl(g, P_U), ax_zero ? (const double *)nullptr : (const double *)pl(g, P_AX), pl(g, P_ADX),
+                                   pl(g, P_L1), pl(g, P_L2), pl(g, P_U2),
                                    pl(g, P_AX2), pl(g, P_L12), pl(g, P_L22), pl(g, P_F12), pl(g, P_F22),
                                    pd_part_slot(g, 1), M.eown);
                 pd_publish(g, {{0, gv(g)}, {1, ge(g)}});
@@ -606,6 +610,7 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
             hipLaunchKernelGGL(k_pd_commit_vert, dim3(gv(g)), dim3(kRowBlock), 0, g.stream, g.no, s_acc, xv(g),
                                g.X.p + g.ng, atv(g), atdv(g));
         }
+        ax_zero = false;
         std::swap(pmap[P_U], pmap[P_U2]);
         std::swap(pmap[P_AX], pmap[P_AX2]);
         std::swap(pmap[P_L1], pmap[P_L12]);

@@ -192,8 +192,11 @@ ResidentStage resident_stage(Resident &r, long n_views, long view_lo, long n_edg
 // f = fixed views (> 0). On success st.Q (n_views x 4, AoS) holds the solved quaternion of every free view.
 // dry: everything runs (allocations, kernels, the solve) but no pose changes, on the device or for the caller -- what
 // irotavg_viewgraph_prepare uses to take the one-time costs of a process out of the first loop closure's latency.
+// A dry run also solves with ONE made-up loop closure (dry_a, dry_b: two free views far apart, identity relative
+// rotation; < 0: none) behind the real records: the closure path of the direct solver (its plan, its kernels) is what
+// the first real call after a loop closure needs, and the graph a caller prepares usually has none yet.
 int resident_rot_avg(Resident &r, long n_views, long view_lo, long n_edges, long edge_lo, int f,
-                     const irotavg_options &opt, irotavg_rotavg_info &loc, bool timing, bool dry) {
+                     const irotavg_options &opt, irotavg_rotavg_info &loc, bool timing, bool dry, int dry_a, int dry_b) {
     if (view_lo > r.n_views || edge_lo > r.n_edges || view_lo < 0 || edge_lo < 0 || f <= 0 || f >= n_views)
         return IROTAVG_ERR_BAD_ARG;
     double tl = now_seconds();
@@ -212,8 +215,8 @@ int resident_rot_avg(Resident &r, long n_views, long view_lo, long n_edges, long
         }
         hipStream_t s = r.stream;
         const size_t nv = (size_t)n_views, ne = (size_t)n_edges;
-        grow_keep(r.I, (size_t)edge_lo, ne, s);
-        grow_keep(r.QQ, (size_t)edge_lo, ne, s);
+        grow_keep(r.I, (size_t)edge_lo, ne + 1, s);
+        grow_keep(r.QQ, (size_t)edge_lo, ne + 1, s);
         grow_keep(r.R, 9 * (size_t)view_lo, 9 * nv, s);
         grow_keep(r.fixed, (size_t)view_lo, nv, s);
         if (r.flag.n < nv + 1) {
@@ -233,6 +236,15 @@ int resident_rot_avg(Resident &r, long n_views, long view_lo, long n_edges, long
         }
         r.n_views = n_views;
         r.n_edges = n_edges;
+        long ne_solve = n_edges;
+        if (dry && dry_a >= 0 && dry_b > dry_a && dry_b < n_views) {  // the made-up closure (never part of the resident records)
+            const int2 e = make_int2(dry_a, dry_b);
+            const double4 q = make_double4(0.0, 0.0, 0.0, 1.0);
+            IRH_CHECK(hipMemcpyAsync(r.I.p + ne, &e, sizeof(e), hipMemcpyHostToDevice, s));
+            IRH_CHECK(hipMemcpyAsync(r.QQ.p + ne, &q, sizeof(q), hipMemcpyHostToDevice, s));
+            IRH_CHECK(hipStreamSynchronize(s));
+            ne_solve = n_edges + 1;
+        }
         // ---- fixed-first relabelling (src/ViewGraph.cpp:1323-1363): a scan over the mask
         hipLaunchKernelGGL(k_res_flags, dim3(grid_of(n_views)), dim3(kT), 0, s, (int)n_views, r.fixed.p, r.flag.p);
         {
@@ -250,7 +262,13 @@ int resident_rot_avg(Resident &r, long n_views, long view_lo, long n_edges, long
         src.I = r.I.p;
         src.QQ = r.QQ.p;
         src.relabel = r.v2i.p;
-        int rc = graph_create_dev(&h, n_edges, n_views, f, src, &opt);
+        // (the handle of a growing graph and everything its solves allocate: blocks half as large again, so that the next
+        // re-solves find them in the pool)
+        struct Headroom {
+            Headroom() { DevPool::headroom_users()++; }
+            ~Headroom() { DevPool::headroom_users()--; }
+        } headroom;
+        int rc = graph_create_dev(&h, ne_solve, n_views, f, src, &opt);
         if (rc != IROTAVG_OK) return rc;
         Graph &g = graph_of(h);
         hipLaunchKernelGGL(k_res_gather, dim3(grid_of(n_views)), dim3(kT), 0, g.stream, (int)n_views, r.R.p, r.v2i.p, g.Q.p);

@@ -298,7 +298,14 @@ bool rotavg_resident(irotavg_viewgraph *vg, irotavg_rotavg_info &loc, bool timin
         // the marks move up BEFORE the call: whatever fails inside invalidates the resident copy as a whole
         vg->res_pose_lo = m;
         vg->res_edge_view = m;
-        *rc = irh::resident_rot_avg(R, m, view_lo, ne, edge_lo, f, vg->opt, loc, timing, dry);
+        int dry_a = -1, dry_b = -1;
+        if (dry) {  // two free views far apart for the dry run's made-up closure
+            for (long x = 0; x < m && dry_a < 0; x++)
+                if (!vg->fixed[(size_t)x]) dry_a = (int)x;
+            for (long x = m - 1; x > dry_a + 1000 && dry_b < 0; x--)
+                if (!vg->fixed[(size_t)x]) dry_b = (int)x;
+        }
+        *rc = irh::resident_rot_avg(R, m, view_lo, ne, edge_lo, f, vg->opt, loc, timing, dry, dry_a, dry_b);
         loc.n_views = (int)m;
         loc.n_edges = (int)ne;
         loc.n_fixed = f;
