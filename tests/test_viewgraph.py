@@ -273,6 +273,29 @@ def test_resident_global_resolves_equal_rebuilt_ones_bit_for_bit(monkeypatch):
             script.append(("avg", 5000000))
         if v == n0 + 151:
             script.append(("avg", 5000000))                        # nothing but one view changed
+    # second phase: the graph grows past the capacity of the resident arrays (half as much again as the first call
+    # needed) and collects 150 loop closures between old views -- more than one LDS system holds, and their records
+    # land all over the resident edge list
+    n1 = n0 + extra
+    more = 3900
+    Qgt2 = rng.normal(size=(more, 4)); Qgt2 /= np.linalg.norm(Qgt2, axis=1, keepdims=True)
+    Qgt = np.concatenate([Qgt, Qgt2])
+    noise = np.concatenate([noise, rng.normal(scale=0.01, size=(8 * more + 400, 3))])
+    for v in range(n1, n1 + more):
+        script.append(("add", v, rot(synth.qmul(synth.qexp(noise[k:k + 1] * 2)[0], Qgt[v])))); k += 1
+        for d in range(1, 5):
+            script.append(("connect", v - d, v, rel(v - d, v, k))); k += 1
+        if v % 20 == 0:
+            script.append(("fix", v, rot(Qgt[v])))
+        if v % 500 == 0:
+            script.append(("avg", 10))
+    cl = rng.integers(0, n1 + more - 200, size=(150, 2))
+    for a, b in cl:
+        a, b = int(min(a, b)), int(max(a, b))
+        if b - a > 100:
+            script.append(("connect", a, b, rel(a, b, k))); k += 1
+    script.append(("avg", 5000000))
+    n_all = n1 + more
     out = {}
     for path in ("resident", "rebuild"):
         if path == "rebuild":
@@ -296,8 +319,9 @@ def test_resident_global_resolves_equal_rebuilt_ones_bit_for_bit(monkeypatch):
                 a = vg.rotAvg(op[1])
                 if op[1] > 10:
                     infos.append((a["skipped"], a["n_views"], a["n_edges"], a["n_fixed"], a["l1_iters"], a["irls_iters"]))
-        out[path] = (infos, np.stack([vg.R(v) for v in range(n0 + extra)]))
-    assert len(out["resident"][0]) == 5 and all(i[0] == 0 for i in out["resident"][0])
+        out[path] = (infos, np.stack([vg.R(v) for v in range(n_all)]))
+    assert len(out["resident"][0]) == 6 and all(i[0] == 0 for i in out["resident"][0])
+    assert out["resident"][0][-1][1] == n_all and out["resident"][0][-1][2] > 4 * n_all + 100
     assert out["resident"][0] == out["rebuild"][0]
     np.testing.assert_array_equal(out["resident"][1], out["rebuild"][1])
     err = synth.angular_distance(np.stack([O.rmat2quat(R) for R in out["resident"][1][::17]]), Qgt[::17])
