@@ -630,6 +630,28 @@ __device__ __forceinline__ double sm_ax(const SmLane &E, double x) {
 // side. Pivot rows stay unscaled (row i -= (h_ik / h_kk) * row k, x_i = b_i / h_ii at the end): one
 // broadcast + one fma per column. A non-positive pivot marks a dead variable (never eliminates,
 // solution 0), like dense_solve above / the oracle's Cholesky. False if a non-finite value appears.
+// NUP: nu rounded up to a multiple of four -- the loops unroll to straight-line code (with nu as a run-time bound every
+// column update sat behind a scalar branch: ~12 clocks per instruction, the solve 30 % of the kernel). Rows and
+// columns nu .. NUP - 1 are zero: their pivots are dead, their multipliers 0.
+template <int NUP>
+__device__ __forceinline__ void sm_solve_t(double (&h)[SM_MAX_NU], double &b, double thr, int lane, double &myip) {
+#pragma unroll
+    for (int k = 0; k < NUP; k++) {
+        // the reciprocal -- the only chain from pivot to pivot -- by v_rcp_f64 + two Newton steps (a third of the IEEE
+        // division's dependent instructions)
+        const double piv = rl_d(h[k], k);
+        double ip = __builtin_amdgcn_rcp(piv);
+        ip = fma(fma(-piv, ip, 1.0), ip, ip);
+        ip = fma(fma(-piv, ip, 1.0), ip, ip);
+        ip = (piv > thr && piv > 0.0) ? ip : 0.0;
+        const bool me = lane == k;
+        if (me) myip = ip;
+        const double mult = me ? 0.0 : -(h[k] * ip);
+#pragma unroll
+        for (int c = k + 1; c < NUP; c++) h[c] = fma(mult, rl_d(h[c], k), h[c]);
+        b = fma(mult, rl_d(b, k), b);
+    }
+}
 __device__ __forceinline__ bool sm_solve(double (&h)[SM_MAX_NU], double &b, int nu, int lane) {
     double myip = 0.0;
     double dg = 0.0;  // own original diagonal entry
@@ -637,21 +659,15 @@ __device__ __forceinline__ bool sm_solve(double (&h)[SM_MAX_NU], double &b, int 
     for (int c = 0; c < SM_MAX_NU; c++)
         if (c == lane) dg = h[c];
     const double thr = kDeadTol * wv_max(lane < nu ? dg : 0.0);  // relative to the largest one
-#pragma unroll
-    for (int k = 0; k < SM_MAX_NU; k++) {
-        if (k < nu) {
-            const double piv = rl_d(h[k], k);
-            const double ip = (piv > thr && piv > 0.0) ? 1.0 / piv : 0.0;
-            const bool me = lane == k;
-            if (me) myip = ip;
-            const double mult = me ? 0.0 : -(h[k] * ip);
-#pragma unroll
-            for (int c = k + 1; c < SM_MAX_NU; c++) {
-                if (c < nu) h[c] = fma(mult, rl_d(h[c], k), h[c]);
-            }
-            b = fma(mult, rl_d(b, k), b);
-        }
-    }
+    if (lane >= nu) b = 0.0;
+    if (nu <= 4)
+        sm_solve_t<4>(h, b, thr, lane, myip);
+    else if (nu <= 8)
+        sm_solve_t<8>(h, b, thr, lane, myip);
+    else if (nu <= 12)
+        sm_solve_t<12>(h, b, thr, lane, myip);
+    else
+        sm_solve_t<16>(h, b, thr, lane, myip);
     b *= myip;
     return __ballot(lane < nu && !isfinite(b)) == 0ull;
 }
@@ -727,7 +743,7 @@ __device__ int sm_l1decode(const SmLane &E, const double y, const int pdmaxiter,
                     } else {
                         hd += s;
                         const int o = (int)((e >> 8) & 255u);
-                        if (o) E.Hrow[o - 1] -= s;
+                        if (o) atomicAdd(&E.Hrow[o - 1], -s);  // ds_add_f64 without return: no read-modify-write round trip per entry; same bits as -= s
                     }
                 }
             }
@@ -1026,7 +1042,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
                 const double s = dk * dk;
                 hd += s;
                 const int o = (int)((e >> 8) & 255u);
-                if (o) E.Hrow[o - 1] -= s;
+                if (o) atomicAdd(&E.Hrow[o - 1], -s);  // ds_add_f64 without return: no read-modify-write round trip per entry; same bits as -= s
                 if (e & ADJ_NEG)
                     b -= s * rk;
                 else
