@@ -609,11 +609,18 @@ struct SmLane {
 // (A' t)_v on lane v: k ascending, +t_k through cj then -t_k through ci (same order as at_dot)
 __device__ __forceinline__ double sm_at(const SmLane &E, double t) {
     double s = 0.0;
-    for (int d = 0; d < E.maxA; d++) {
-        const bool on = d < E.degA;
-        const unsigned e = on ? E.adjA[d] : 0u;
-        const double tk = __shfl(t, (int)(e & 63u), 64);
-        if (on) s += (e & ADJ_NEG) ? -tk : tk;
+    // four entries per step: the list loads and the lane exchanges of a step are independent of each other (one by one
+    // each entry was an LDS load -> ds_bpermute -> add chain); the sum keeps its order
+    for (int d0 = 0; d0 < E.maxA; d0 += 4) {
+        unsigned e[4];
+        double tk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = d0 + u < E.degA ? E.adjA[d0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) tk[u] = __shfl(t, (int)(e[u] & 63u), 64);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (d0 + u < E.degA) s += (e[u] & ADJ_NEG) ? -tk[u] : tk[u];
     }
     return s;
 }
@@ -733,17 +740,24 @@ __device__ int sm_l1decode(const SmLane &E, const double y, const int pdmaxiter,
 #pragma unroll
                 for (int c = 0; c < SM_MAX_NU; c++) E.Hrow[c] = 0.0;
             }
-            for (int d = 0; d < E.maxH; d++) {
-                const bool on = d < E.degH;
-                const unsigned e = on ? E.adjH[d] : 0u;
-                const double s = __shfl(sigx, (int)(e & 63u), 64);
-                if (on) {
-                    if (e & ADJ_SELF) {
-                        hd -= s;
-                    } else {
-                        hd += s;
-                        const int o = (int)((e >> 8) & 255u);
-                        if (o) atomicAdd(&E.Hrow[o - 1], -s);  // ds_add_f64 without return: no read-modify-write round trip per entry; same bits as -= s
+            for (int d0 = 0; d0 < E.maxH; d0 += 4) {  // (four entries per step, as sm_at)
+                unsigned e[4];
+                double sk[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) e[u] = d0 + u < E.degH ? E.adjH[d0 + u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) sk[u] = __shfl(sigx, (int)(e[u] & 63u), 64);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (d0 + u < E.degH) {
+                        const double s = sk[u];
+                        if (e[u] & ADJ_SELF) {
+                            hd -= s;
+                        } else {
+                            hd += s;
+                            const int o = (int)((e[u] >> 8) & 255u);
+                            if (o) atomicAdd(&E.Hrow[o - 1], -s);  // ds_add_f64 without return: no read-modify-write round trip per entry; same bits as -= s
+                        }
                     }
                 }
             }
@@ -983,7 +997,8 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
             const double th = sqrt(x * x + y * y + z * z);
             acc = th;
             if (wave == 0) {
-                const double sn = sin(th / 2.0), cs = cos(th / 2.0);
+                double sn, cs;
+                sincos(th / 2.0, &sn, &cs);  // (one argument reduction for both; k_apply_step of solver.hip does the same)
                 const double coef = sn / th;
                 double4 w = make_double4(x * coef, y * coef, z * coef, cs);
                 if (!isfinite(w.x)) w.x = 0.0;
@@ -1034,19 +1049,28 @@ __global__ __launch_bounds__(SM_THREADS) void k_window_wave(WinParams Pk, const 
 #pragma unroll
             for (int c = 0; c < SM_MAX_NU; c++) E.Hrow[c] = 0.0;
         }
-        for (int q = 0; q < E.maxA; q++) {
-            const bool on = q < E.degA;
-            const unsigned e = on ? E.adjA[q] : 0u;
-            const double dk = __shfl(d, (int)(e & 63u), 64), rk = __shfl(rc, (int)(e & 63u), 64);
-            if (on) {
-                const double s = dk * dk;
-                hd += s;
-                const int o = (int)((e >> 8) & 255u);
-                if (o) atomicAdd(&E.Hrow[o - 1], -s);  // ds_add_f64 without return: no read-modify-write round trip per entry; same bits as -= s
-                if (e & ADJ_NEG)
-                    b -= s * rk;
-                else
-                    b += s * rk;
+        for (int q0 = 0; q0 < E.maxA; q0 += 4) {  // (four entries per step, as sm_at)
+            unsigned e[4];
+            double dk[4], rk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = q0 + u < E.degA ? E.adjA[q0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                dk[u] = __shfl(d, (int)(e[u] & 63u), 64);
+                rk[u] = __shfl(rc, (int)(e[u] & 63u), 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (q0 + u < E.degA) {
+                    const double s = dk[u] * dk[u];
+                    hd += s;
+                    const int o = (int)((e[u] >> 8) & 255u);
+                    if (o) atomicAdd(&E.Hrow[o - 1], -s);  // ds_add_f64 without return: no read-modify-write round trip per entry; same bits as -= s
+                    if (e[u] & ADJ_NEG)
+                        b -= s * rk[u];
+                    else
+                        b += s * rk[u];
+                }
             }
         }
         if (vk) E.Hrow[lane] = hd;
