@@ -100,6 +100,10 @@ struct Graph {
     DevBuf<double> pdn;     // nu-length planes
     DevBuf<double> pd_part; // reduction partials
     bool pd_ready = false;
+    // l1decode -> assemble_values: the operand t of the Hessian system's right-hand side A' t; when the windowed assembly
+    // takes it along (k_assemble0w<2>) it says so in pd_rhs_done and k_pd_rhs is not launched
+    const double *pd_rhs_src = nullptr;
+    bool pd_rhs_done = false;
     // L1RA solves its three coordinates concurrently: three solver clones (own stream, own
     // matrix values / vectors / dense level; static structure aliased from this handle)
     std::vector<std::unique_ptr<Graph>> l1_clones;

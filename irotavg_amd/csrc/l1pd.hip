@@ -528,11 +528,15 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
             {
                 const double keep = g.stale_spread;
                 g.stale_spread = kPdSpread;
+                g.pd_rhs_src = pl(g, P_T2);  // the windowed assembly forms the right-hand side A' t12 in the same walk
+                g.pd_rhs_done = false;
                 assemble(g, 1, pl(g, P_SIGX), g.opt.dense_always_refresh == 1);
+                g.pd_rhs_src = nullptr;
                 g.stale_spread = keep;
             }
-            hipLaunchKernelGGL(k_pd_rhs, dim3(gr(g)), dim3(kRowBlock), 0, st, g.no, L0.nsl, L0.sl_off.p,
-                               g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, P_T2), L0.b.p);
+            if (!g.pd_rhs_done)
+                hipLaunchKernelGGL(k_pd_rhs, dim3(gr(g)), dim3(kRowBlock), 0, st, g.no, L0.nsl, L0.sl_off.p,
+                                   g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, P_T2), L0.b.p);
         }
         // the primal-dual Hessians (weights 1/f^2 spread over decades) want less over-correction than
         // the IRLS systems of a band graph: 1.6 measured best on both topologies

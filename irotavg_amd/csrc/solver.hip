@@ -334,6 +334,9 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0(
 constexpr int kAsmWin = 1664;  // edges staged per slice: (64 + 19) * 19 = 1577 at 100k views / 2M edges
 constexpr int kAsmCW = 8;      // level-1 entries per row handled in the fused form
 
+// MODE 2 (round 4): MODE 1 -- the primal-dual Hessian from wsrc = sigx under make_AtA's boundary rule -- AND the
+// right-hand side of its system in the same walk over the slice's entries: rhs_v = (A' t)_v with make_A's coefficients,
+// t = the plane `er` points to (k_pd_rhs's walk of the same slots, a launch and 16 MB of slot ids per solve, until then).
 template <int MODE, bool L1>
 __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
     int n, int nsl, long long m, long long mpad, const int *__restrict__ sl_off,
@@ -344,8 +347,8 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
     double *__restrict__ idg, double4 *__restrict__ rhs, double *__restrict__ bval, int n1,
     const int *__restrict__ sl_off1, double *__restrict__ val1, double *__restrict__ excess1,
     double *__restrict__ diag1, double *__restrict__ idg1) {
-    __shared__ double sT[MODE == 0 ? 4 : 1][kAsmWin];
-    __shared__ double part[MODE == 0 ? 4 : 1][4][64];
+    __shared__ double sT[MODE == 0 ? 4 : (MODE == 2 ? 2 : 1)][kAsmWin];
+    __shared__ double part[MODE == 0 ? 4 : (MODE == 2 ? 2 : 1)][4][64];
     __shared__ double acc1[L1 ? 4 : 1][L1 ? kAsmCW : 1][64];
     __shared__ double sEx[64];
     const int nb = gridDim.x, b = blockIdx.x;  // nb is a multiple of 8: neighbouring slices share an XCD (L2)
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
                     ry[it] = er[mpad + e];
                     rz[it] = er[2 * mpad + e];
                 }
+                if (MODE == 2) rx[it] = er[e];
             }
         }
 #pragma unroll
@@ -402,6 +406,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
                     sT[2][q] = w * ry[it];
                     sT[3][q] = w * rz[it];
                 }
+                if (MODE == 2) sT[1][q] = rx[it];
             }
         }
     }
@@ -419,6 +424,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
                 y = sT[2][q];
                 z = sT[3][q];
             }
+            if (MODE == 2) x = sT[1][q];
         } else {
             w = wsrc[e];
             if (MODE == 0) {
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
                 y = w * er[mpad + e];
                 z = w * er[2 * mpad + e];
             }
+            if (MODE == 2) x = er[e];
         }
     };
     double sw = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
@@ -448,6 +455,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
                     b1 += sg * y;
                     b2 += sg * z;
                 }
+                if (MODE == 2) b0 += (s & 1u) ? x : -x;
                 sw += w;
                 wv[h] = w;
                 if (L1) {
@@ -464,6 +472,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
         part[2][wave][lane] = b1;
         part[3][wave][lane] = b2;
     }
+    if (MODE == 2) part[1][wave][lane] = b0;
     __syncthreads();
     if (wave == 0) {
         double ex = 0.0;
@@ -474,8 +483,15 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
                 b1 = ((part[2][0][lane] + part[2][1][lane]) + part[2][2][lane]) + part[2][3][lane];
                 b2 = ((part[3][0][lane] + part[3][1][lane]) + part[3][2][lane]) + part[3][3][lane];
             }
+            if (MODE == 2) b0 = ((part[1][0][lane] + part[1][1][lane]) + part[1][2][lane]) + part[1][3][lane];
             for (int s = bptr[row]; s < bptr[row + 1]; s++) {
                 const uint8_t fl = bflag[s];
+                if (MODE == 2 && (fl & BF_IRLS) && !(fl & BF_L1H)) {  // (cannot happen: every make_A coefficient is one of make_AtA's)
+                    double wk, x = 0.0, y = 0.0, z = 0.0;
+                    const uint32_t se = beid[s];
+                    fetch(se >> 1, wk, x, y, z);
+                    b0 += (se & 1u) ? x : -x;
+                }
                 if (!(fl & (MODE == 0 ? BF_IRLS : BF_L1H))) {
                     bval[s] = 0.0;
                     continue;
@@ -483,6 +499,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
                 const uint32_t se = beid[s];
                 double wk, x = 0.0, y = 0.0, z = 0.0;
                 fetch(se >> 1, wk, x, y, z);
+                if (MODE == 2 && (fl & BF_IRLS)) b0 += (se & 1u) ? x : -x;  // make_A kept this coefficient: part of A' t
                 if (MODE == 0) {
                     const double sg = (se & 1u) ? 1.0 : -1.0;
                     b0 += sg * x;
@@ -499,6 +516,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
             diag[row] = d;
             idg[row] = d > 0.0 ? 1.0 / d : 0.0;
             if (MODE == 0) rhs[row] = make_double4(b0, b1, b2, 0.0);
+            if (MODE == 2) rhs[row] = make_double4(b0, 0.0, 0.0, 0.0);
         }
         if (L1) sEx[lane] = ex;
     }
@@ -1752,7 +1770,14 @@ void assemble_values(Graph &g, int mode, const double *wsrc) {
             hipLaunchKernelGGL((k_assemble0w<0, false>), dim3(gw), dim3(kRowBlock), 0, g.stream, IRH_ASM_ARGS);
         else if (l1)
             hipLaunchKernelGGL((k_assemble0w<1, true>), dim3(gw), dim3(kRowBlock), 0, g.stream, IRH_ASM_ARGS);
-        else
+        else if (g.pd_rhs_src) {
+            // the primal-dual Hessian and the right-hand side of its system in one walk (MODE 2): t instead of the residuals
+            const double *er_keep = g.er.p;
+            g.er.p = const_cast<double *>(g.pd_rhs_src);
+            hipLaunchKernelGGL((k_assemble0w<2, false>), dim3(gw), dim3(kRowBlock), 0, g.stream, IRH_ASM_ARGS);
+            g.er.p = const_cast<double *>(er_keep);
+            g.pd_rhs_done = true;
+        } else
             hipLaunchKernelGGL((k_assemble0w<1, false>), dim3(gw), dim3(kRowBlock), 0, g.stream, IRH_ASM_ARGS);
 #undef IRH_ASM_ARGS
         if (l1) first_coarse = 2;

@@ -1,14 +1,21 @@
 set -u
+# The round's judged numbers in one go (GPU box, from the repo root): the default bench line with its own rocprofv3 passes
+# (kernel trace + FETCH_SIZE + WRITE_SIZE, gpurun_out/bench_profile/), the other sizes, l1ra under the kernel trace, config 5.
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/final
-timeout 300 python bench.py > gpurun_out/final/bench_final.json 2> gpurun_out/final/bench_final.err
-timeout 1500 bash tools/profile_counters.sh gpurun_out/final/prof > gpurun_out/final/prof.log 2>&1
-timeout 300 python bench.py --views 1000000 --edges 20000000 --steps 5 --warmup 1 --ramp 5 > gpurun_out/final/bench_1M20M.json 2> gpurun_out/final/bench_1M20M.err
-timeout 200 python bench.py --views 10000 --edges 150000 > gpurun_out/final/bench_10k150k.json 2> gpurun_out/final/bench_10k.err
-timeout 200 python bench.py --views 10000 --edges 150000 --p-loop 0.02 > gpurun_out/final/bench_10k150k_loop02.json 2>> gpurun_out/final/bench_10k.err
+OUT=gpurun_out/final
+mkdir -p $OUT
+timeout 900 python bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err
+cp -r gpurun_out/bench_profile $OUT/bench_profile 2>/dev/null
+timeout 400 python bench.py --views 1000000 --edges 20000000 --steps 20 --warmup 2 --ramp 5 --no-pmc > $OUT/bench_1M20M.json 2> $OUT/bench_1M20M.err
+timeout 300 python bench.py --views 10000 --edges 150000 --no-pmc > $OUT/bench_10k150k.json 2> $OUT/bench_10k.err
+timeout 300 python bench.py --views 10000 --edges 150000 --p-loop 0.02 --steps 50 --no-pmc > $OUT/bench_10k150k_loop02.json 2>> $OUT/bench_10k.err
+timeout 600 python bench.py --p-loop 0.02 --steps 20 > $OUT/bench_loop02.json 2> $OUT/bench_loop02.err
+cp -r gpurun_out/bench_profile $OUT/bench_profile_loop02 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/l1band -o l -- python $GRAFT_REPO_ROOT/tools/prof_case.py --what l1ra --reps 7 > $GRAFT_REPO_ROOT/gpurun_out/final/l1band.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/l1band -o l -- python $GRAFT_REPO_ROOT/tools/prof_case.py --what l1ra --reps 7 > $GRAFT_REPO_ROOT/$OUT/l1band.log 2>&1
 cd $GRAFT_REPO_ROOT
-timeout 300 irotavg_amd/bin/stream_bench 50000 50000 10 0 1 > gpurun_out/final/stream_c4.json 2> gpurun_out/final/stream.err
-timeout 200 python tools/time_global_resolve.py > gpurun_out/final/global_resolve.log 2>&1
-ls -la gpurun_out/final
+for rep in 1 2 3; do timeout 300 irotavg_amd/bin/stream_bench 50000 50000 10 0 1 1; done > $OUT/stream_c4.json 2> $OUT/stream.err
+timeout 300 irotavg_amd/bin/stream_bench 50000 50000 10 0 1 0 > $OUT/stream_c4_no_prepare.json 2>> $OUT/stream.err
+for s in 1 8 64; do timeout 300 irotavg_amd/bin/stream_bench 5000 5000 0 0 $s 0 | cut -c1-700; done > $OUT/stream_sessions.jsonl 2>> $OUT/stream.err
+timeout 200 python tools/time_global_resolve.py > $OUT/global_resolve.log 2>&1
+ls -la $OUT
