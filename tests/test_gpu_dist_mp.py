@@ -61,7 +61,7 @@ def test_bench_runs_with_two_ranks():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MASTER_ADDR"] = "127.0.0.1"
     env["IROTAVG_BENCH_SHARE_GPU"] = "1"
-    common = ["--views", "20000", "--edges", "300000", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extra"]
+    common = ["--views", "20000", "--edges", "300000", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extra", "--no-pmc"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
            "--gpus", "2"] + common
