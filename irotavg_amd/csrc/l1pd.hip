@@ -99,8 +99,14 @@ __device__ __forceinline__ void block_sum4_store(double a0, double a1, double a2
     __syncthreads();
 }
 
-#define EDGE_LOOP(k) \
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += (long long)gridDim.x * blockDim.x)
+// The edge kernels of the primal-dual iteration take TWO edges per thread (round 4: every plane moves as 16 B per lane,
+// as in K1; with one edge and 8-byte loads they ran at 0.4 of the HBM rate where K1 reaches 0.77). Planes are padded to
+// mpad (a multiple of 64), so the pair of the last edge of an odd m lies inside every plane; its values are never summed
+// and what is stored there is never read as an edge.
+#define EDGE_LOOP2(k) \
+    for (long long k = 2 * ((long long)blockIdx.x * blockDim.x + threadIdx.x); k < m; k += 2 * (long long)gridDim.x * blockDim.x)
+__device__ __forceinline__ double2 ld2(const double *p, long long k) { return *reinterpret_cast<const double2 *>(p + k); }
+__device__ __forceinline__ void st2(double *p, long long k, double a, double b) { *reinterpret_cast<double2 *>(p + k) = make_double2(a, b); }
 
 // max_k |y - Ax|   (ral/l1_irls.cpp:250-253)
 // (Ax == nullptr: x0 = 0, so Ax = A x0 is the zero vector -- l1ra always starts there, ral/l1_irls.cpp:889-892 -- and the
@@ -109,7 +115,11 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_absmax(long long m, const doub
                                                       const double *__restrict__ Ax,
                                                       double *__restrict__ part) {
     double v = -HUGE_VAL;
-    EDGE_LOOP(k) v = fmax(v, fabs(y[k] - (Ax ? Ax[k] : 0.0)));
+    EDGE_LOOP2(k) {
+        const double2 yy = ld2(y, k), ax = Ax ? ld2(Ax, k) : make_double2(0.0, 0.0);
+        v = fmax(v, fabs(yy.x - ax.x));
+        if (k + 1 < m) v = fmax(v, fabs(yy.y - ax.y));
+    }
     block_ext_store<true>(v, part + 4 * blockIdx.x);
 }
 
@@ -122,22 +132,33 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_init(long long m, const double
                                                     double *__restrict__ part,
                                                     const uint8_t *__restrict__ own) {
     double a0 = 0, a1 = 0, a2 = 0;
-    EDGE_LOOP(k) {
-        const double ax = Ax ? Ax[k] : 0.0, yy = y[k];
-        const double uu = fabs(yy - ax) * 0.95 + maxabs * 0.10;
-        const double g1 = ax - yy - uu, g2 = -ax + yy - uu;
-        const double m1 = -(1.0 / g1), m2 = -(1.0 / g2);
-        u[k] = uu;
-        f1[k] = g1;
-        f2[k] = g2;
-        l1[k] = m1;
-        l2[k] = m2;
-        t[k] = m1 - m2;
-        if (own != nullptr && !own[k]) continue;  // sharded: a cross-shard edge is summed by one shard only
-        a0 += g1 * m1;
-        a1 += g2 * m2;
-        const double rd = 1.0 - m1 - m2;
-        a2 += rd * rd;
+    EDGE_LOOP2(k) {
+        const double2 y2 = ld2(y, k), ax2 = Ax ? ld2(Ax, k) : make_double2(0.0, 0.0);
+        double uu[2], g1[2], g2[2], m1[2], m2[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const double ax = h ? ax2.y : ax2.x, yy = h ? y2.y : y2.x;
+            uu[h] = fabs(yy - ax) * 0.95 + maxabs * 0.10;
+            g1[h] = ax - yy - uu[h];
+            g2[h] = -ax + yy - uu[h];
+            m1[h] = -(1.0 / g1[h]);
+            m2[h] = -(1.0 / g2[h]);
+        }
+        st2(u, k, uu[0], uu[1]);
+        st2(f1, k, g1[0], g1[1]);
+        st2(f2, k, g2[0], g2[1]);
+        st2(l1, k, m1[0], m1[1]);
+        st2(l2, k, m2[0], m2[1]);
+        st2(t, k, m1[0] - m2[0], m1[1] - m2[1]);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (k + h >= m) continue;
+            if (own != nullptr && !own[k + h]) continue;  // sharded: a cross-shard edge is summed by one shard only
+            a0 += g1[h] * m1[h];
+            a1 += g2[h] * m2[h];
+            const double rd = 1.0 - m1[h] - m2[h];
+            a2 += rd * rd;
+        }
     }
     block_sum3_store(a0, a1, a2, part + 4 * blockIdx.x);
 }
@@ -155,19 +176,27 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_sig(long long m, const double 
                                                    double *__restrict__ part, const uint8_t *__restrict__ own) {
     double a0 = 0;
     const double c1 = -itau, c2 = -1.0;
-    EDGE_LOOP(k) {
-        const double g1 = f1[k], g2 = f2[k], m1 = l1[k], m2 = l2[k];
-        const double if1 = 1.0 / g1, if2 = 1.0 / g2;
-        const double w2 = -1 - itau * (if1 + if2);
-        const double a = m1 / g1, b = m2 / g2;
-        const double s1 = -a - b, s2 = a - b;
-        sigx[k] = s1 - (s2 * s2) / s1;
-        const double t1 = -if1 + if2;
-        const double t2 = (s2 / s1) * w2;
-        t12[k] = c1 * t1 + c2 * t2;
-        if (own != nullptr && !own[k]) continue;  // sharded: a cross-shard edge is summed by one shard only
-        const double r1 = -m1 * g1 - itau, r2 = -m2 * g2 - itau;
-        a0 += r1 * r1 + r2 * r2;
+    EDGE_LOOP2(k) {
+        const double2 g1v = ld2(f1, k), g2v = ld2(f2, k), m1v = ld2(l1, k), m2v = ld2(l2, k);
+        double sx[2], tt[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const double g1 = h ? g1v.y : g1v.x, g2 = h ? g2v.y : g2v.x, m1 = h ? m1v.y : m1v.x, m2 = h ? m2v.y : m2v.x;
+            const double if1 = 1.0 / g1, if2 = 1.0 / g2;
+            const double w2 = -1 - itau * (if1 + if2);
+            const double a = m1 / g1, b = m2 / g2;
+            const double s1 = -a - b, s2 = a - b;
+            sx[h] = s1 - (s2 * s2) / s1;
+            const double t1 = -if1 + if2;
+            const double t2 = (s2 / s1) * w2;
+            tt[h] = c1 * t1 + c2 * t2;
+            if (k + h >= m) continue;
+            if (own != nullptr && !own[k + h]) continue;  // sharded: a cross-shard edge is summed by one shard only
+            const double r1 = -m1 * g1 - itau, r2 = -m2 * g2 - itau;
+            a0 += r1 * r1 + r2 * r2;
+        }
+        st2(sigx, k, sx[0], sx[1]);
+        st2(t12, k, tt[0], tt[1]);
     }
     block_sum3_store(a0, 0.0, 0.0, part + 4 * blockIdx.x);
 }
@@ -276,30 +305,41 @@ __device__ __forceinline__ void pd_direction(double adx, double g1, double g2, d
     d2 -= itau * if2;
 }
 
-// :324-381 -- Adx, the operand of A' (Atdv), and the four guarded step bounds
+// :324-381 -- Adx, the operand of A' (Atdv), and the four guarded step bounds. (The make_A coefficients of an edge follow
+// from its endpoints and f -- the rule of the builds, build.cpp / gbuild.hip -- so the flag byte is not read.)
 __global__ __launch_bounds__(kRowBlock) void k_pd_dir(
     long long m, int f, const int *__restrict__ ei, const int *__restrict__ ej,
     const uint8_t *__restrict__ eflag, const double4 *__restrict__ DX,
     const double *__restrict__ f1, const double *__restrict__ f2, const double *__restrict__ l1,
     const double *__restrict__ l2, double itau, double *__restrict__ Adx, double *__restrict__ t3,
     double *__restrict__ part) {
+    (void)eflag;
     double smin = HUGE_VAL;
-    EDGE_LOOP(k) {
-        const uint8_t fl = eflag[k];
-        double adx = 0.0;
-        if (fl & EF_CJ) adx += DX[ej[k] - f].x;
-        if (fl & EF_CI) adx -= DX[ei[k] - f].x;
-        const double g1 = f1[k], g2 = f2[k], m1 = l1[k], m2 = l2[k];
-        double d_u, d1, d2;
-        pd_direction(adx, g1, g2, m1, m2, itau, d_u, d1, d2);
-        Adx[k] = adx;
-        t3[k] = d1 - d2;
-        if (d1 < 0) smin = fmin(smin, -m1 / d1);
-        if (d2 < 0) smin = fmin(smin, -m2 / d2);
-        const double p = adx - d_u;
-        if (p > 0) smin = fmin(smin, -g1 / p);
-        const double q = -adx - d_u;
-        if (q > 0) smin = fmin(smin, -g2 / q);
+    EDGE_LOOP2(k) {
+        const int2 ii = *reinterpret_cast<const int2 *>(ei + k), jj = *reinterpret_cast<const int2 *>(ej + k);
+        const double2 g1v = ld2(f1, k), g2v = ld2(f2, k), m1v = ld2(l1, k), m2v = ld2(l2, k);
+        double ad[2], tt[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int i = h ? ii.y : ii.x, j = h ? jj.y : jj.x;
+            double adx = 0.0;
+            if (j >= f && i != j) adx += DX[j - f].x;   // EF_CJ
+            if (j >= f && i >= f) adx -= DX[i - f].x;   // EF_CI
+            const double g1 = h ? g1v.y : g1v.x, g2 = h ? g2v.y : g2v.x, m1 = h ? m1v.y : m1v.x, m2 = h ? m2v.y : m2v.x;
+            double d_u, d1, d2;
+            pd_direction(adx, g1, g2, m1, m2, itau, d_u, d1, d2);
+            ad[h] = adx;
+            tt[h] = d1 - d2;
+            if (k + h >= m) continue;
+            if (d1 < 0) smin = fmin(smin, -m1 / d1);
+            if (d2 < 0) smin = fmin(smin, -m2 / d2);
+            const double p = adx - d_u;
+            if (p > 0) smin = fmin(smin, -g1 / p);
+            const double q = -adx - d_u;
+            if (q > 0) smin = fmin(smin, -g2 / q);
+        }
+        st2(Adx, k, ad[0], ad[1]);
+        st2(t3, k, tt[0], tt[1]);
     }
     block_ext_store<false>(smin, part + 4 * blockIdx.x);
 }
@@ -315,28 +355,38 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_trial_edge(
     double *__restrict__ l22, double *__restrict__ f12, double *__restrict__ f22, double *__restrict__ part,
     const uint8_t *__restrict__ own) {
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    EDGE_LOOP(k) {
-        const double yy = y[k], u0 = u[k], ax0 = Ax ? Ax[k] : 0.0, adx = Adx[k], m10 = l1[k], m20 = l2[k];
-        const double g10 = ax0 - yy - u0, g20 = -ax0 + yy - u0;
-        double d_u, d1, d2;
-        pd_direction(adx, g10, g20, m10, m20, itau, d_u, d1, d2);
-        const double up = u0 + s * d_u;
-        const double axp = ax0 + s * adx;
-        const double m1 = m10 + s * d1, m2 = m20 + s * d2;
-        const double g1 = axp - yy - up, g2 = -axp + yy - up;
-        u2[k] = up;
-        Ax2[k] = axp;
-        l12[k] = m1;
-        l22[k] = m2;
-        f12[k] = g1;
-        f22[k] = g2;
-        if (own != nullptr && !own[k]) continue;
-        const double r = 1.0 + (-m1 - m2);
-        a0 += r * r;
-        const double c1 = -m1 * g1 - itau, c2 = -m2 * g2 - itau;
-        a1 += c1 * c1 + c2 * c2;
-        a2 += g1 * m1;
-        a3 += g2 * m2;
+    EDGE_LOOP2(k) {
+        const double2 yv = ld2(y, k), uv = ld2(u, k), axv = Ax ? ld2(Ax, k) : make_double2(0.0, 0.0), adv = ld2(Adx, k),
+                      m1v = ld2(l1, k), m2v = ld2(l2, k);
+        double up[2], axp[2], m1[2], m2[2], g1[2], g2[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const double yy = h ? yv.y : yv.x, u0 = h ? uv.y : uv.x, ax0 = h ? axv.y : axv.x, adx = h ? adv.y : adv.x,
+                         m10 = h ? m1v.y : m1v.x, m20 = h ? m2v.y : m2v.x;
+            const double g10 = ax0 - yy - u0, g20 = -ax0 + yy - u0;
+            double d_u, d1, d2;
+            pd_direction(adx, g10, g20, m10, m20, itau, d_u, d1, d2);
+            up[h] = u0 + s * d_u;
+            axp[h] = ax0 + s * adx;
+            m1[h] = m10 + s * d1;
+            m2[h] = m20 + s * d2;
+            g1[h] = axp[h] - yy - up[h];
+            g2[h] = -axp[h] + yy - up[h];
+            if (k + h >= m) continue;
+            if (own != nullptr && !own[k + h]) continue;
+            const double r = 1.0 + (-m1[h] - m2[h]);
+            a0 += r * r;
+            const double c1 = -m1[h] * g1[h] - itau, c2 = -m2[h] * g2[h] - itau;
+            a1 += c1 * c1 + c2 * c2;
+            a2 += g1[h] * m1[h];
+            a3 += g2[h] * m2[h];
+        }
+        st2(u2, k, up[0], up[1]);
+        st2(Ax2, k, axp[0], axp[1]);
+        st2(l12, k, m1[0], m1[1]);
+        st2(l22, k, m2[0], m2[1]);
+        st2(f12, k, g1[0], g1[1]);
+        st2(f22, k, g2[0], g2[1]);
     }
     block_sum4_store(a0, a1, a2, a3, part + 4 * blockIdx.x);
 }
@@ -373,8 +423,8 @@ __global__ __launch_bounds__(kRowBlock) void k_pack3(int n, const double *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-static int grid_edges(long long m) {
-    long long gsz = std::min<long long>((m + kRowBlock - 1) / kRowBlock, kMaxParts);
+static int grid_edges(long long m) {  // (two edges per thread)
+    long long gsz = std::min<long long>(((m + 1) / 2 + kRowBlock - 1) / kRowBlock, kMaxParts);
     if (gsz >= 8) gsz &= ~7ll;
     return (int)std::max<long long>(gsz, 1);
 }
