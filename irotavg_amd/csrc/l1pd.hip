@@ -271,6 +271,70 @@ __global__ __launch_bounds__(kRowBlock) void k_at_mul(int n, int nsl, const int 
     block_sum3_store(acc, 0.0, 0.0, part + 4 * blockIdx.x);
 }
 
+// The same product with the entries of a slice dealt to the FOUR waves of the workgroup (round 4). k_at_mul keeps one
+// lane per row and walks its ~40 entries in batches of eight behind dependent loads (slot id -> edge value): with ~390
+// workgroups that is six waves per CU and five serial round trips of ~2 us, 41 us under l1ra's three chains for 32 MB.
+// Here wave w takes the entry pairs w, w + 4, ... of every row of the slice -- all its slot ids are requested at once, then
+// all its edge values --, the four partial sums meet in LDS ((p0 + p1) + p2) + p3, then the boundary slots. A workgroup
+// walks a contiguous range of slices (at most kMaxParts workgroups: one partial row each for the sum of squares). The
+// order of the sum differs from at_row's; it is fixed.
+__global__ __launch_bounds__(kRowBlock) void k_at_mul4(int n, int nsl, const int *__restrict__ sl_off,
+                                                       const uint32_t *__restrict__ slot_eid,
+                                                       const int *__restrict__ bptr,
+                                                       const uint32_t *__restrict__ beid,
+                                                       const uint8_t *__restrict__ bflag,
+                                                       const double *__restrict__ t,
+                                                       double *__restrict__ out,
+                                                       double *__restrict__ part) {
+    __shared__ double sp4[4][64];
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int s0, s1;
+    tile_range(nsl, s0, s1);
+    double acc = 0.0;
+    for (int sl = s0; sl < s1; sl++) {
+        const int row = sl * 64 + lane;
+        const int o0 = sl_off[sl], np = (sl_off[sl + 1] - o0) / 2;
+        const v2u *__restrict__ sp = reinterpret_cast<const v2u *>(slot_eid) + (size_t)(o0 / 2) * 64 + lane;
+        double s = 0.0;
+        constexpr int PB = 6;  // pairs of this wave per batch (rows of up to 48 entries in one batch)
+        for (int p0 = wave; p0 < np; p0 += 4 * PB) {
+            v2u se[PB];
+            double v[2 * PB];
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int p = p0 + 4 * u;
+                se[u] = p < np ? sp[(size_t)p * 64] : v2u{0xffffffffu, 0xffffffffu};
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * PB; u++) {
+                const unsigned e = (u & 1) ? se[u >> 1].y : se[u >> 1].x;
+                const bool ok = e != 0xffffffffu;
+                double x = t[ok ? (size_t)(e >> 1) : 0];
+                x = (e & 1u) ? x : -x;
+                v[u] = ok ? x : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * PB; u++) s += v[u];
+        }
+        sp4[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && row < n) {
+            double tot = ((sp4[0][lane] + sp4[1][lane]) + sp4[2][lane]) + sp4[3][lane];
+            for (int q = bptr[row]; q < bptr[row + 1]; q++) {
+                if (!(bflag[q] & BF_IRLS)) continue;
+                const uint32_t se = beid[q];
+                const double x = t[se >> 1];
+                tot += (se & 1u) ? x : -x;
+            }
+            out[row] = tot;
+            acc += tot * tot;
+        }
+        __syncthreads();
+    }
+    block_sum3_store(acc, 0.0, 0.0, part + 4 * blockIdx.x);
+}
+
 // rhs = w1p = -(1/tau) A' t1 - A' t2 = A' t12  (:300-306; t12 from k_pd_sig), stored in component 0 of the solver's rhs
 __global__ __launch_bounds__(kRowBlock) void k_pd_rhs(int n, int nsl, const int *__restrict__ sl_off,
                                                       const uint32_t *__restrict__ slot_eid,
@@ -528,13 +592,25 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
     }
     sync_all();
     const double maxabs = ext_members(0, ge, true);
+    static const bool at_classic = getenv("IROTAVG_AT_MUL_CLASSIC") != nullptr;  // A/B: one lane per row (k_at_mul)
+    auto gr4 = [](Graph &g) {  // k_at_mul4: a workgroup per slice, at most kMaxParts of them
+        long long gsz = std::min<long long>(g.levels[0].nsl, kMaxParts);
+        if (gsz >= 8) gsz &= ~7ll;
+        return (int)std::max<long long>(gsz, 1);
+    };
+    auto gat = [&](Graph &g) { return at_classic ? gr(g) : gr4(g); };  // partial rows of the A' t product
     auto at_mul = [&](int tplane, bool into_atdv, int slot) {
         for (auto &M : G.mem) {
             Graph &g = *M.g;
             Level &L0 = g.levels[0];
-            hipLaunchKernelGGL(k_at_mul, dim3(gr(g)), dim3(kRowBlock), 0, g.stream, g.no, L0.nsl, L0.sl_off.p,
-                               g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, tplane),
-                               into_atdv ? atdv(g) : atv(g), pd_part_slot(g, slot));
+            if (at_classic)
+                hipLaunchKernelGGL(k_at_mul, dim3(gr(g)), dim3(kRowBlock), 0, g.stream, g.no, L0.nsl, L0.sl_off.p,
+                                   g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, tplane),
+                                   into_atdv ? atdv(g) : atv(g), pd_part_slot(g, slot));
+            else
+                hipLaunchKernelGGL(k_at_mul4, dim3(gr4(g)), dim3(kRowBlock), 0, g.stream, g.no, L0.nsl, L0.sl_off.p,
+                                   g.slot_eid.p, g.bptr.p, g.beid.p, g.bflag.p, pl(g, tplane),
+                                   into_atdv ? atdv(g) : atv(g), pd_part_slot(g, slot));
         }
     };
     for (auto &M : G.mem) {
@@ -544,11 +620,11 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
                            pd_part_slot(g, 0), M.eown);
     }
     at_mul(P_T1, false, 1);  // Atv = A'(lamu1 - lamu2) (:262) and its sum of squares
-    for (auto &M : G.mem) pd_publish(*M.g, {{0, ge(*M.g)}, {1, gr(*M.g)}});
+    for (auto &M : G.mem) pd_publish(*M.g, {{0, ge(*M.g)}, {1, gat(*M.g)}});
     sync_all();
     double s4[4], v4[4];
     sum_members(0, ge, s4);
-    sum_members(1, gr, v4);
+    sum_members(1, gat, v4);
     s4[3] = v4[0];
     if (G.combine) G.combine(s4, 4, 0);
     double sdg = -(s4[0] + s4[1]);      // :264
