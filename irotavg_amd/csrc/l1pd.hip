@@ -417,7 +417,18 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_trial_edge(
     const double *__restrict__ Ax, const double *__restrict__ Adx, const double *__restrict__ l1,
     const double *__restrict__ l2, double *__restrict__ u2, double *__restrict__ Ax2, double *__restrict__ l12,
     double *__restrict__ l22, double *__restrict__ f12, double *__restrict__ f22, double *__restrict__ part,
-    const uint8_t *__restrict__ own) {
+    const uint8_t *__restrict__ own, int nv, const double *__restrict__ Atv, const double *__restrict__ Atdv,
+    double *__restrict__ part_v) {
+    // the views' share of the trial residual (:407-410: |Atv + s Atdv|^2) rides along -- a launch of its own
+    // (k_pd_trial_vert, 9 us for 100k views) until round 4; its partial rows keep their slot and their order
+    if (part_v != nullptr) {
+        double b0 = 0;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+            const double v = Atv[i] + s * Atdv[i];
+            b0 += v * v;
+        }
+        block_sum3_store(b0, 0.0, 0.0, part_v + 4 * blockIdx.x);
+    }
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     EDGE_LOOP2(k) {
         const double2 yv = ld2(y, k), uv = ld2(u, k), axv = Ax ? ld2(Ax, k) : make_double2(0.0, 0.0), adv = ld2(Adx, k),
@@ -453,18 +464,6 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_trial_edge(
         st2(f22, k, g2[0], g2[1]);
     }
     block_sum4_store(a0, a1, a2, a3, part + 4 * blockIdx.x);
-}
-
-__global__ __launch_bounds__(kRowBlock) void k_pd_trial_vert(int n, double s,
-                                                          const double *__restrict__ Atv,
-                                                          const double *__restrict__ Atdv,
-                                                          double *__restrict__ part) {
-    double a0 = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double v = Atv[i] + s * Atdv[i];
-        a0 += v * v;
-    }
-    block_sum3_store(a0, 0.0, 0.0, part + 4 * blockIdx.x);
 }
 
 // accept the trial point (:432-442): the views (the edges were stored by the trial kernel)
@@ -705,18 +704,16 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
         while (!suffdec) {
             for (auto &M : G.mem) {
                 Graph &g = *M.g;
-                hipLaunchKernelGGL(k_pd_trial_vert, dim3(gv(g)), dim3(kRowBlock), 0, g.stream, g.no, s, atv(g),
-                                   atdv(g), pd_part_slot(g, 0));
                 hipLaunchKernelGGL(k_pd_trial_edge, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, M.y, s,
                                    itau, pl(g, P_U), ax_zero ? (const double *)nullptr : (const double *)pl(g, P_AX), pl(g, P_ADX),
                                    pl(g, P_L1), pl(g, P_L2), pl(g, P_U2),
                                    pl(g, P_AX2), pl(g, P_L12), pl(g, P_L22), pl(g, P_F12), pl(g, P_F22),
-                                   pd_part_slot(g, 1), M.eown);
-                pd_publish(g, {{0, gv(g)}, {1, ge(g)}});
+                                   pd_part_slot(g, 1), M.eown, g.no, atv(g), atdv(g), pd_part_slot(g, 0));
+                pd_publish(g, {{0, ge(g)}, {1, ge(g)}});
             }
             sync_all();
             double tv[4], te[4], all[6];
-            sum_members(0, gv, tv);
+            sum_members(0, ge, tv);
             sum_members(1, ge, te);
             all[0] = tv[0];
             for (int c = 0; c < 4; c++) all[1 + c] = te[c];
