@@ -523,7 +523,10 @@ int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldq
                     e = hipMemcpyAsync(dst + (size_t)c * mp, QQ + (size_t)c * ldqq, sizeof(double) * (size_t)m,
                                        hipMemcpyHostToDevice, s2);
                 if (e == hipSuccess) e = hipStreamSynchronize(s2);
-                if (s2 && e == hipSuccess) StreamPool::get().give(s2, dev);
+                if (s2 && e == hipSuccess)
+                    StreamPool::get().give(s2, dev);
+                else if (s2)
+                    (void)hipStreamDestroy(s2);  // (a stream that failed is not handed to the next build)
                 qq_up.err[t] = e;
             });
     } else {

@@ -5,6 +5,8 @@
 //   K4 spmv / V-cycle     PCG with an aggregation-multigrid preconditioner replacing
 //                         SuiteSparseQR (:550) and UMFPACK (:147-169)
 //   K6 apply_step         score, exp_map, Q update       (ral/l1_irls.cpp:729-737, 471-492)
+#include <sched.h>
+
 #include "graph.hpp"
 #include "kernels.hpp"
 
@@ -1624,7 +1626,10 @@ __global__ __launch_bounds__(kRowBlock) void k_apply_step(int n, int f, int ngho
         if (!isfinite(w.z)) w.z = 0.0;
         if (!isfinite(w.w)) w.w = 0.0;
         const double4 q = qmul(Q[i + f], w);  // right-multiply, no renormalisation (:734-737)
-        if (write) Q[i + f] = q;
+        // A step that is not finite (a solve that broke down on non-finite inputs or weights) leaves its rotation alone:
+        // the score turns non-finite, the caller gets IROTAVG_ERR_SOLVER, and the handle still holds the rotations it had
+        // (the reference would store zero quaternions there, :491 -- and exit)
+        if (write && isfinite(th)) Q[i + f] = q;
     }
     block_sum3_store(acc, 0.0, 0.0, part_score + 4 * blockIdx.x);
 }
@@ -2179,13 +2184,21 @@ void publish_parts(Graph &g, const PubPart *parts, int nparts) {
 }
 
 void wait_published(Graph &g) {
-    static const bool no_poll = std::getenv("IROTAVG_NO_POLL") != nullptr;
+    // (a pinned block that is not coherent -- the IROTAVG_PIN_DEFAULT experiment -- cannot be polled: every wait would run
+    // into the 2 ms limit)
+    static const bool no_poll = std::getenv("IROTAVG_NO_POLL") != nullptr || std::getenv("IROTAVG_PIN_DEFAULT") != nullptr;
     bool seen = false;
     if (!no_poll) {
         const double t0 = now_seconds();
         int spins = 0;
         while (!(seen = __atomic_load_n(g.h_seq(), __ATOMIC_ACQUIRE) == g.pub_seq)) {
-            if ((++spins & 255) == 0 && now_seconds() - t0 > 2e-3) break;
+            if ((++spins & 255) == 0) {
+                const double dt = now_seconds() - t0;
+                if (dt > 2e-3) break;
+                // a wait that outlasts every kernel of a step (l1ra's three polling threads on a host with few cores):
+                // give the core away between looks
+                if (dt > 100e-6) sched_yield();
+            }
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif

@@ -342,6 +342,25 @@ def test_isolated_views_are_dead_pivots():
     np.testing.assert_array_equal(Q[lonely], Q0[lonely])
 
 
+def test_a_non_finite_solve_leaves_the_rotations_alone():
+    """A relative rotation that is not a number poisons the normal equations; the direct solve then returns non-finite
+    steps, irls reports IROTAVG_ERR_SOLVER -- and the handle still holds the rotations it was given (the step of a view is
+    applied only when it is finite; the reference would store zero quaternions, ral/l1_irls.cpp:491, and exit)."""
+    n = 3000
+    S = synth.make_graph(n, 45000, 0.0, seed=8)
+    QQ = S["QQ"].copy()
+    QQ[1234] = np.nan
+    rng = np.random.default_rng(2)
+    Q0 = synth.qmul(synth.qexp(rng.normal(scale=0.03, size=(n, 3))), S["Qgt"]); Q0[0] = S["Qgt"][0]
+    with capi.Graph(S["I"], QQ, n, 1, band_direct=1) as G:
+        G.set_rotations(Q0)
+        with pytest.raises(capi.IrotavgError) as e:
+            G.irls(4, SIG, 30, 1e-6)
+        assert e.value.code == capi.ERR_SOLVER
+        assert G.stats()["direct_solves"] >= 1
+        np.testing.assert_array_equal(G.get_rotations(), Q0)
+
+
 def test_direct_path_is_bitwise_reproducible():
     S = synth.make_graph(5000, 100000, 0.0, seed=4, p_band_out=0.02)
     Qm = mst_init(S, 5000)
