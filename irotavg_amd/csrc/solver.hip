@@ -349,7 +349,10 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
     double *__restrict__ idg, double4 *__restrict__ rhs, double *__restrict__ bval, int n1,
     const int *__restrict__ sl_off1, double *__restrict__ val1, double *__restrict__ excess1,
     double *__restrict__ diag1, double *__restrict__ idg1) {
-    __shared__ double sT[MODE == 0 ? 4 : (MODE == 2 ? 2 : 1)][kAsmWin];
+    // (one pad word per 64: the rows of a wave read edges a constant stride apart -- 20 per row on the headline graph --,
+    // and a stride of 4 mod 16 doubles puts every fourth lane on the same banks)
+    __shared__ double sT[MODE == 0 ? 4 : (MODE == 2 ? 2 : 1)][kAsmWin + kAsmWin / 32 + 1];
+#define IRH_QI(q) ((q) + ((q) >> 5))
     __shared__ double part[MODE == 0 ? 4 : (MODE == 2 ? 2 : 1)][4][64];
     __shared__ double acc1[L1 ? 4 : 1][L1 ? kAsmCW : 1][64];
     __shared__ double sEx[64];
@@ -402,13 +405,13 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
             const int q = tid + it * kRowBlock;
             if (q < kAsmWin) {
                 const double w = MODE == 0 ? rw[it] * rw[it] : rw[it];
-                sT[0][q] = w;
+                sT[0][IRH_QI(q)] = w;
                 if (MODE == 0) {
-                    sT[1][q] = w * rx[it];
-                    sT[2][q] = w * ry[it];
-                    sT[3][q] = w * rz[it];
+                    sT[1][IRH_QI(q)] = w * rx[it];
+                    sT[2][IRH_QI(q)] = w * ry[it];
+                    sT[3][IRH_QI(q)] = w * rz[it];
                 }
-                if (MODE == 2) sT[1][q] = rx[it];
+                if (MODE == 2) sT[1][IRH_QI(q)] = rx[it];
             }
         }
     }
@@ -420,13 +423,13 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
     auto fetch = [&](uint32_t e, double &w, double &x, double &y, double &z) {
         const uint32_t q = e - (uint32_t)e0;
         if (q < (uint32_t)kAsmWin) {
-            w = sT[0][q];
+            w = sT[0][IRH_QI(q)];
             if (MODE == 0) {
-                x = sT[1][q];
-                y = sT[2][q];
-                z = sT[3][q];
+                x = sT[1][IRH_QI(q)];
+                y = sT[2][IRH_QI(q)];
+                z = sT[3][IRH_QI(q)];
             }
-            if (MODE == 2) x = sT[1][q];
+            if (MODE == 2) x = sT[1][IRH_QI(q)];
         } else {
             w = wsrc[e];
             if (MODE == 0) {
@@ -522,6 +525,7 @@ __global__ __launch_bounds__(kRowBlock) void k_assemble0w(
         }
         if (L1) sEx[lane] = ex;
     }
+#undef IRH_QI
     if (!L1) return;
     __syncthreads();
     if (wave == 0) {
