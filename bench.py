@@ -104,8 +104,12 @@ def kernel_rooflines(G, S, st, sharded=False):
                                          workgroups=lev[1]["chunks"], levels="1..%d in one launch (k_bcr_back_top)" % (nl - 1))
             tot_ms += msb
         ms = G.time_kernel(19, 50)
+        # the reductions of the levels >= 1 run as ONE launch (k_bcr_reduce_up) under the library's rule: three or more
+        # levels, blocks <= 24, no closures (the per-level figures above are separate launches of the same bodies)
+        fused_up = nl >= 3 and B <= 24 and di.get("closures", 0) == 0 and lev[1]["chunks"] <= 256
         out["bcr_solve"] = dict(ms=ms, bytes=tot_by, gbs=tot_by / (ms * 1e-3) / 1e9, flops=tot_fl,
-                                tflops=tot_fl / (ms * 1e-3) / 1e12, launches=nl + (2 if nl >= 2 else 1),
+                                tflops=tot_fl / (ms * 1e-3) / 1e12,
+                                launches=4 if fused_up else nl + (2 if nl >= 2 else 1), fused_upper_reduce=fused_up,
                                 sum_of_launches_ms=tot_ms, block=B, levels=lev)
         return out
     try:  # band-only graphs on one GPU run the p-update fused into the SpMV (k_pspmv_dot)
@@ -583,20 +587,26 @@ def main():
             nl = len(bs["levels"])
             # (kernel, template arguments that pick the instantiation, launches per solve)
             parts = [("bcr_reduce_l0", "k_bcr_reduce", {2: "true"}, 1)]
-            if nl >= 3:
-                parts.append(("bcr_reduce_mid", "k_bcr_reduce", {2: "false", 3: "false"}, nl - 2))
-            if nl >= 2:
-                parts.append(("bcr_reduce_top", "k_bcr_reduce", {2: "false", 3: "true"}, 1))
+            if bs.get("fused_upper_reduce"):
+                parts.append(("bcr_reduce_upper", "k_bcr_reduce_up", None, 1))
                 parts.append(("bcr_back_upper", "k_bcr_back_top", None, 1))
+            else:
+                if nl >= 3:
+                    parts.append(("bcr_reduce_mid", "k_bcr_reduce", {2: "false", 3: "false"}, nl - 2))
+                if nl >= 2:
+                    parts.append(("bcr_reduce_top", "k_bcr_reduce", {2: "false", 3: "true"}, 1))
+                    parts.append(("bcr_back_upper", "k_bcr_back_top", None, 1))
             parts.append(("bcr_back_l0", "k_bcr_back", {2: "true"}, 1))
             tr = [traffic(k, ta) for _, k, ta, _ in parts]
             du = [insitu_ms(k, ta) for _, k, ta, _ in parts]
             tr_solve = sum(t * c for t, (_, _, _, c) in zip(tr, parts)) if all(t is not None for t in tr) else None
             ms_insitu = sum(d * c for d, (_, _, _, c) in zip(du, parts)) if all(d is not None for d in du) else None
             line["roofline"] = {
-                "kernel": "one banded direct solve = %d launches: k_bcr_reduce x %d (level 0 gathers the blocks from the SELL-64 "
-                          "operator; every level eliminates 7 of 8 blocks per chunk on the matrix cores and writes W), "
-                          "k_bcr_back_top (ways back of the levels >= 1), k_bcr_back (level 0 -> X)" % (bs["launches"], nl),
+                "kernel": "one banded direct solve = %d launches over %d levels: k_bcr_reduce (level 0 gathers the blocks from the "
+                          "SELL-64 operator; every level eliminates 7 of 8 blocks per chunk on the matrix cores and writes W), "
+                          "%s, k_bcr_back_top (ways back of the levels >= 1), k_bcr_back (level 0 -> X)" % (
+                              bs["launches"], nl, "k_bcr_reduce_up (the reductions of all levels >= 1 in one launch)"
+                              if bs.get("fused_upper_reduce") else "k_bcr_reduce per upper level"),
                 "bound": "hbm", "achieved": bs["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bs["gbs"] / HBM_PEAK_GBS,
                 "algorithmic_bytes": bs["bytes"], "ms_per_launch": bs["ms"], "launches_per_solve": bs["launches"],
                 "traffic": tr_solve, "ms_per_launch_in_situ": ms_insitu,
@@ -613,7 +623,14 @@ def main():
                                          ms_in_situ=d, traffic=t)
                               for (name, _, _, c), t, d in zip(parts, tr, du)},
                 "block": bs["block"], "levels": bs["levels"]}
-            if nl >= 3:   # levels 1 .. nl-2 share one instantiation: HIP-event figures per level
+            if bs.get("fused_upper_reduce"):   # one launch for the levels >= 1: the HIP-event figures of its levels, launched one by one
+                up_ms = [kr["bcr_reduce_l%d" % l]["ms"] for l in range(1, nl)]
+                up_by = [kr["bcr_reduce_l%d" % l]["bytes"] for l in range(1, nl)]
+                line["roofline"]["by_launch"]["bcr_reduce_upper"].update(
+                    levels_one_by_one_ms=up_ms, algorithmic_bytes=sum(up_by), levels_algorithmic_bytes=up_by,
+                    note="k_bcr_reduce_up: levels 1 .. %d in one launch, workgroup c runs chunk c of every level, a counter "
+                         "between levels, separator data through device-scope atomic stores / loads" % (nl - 1))
+            elif nl >= 3:   # levels 1 .. nl-2 share one instantiation: HIP-event figures per level
                 line["roofline"]["by_launch"]["bcr_reduce_mid"].update(
                     ms=[kr["bcr_reduce_l%d" % l]["ms"] for l in range(1, nl - 1)],
                     algorithmic_bytes=[kr["bcr_reduce_l%d" % l]["bytes"] for l in range(1, nl - 1)],

@@ -66,6 +66,8 @@ struct BcrState {
     // a shard of a sharded sequence (dist.hip): the separator before the first chunk is the previous rank's
     int ext0 = 0;
     DevBuf<long long> stamps;  // development aid: bcr_stamp
+    DevBuf<unsigned> up_cnt;   // k_bcr_reduce_up: arrivals per level boundary (they only grow: solve g waits for g x chunks)
+    unsigned up_gen = 0;
     DevBuf<int> ghost_extcol;  // per ghost view: its row in the previous rank's last block, or -1
     DevBuf<double> remD, remR; // what this shard's eliminations subtract from that separator (sum over its levels)
 };
@@ -484,8 +486,31 @@ __device__ __forceinline__ int bcr_ridx(bool placed, int k, int i) {
 // Output per chunk c: W (seven blocks), sepD / sepR (block 7 after the eliminations), extD / extR (what the
 // chunk's eliminations subtract from the separator of chunk c - 1), extG (coupling of that separator to block 7).
 // TOP (one chunk, nothing before it): block 7 is solved and written to xtop.
-template <int B, int NR, bool L0, bool TOP, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) void k_bcr_reduce(
+// What one level writes for the next inside ONE launch (k_bcr_reduce_up) crosses the XCDs' L2s: device-scope atomic
+// stores / loads (write-through, read at the coherence point) instead of fences -- a device-scope release writes back a
+// whole L2, and tools/micro/xcdbar.hip measures a counter barrier + exchange among sixteen workgroups at 1.2 us this way.
+template <bool COH>
+__device__ __forceinline__ double bcr_ld(const double *p) {
+    if (!COH) return *p;
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)v);
+}
+template <bool COH>
+__device__ __forceinline__ void bcr_st(double *p, double v) {
+    if (!COH)
+        *p = v;
+    else
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The reduction of one chunk (the body of k_bcr_reduce; k_bcr_reduce_up runs it for the chunks of several levels in
+// turn). sDG: 16 blocks, sR: 9 right-hand-side slots, sZ: 2 doubles of LDS. COH: the level below was written, and this
+// level's separator data is read, inside the same launch (bcr_ld / bcr_st).
+template <int B, int NR, bool L0, bool TOP, int NW, bool COH>
+__device__ __forceinline__ void bcr_reduce_body(
+    const int chunk, double (*sDG)[B * B], double (*sR)[B * NR], double *sZ,
+
     int nb, int nred, int n, const int *__restrict__ sl_off, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ diag, const double4 *__restrict__ rhs, const double *__restrict__ inD,
     const double *__restrict__ inR, const double *__restrict__ inXD, const double *__restrict__ inXR,
@@ -497,14 +522,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
     int reg) {
     typedef BcrDim<B, NR> Dm;
     constexpr int BB = B * B;
-    __shared__ double sDG[16][BB];
     double(*sD)[BB] = sDG;       // sD[0] becomes the chunk's contribution to the separator before it
     double(*sG)[BB] = sDG + 8;   // slot 0: coupling (separator before the chunk) -> block 0; slot j + 1: block j -> j + 1
-    __shared__ double sR[9][B * NR];  // slot 0: contribution to the right-hand side of the separator before the chunk
-    __shared__ double sZ[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int chunk = blockIdx.x;
     // ext0: this handle is a SHARD of a sequence (dist.hip) and the separator before its first chunk is the last block
     // of the rank before it -- same algebra, the coupling comes from the boundary slots of the ghost views
     const bool hasExt = chunk > 0 || ext0;
@@ -570,9 +591,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
                 int gb, slot;
                 const int t = e < 8 * BB ? where(i, gb, slot) : -1;
                 const bool ok = t >= 0 && gb < nred;
-                vd[u] = ok ? inD[(size_t)gb * BB + el] : 0.0;
-                vx[u] = ok && gb + 1 < nred ? inXD[(size_t)(gb + 1) * BB + el] : 0.0;
-                vg[u] = ok && (gb > 0 || ext0) ? inXG[(size_t)gb * BB + el] : 0.0;
+                vd[u] = ok ? bcr_ld<COH>(inD + (size_t)gb * BB + el) : 0.0;
+                vx[u] = ok && gb + 1 < nred ? bcr_ld<COH>(inXD + (size_t)(gb + 1) * BB + el) : 0.0;
+                vg[u] = ok && (gb > 0 || ext0) ? bcr_ld<COH>(inXG + (size_t)gb * BB + el) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -597,8 +618,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
                 int gb, slot;
                 const int t = e < 8 * B * NR ? where(i, gb, slot) : -1;
                 const bool ok = t >= 0 && gb < nred;
-                vr[u] = ok ? inR[(size_t)gb * B * NR + el] : 0.0;
-                vy[u] = ok && gb + 1 < nred ? inXR[(size_t)(gb + 1) * B * NR + el] : 0.0;
+                vr[u] = ok ? bcr_ld<COH>(inR + (size_t)gb * B * NR + el) : 0.0;
+                vy[u] = ok && gb + 1 < nred ? bcr_ld<COH>(inXR + (size_t)(gb + 1) * B * NR + el) : 0.0;
                 if (ok) sR[i + 1][el] = vr[u] + vy[u];
             }
         }
@@ -693,18 +714,116 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
         }
     } else {
         for (int e = tid; e < BB; e += NT_) {
-            sepD[(size_t)chunk * BB + e] = sD[7][e];
+            bcr_st<COH>(sepD + (size_t)chunk * BB + e, sD[7][e]);
             if (hasExt) {
-                extD[(size_t)chunk * BB + e] = sD[0][e];
-                extG[(size_t)chunk * BB + e] = sG[0][e];
+                bcr_st<COH>(extD + (size_t)chunk * BB + e, sD[0][e]);
+                bcr_st<COH>(extG + (size_t)chunk * BB + e, sG[0][e]);
             }
         }
         for (int e = tid; e < B * NR; e += NT_) {
-            sepR[(size_t)chunk * B * NR + e] = sR[8][e];
-            if (hasExt) extR[(size_t)chunk * B * NR + e] = sR[0][e];
+            bcr_st<COH>(sepR + (size_t)chunk * B * NR + e, sR[8][e]);
+            if (hasExt) bcr_st<COH>(extR + (size_t)chunk * B * NR + e, sR[0][e]);
         }
     }
     bcr_stamp(stamps, 15);
+}
+
+template <int B, int NR, bool L0, bool TOP, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) void k_bcr_reduce(
+
+    int nb, int nred, int n, const int *__restrict__ sl_off, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ diag, const double4 *__restrict__ rhs, const double *__restrict__ inD,
+    const double *__restrict__ inR, const double *__restrict__ inXD, const double *__restrict__ inXR,
+    const double *__restrict__ inXG, double *__restrict__ W, double *__restrict__ sepD, double *__restrict__ sepR,
+    double *__restrict__ extD, double *__restrict__ extR, double *__restrict__ extG, double *__restrict__ xtop, int dbg,
+    int nfar, const int *__restrict__ far_i, const int *__restrict__ far_j, int ext0, const int *__restrict__ bptr,
+    const int *__restrict__ bghost, const double *__restrict__ bval, const int *__restrict__ ghost_extcol, int place,
+    long long *__restrict__ stamps, double *__restrict__ Dinvg, double *__restrict__ topDinv, int *__restrict__ deadctr,
+    int reg) {
+    __shared__ double sDG[16][B * B];
+    __shared__ double sR[9][B * NR];  // slot 0: contribution to the right-hand side of the separator before the chunk
+    __shared__ double sZ[2];
+    bcr_reduce_body<B, NR, L0, TOP, NW, false>(blockIdx.x, sDG, sR, sZ, nb, nred, n, sl_off, col, val, diag, rhs, inD, inR, inXD, inXR,
+                                               inXG, W, sepD, sepR, extD, extR, extG, xtop, dbg, nfar, far_i, far_j, ext0, bptr,
+                                               bghost, bval, ghost_extcol, place, stamps, Dinvg, topDinv, deadctr, reg);
+}
+
+// The reductions of ALL levels above level 0 in ONE launch (round 4). Those levels hold 1.6 % of the rows; each was a
+// launch of 73 / 10 / 2 / 1 workgroups that spends ~5 us of its 20 - 38 us starting, filling and draining. Here workgroup c
+// runs chunk c of every level that has one, level after level; between two levels the workgroups that go on wait for a
+// counter every workgroup of the level before has passed. What the first attempt at this lost (round 3: 325 instead of
+// 290 us per solve) was the way the data crossed the level boundary -- a device-scope release and acquire per workgroup
+// and boundary, i.e. L2 write-backs and invalidates, 7 us each. Now the separator data is WRITTEN by device-scope
+// atomic stores and READ by device-scope atomic loads (bcr_st / bcr_ld: the coherence point of the eight L2s, no
+// fence), the counter is a relaxed atomic: ~1.2 us per boundary (tools/micro/xcdbar.hip, sixteen workgroups on eight
+// XCDs). All workgroups of the launch fit the chip at once (one per CU), so nobody waits for a workgroup that cannot
+// start. A wait that does not end (~1 s) poisons the top separator: the solve then fails with IROTAVG_ERR_SOLVER at the
+// next score instead of hanging the device. W goes to memory as before: the ways back are later launches.
+constexpr int kUpLevels = 8;
+struct BcrUpLevel {
+    int nb, nred, nch;
+    const double *inD, *inR, *inXD, *inXR, *inXG;  // from the level below
+    double *W, *sepD, *sepR, *extD, *extR, *extG;
+};
+struct BcrUpArgs {
+    int nl;  // levels of the launch; lev[0] = level 1 of the solve
+    BcrUpLevel lev[kUpLevels];
+    // the level-0 operator, for the blocks of a mixed level 1 that no chunk reduced
+    int n;
+    const int *sl_off, *col;
+    const double *val, *diag;
+    const double4 *rhs;
+    double *xtop;
+    unsigned *cnt;
+    unsigned gen;
+    int dbg;
+};
+template <int B>
+__global__ __launch_bounds__(512, 1) void k_bcr_reduce_up(BcrUpArgs A) {
+    constexpr int NR = 3;
+    __shared__ double sDG[16][B * B];
+    __shared__ double sR[9][B * NR];
+    __shared__ double sZ[2];
+    __shared__ int s_ok;
+    const int wg = blockIdx.x;
+    bool fine = true;
+    for (int i = 0; i < A.nl; i++) {
+        const BcrUpLevel &L = A.lev[i];
+        if (wg >= L.nch) break;  // (the chunk counts shrink level by level)
+        if (i > 0) {
+            if (threadIdx.x == 0) {
+                const unsigned target = A.gen * (unsigned)A.lev[i - 1].nch;
+                int good = 0;
+                for (int spin = 0; spin < (1 << 21); spin++) {
+                    // (a difference: the counter may wrap)
+                    if ((int)(__hip_atomic_load(A.cnt + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) {
+                        good = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                s_ok = good;
+            }
+            __syncthreads();
+            fine = fine && s_ok != 0;
+        }
+#define IRH_UP_ARGS                                                                                                     \
+    wg, sDG, sR, sZ, L.nb, L.nred, A.n, A.sl_off, A.col, A.val, A.diag, A.rhs, L.inD, L.inR, L.inXD, L.inXR, L.inXG, L.W,     \
+        L.sepD, L.sepR, L.extD, L.extR, L.extG, A.xtop, A.dbg, 0, (const int *)nullptr, (const int *)nullptr, 0,             \
+        (const int *)nullptr, (const int *)nullptr, (const double *)nullptr, (const int *)nullptr, 0, (long long *)nullptr, \
+        (double *)nullptr, (double *)nullptr, (int *)nullptr, 0
+        if (i == A.nl - 1) {
+            bcr_reduce_body<B, NR, false, true, 8, true>(IRH_UP_ARGS);
+            if (!fine && threadIdx.x == 0) A.xtop[0] = __builtin_nan("");
+        } else {
+            bcr_reduce_body<B, NR, false, false, 8, true>(IRH_UP_ARGS);
+            // every thread's separator stores have been acknowledged before the workgroup is counted
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(A.cnt + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#undef IRH_UP_ARGS
+    }
 }
 
 // The three rounds of the way back of one chunk: its W in sW, the solutions of the separator before it and of its own
@@ -1610,8 +1729,46 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     const int nfar = 0;
     const int *fi = nullptr, *fj = nullptr;
     (void)pass;
+    // the reductions of all levels above level 0 in one launch (k_bcr_reduce_up): three right-hand sides, blocks up to 24
+    // (the eight-wave workgroups), at least two such levels, level 1 of at most 256 chunks (one workgroup per CU: all
+    // resident), no closures (their inverses and dead-pivot count ride on the separate launches), not a shard, not
+    // when single levels are timed
+    bool fused_up = false;
+    if constexpr (NR == 3 && B <= 24) {
+        fused_up = nl >= 3 && nl - 1 <= kUpLevels && only < 0 && phase == 0 && !open_top && !g.bcr_shard && S.nfar == 0 &&
+                   S.lev[1].nch <= 256 && !(dbg & 64) && !getenv("IROTAVG_BCR_NARROW") && !getenv("IROTAVG_BCR_NO_FUSED_UP");
+    }
     for (int l = 0; l < nl && phase != 2; l++) {
         if (only >= 0 && only != l) continue;
+        if constexpr (NR == 3 && B <= 24) {
+            if (fused_up && l >= 1) {
+                if (l > 1) continue;
+                if (S.up_cnt.n < (size_t)kUpLevels) {
+                    S.up_cnt.alloc(kUpLevels);
+                    S.up_cnt.zero(st);
+                    S.up_gen = 0;
+                }
+                BcrUpArgs A;
+                A.nl = nl - 1;
+                for (int i = 0; i < A.nl; i++) {
+                    BcrLevel &Li = S.lev[1 + i], &Fi = S.lev[i];
+                    A.lev[i] = BcrUpLevel{Li.nb,   Li.nred,  Li.nch,   Fi.sepD.p, Fi.sepR.p, Fi.extD.p, Fi.extR.p, Fi.extG.p,
+                                          Li.W.p,  Li.sepD.p, Li.sepR.p, Li.extD.p, Li.extR.p, Li.extG.p};
+                }
+                A.n = L0.n;
+                A.sl_off = L0.sl_off.p;
+                A.col = L0.col.p;
+                A.val = L0.val.p;
+                A.diag = L0.diag.p;
+                A.rhs = L0.b.p;
+                A.xtop = S.xtop.p;
+                A.cnt = S.up_cnt.p;
+                A.gen = ++S.up_gen;
+                A.dbg = dbg;
+                hipLaunchKernelGGL((k_bcr_reduce_up<B>), dim3(S.lev[1].nch), dim3(512), 0, st, A);
+                continue;
+            }
+        }
         BcrLevel &L = S.lev[l];
         const BcrLevel *F = l > 0 ? &S.lev[l - 1] : nullptr;
         const bool top = l == nl - 1 && !open_top;
