@@ -383,7 +383,19 @@ def pcg_iteration_roofline(S, st, kr, ia=None, iu=None):
             "own_bytes_both_kernels": kr["cg_apply"]["bytes"] + kr["cg_update"]["bytes"]}
 
 
+def host_throttled_usec():
+    """Microseconds this process's cgroup has spent throttled by its CPU quota so far (cgroup v2 cpu.stat), or None."""
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                return int(ln.split()[1])
+    except OSError:
+        pass
+    return None
+
+
 def main():
+    thr0 = host_throttled_usec()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300,
@@ -492,11 +504,13 @@ def main():
     for _ in range(args.warmup):
         res = step()
     barrier()
+    thr_a = host_throttled_usec()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     barrier()
     dt = time.perf_counter() - t0
+    thr_b = host_throttled_usec()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -562,8 +576,13 @@ def main():
             # every CPU-oracle baseline runs in a process of its own while the GPU legs below go on (cpu_baselines_main)
             import subprocess
             spec = dict(views=args.views, edges=args.edges, p_loop=args.p_loop, seed=args.seed, extras=extras)
+            # (one thread, as its "cores": 1 says, and no GPU: the box's cgroup allows 16 CPUs per 100 ms, and a burst of
+            # library worker threads in that process got the whole group throttled for 60-80 ms -- seen as one slow l1ra
+            # call out of five at 10k/150k; "host_throttled_usec" below reports what the group lost during this run)
             cpu_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-only", json.dumps(spec)],
-                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                        env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+                                                 OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1"))
         kr = kernel_rooflines(G, S, st, sharded=dstats is not None)
         FP64_PEAK_TF = 78.6   # AMD's MI355X data sheet (fp64 vector = matrix); the guide lists no fp64 figure
         # HBM traffic and in-solve kernel durations: measured NOW, by rocprofv3 passes of this command (live_profile)
@@ -926,6 +945,11 @@ def main():
                 line["cpu_baseline"] = dict(value=None, unit="edge-updates/s", cores=1, kind="port",
                                             sample="the baseline process failed: %s" % e)
         G.close()
+        thr1 = host_throttled_usec()
+        # the box's cgroup caps the CPU time of everything this run starts; time the group spent throttled, over the whole
+        # run (profiling passes and the CPU baselines included) and inside the timed region (must be 0 for `value`)
+        line["host_throttled_usec"] = None if thr0 is None or thr1 is None else thr1 - thr0
+        line["host_throttled_usec_timed_region"] = None if thr_a is None or thr_b is None else thr_b - thr_a
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
