@@ -252,7 +252,9 @@ struct BcrElim {
         constexpr int NS = (Dm::NT + WPE - 1) / WPE;
         static_assert(NS <= NTPW, "slots");
         double aop[Dm::MT][Dm::KS];
-        bcr_load_a<B, false>(Di, lane, aop);
+        // (the inverse is symmetric: read by columns -- consecutive lanes, consecutive words -- instead of by rows, whose
+        // stride of 2 B words puts sixteen lanes on four banks)
+        bcr_load_a<B, true>(Di, lane, aop);
         const int lj = lane & 15, lk = lane >> 4;
         const double *base[NS];
         int stride[NS];
@@ -413,13 +415,18 @@ __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int
     const v2i *__restrict__ cp = reinterpret_cast<const v2i *>(col) + (size_t)(o0 / 2) * 64 + ln;
     const v2d *__restrict__ vp = reinterpret_cast<const v2d *>(val) + (size_t)(o0 / 2) * 64 + ln;
     const int c0 = lb * B;
-    // the row's entries in batches of eight pairs: all loads of a batch are issued before the first value is
+    // (diagonal and right-hand side are requested ahead of the entries: behind them they were a memory round trip of
+    // their own)
+    const double dgv = diag[row];
+    const double4 bb = rhs[row];
+    // the row's entries in batches of NBT pairs: all loads of a batch are issued before the first value is
     // scattered (a load per scatter was a memory round trip per pair)
-    for (int q0 = 0; q0 < w / 2; q0 += 8) {
-        v2i cc[8];
-        v2d vv[8];
+    constexpr int NBT = 12;
+    for (int q0 = 0; q0 < w / 2; q0 += NBT) {
+        v2i cc[NBT];
+        v2d vv[NBT];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < NBT; u++) {
             const int q = q0 + u < w / 2 ? q0 + u : w / 2 - 1;
             cc[u] = __builtin_nontemporal_load(&cp[(size_t)q * 64]);
             vv[u] = __builtin_nontemporal_load(&vp[(size_t)q * 64]);
@@ -428,7 +435,7 @@ __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int
         // the sum of a row's duplicates keeps its order; a read-modify-write per entry was an LDS round trip and four
         // divergent branches each: a third of the load phase)
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < NBT; u++) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int c = h ? cc[u].y : cc[u].x;
@@ -446,8 +453,7 @@ __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int
             }
         }
     }
-    Dblk[r * B + r] += diag[row];
-    const double4 bb = rhs[row];
+    Dblk[r * B + r] += dgv;
     Rblk[r * NR + 0] = bb.x;
     Rblk[r * NR + 1] = bb.y;
     Rblk[r * NR + 2] = bb.z;
