@@ -141,8 +141,13 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane, int *dead = nul
         const double f = rowk * pinv;
         const double g = isk ? -pinv : f;
         // general element: t -= colk (rowk pinv); column k: colk pinv; row k: rowk pinv; (k, k): -pinv
+        // (the lane of column k drops its old values by a product with 0, one instruction, not by a 64-bit select, two:
+        // 24 of the ~105 instructions of a pivot; taking the LDS round trip of the row out of the pivot-to-pivot chain --
+        // the element of row k + 1 updated from registers alone, its multiplier through an SGPR like the pivot -- cost ten
+        // instructions per pivot and made the sweep slower, 11 600 instead of 10 150 clocks: the chain is the reciprocal's)
+        const double keep = isk ? 0.0 : 1.0;
         auto upd = [&](int i) {
-            const double a = isk ? 0.0 : t[i];
+            const double a = t[i] * keep;
             double u = fma(-colk[i], g, a);
             if (i == ki) u = (h == kh) ? g : u;
             t[i] = u;
