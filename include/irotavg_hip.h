@@ -215,6 +215,14 @@ int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_
  * back. Returns the number of values written (<= cap) or a negative error. */
 int irotavg_graph_direct_info(irotavg_graph *g, int64_t *info, int cap);
 
+/* The direct solver has no tolerance and no residual test of its own (SuiteSparseQR / UMFPACK in ral/l1_irls.cpp:131-184,
+ * 536-556 have none either). On demand: relres[c] = ||b - A x||_2 / ||b||_2 for the three coordinates of the handle's most
+ * recent direct solve -- the level-0 operator as last assembled (loop closures included), its right-hand side, the
+ * solution the last step was made from; one pass over level 0 and a host round trip, also stored in
+ * irotavg_stats.last_relres. IROTAVG_ERR_BAD_ARG if the handle's systems do not run through the direct solver or none
+ * has been solved yet. */
+int irotavg_graph_direct_residual(irotavg_graph *g, double *relres);
+
 /* Testing aid: fingerprint of the handle's static structure -- every index array the build produces (edge
  * streams, boundary slots, per level the SELL-64 pattern and the value-refresh maps) as one 64-bit FNV-1a hash
  * each, followed by the scalars that choose kernels (level shapes, far-entry count, fused-assembly / two-launch

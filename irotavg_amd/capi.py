@@ -36,6 +36,7 @@ SYMBOLS = [
     "irotavg_dist_irls", "irotavg_dist_get_stats", "irotavg_dist_info", "irotavg_dist_plan", "irotavg_dist_plan_host",
     "irotavg_dist_l1ra", "irotavg_dist_create_hosted",
     "irotavg_graph_direct_info",
+    "irotavg_graph_direct_residual",
     "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_trim_memory", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
 ]
 
@@ -131,6 +132,7 @@ def lib():
     L.irotavg_graph_time_kernel.argtypes = [vp, C.c_int, C.c_int, _dp]
     L.irotavg_graph_fingerprint.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.irotavg_graph_direct_info.argtypes = [vp, _i64p, C.c_int]
+    L.irotavg_graph_direct_residual.argtypes = [vp, _dp]
     L.irotavg_viewgraph_create.argtypes = [C.POINTER(vp), C.POINTER(Options)]
     L.irotavg_viewgraph_destroy.argtypes = [vp]
     L.irotavg_viewgraph_destroy.restype = None
@@ -361,6 +363,12 @@ class Graph:
         return dict(block=int(out[0]), levels=[dict(blocks=int(out[2 + 3 * l]), chunks=int(out[3 + 3 * l]),
                                                     reduced=int(out[4 + 3 * l])) for l in range(nl)],
                     closures=int(out[2 + 3 * nl]))
+
+    def direct_residual(self):
+        """irotavg_graph_direct_residual: ||b - A x|| / ||b|| per coordinate of the most recent direct solve."""
+        out = np.zeros(3)
+        check(lib().irotavg_graph_direct_residual(self._h, _d(out)), "direct_residual")
+        return out
 
     def fingerprint(self):
         """Hashes of every structural array + the kernel-choosing scalars (irotavg_graph_fingerprint)."""

@@ -2005,6 +2005,77 @@ int bcr_solve(Graph &g, int only) {
     return IROTAVG_OK;
 }
 
+// ||b - A x||^2 and ||b||^2 per coordinate of the level-0 system as it stands (values and diagonal of the last assembly,
+// its right-hand side, g.X): a row per thread walks its SELL-64 row like bcr_gather_row does. The loop closures' entries
+// are part of these rows, so the Woodbury correction is checked as well.
+__global__ __launch_bounds__(256) void k_bcr_residual(int n, const int *__restrict__ sl_off, const int *__restrict__ col,
+                                                       const double *__restrict__ val, const double *__restrict__ diag,
+                                                       const double4 *__restrict__ rhs, const double4 *__restrict__ X,
+                                                       double *__restrict__ part) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+    if (row < n) {
+        const int sl = row >> 6, ln = row & 63;
+        const int o0 = sl_off[sl], w = sl_off[sl + 1] - o0;
+        const v2i *__restrict__ cp = reinterpret_cast<const v2i *>(col) + (size_t)(o0 / 2) * 64 + ln;
+        const v2d *__restrict__ vp = reinterpret_cast<const v2d *>(val) + (size_t)(o0 / 2) * 64 + ln;
+        const double4 x = X[row], bb = rhs[row];
+        const double d = diag[row];
+        double s0 = d * x.x, s1 = d * x.y, s2 = d * x.z;
+        for (int q = 0; q < w / 2; q++) {
+            const v2i cc = cp[(size_t)q * 64];
+            const v2d vv = vp[(size_t)q * 64];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const double v = h ? vv.y : vv.x;
+                const int c = h ? cc.y : cc.x;
+                if (v != 0.0) {  // (zero: padding)
+                    const double4 xc = X[c];
+                    s0 += v * xc.x;
+                    s1 += v * xc.y;
+                    s2 += v * xc.z;
+                }
+            }
+        }
+        r0 = (bb.x - s0) * (bb.x - s0);
+        r1 = (bb.y - s1) * (bb.y - s1);
+        r2 = (bb.z - s2) * (bb.z - s2);
+        b0 = bb.x * bb.x;
+        b1 = bb.y * bb.y;
+        b2 = bb.z * bb.z;
+    }
+    block_sum3_store(r0, r1, r2, part + 8 * blockIdx.x);
+    __syncthreads();
+    block_sum3_store(b0, b1, b2, part + 8 * blockIdx.x + 4);
+}
+
+// a direct solve has no residual test of its own. On demand (one pass over level 0, a host round trip):
+// ||b - A x|| / ||b|| per coordinate of the handle's most recent direct solve -> relres[3] and stats.last_relres.
+int bcr_residual(Graph &g, double *relres) {
+    if (!g.bcr_B || g.stats.direct_solves == 0 || g.levels.empty()) return IROTAVG_ERR_BAD_ARG;
+    Level &L0 = g.levels[0];
+    const int grid = (L0.n + 255) / 256;
+    DevBuf<double> part;
+    part.alloc((size_t)grid * 8);
+    hipLaunchKernelGGL(k_bcr_residual, dim3(grid), dim3(256), 0, g.stream, L0.n, L0.sl_off.p, L0.col.p, L0.val.p, L0.diag.p,
+                       L0.b.p, g.X.p, part.p);
+    IRH_CHECK(hipGetLastError());
+    std::vector<double> h((size_t)grid * 8);
+    IRH_CHECK(hipMemcpyAsync(h.data(), part.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    double rr[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
+    for (int b = 0; b < grid; b++)
+        for (int c = 0; c < 3; c++) {
+            rr[c] += h[(size_t)b * 8 + c];
+            bb[c] += h[(size_t)b * 8 + 4 + c];
+        }
+    for (int c = 0; c < 3; c++) {
+        relres[c] = bb[c] > 0.0 ? std::sqrt(rr[c] / bb[c]) : (rr[c] > 0.0 ? HUGE_VAL : 0.0);
+        g.stats.last_relres[c] = relres[c];
+    }
+    return IROTAVG_OK;
+}
+
 int bcr_info(Graph &g, int64_t *out, int cap) {
     int k = 0;
     auto put = [&](int64_t v) {

@@ -402,6 +402,13 @@ int irotavg_graph_direct_info(irotavg_graph *h, int64_t *info, int cap) {
     API_CATCH
 }
 
+int irotavg_graph_direct_residual(irotavg_graph *h, double *relres) {
+    if (!h || !relres) return IROTAVG_ERR_BAD_ARG;
+    API_TRY
+    return bcr_residual(h->g, relres);
+    API_CATCH
+}
+
 void irotavg_graph_reset_stats(irotavg_graph *h) {
     if (!h) return;
     irotavg_stats keep = h->g.stats;

@@ -277,6 +277,7 @@ void bcr_plan_dev(Graph &g, const DevEdgeSrc &src);  // the same from an edge li
 int bcr_solve(Graph &g, int only = -1);     // levels[0] values / diagonal / right-hand side -> g.X, asynchronous
 int bcr_levels(Graph &g);
 int bcr_info(Graph &g, int64_t *out, int cap);
+int bcr_residual(Graph &g, double *relres);  // ||b - A x|| / ||b|| per coordinate of the last direct solve (one pass over level 0)
 int bcr_closures(Graph &g);  // loop closures the direct solver of this handle carries
 void bcr_gate(Graph &g);  // flags[FL_DONE] = 1 unless the last direct solve with closures saw a dead pivot (flags[3] = their number)
 void dense_invert_spd(Graph &g, double *A, int npad);  // in place, npad a multiple of 64 (dense.hip)

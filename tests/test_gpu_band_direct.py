@@ -361,6 +361,30 @@ def test_a_non_finite_solve_leaves_the_rotations_alone():
         np.testing.assert_array_equal(G.get_rotations(), Q0)
 
 
+@pytest.mark.parametrize("n,m,nclose", [(3000, 45000, 0), (20000, 400000, 0), (4000, 80000, 40), (20000, 300000, 1000)])
+def test_residual_of_the_last_direct_solve(n, m, nclose):
+    """The direct solver has no residual test of its own; irotavg_graph_direct_residual computes ||b - A x|| / ||b|| of the
+    handle's most recent direct solve on demand (one pass over level 0, the closures' entries included). A solve of a
+    well-conditioned IRLS system is accurate to rounding; a handle whose systems run through the PCG says BAD_ARG."""
+    S = closure_graph(n, m, nclose, 7, nclose // 10) if nclose else synth.make_graph(n, m, 0.0, seed=5)
+    Qm = mst_init(S, n)
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        G.set_rotations(Qm)
+        with pytest.raises(capi.IrotavgError) as e:   # nothing solved yet
+            G.direct_residual()
+        assert e.value.code == capi.ERR_BAD_ARG
+        G.irls(4, SIG, 50, 1e-3)
+        rr = G.direct_residual()
+        assert rr.shape == (3,) and np.all(np.isfinite(rr)) and rr.max() < (1e-9 if nclose else 1e-11), rr
+        np.testing.assert_array_equal(G.stats()["last_relres"], rr)
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=-1) as G:
+        G.set_rotations(Qm)
+        G.irls(4, SIG, 3, 1e-3)
+        with pytest.raises(capi.IrotavgError) as e:
+            G.direct_residual()
+        assert e.value.code == capi.ERR_BAD_ARG
+
+
 def test_direct_path_is_bitwise_reproducible():
     S = synth.make_graph(5000, 100000, 0.0, seed=4, p_band_out=0.02)
     Qm = mst_init(S, 5000)
