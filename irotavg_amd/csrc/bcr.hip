@@ -23,6 +23,8 @@
 // formed by a symmetric sweep (Gauss-Jordan without pivoting: SPD), a column per lane, the pivot row
 // broadcast through LDS (bcr_invert). A pivot not above kDeadTol x its original diagonal entry is dead
 // (an isolated view, a floating component): its unknown solves to 0, as everywhere else in this library.
+#include <atomic>
+
 #include "graph.hpp"
 #include "kernels.hpp"
 
@@ -834,6 +836,57 @@ __global__ __launch_bounds__(512, 1) void k_bcr_reduce_up(BcrUpArgs A) {
             if (threadIdx.x == 0) __hip_atomic_fetch_add(A.cnt + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #undef IRH_UP_ARGS
+    }
+}
+
+// k_bcr_reduce_up's workgroups WAIT for each other, so all workgroups of a launch must be resident at the same time -- and
+// so must those of every other such launch that is dispatched next to it (l1ra's three chains, other handles, other
+// sessions): two launches that each hold a part of the device and spin for the rest would wait until the bounded spin
+// gives up. The launches of one process therefore RESERVE their share of the device first: a launch of N workgroups
+// costs N / (workgroups of this kernel that fit the device, from the occupancy query) and is admitted while the sum over
+// all handles stays within the device; a handle keeps its share (its launches are ordered on its stream: the largest
+// counts, not the sum) until it is idle. A launch that is not admitted runs level by level, as before round 4.
+// IROTAVG_BCR_UP_CAP: the capacity in 1/1024ths (tests).
+namespace {
+std::atomic<int> g_up_used[16];
+template <int B>
+int bcr_up_capacity(int dev) {
+    static std::atomic<int> cap[16];
+    const int d = dev & 15;
+    int c = cap[d].load(std::memory_order_relaxed);
+    if (c == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bcr_reduce_up<B>, 512, 0) != hipSuccess) per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        (void)hipGetLastError();
+        c = per_cu > 0 && cus > 0 ? per_cu * cus : -1;
+        cap[d].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+template <int B>
+bool bcr_up_reserve(Graph &g, int nwg) {
+    const int capwg = bcr_up_capacity<B>(g.device);
+    if (capwg <= 0) return false;
+    int total = 1024;
+    if (const char *e = getenv("IROTAVG_BCR_UP_CAP")) total = atoi(e);
+    const int cost = (int)(((long long)nwg * 1024 + capwg - 1) / capwg);
+    const int need = cost - g.bcr_up_held;
+    if (need <= 0) return true;
+    std::atomic<int> &used = g_up_used[g.device & 15];
+    const int before = used.fetch_add(need, std::memory_order_acq_rel);
+    if (before + need > total) {
+        used.fetch_sub(need, std::memory_order_acq_rel);
+        return false;
+    }
+    g.bcr_up_held += need;
+    return true;
+}
+}  // namespace
+void bcr_up_release(Graph &g) noexcept {
+    if (g.bcr_up_held > 0) {
+        g_up_used[g.device & 15].fetch_sub(g.bcr_up_held, std::memory_order_acq_rel);
+        g.bcr_up_held = 0;
     }
 }
 
@@ -1748,6 +1801,7 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     if constexpr (NR == 3 && B <= 24) {
         fused_up = nl >= 3 && nl - 1 <= kUpLevels && only < 0 && phase == 0 && !open_top && !g.bcr_shard && S.nfar == 0 &&
                    S.lev[1].nch <= 256 && !(dbg & 64) && !getenv("IROTAVG_BCR_NARROW") && !getenv("IROTAVG_BCR_NO_FUSED_UP");
+        if (fused_up) fused_up = bcr_up_reserve<B>(g, S.lev[1].nch);
     }
     for (int l = 0; l < nl && phase != 2; l++) {
         if (only >= 0 && only != l) continue;

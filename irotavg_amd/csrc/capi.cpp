@@ -422,7 +422,9 @@ void irotavg_graph_reset_stats(irotavg_graph *h) {
 
 int irotavg_graph_synchronize(irotavg_graph *h) {
     if (!h) return IROTAVG_ERR_BAD_ARG;
-    return hipStreamSynchronize(h->g.stream) == hipSuccess ? IROTAVG_OK : IROTAVG_ERR_HIP;
+    if (hipStreamSynchronize(h->g.stream) != hipSuccess) return IROTAVG_ERR_HIP;
+    bcr_up_release(h->g);
+    return IROTAVG_OK;
 }
 
 int irotavg_graph_edge_residual(irotavg_graph *h) {

@@ -8,6 +8,10 @@
 
 namespace irh {
 
+struct Graph;
+// bcr.hip: the share of the device a handle has reserved for its single-launch upper reductions (k_bcr_reduce_up) is
+// handed back when the handle is idle -- end of irls / l1ra / l1decode_pd / time_kernel, destruction
+void bcr_up_release(Graph &g) noexcept;
 struct BcrState;  // bcr.hip: buffers of the direct solve of a banded level-0 operator
 struct BcrDeleter {
     void operator()(BcrState *p) const;
@@ -121,6 +125,7 @@ struct Graph {
     int *h_seq() { return reinterpret_cast<int *>(hpin + 8192); }
     int pub_seq = 0;
     ~Graph() {
+        bcr_up_release(*this);
         if (hpin) PinPool::get().give(hpin);
     }
     Graph() = default;
@@ -130,6 +135,7 @@ struct Graph {
     // direct solve of a banded level-0 operator by block cyclic reduction (bcr.hip): block size (8 / 16 / 24 / 32;
     // 0 = the solves run through the PCG) and the half-bandwidth found at creation (-1: not looked at)
     int bcr_B = 0, band0 = -1;
+    int bcr_up_held = 0;  // 1/1024ths of the device reserved for k_bcr_reduce_up's workgroups (bcr_up_reserve)
     std::unique_ptr<BcrState, BcrDeleter> bcr;
     std::vector<int> bcr_far_i, bcr_far_j, bcr_far_e;  // long-range edges (rows, edge id): Woodbury correction
     const double *bcr_wsrc = nullptr;                  // per-edge weights of the last assembly and whether the

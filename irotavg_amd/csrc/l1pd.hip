@@ -920,6 +920,7 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
         for (int c = 0; c < 3; c++) {
             if (rcs[c] != IROTAVG_OK && rc == IROTAVG_OK) rc = rcs[c];
             Graph &q = *g.l1_clones[c];
+            bcr_up_release(q);  // (its solves lie before the last decision it waited for)
             g.stats.pcg_solves += q.stats.pcg_solves;
             g.stats.pcg_iters += q.stats.pcg_iters;
             g.stats.pcg_iters_last = q.stats.pcg_iters_last;
@@ -941,6 +942,7 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
         it++;
     }
     IRH_CHECK(hipStreamSynchronize(g.stream));
+    bcr_up_release(g);
     const double toc = now_seconds();
     *iters = it;
     *runtime = toc - tic;

@@ -2390,6 +2390,7 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     }
     g.irls_settle = -1.0;
     IRH_CHECK(hipStreamSynchronize(g.stream));
+    bcr_up_release(g);
     const double toc = now_seconds();
     *iters = it;
     *runtime = toc - tic;
@@ -2467,6 +2468,7 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
     for (int r = 0; r < reps; r++) once();
     IRH_CHECK(hipEventRecord(e1, g.stream));
     IRH_CHECK(hipEventSynchronize(e1));
+    bcr_up_release(g);
     float t = 0.f;
     IRH_CHECK(hipEventElapsedTime(&t, e0, e1));
     *ms = (double)t / std::max(reps, 1);

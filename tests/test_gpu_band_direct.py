@@ -385,6 +385,41 @@ def test_residual_of_the_last_direct_solve(n, m, nclose):
         assert e.value.code == capi.ERR_BAD_ARG
 
 
+def test_single_launch_upper_reduction_is_admitted_by_reservation(monkeypatch):
+    """The workgroups of the single-launch upper reduction wait for each other, so every such launch reserves its share of
+    the device first (bcr.hip, bcr_up_reserve); one that is not admitted runs level by level. Both routes are the same
+    arithmetic: with the capacity forced to nothing (IROTAVG_BCR_UP_CAP=0), and with a capacity that admits only the first
+    of l1ra's three chains, rotations and weights are bit-identical to the default."""
+    n, m = 20000, 400000            # five levels: levels 1-4 in one launch
+    S = synth.make_graph(n, m, 0.0, seed=6)
+    Qm = mst_init(S, n)
+
+    def run():
+        with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+            assert len(G.direct_info()["levels"]) >= 3
+            G.set_rotations(Qm)
+            G.l1ra(2, 1e-3)
+            G.irls(4, SIG, 50, 1e-3)
+            return G.get_rotations(), G.get_weights()
+
+    ref = run()
+    for cap in ("0", "70", "1024"):   # 20000 views: level 1 has 14 chunks = 55 / 1024 of the device per chain
+        monkeypatch.setenv("IROTAVG_BCR_UP_CAP", cap)
+        out = run()
+        np.testing.assert_array_equal(out[0], ref[0])
+        np.testing.assert_array_equal(out[1], ref[1])
+    monkeypatch.delenv("IROTAVG_BCR_UP_CAP")
+    # two handles alive at the same time give their shares back when they are idle: nothing is left reserved
+    with capi.Graph(S["I"], S["QQ"], n, 1) as A, capi.Graph(S["I"], S["QQ"], n, 1) as Bh:
+        for G in (A, Bh):
+            G.set_rotations(Qm)
+            G.irls(4, SIG, 50, 1e-3)
+        np.testing.assert_array_equal(A.get_rotations(), Bh.get_rotations())
+    monkeypatch.setenv("IROTAVG_BCR_UP_CAP", "56")   # exactly one launch of this size
+    out = run()
+    np.testing.assert_array_equal(out[0], ref[0])
+
+
 def test_direct_path_is_bitwise_reproducible():
     S = synth.make_graph(5000, 100000, 0.0, seed=4, p_band_out=0.02)
     Qm = mst_init(S, 5000)
