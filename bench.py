@@ -54,6 +54,10 @@ def kernel_rooflines(G, S, st, sharded=False):
         "spmv": nnz0 * (8 + 4) + 4 * (nu + 1) + 2 * 24 * nu,
     }
     which = {"edge_residual": 1, "update_weights": 2, "assemble": 3, "spmv": 4}
+    if not sharded:
+        # K2 and the next iteration's K1 as one kernel (the direct solver's irls loop; solver.hip, k_weights_then_residual)
+        alg["weights_then_residual"] = m * (8 + 24 + 8 + 32 + 24) + 32 * n_t + 24 * nu
+        which["weights_then_residual"] = 11
     out = {}
     di = G.direct_info() if not sharded else dict(block=0, levels=[])
     if di["block"]:
@@ -678,7 +682,12 @@ def main():
         for key, kn, label, targs in (
                 ("update_weights", "k_update_weights", "K2: k_update_weights (residual of the step + the robust weight, "
                                                        "ral/l1_irls.cpp:614-727)", None),
-                ("edge_residual", "k_edge_residual", "k_edge_residual (K1, the kernel north_star names)", None)):
+                ("edge_residual", "k_edge_residual", "k_edge_residual (K1, the kernel north_star names)", None),
+                ("weights_then_residual", "k_weights_then_residual",
+                 "K2 + the next iteration's K1 in one pass over the edges (what the direct solver's irls loop runs from its "
+                 "second iteration on: k_update_weights then has no launch inside a solve, k_edge_residual one)", None)):
+            if key not in kr:
+                continue
             ins = insitu_ms(kn, targs)
             line["roofline_" + key] = {
                 "kernel": label, "bound": "hbm", "achieved": kr[key]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -203,7 +203,8 @@ int irotavg_graph_l1decode_pd(irotavg_graph *g, const double *y, int pdmaxiter, 
  * (q = L p), 5 = one preconditioner application, 6 = so(3) step kernel (non-destructive variant),
  * 7 = dense coarse-level inversion (blocked Gauss-Jordan), 8 = the PCG p-update fused into the
  * level-0 SpMV (what a single-GPU solve of a graph without far entries runs instead of 4;
- * IROTAVG_ERR_BAD_ARG if this graph's PCG does not use it). */
+ * IROTAVG_ERR_BAD_ARG if this graph's PCG does not use it), 11 = K2 and the next iteration's K1 in one pass over the
+ * edges (what the direct solver's irls loop runs from its second iteration on). */
 int irotavg_graph_time_kernel(irotavg_graph *g, int which, int reps, double *ms_per_launch);
 
 /* The banded direct solver of this handle (options.band_direct; irotavg_amd/csrc/bcr.hip): info[0] = block size (0: the

@@ -190,7 +190,7 @@ int ls_solve(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_r
 void launch_update_weights(Graph &g, int cost, double sigma, bool gated = false);
 void launch_apply_step(Graph &g, bool gated);
 double finish_apply_step(Graph &g);
-double apply_step(Graph &g, bool gated = false);
+double apply_step(Graph &g, bool gated = false, const std::function<void()> *behind = nullptr);
 // Small read-backs that steer a solve without the runtime's copy + wait (~25 us of idle GPU per decision): ONE tiny
 // kernel behind the producers copies up to three partial arrays into the handle's pinned block and stores a sequence
 // number last (system scope); wait_published polls it (2 ms, then the stream is synchronised: long kernels, faults).

@@ -214,6 +214,61 @@ void launch_update_weights(Graph &g, int cost, double sigma, bool gated) {
                            g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, gate);
 }
 
+// K2 and the NEXT iteration's K1 in one pass over the edges (round 4; the direct solver's irls loop, run_irls): the
+// weights from the old residuals and the step -- exactly k_update_weights -- and then the residuals of the rotations the
+// step has just produced (k_apply_step runs in front of this kernel; it reads X, not the weights). The index pairs are
+// read once instead of twice, one launch less per iteration, and the host reads the score of the step while this runs.
+// Algorithmic traffic: 8 B indices + 24 B old residual + 8 B weight + 32 B relative rotation + 24 B new residual per edge.
+template <bool PREV>
+__global__ __launch_bounds__(256) void k_weights_then_residual(long long m, long long mpad, int f,
+                                                               const int *__restrict__ ei, const int *__restrict__ ej,
+                                                               double *__restrict__ er, const double4 *__restrict__ X,
+                                                               int cost, double sigma, double *__restrict__ dw,
+                                                               const double *__restrict__ qq,
+                                                               const double4 *__restrict__ Q) {
+    const long long k = 2ll * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (k >= mpad) return;
+    const int2 ii = *reinterpret_cast<const int2 *>(ei + k);
+    const int2 jj = *reinterpret_cast<const int2 *>(ej + k);
+    const double2 r0 = *reinterpret_cast<const double2 *>(er + k);
+    const double2 r1 = *reinterpret_cast<const double2 *>(er + mpad + k);
+    const double2 r2 = *reinterpret_cast<const double2 *>(er + 2 * mpad + k);
+    const double2 qx = *reinterpret_cast<const double2 *>(qq + k);
+    const double2 qy = *reinterpret_cast<const double2 *>(qq + mpad + k);
+    const double2 qz = *reinterpret_cast<const double2 *>(qq + 2 * mpad + k);
+    const double2 qw = *reinterpret_cast<const double2 *>(qq + 3 * mpad + k);
+    double2 prev = make_double2(0.0, 0.0);
+    if (PREV && k < m) prev = *reinterpret_cast<const double2 *>(dw + k);
+    const double4 qi0 = Q[ii.x], qj0 = Q[jj.x], qi1 = Q[ii.y], qj1 = Q[jj.y];
+    if (k < m) {
+        const double ea = step_residual2(ii.x, jj.x, f, r0.x, r1.x, r2.x, X);
+        const double wa = robust_weight(cost, sigma, ea, prev.x);
+        if (k + 1 < m) {
+            const double eb = step_residual2(ii.y, jj.y, f, r0.y, r1.y, r2.y, X);
+            *reinterpret_cast<double2 *>(dw + k) = make_double2(wa, robust_weight(cost, sigma, eb, prev.y));
+        } else {
+            dw[k] = wa;  // the pad entry behind an odd m keeps its value
+        }
+    }
+    double2 rx, ry, rz;
+    edge_log(qi0, qj0, make_double4(qx.x, qy.x, qz.x, qw.x), rx.x, ry.x, rz.x);
+    edge_log(qi1, qj1, make_double4(qx.y, qy.y, qz.y, qw.y), rx.y, ry.y, rz.y);
+    *reinterpret_cast<double2 *>(er + k) = rx;
+    *reinterpret_cast<double2 *>(er + mpad + k) = ry;
+    *reinterpret_cast<double2 *>(er + 2 * mpad + k) = rz;
+}
+
+void launch_weights_then_residual(Graph &g, int cost, double sigma) {
+    const long long threads = g.mpad / 2;
+    const int grid = (int)((threads + 255) / 256);
+    if (cost == IROTAVG_L2 || cost == IROTAVG_HUBER)
+        hipLaunchKernelGGL((k_weights_then_residual<true>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
+                           (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p);
+    else
+        hipLaunchKernelGGL((k_weights_then_residual<false>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
+                           (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p);
+}
+
 // =============================================================================================
 // K3 -- level-0 assembly. The lane that owns a free view walks the view's incident-edge entries
 // (SELL layout, wave-uniform trip count): off-diagonal value -w, diagonal sum, Dirichlet excess
@@ -2229,7 +2284,8 @@ double finish_apply_step(Graph &g) {
     return s / (double)g.no;
 }
 // gated: the step is applied only if flags[FL_DONE] == 1, and the flags come back with the score (h_flags())
-double apply_step(Graph &g, bool gated) {
+// behind: launches enqueued behind the publishing kernel, before the host waits for the score (they run while it does)
+double apply_step(Graph &g, bool gated, const std::function<void()> *behind) {
     const int n = g.nu;
     const int grid = grid_for_elems(n);
     hipLaunchKernelGGL(k_apply_step, dim3(grid), dim3(kRowBlock), 0, g.stream, n, g.f, g.ng, g.X.p, g.Q.p,
@@ -2237,6 +2293,7 @@ double apply_step(Graph &g, bool gated) {
     PubPart part[2] = {{g.part_score.p, g.h_part(), 4 * grid},
                        {reinterpret_cast<const double *>(g.flags.p), reinterpret_cast<double *>(g.h_flags()), FL_COUNT / 2}};
     publish_parts(g, part, gated ? 2 : 1);
+    if (behind) (*behind)();
     wait_published(g);
     return finish_apply_step(g);
 }
@@ -2249,8 +2306,14 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     double score = HUGE_VAL;
     int it = 0, rc = IROTAVG_OK;
     fill(g, g.dw.p, (long long)g.mpad, 1.0);  // weights.setOnes() (:577)
+    // the direct solver's plain loop (no closures, one GPU) runs the weight update and the NEXT iteration's residuals as
+    // one kernel behind the step (k_weights_then_residual): er_fresh = the residual planes already belong to Q
+    const bool fuse_wr = g.bcr_B && g.ng == 0 && !g.bcr_shard && !std::getenv("IROTAVG_NO_FUSED_WR");
+    bool er_fresh = false;
+    const std::function<void()> wr_tail = [&]() { launch_weights_then_residual(g, cost, sigma); };
     while (score > change_th && it < max_iters) {  // :590, strict >
-        launch_edge_residual(g);
+        if (!er_fresh) launch_edge_residual(g);
+        er_fresh = false;
         if (g.bcr_B) {
             // banded operator: assembly of level 0, direct solve, weight and rotation update -- ~14 launches and
             // ONE host round trip (the score) per iteration
@@ -2277,6 +2340,9 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                     launch_update_weights(g, cost, sigma);
                     score = apply_step(g);
                 }
+            } else if (fuse_wr) {
+                score = apply_step(g, false, &wr_tail);
+                er_fresh = true;
             } else {
                 launch_update_weights(g, cost, sigma);
                 score = apply_step(g);
@@ -2441,6 +2507,7 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         }
         case 9: cg2_time_once(g, 0); break;   // k_cg_apply (u = M^-1 r, w = L u) of the two-launch iteration
         case 10: cg2_time_once(g, 1); break;  // k_cg_update
+        case 11: launch_weights_then_residual(g, IROTAVG_GEMAN_MCCLURE, 5 * IRH_PI / 180.0); break;  // K2 + the next K1
         case 6:
             hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kRowBlock), 0, g.stream,
                                g.nu, g.f, g.ng, g.X.p, g.Q.p, g.part_score.p, 0, (const int *)nullptr);
@@ -2457,7 +2524,7 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         if (!g.bcr_B) return IROTAVG_ERR_BAD_ARG;
         const int nl = bcr_levels(g);
         if ((which >= 20 && which < 40 && which - 20 >= nl) || (which >= 40 && which - 40 >= nl)) return IROTAVG_ERR_BAD_ARG;
-    } else if (which < 1 || which > 10) return IROTAVG_ERR_BAD_ARG;
+    } else if (which < 1 || which > 11) return IROTAVG_ERR_BAD_ARG;
     if ((which == 9 || which == 10) && !g.cg2) return IROTAVG_ERR_BAD_ARG;  // not this graph's PCG
     if (which == 8 && !(g.additive_top && g.levels.size() > 1 && g.ng == 0 && g.l0_far_entries == 0 &&
                         g.opt.no_fused_pspmv != 1))
