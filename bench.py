@@ -637,7 +637,9 @@ def main():
                 "note": "HIP-event time of the whole solve (all launches back to back on the handle's stream) against the "
                         "algorithmic bytes of all its launches (DESIGN.md 5d). Not bandwidth-bound: ~14 dependent rounds of "
                         "block eliminations (sweep of a %d x %d block, five products on the matrix cores) set the time; "
-                        "1.6 %% of the rows (levels >= 1) take half of it" % (bs["block"], bs["block"]),
+                        "1.6 %% of the rows (levels >= 1) take half of it. Inside irls the two ways back also make the "
+                        "step of every view (K6: exp map, rotation update, score partials -- the in-situ durations "
+                        "include it, the algorithmic bytes do not count its 6.4 MB)" % (bs["block"], bs["block"]),
                 "mfma": {"bound": "mfma", "achieved": bs["tflops"], "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
                          "frac": bs["tflops"] / FP64_PEAK_TF, "flops_per_solve": bs["flops"]},
                 "by_launch": {name: dict(launches=c, ms=(kr[name]["ms"] if name in kr else None),

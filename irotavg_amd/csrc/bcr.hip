@@ -1001,6 +1001,18 @@ __device__ __forceinline__ void bcr_back_rounds(const double *sW, double (*sX)[B
     }
 }
 
+// K6 inside the way back (run_irls on the plain direct path; Graph::bcr_apply): the threads that write a view's solution
+// row also make its step (step_apply) and sum ||x||; the workgroup's sum goes to slot `slot` of the partial array (a
+// DOUBLE per workgroup, not a row of four: level 0 at 100k views has 512 workgroups and level 1 another 73, the pinned
+// block 512 rows), summed by the host in slot order like k_apply_step's partials.
+__device__ __forceinline__ void bcr_apply_sum(double acc, double *__restrict__ part, int slot) {
+    __shared__ double sm[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[slot] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
 // The way back for one chunk: x_7 and the separator before the chunk come from the coarser level. The chunk's
 // W (7 blocks of B x (2B + 3)) is staged in LDS first -- every load of the launch is in flight at once; read row
 // by row behind the three dependent rounds it cost a memory round trip per four rows.
@@ -1008,7 +1020,9 @@ template <int B, int NR, bool L0>
 __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const double *__restrict__ W,
                                                    const double *__restrict__ xc, double *__restrict__ xl,
                                                    double4 *__restrict__ X, double *__restrict__ Z, int zstride,
-                                                   int zoff, int nfar, const double *__restrict__ xext, int place) {
+                                                   int zoff, int nfar, const double *__restrict__ xext, int place,
+                                                   double4 *__restrict__ Qap = nullptr, int fap = 0,
+                                                   double *__restrict__ part_ap = nullptr, int slot0 = 0) {
     typedef BcrDim<B, NR> Dm;
     constexpr int WB = B * Dm::NC;     // doubles of one W block
     __shared__ double sW[7 * WB];
@@ -1050,11 +1064,13 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
     }
     __syncthreads();
     bcr_back_rounds<B, NR>(sW, sX, placed, kreal, wave, lane);
+    double acc_ap = 0.0;
     auto put_row = [&](int row, int t) {
         const double *xs = &sX[1][0] + t * NR;
         X[row] = double4{xs[0], xs[1], xs[2], 0.0};
         if (NR > 3)
             for (int q = 0; q < nfar; q++) Z[(size_t)row * zstride + zoff + q] = xs[3 + q];
+        if (NR == 3 && Qap) acc_ap += step_apply(xs[0], xs[1], xs[2], Qap, row + fap, true);
     };
     if (L0) {
         const int row0 = chunk * 8 * B;
@@ -1078,6 +1094,7 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
                 }
             }
     }
+    if (NR == 3 && Qap) bcr_apply_sum(acc_ap, part_ap, slot0 + chunk);
 }
 
 // The ways back of ALL levels above level 0 in one launch (round 4; they were a launch per level, 11 - 16 us each for
@@ -1093,7 +1110,9 @@ struct BcrBackPlan {
 };
 template <int B>
 __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const double *__restrict__ xtop, double *__restrict__ xl,
-                                                       double4 *__restrict__ X, int n, int nred) {
+                                                       double4 *__restrict__ X, int n, int nred,
+                                                       double4 *__restrict__ Qap = nullptr, int fap = 0,
+                                                       double *__restrict__ part_ap = nullptr, int slot0 = 0) {
     constexpr int NR = 3;
     typedef BcrDim<B, NR> Dm;
     constexpr int WB = B * Dm::NC, XB = B * NR;
@@ -1144,6 +1163,7 @@ __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const doubl
             if (e < 7 * WB / 2) dst[e] = wreg[v];
         }
     };
+    double acc_ap = 0.0;
     int L = P.top, lo, hi;
     range(L, lo, hi);
     int q = lo;
@@ -1192,7 +1212,10 @@ __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const doubl
                     if (gb >= nred && gb < P.nb[L]) {
                         const int row = (8 * nred + (gb - nred)) * B + r;
                         const double *xs = &sX[1][0] + t * NR;
-                        if (row < n) X[row] = double4{xs[0], xs[1], xs[2], 0.0};
+                        if (row < n) {
+                            X[row] = double4{xs[0], xs[1], xs[2], 0.0};
+                            if (Qap) acc_ap += step_apply(xs[0], xs[1], xs[2], Qap, row + fap, true);
+                        }
                     }
                 }
         }
@@ -1201,6 +1224,7 @@ __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const doubl
         L = Ln;
         q = qn;
     }
+    if (Qap) bcr_apply_sum(acc_ap, part_ap, slot0 + cbase);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1871,6 +1895,10 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     double4 *Xout = g.bcr_out ? g.bcr_out : g.X.p + g.ng;
     bool fused_back = false;
     if constexpr (NR == 3) fused_back = nl >= 2 && !g.bcr_shard && !open_top && !getenv("IROTAVG_BCR_NO_FUSED_BACK");
+    // K6 inside the ways back (run_irls asked for it and bcr_apply_ok() said yes): every solution row of level 0 is written
+    // by k_bcr_back (level 0's chunks: slots 0 .. nch0 - 1) or, on a mixed level 1, by k_bcr_back_top (slots nch0 ...)
+    const bool apply = NR == 3 && g.bcr_apply && only < 0 && phase == 0 && fused_back && !g.bcr_out && g.ng == 0;
+    g.bcr_applied = apply;
     for (int l = nl - 1; l >= 0 && phase != 1; l--) {
         if (only >= 0 && only != 100 + l) continue;
         BcrLevel &L = S.lev[l];
@@ -1885,14 +1913,15 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
                 P.top = nl - 1;
                 P.base = 1;
                 hipLaunchKernelGGL((k_bcr_back_top<B>), dim3(L.nch), dim3(256), 0, st, P, S.xtop.p, L.x.p, Xout, L0.n,
-                                   L.nred);
+                                   L.nred, apply ? g.Q.p : (double4 *)nullptr, g.f, g.part_score.p, S.lev[0].nch);
                 continue;
             }
         }
         const double *xc = l == nl - 1 ? (open_top ? xc_top : S.xtop.p) : S.lev[l + 1].x.p;
         if (l == 0)
             hipLaunchKernelGGL((k_bcr_back<B, NR, true>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
-                               (double *)nullptr, Xout, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard);
+                               (double *)nullptr, Xout, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard,
+                               apply ? g.Q.p : (double4 *)nullptr, g.f, g.part_score.p, 0);
         else
             hipLaunchKernelGGL((k_bcr_back<B, NR, false>), dim3(L.nch), dim3(256), 0, st, L.nb, L.nred, L0.n, L.W.p, xc,
                                L.x.p, Xout, (double *)nullptr, 0, 0, nfar, xext, (int)g.bcr_shard);
@@ -2182,6 +2211,20 @@ void bcr_gate(Graph &g) {
 }
 
 int bcr_closures(Graph &g) { return g.bcr_B ? (int)g.bcr_far_e.size() : 0; }
+
+// partial sums of the score a solve with Graph::bcr_apply leaves in part_score (one double per workgroup of the two ways
+// back), or 0 when such a solve cannot make the step itself: closures, a shard, one level, more slots than the pinned block
+// has doubles for
+int bcr_apply_slots(Graph &g) {
+    if (!g.bcr_B || !g.bcr_far_e.empty() || g.bcr_shard || g.ng != 0 || getenv("IROTAVG_BCR_NO_FUSED_BACK") ||
+        getenv("IROTAVG_BCR_NO_APPLY"))
+        return 0;
+    bcr_alloc(g);
+    const BcrState &S = *g.bcr;
+    if (S.lev.size() < 2 || S.nfar != 0) return 0;
+    const int slots = S.lev[0].nch + S.lev[1].nch;
+    return slots <= 4 * kMaxParts ? slots : 0;
+}
 
 int bcr_levels(Graph &g) {
     if (!g.bcr_B) return 0;

@@ -135,6 +135,9 @@ struct Graph {
     // direct solve of a banded level-0 operator by block cyclic reduction (bcr.hip): block size (8 / 16 / 24 / 32;
     // 0 = the solves run through the PCG) and the half-bandwidth found at creation (-1: not looked at)
     int bcr_B = 0, band0 = -1;
+    // run_irls, plain direct path: the ways back of the solve also make the step (K6) and leave the score's partial sums
+    // in part_score, bcr_apply_slots() doubles; bcr_applied = the last solve did
+    bool bcr_apply = false, bcr_applied = false;
     int bcr_up_held = 0;  // 1/1024ths of the device reserved for k_bcr_reduce_up's workgroups (bcr_up_reserve)
     std::unique_ptr<BcrState, BcrDeleter> bcr;
     std::vector<int> bcr_far_i, bcr_far_j, bcr_far_e;  // long-range edges (rows, edge id): Woodbury correction
@@ -285,6 +288,7 @@ int bcr_levels(Graph &g);
 int bcr_info(Graph &g, int64_t *out, int cap);
 int bcr_residual(Graph &g, double *relres);  // ||b - A x|| / ||b|| per coordinate of the last direct solve (one pass over level 0)
 int bcr_closures(Graph &g);  // loop closures the direct solver of this handle carries
+int bcr_apply_slots(Graph &g);
 void bcr_gate(Graph &g);  // flags[FL_DONE] = 1 unless the last direct solve with closures saw a dead pivot (flags[3] = their number)
 void dense_invert_spd(Graph &g, double *A, int npad);  // in place, npad a multiple of 64 (dense.hip)
 int bcr_stamps(Graph &g, int level, int chunk, double *out);  // development aid

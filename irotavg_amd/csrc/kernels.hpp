@@ -312,4 +312,22 @@ __device__ __forceinline__ double4 qmul(const double4 a, const double4 b) {
     return r;
 }
 
+// One view's share of K6 (ral/l1_irls.cpp:729-737, exp_map :471-492): returns ||x|| (the view's term of the score, taken
+// BEFORE the exp map), Q[idx] <- Q[idx] (x) exp(x) (right-multiply, no renormalisation; every non-finite entry of the
+// exponential -> 0, :491). A step that is not finite leaves its rotation alone (the score turns non-finite instead).
+__device__ __forceinline__ double step_apply(double x0, double x1, double x2, double4 *__restrict__ Q, int idx, bool write) {
+    const double th = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+    double sn, cs;
+    sincos(th / 2.0, &sn, &cs);
+    const double coef = sn / th;
+    double4 w = make_double4(x0 * coef, x1 * coef, x2 * coef, cs);
+    if (!isfinite(w.x)) w.x = 0.0;
+    if (!isfinite(w.y)) w.y = 0.0;
+    if (!isfinite(w.z)) w.z = 0.0;
+    if (!isfinite(w.w)) w.w = 0.0;
+    const double4 q = qmul(Q[idx], w);
+    if (write && isfinite(th)) Q[idx] = q;
+    return th;
+}
+
 }  // namespace irh

@@ -1674,21 +1674,11 @@ __global__ __launch_bounds__(kRowBlock) void k_apply_step(int n, int f, int ngho
     double acc = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double4 x = X[i];
-        const double th = sqrt(x.x * x.x + x.y * x.y + x.z * x.z);
-        if (i >= nghost) acc += th;  // score = mean ||W3 row|| BEFORE the exp map (ral/l1_irls.cpp:729); ghosts are scored by their owner
-        double sn, cs;
-        sincos(th / 2.0, &sn, &cs);
-        const double coef = sn / th;
-        double4 w = make_double4(x.x * coef, x.y * coef, x.z * coef, cs);
-        if (!isfinite(w.x)) w.x = 0.0;  // ral/l1_irls.cpp:491
-        if (!isfinite(w.y)) w.y = 0.0;
-        if (!isfinite(w.z)) w.z = 0.0;
-        if (!isfinite(w.w)) w.w = 0.0;
-        const double4 q = qmul(Q[i + f], w);  // right-multiply, no renormalisation (:734-737)
         // A step that is not finite (a solve that broke down on non-finite inputs or weights) leaves its rotation alone:
         // the score turns non-finite, the caller gets IROTAVG_ERR_SOLVER, and the handle still holds the rotations it had
         // (the reference would store zero quaternions there, :491 -- and exit)
-        if (write && isfinite(th)) Q[i + f] = q;
+        const double th = step_apply(x.x, x.y, x.z, Q, i + f, write != 0);
+        if (i >= nghost) acc += th;  // score = mean ||W3 row|| BEFORE the exp map (ral/l1_irls.cpp:729); ghosts are scored by their owner
     }
     block_sum3_store(acc, 0.0, 0.0, part_score + 4 * blockIdx.x);
 }
@@ -2311,13 +2301,19 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     const bool fuse_wr = g.bcr_B && g.ng == 0 && !g.bcr_shard && !std::getenv("IROTAVG_NO_FUSED_WR");
     bool er_fresh = false;
     const std::function<void()> wr_tail = [&]() { launch_weights_then_residual(g, cost, sigma); };
+    // ... and the ways back of its solve make the step themselves (K6 inside k_bcr_back / k_bcr_back_top, bcr.hip): the
+    // score comes back as one partial sum per workgroup of those two launches
+    const int ap_slots = fuse_wr ? bcr_apply_slots(g) : 0;
     while (score > change_th && it < max_iters) {  // :590, strict >
         if (!er_fresh) launch_edge_residual(g);
         er_fresh = false;
         if (g.bcr_B) {
             // banded operator: assembly of level 0, direct solve, weight and rotation update -- ~14 launches and
             // ONE host round trip (the score) per iteration
+            g.bcr_apply = ap_slots > 0;
+            g.bcr_applied = false;
             rc = ls_solve(g);
+            g.bcr_apply = false;
             if (rc != IROTAVG_OK) break;
             if (bcr_closures(g) > 0) {
                 // The Woodbury correction of the closures needs the BAND part alone to be positive definite. A cost whose
@@ -2340,6 +2336,16 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                     launch_update_weights(g, cost, sigma);
                     score = apply_step(g);
                 }
+            } else if (fuse_wr && g.bcr_applied) {
+                const PubPart part = {g.part_score.p, g.h_part(), ap_slots};
+                publish_parts(g, &part, 1);
+                wr_tail();
+                wait_published(g);
+                double ssum = 0.0;
+                for (int b = 0; b < ap_slots; b++) ssum += g.h_part()[b];
+                g.last_score_sum = ssum;
+                score = ssum / (double)g.no;
+                er_fresh = true;
             } else if (fuse_wr) {
                 score = apply_step(g, false, &wr_tail);
                 er_fresh = true;
