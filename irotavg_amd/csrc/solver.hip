@@ -225,7 +225,18 @@ __global__ __launch_bounds__(256) void k_weights_then_residual(long long m, long
                                                                double *__restrict__ er, const double4 *__restrict__ X,
                                                                int cost, double sigma, double *__restrict__ dw,
                                                                const double *__restrict__ qq,
-                                                               const double4 *__restrict__ Q) {
+                                                               const double4 *__restrict__ Q,
+                                                               const double *__restrict__ pub_src,
+                                                               double *__restrict__ pub_dst, int pub_n,
+                                                               int *__restrict__ seqp, int seq) {
+    // the first workgroup hands the score's partial sums (left by the kernel in front of this one) to the host before it
+    // turns to its edges -- what the one-workgroup k_publish did in a launch of its own (5 us per iteration)
+    if (pub_n > 0 && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < pub_n; i += 256) pub_dst[i] = pub_src[i];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(seqp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const long long k = 2ll * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
     if (k >= mpad) return;
     const int2 ii = *reinterpret_cast<const int2 *>(ei + k);
@@ -258,15 +269,21 @@ __global__ __launch_bounds__(256) void k_weights_then_residual(long long m, long
     *reinterpret_cast<double2 *>(er + 2 * mpad + k) = rz;
 }
 
-void launch_weights_then_residual(Graph &g, int cost, double sigma) {
+// pub (n > 0): the kernel's first workgroup publishes that part first (publish_begin has been called)
+void launch_weights_then_residual(Graph &g, int cost, double sigma, const PubPart *pub) {
     const long long threads = g.mpad / 2;
     const int grid = (int)((threads + 255) / 256);
+    const double *ps = pub ? pub->src : nullptr;
+    double *pd = pub ? pub->dst : nullptr;
+    const int pn = pub ? pub->n : 0;
     if (cost == IROTAVG_L2 || cost == IROTAVG_HUBER)
         hipLaunchKernelGGL((k_weights_then_residual<true>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
-                           (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p);
+                           (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p, ps, pd,
+                           pn, g.h_seq(), g.pub_seq);
     else
         hipLaunchKernelGGL((k_weights_then_residual<false>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
-                           (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p);
+                           (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p, ps, pd,
+                           pn, g.h_seq(), g.pub_seq);
 }
 
 // =============================================================================================
@@ -2221,11 +2238,16 @@ __global__ __launch_bounds__(256) void k_publish(const double *__restrict__ s0, 
     if (threadIdx.x == 0) __hip_atomic_store(seqp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the host's half of a publication: a new sequence number (g.pub_seq), the pinned copy of it cleared; the kernel that
+// stores it last is launched by the caller (k_publish below, or a kernel that publishes on its way)
+void publish_begin(Graph &g) {
+    g.pub_seq = (g.pub_seq + 1 == 0) ? 1 : g.pub_seq + 1;
+    __atomic_store_n(g.h_seq(), 0, __ATOMIC_RELEASE);
+}
 void publish_parts(Graph &g, const PubPart *parts, int nparts) {
     PubPart p[3] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
     for (int i = 0; i < nparts && i < 3; i++) p[i] = parts[i];
-    g.pub_seq = (g.pub_seq + 1 == 0) ? 1 : g.pub_seq + 1;
-    __atomic_store_n(g.h_seq(), 0, __ATOMIC_RELEASE);
+    publish_begin(g);
     // (the pinned block is mapped: under unified addressing the device uses the host's pointer)
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, g.stream, p[0].src, p[0].dst, p[0].n, p[1].src, p[1].dst,
                        p[1].n, p[2].src, p[2].dst, p[2].n, g.h_seq(), g.pub_seq);
@@ -2300,7 +2322,7 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     // one kernel behind the step (k_weights_then_residual): er_fresh = the residual planes already belong to Q
     const bool fuse_wr = g.bcr_B && g.ng == 0 && !g.bcr_shard && !std::getenv("IROTAVG_NO_FUSED_WR");
     bool er_fresh = false;
-    const std::function<void()> wr_tail = [&]() { launch_weights_then_residual(g, cost, sigma); };
+    const std::function<void()> wr_tail = [&]() { launch_weights_then_residual(g, cost, sigma, nullptr); };
     // ... and the ways back of its solve make the step themselves (K6 inside k_bcr_back / k_bcr_back_top, bcr.hip): the
     // score comes back as one partial sum per workgroup of those two launches
     const int ap_slots = fuse_wr ? bcr_apply_slots(g) : 0;
@@ -2338,8 +2360,8 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                 }
             } else if (fuse_wr && g.bcr_applied) {
                 const PubPart part = {g.part_score.p, g.h_part(), ap_slots};
-                publish_parts(g, &part, 1);
-                wr_tail();
+                publish_begin(g);
+                launch_weights_then_residual(g, cost, sigma, &part);  // (its first workgroup publishes)
                 wait_published(g);
                 double ssum = 0.0;
                 for (int b = 0; b < ap_slots; b++) ssum += g.h_part()[b];
@@ -2513,7 +2535,7 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         }
         case 9: cg2_time_once(g, 0); break;   // k_cg_apply (u = M^-1 r, w = L u) of the two-launch iteration
         case 10: cg2_time_once(g, 1); break;  // k_cg_update
-        case 11: launch_weights_then_residual(g, IROTAVG_GEMAN_MCCLURE, 5 * IRH_PI / 180.0); break;  // K2 + the next K1
+        case 11: launch_weights_then_residual(g, IROTAVG_GEMAN_MCCLURE, 5 * IRH_PI / 180.0, nullptr); break;  // K2 + the next K1
         case 6:
             hipLaunchKernelGGL(k_apply_step, dim3(grid_for_elems(g.nu)), dim3(kRowBlock), 0, g.stream,
                                g.nu, g.f, g.ng, g.X.p, g.Q.p, g.part_score.p, 0, (const int *)nullptr);
