@@ -188,7 +188,7 @@ int build_graph_device(Graph &g, const int32_t *I, const double *QQ, int64_t ldq
 int finish_build(Graph &g, const BuildTail &T);
 
 // solver entry points (solver.hip)
-void launch_edge_residual(Graph &g);
+void launch_edge_residual(Graph &g, bool weights_to_one = false);
 int ls_solve(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr);  // assemble (IRLS weights) + PCG; result in g.X
 void launch_update_weights(Graph &g, int cost, double sigma, bool gated = false);
 void launch_apply_step(Graph &g, bool gated);

@@ -44,9 +44,11 @@ __global__ __launch_bounds__(256) void k_edge_residual(long long mpad, const int
                                                        const int *__restrict__ ej,
                                                        const double *__restrict__ qq,
                                                        const double4 *__restrict__ Q,
-                                                       double *__restrict__ er) {
+                                                       double *__restrict__ er, double *__restrict__ ones) {
     const long long k = 2ll * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
     if (k >= mpad) return;
+    // (irls' first pass: weights.setOnes(), ral/l1_irls.cpp:577, on the way -- a fill kernel of its own until round 4)
+    if (ones) *reinterpret_cast<double2 *>(ones + k) = make_double2(1.0, 1.0);
     const int2 ii = *reinterpret_cast<const int2 *>(ei + k);
     const int2 jj = *reinterpret_cast<const int2 *>(ej + k);
     const double2 qx = *reinterpret_cast<const double2 *>(qq + k);
@@ -62,11 +64,11 @@ __global__ __launch_bounds__(256) void k_edge_residual(long long mpad, const int
     *reinterpret_cast<double2 *>(er + 2 * mpad + k) = rz;
 }
 
-void launch_edge_residual(Graph &g) {
+void launch_edge_residual(Graph &g, bool weights_to_one) {
     const long long threads = g.mpad / 2;
     const int grid = (int)((threads + 255) / 256);
     hipLaunchKernelGGL(k_edge_residual, dim3(grid), dim3(256), 0, g.stream, (long long)g.mpad,
-                       g.ei.p, g.ej.p, g.qq.p, g.Q.p, g.er.p);
+                       g.ei.p, g.ej.p, g.qq.p, g.Q.p, g.er.p, weights_to_one ? g.dw.p : (double *)nullptr);
 }
 
 // =============================================================================================
@@ -2317,7 +2319,8 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     const double tic = now_seconds();
     double score = HUGE_VAL;
     int it = 0, rc = IROTAVG_OK;
-    fill(g, g.dw.p, (long long)g.mpad, 1.0);  // weights.setOnes() (:577)
+    // weights.setOnes() (:577): by the first pass of K1 (an irls call that makes no iteration fills them here)
+    if (!(score > change_th && 0 < max_iters)) fill(g, g.dw.p, (long long)g.mpad, 1.0);
     // the direct solver's plain loop (no closures, one GPU) runs the weight update and the NEXT iteration's residuals as
     // one kernel behind the step (k_weights_then_residual): er_fresh = the residual planes already belong to Q
     const bool fuse_wr = g.bcr_B && g.ng == 0 && !g.bcr_shard && !std::getenv("IROTAVG_NO_FUSED_WR");
@@ -2327,7 +2330,7 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
     // score comes back as one partial sum per workgroup of those two launches
     const int ap_slots = fuse_wr ? bcr_apply_slots(g) : 0;
     while (score > change_th && it < max_iters) {  // :590, strict >
-        if (!er_fresh) launch_edge_residual(g);
+        if (!er_fresh) launch_edge_residual(g, it == 0);
         er_fresh = false;
         if (g.bcr_B) {
             // banded operator: assembly of level 0, direct solve, weight and rotation update -- ~14 launches and
