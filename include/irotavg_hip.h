@@ -183,7 +183,9 @@ int irotavg_graph_synchronize(irotavg_graph *g);
 
 /* K1: r_k = log(Qinv_j (x) QQ_k (x) Q_i) for every edge (ral/l1_irls.cpp:109-127 + :498-532). */
 int irotavg_graph_edge_residual(irotavg_graph *g);
-/* D2H of the residual rows: out is m x 3 column-major, ld >= m */
+/* D2H of the residual rows: out is m x 3 column-major, ld >= m. They are what the last irotavg_graph_edge_residual call
+ * computed; irotavg_graph_irls / _l1ra use the planes as scratch and leave them unspecified (the residuals of the
+ * rotations before OR after the last step, depending on the solver path). */
 int irotavg_graph_get_residuals(irotavg_graph *g, double *out, int64_t ld);
 /* one weighted least-squares solve with the current weights and residuals
  * (ral/l1_irls.cpp:596-612); X is n_u x 3 column-major (ld >= n_u), may be NULL. */
