@@ -9,6 +9,7 @@
 // make_AtA's boundary rule (:825-843). Control flow (step length, backtracking, stopping) runs on
 // the host from fixed-order reductions; the decisions are the reference's, statement for statement, the kernels are
 // grouped so that a primal-dual iteration needs two host round trips.
+#include <atomic>
 #include <thread>
 
 #include "graph.hpp"
@@ -871,10 +872,62 @@ void release_l1_clones(Graph &g) {
     g.l1_clones.clear();
 }
 
+// The host threads of coordinates 1 and 2 (coordinate 0 runs on the caller): started once per l1ra call and handed one
+// job per outer iteration, instead of three threads created and joined per outer iteration (their creation delayed the
+// last chain by the time two creations take, every iteration). A waiting thread spins, then yields.
+namespace {
+struct L1Crew {
+    std::thread th[2];
+    std::atomic<int> go{0}, done{0};
+    std::atomic<bool> quit{false};
+    std::function<void(int)> job;  // set by the caller before go is raised
+    bool started = false;
+    static void pause_some(int &spins) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if (++spins > 4000) std::this_thread::yield();
+    }
+    void start() {
+        if (started) return;
+        started = true;
+        for (int w = 0; w < 2; w++)
+            th[w] = std::thread([this, w]() {
+                int seen = 0;
+                for (;;) {
+                    int spins = 0;
+                    while (go.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_acquire)) pause_some(spins);
+                    if (go.load(std::memory_order_acquire) == seen) return;  // quit
+                    seen++;
+                    job(w + 1);
+                    done.fetch_add(1, std::memory_order_release);
+                }
+            });
+    }
+    // job(0) on the caller, job(1), job(2) on the crew; returns when all three have ended
+    void run(const std::function<void(int)> &fn) {
+        start();
+        job = fn;
+        const int target = done.load(std::memory_order_acquire) + 2;
+        go.fetch_add(1, std::memory_order_release);
+        fn(0);
+        int spins = 0;
+        while (done.load(std::memory_order_acquire) != target) pause_some(spins);
+    }
+    ~L1Crew() {
+        quit.store(true, std::memory_order_release);
+        for (auto &t : th)
+            if (t.joinable()) t.join();
+    }
+};
+}  // namespace
+
 // ral/l1_irls.cpp:851-912
 int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runtime,
              double *trace) {
     pd_prepare(g);
+    L1Crew crew;
+    const bool use_crew = !std::getenv("IROTAVG_L1_THREADS_PER_ITERATION");
     const double tic = now_seconds();
     double score = HUGE_VAL;
     int l1_step = 2;  // :868
@@ -903,20 +956,23 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
             g.l1_clones = std::move(cl);
         }
         int rcs[3] = {IROTAVG_OK, IROTAVG_OK, IROTAVG_OK};
-        std::thread th[3];
-        for (int c = 0; c < 3; c++) {
-            th[c] = std::thread([&, c]() {
-                try {
-                    (void)hipSetDevice(g.device);
-                    Graph &q = *g.l1_clones[c];
-                    pd_prepare(q);
-                    rcs[c] = l1decode_core(q, g.er.p + (size_t)c * g.mpad, l1_step, N_X0, nullptr);
-                } catch (...) {
-                    rcs[c] = IROTAVG_ERR_HIP;
-                }
-            });
+        const std::function<void(int)> chain = [&](int c) {
+            try {
+                (void)hipSetDevice(g.device);
+                Graph &q = *g.l1_clones[c];
+                pd_prepare(q);
+                rcs[c] = l1decode_core(q, g.er.p + (size_t)c * g.mpad, l1_step, N_X0, nullptr);
+            } catch (...) {
+                rcs[c] = IROTAVG_ERR_HIP;
+            }
+        };
+        if (use_crew) {
+            crew.run(chain);
+        } else {
+            std::thread th[3];
+            for (int c = 0; c < 3; c++) th[c] = std::thread(chain, c);
+            for (int c = 0; c < 3; c++) th[c].join();
         }
-        for (int c = 0; c < 3; c++) th[c].join();
         for (int c = 0; c < 3; c++) {
             if (rcs[c] != IROTAVG_OK && rc == IROTAVG_OK) rc = rcs[c];
             Graph &q = *g.l1_clones[c];

@@ -10,4 +10,4 @@ ts = []
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     G.restore_rotations(); G.synchronize()
     t = time.perf_counter(); r = G.l1ra(5, 1e-3); G.synchronize(); ts.append(1e3 * (time.perf_counter() - t) / r["iters"])
-print("l1ra ms per outer iteration: mean %.3f min %.3f max %.3f" % (np.mean(ts), min(ts), max(ts)))
+print("l1ra ms per outer iteration: mean %.3f median %.3f min %.3f max %.3f" % (np.mean(ts), np.median(ts), min(ts), max(ts)))
