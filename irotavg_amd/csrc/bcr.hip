@@ -662,7 +662,11 @@ __device__ __forceinline__ void bcr_reduce_body(
     {                                                                                                               \
         constexpr int NE = 4 >> RND;                                                                                \
         constexpr int WPE = NW / NE < Dm::NT ? NW / NE : Dm::NT;                                                    \
-        const int e = wave / WPE, part = wave - e * WPE;                                                            \
+        /* (two waves per elimination, four eliminations: the wave that owns the column tiles 1 and 3 issues 72 products, */ \
+        /* the other one 60, and wave w sits on SIMD w % 4 -- the roles are swapped in eliminations 2 and 3 so that every */ \
+        /* SIMD gets one wave of each kind: 132 instead of 144 / 120 products of 64 clocks per SIMD)                      */ \
+        const int e = wave / WPE, part0 = wave - e * WPE;                                                           \
+        const int part = (WPE == 2 && NE == 4) ? (part0 ^ ((e >> 1) & 1)) : part0;                                  \
         int i = -1, a = -1, c = 7;                                                                                  \
         if (e < NE) {                                                                                               \
             if (RND == 0) {                                                                                         \
