@@ -112,20 +112,28 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane, int *dead = nul
 #pragma unroll
     for (int i = 0; i < HB; i++) t[i] = Dm[(h * HB + i) * B + cl];
     const double dg = Dm[cl * B + cl];
+    const double dgt = kDeadTol * dg;  // (the dead-pivot limit of the lane's row, formed once: a product per pivot less)
     int ndead = 0;
     auto pivot_inverse = [&](double tk, int k, int kh) {
         // reciprocal by v_rcp_f64 + two Newton steps (the IEEE division sequence is three times as long and sits on
         // the chain from pivot to pivot)
-        const double p0 = bcr_readlane(tk, k + 32 * kh), ref = bcr_readlane(dg, k);
-        const bool alive = p0 > kDeadTol * ref;
+        const double p0 = bcr_readlane(tk, k + 32 * kh);
+        const bool alive = p0 > bcr_readlane(dgt, k);
         ndead += alive ? 0 : 1;
-        const double p = (alive || !reg) ? p0 : (ref > 0.0 ? ref : 1.0);
+        double p = p0;
+        if (reg && !alive) {
+            const double ref = bcr_readlane(dg, k);
+            p = ref > 0.0 ? ref : 1.0;
+        }
         double x = __builtin_amdgcn_rcp(p);
         x = fma(fma(-p, x, 1.0), x, x);
         x = fma(fma(-p, x, 1.0), x, x);
         return (alive || reg) ? x : 0.0;
     };
-    if (h == 0 && act) Dm[c] = t[0];
+    // (the row's own diagonal position carries -1 instead of the pivot: nobody reads the pivot there -- it travels through
+    // an SGPR --, and the lane of column k, which reads it as its multiplier of the pivot row, gets rowk pinv = -pinv, the
+    // (k, k) entry of the swept matrix, without a select of its own)
+    if (h == 0 && act) Dm[c] = c == 0 ? -1.0 : t[0];
     asm volatile("" ::: "memory");
     double pinv = pivot_inverse(t[0], 0, 0);
     double rowk = Dm[cl], colk[HB];
@@ -141,7 +149,7 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane, int *dead = nul
         const int k1 = k + 1, kh1 = k1 / HB, ki1 = k1 - kh1 * HB;  // the next pivot (when k1 < B)
         const bool isk = c == k;
         const double f = rowk * pinv;
-        const double g = isk ? -pinv : f;
+        const double g = f;
         // general element: t -= colk (rowk pinv); column k: colk pinv; row k: rowk pinv; (k, k): -pinv
         // (the lane of column k drops its old values by a product with 0, one instruction, not by a 64-bit select, two:
         // 24 of the ~105 instructions of a pivot; taking the LDS round trip of the row out of the pivot-to-pivot chain --
@@ -157,7 +165,7 @@ __device__ __forceinline__ void bcr_invert(double *Dm, int lane, int *dead = nul
         double pinv1 = 0.0, rowk1 = 0.0, colk1[HB];
         if (k1 < B) {
             upd(ki1);
-            if (h == kh1 && act) Dm[c] = t[ki1];
+            if (h == kh1 && act) Dm[c] = c == k1 ? -1.0 : t[ki1];
             asm volatile("" ::: "memory");
             pinv1 = pivot_inverse(t[ki1], k1, kh1);
             rowk1 = Dm[cl];
