@@ -914,7 +914,7 @@ __device__ __forceinline__ int bcr_back_mask(int m) {
     if (m & 0x36) m |= 0x08;   // 1, 2, 4, 5 need 3
     return m;
 }
-template <int B, int NR>
+template <int B, int NR, int NWB = 4>
 __device__ __forceinline__ void bcr_back_rounds(const double *sW, double (*sX)[B * NR], bool placed, int kreal, int wave,
                                                 int lane, int mask = 0x7f) {
     typedef BcrDim<B, NR> Dm;
@@ -925,7 +925,7 @@ __device__ __forceinline__ void bcr_back_rounds(const double *sW, double (*sX)[B
         if (NR == 3) {
             constexpr int UPB = B / 4;                  // units per block
             const int nbk = 4 >> rnd;                   // blocks of the round: 3 | 1 5 | 0 2 4 6
-            for (int u = wave; u < nbk * UPB; u += 4) {
+            for (int u = wave; u < nbk * UPB; u += NWB) {
                 const int e = u / UPB, it = u - e * UPB;
                 int i, a, c;
                 if (rnd == 0) {
@@ -980,6 +980,7 @@ __device__ __forceinline__ void bcr_back_rounds(const double *sW, double (*sX)[B
                 }
             }
         } else {
+            static_assert(NR == 3 || NWB == 4, "the closures' right-hand sides ride on four-wave workgroups");
             int i = -1, a = -1, c = 7;
             if (rnd == 0) {
                 i = 2 * wave;
@@ -1018,11 +1019,15 @@ __device__ __forceinline__ void bcr_back_rounds(const double *sW, double (*sX)[B
 // DOUBLE per workgroup, not a row of four: level 0 at 100k views has 512 workgroups and level 1 another 73, the pinned
 // block 512 rows), summed by the host in slot order like k_apply_step's partials.
 __device__ __forceinline__ void bcr_apply_sum(double acc, double *__restrict__ part, int slot) {
-    __shared__ double sm[4];
+    __shared__ double sm[16];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[slot] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += sm[w];   // fixed order
+        part[slot] = t;
+    }
 }
 
 // The way back for one chunk: x_7 and the separator before the chunk come from the coarser level. The chunk's
@@ -1120,15 +1125,17 @@ struct BcrBackPlan {
     int nb[kMaxLevels];
     int top, base;
 };
+// (eight waves: the rounds of a chunk are 24 / 12 / 6 units of four rows, and a workgroup has a CU to itself)
+constexpr int kBackTopThreads = 512;
 template <int B>
-__global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const double *__restrict__ xtop, double *__restrict__ xl,
+__global__ __launch_bounds__(kBackTopThreads) void k_bcr_back_top(BcrBackPlan P, const double *__restrict__ xtop, double *__restrict__ xl,
                                                        double4 *__restrict__ X, int n, int nred,
                                                        double4 *__restrict__ Qap = nullptr, int fap = 0,
                                                        double *__restrict__ part_ap = nullptr, int slot0 = 0) {
     constexpr int NR = 3;
     typedef BcrDim<B, NR> Dm;
     constexpr int WB = B * Dm::NC, XB = B * NR;
-    constexpr int NV = (7 * WB / 2 + 255) / 256;   // 16-byte pieces of a chunk's W per thread
+    constexpr int NV = (7 * WB / 2 + kBackTopThreads - 1) / kBackTopThreads;   // 16-byte pieces of a chunk's W per thread
     __shared__ double sW[7 * WB];
     __shared__ double sX[9][XB];
     __shared__ double sWin[2][16][XB];
@@ -1163,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const doubl
         const v2d *__restrict__ src = reinterpret_cast<const v2d *>(P.W[L] + (size_t)q * 7 * WB);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            const int e = tid + 256 * v, blk = e / (WB / 2);
+            const int e = tid + kBackTopThreads * v, blk = e / (WB / 2);
             wreg[v] = (blk < nblk && ((mask >> blk) & 1)) ? __builtin_nontemporal_load(&src[e]) : v2d{0.0, 0.0};
         }
     };
@@ -1171,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const doubl
         v2d *dst = reinterpret_cast<v2d *>(sW);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            const int e = tid + 256 * v;
+            const int e = tid + kBackTopThreads * v;
             if (e < 7 * WB / 2) dst[e] = wreg[v];
         }
     };
@@ -1188,8 +1195,8 @@ __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const doubl
         const int kreal = P.nb[L] - q * 8 < 8 ? P.nb[L] - q * 8 : 8;
         const int mask = wanted(L, q);
         deposit();
-        for (int e = tid; e < 7 * XB; e += 256) (&sX[1][0])[e] = 0.0;
-        for (int e = tid; e < XB; e += 256) {
+        for (int e = tid; e < 7 * XB; e += kBackTopThreads) (&sX[1][0])[e] = 0.0;
+        for (int e = tid; e < XB; e += kBackTopThreads) {
             sX[8][e] = L == P.top ? xtop[e] : winP[q - 8 * plo][e];
             sX[0][e] = (L == P.top || q == 0) ? 0.0 : winP[q - 1 - 8 * plo][e];
         }
@@ -1204,22 +1211,22 @@ __global__ __launch_bounds__(256) void k_bcr_back_top(BcrBackPlan P, const doubl
         }
         if (Ln >= P.base) request(Ln, qn);
         __syncthreads();
-        bcr_back_rounds<B, NR>(sW, sX, false, kreal, wave, lane, mask);
+        bcr_back_rounds<B, NR, kBackTopThreads / 64>(sW, sX, false, kreal, wave, lane, mask);
         if (L > P.base) {
             int clo, chi;
             range(L, clo, chi);
-            for (int e = tid; e < 8 * XB; e += 256) {
+            for (int e = tid; e < 8 * XB; e += kBackTopThreads) {
                 const int blk = e / XB;
                 winC[(q - clo) * 8 + blk][e - blk * XB] = blk < kreal ? (&sX[1][0])[e] : 0.0;
             }
         } else {
-            for (int e = tid; e < 8 * XB; e += 256) {
+            for (int e = tid; e < 8 * XB; e += kBackTopThreads) {
                 const int blk = e / XB;
                 xl[(size_t)q * 8 * XB + e] = blk < kreal ? (&sX[1][0])[e] : 0.0;
             }
             // blocks of a mixed level that are level-0 blocks themselves: their solution rows
             if (q * 8 + 8 > nred && nred < P.nb[L])
-                for (int t = tid; t < 8 * B; t += 256) {
+                for (int t = tid; t < 8 * B; t += kBackTopThreads) {
                     const int i = t / B, r = t - i * B, gb = q * 8 + i;
                     if (gb >= nred && gb < P.nb[L]) {
                         const int row = (8 * nred + (gb - nred)) * B + r;
@@ -1924,7 +1931,7 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
                 }
                 P.top = nl - 1;
                 P.base = 1;
-                hipLaunchKernelGGL((k_bcr_back_top<B>), dim3(L.nch), dim3(256), 0, st, P, S.xtop.p, L.x.p, Xout, L0.n,
+                hipLaunchKernelGGL((k_bcr_back_top<B>), dim3(L.nch), dim3(kBackTopThreads), 0, st, P, S.xtop.p, L.x.p, Xout, L0.n,
                                    L.nred, apply ? g.Q.p : (double4 *)nullptr, g.f, g.part_score.p, S.lev[0].nch);
                 continue;
             }
