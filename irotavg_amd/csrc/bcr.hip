@@ -1065,10 +1065,23 @@ __global__ __launch_bounds__(256) void k_bcr_back(int nb, int nred, int n, const
         }
     }
     {
+        // (every piece of W requested before the first one is put down: a loop of load -> LDS store pairs left it to the
+        // compiler how many round trips that became)
         const v2d *__restrict__ src = reinterpret_cast<const v2d *>(W + (size_t)chunk * 7 * WB);
         v2d *dst = reinterpret_cast<v2d *>(sW);
         const int cnt = nblk * WB / 2;  // B is a multiple of 8: WB is even
-        for (int e = tid; e < cnt; e += 256) dst[e] = __builtin_nontemporal_load(&src[e]);
+        constexpr int NVW = (7 * WB / 2 + 255) / 256;
+        v2d wreg[NVW];
+#pragma unroll
+        for (int v = 0; v < NVW; v++) {
+            const int e = tid + 256 * v;
+            wreg[v] = e < cnt ? __builtin_nontemporal_load(&src[e]) : v2d{0.0, 0.0};
+        }
+#pragma unroll
+        for (int v = 0; v < NVW; v++) {
+            const int e = tid + 256 * v;
+            if (e < cnt) dst[e] = wreg[v];
+        }
     }
     for (int e = tid; e < 7 * B * NR; e += 256) (&sX[1][0])[e] = 0.0;
 #pragma unroll
