@@ -112,6 +112,9 @@ typedef struct irotavg_stats {
                                  weights cut a view off its band neighbours while a closure may still hold it): repeated as a
                                  conjugate-gradient solve of the full operator preconditioned by the regularised direct solve */
     int64_t direct_dead_pivots; /* dead pivots of the band factor seen by the last such solve */
+    int64_t direct_up_fallbacks; /* direct solves repeated level by level because a workgroup of the single-launch upper
+                                    reduction gave up waiting for the others (another process held the device): the handle
+                                    keeps the level-by-level launches from then on */
 } irotavg_stats;
 
 /* ---------------------------------------------------------------------------------------------

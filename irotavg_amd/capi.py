@@ -58,7 +58,8 @@ class Stats(C.Structure):
                 ("last_relres", C.c_double * 3), ("pcg_stagnated", C.c_int64),
                 ("dense_inversions", C.c_int64), ("dense_repairs", C.c_int64),
                 ("pcg_handed_over", C.c_int64), ("direct_solves", C.c_int64), ("band", C.c_int64),
-                ("band_block", C.c_int64), ("direct_guarded", C.c_int64), ("direct_dead_pivots", C.c_int64)]
+                ("band_block", C.c_int64), ("direct_guarded", C.c_int64), ("direct_dead_pivots", C.c_int64),
+                ("direct_up_fallbacks", C.c_int64)]
 
 
 class RotAvgInfo(C.Structure):

@@ -34,6 +34,54 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
+constexpr int kTopMax = 16, kTopRounds = 6;
+struct BcrTopSched {
+    int n = 0, nr = 0, last = 0;   // blocks, rounds, the block that is left
+    signed char ne[kTopRounds];    // eliminations of a round (<= 4)
+    signed char i[kTopRounds][4], a[kTopRounds][4], c[kTopRounds][4];  // block, left / right neighbour (-1: none)
+};
+
+// (the arguments of k_bcr_reduce_up, see there). They live in device memory and are read by functions that are not inlined
+// into the kernel: a pointer loaded from memory is GENERIC to the compiler (flat loads / stores, which also count on the
+// LDS counter) unless its type says global -- so the fields are typed global for the device pass.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IRH_GPTR(T) T __attribute__((address_space(1))) *
+#else
+#define IRH_GPTR(T) T *
+#endif
+typedef IRH_GPTR(const double) gp_cd;
+typedef IRH_GPTR(double) gp_d;
+typedef IRH_GPTR(const int) gp_ci;
+typedef IRH_GPTR(int) gp_i;
+typedef IRH_GPTR(unsigned) gp_u;
+typedef IRH_GPTR(const double4) gp_cd4;
+constexpr int kUpLevels = 8;
+struct BcrUpLevel {
+    int nb, nred, nch;
+    gp_cd inD, inR, inXD, inXR, inXG;  // from the level below
+    gp_d W, sepD, sepR, extD, extR, extG;
+};
+struct BcrUpArgs {
+    int nl;  // levels of the launch; lev[0] = level 1 of the solve
+    BcrUpLevel lev[kUpLevels];
+    // the level-0 operator, for the blocks of a mixed level 1 that no chunk reduced
+    int n;
+    gp_ci sl_off, col;
+    gp_cd val, diag;
+    gp_cd4 rhs;
+    gp_d xtop;
+    gp_u cnt;
+    // round 5: the last level as ONE workgroup of up to sixteen blocks that also makes its way back (bcr_top_body):
+    // top16 != 0, its schedule, where the solutions of its blocks go
+    int top16;
+    BcrTopSched top;
+    gp_d xtop_all;
+    // a wait that did not end: every workgroup that gives up says so here (cnt + kUpLevels), skips its chunk but still
+    // counts itself -- nobody else waits a second for it --, and the top workgroup poisons the solution when the word is
+    // set; the host then repeats the solve level by level (bcr_up_failed)
+    gp_i fail;
+};
+
 struct BcrLevel {
     int nb = 0;   // blocks
     int nred = 0; // ... of which the first nred come from the level below (the others: raw level-0 blocks)
@@ -68,8 +116,14 @@ struct BcrState {
     // a shard of a sharded sequence (dist.hip): the separator before the first chunk is the previous rank's
     int ext0 = 0;
     DevBuf<long long> stamps;  // development aid: bcr_stamp
-    DevBuf<unsigned> up_cnt;   // k_bcr_reduce_up: arrivals per level boundary (they only grow: solve g waits for g x chunks)
+    DevBuf<unsigned> up_cnt;   // k_bcr_reduce_up: arrivals per level boundary (they only grow: solve g waits for g x chunks);
+                               // word kUpLevels: a wait gave up (bcr_up_failed)
     unsigned up_gen = 0;
+    DevBuf<BcrUpArgs> up_args; // k_bcr_reduce_up's arguments (written once)
+    bool up_used = false;      // the last solve went through k_bcr_reduce_up
+    bool top16 = false;        // the last level is one workgroup of <= 16 blocks that makes its own way back (bcr_top_body)
+    BcrTopSched tsched;
+    DevBuf<BcrTopSched> tsched_dev;
     DevBuf<int> ghost_extcol;  // per ghost view: its row in the previous rank's last block, or -1
     DevBuf<double> remD, remR; // what this shard's eliminations subtract from that separator (sum over its levels)
 };
@@ -81,6 +135,25 @@ __device__ __forceinline__ double bcr_readlane(double v, int lane) {
     lo = __builtin_amdgcn_readlane(lo, lane);
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
+}
+
+// Sum over aligned groups of sixteen lanes, every lane gets it: the butterfly of __shfl_xor(1, 2, 4, 8) -- the same
+// additions, bit for bit -- by DPP moves (quad permutes, then the mirrors of half a row and of a row: after two steps all
+// four lanes of a quad hold the quad's sum, so WHICH lane of the other quad / half a lane adds does not matter) instead
+// of ds_bpermute: a step costs ~20 clocks instead of an LDS round trip (round 5: the ways back are chains of such sums).
+template <int CTRL>
+__device__ __forceinline__ double bcr_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcr_row16_sum(double v) {
+    v += bcr_dpp<0xB1>(v);   // quad_perm [1 0 3 2]
+    v += bcr_dpp<0x4E>(v);   // quad_perm [2 3 0 1]
+    v += bcr_dpp<0x141>(v);  // row_half_mirror
+    v += bcr_dpp<0x140>(v);  // row_mirror
+    return v;
 }
 
 // In-place inverse of the SPD B x B matrix Dm (LDS, row-major) by one wave; B even, B <= 32. Symmetric sweep: after
@@ -260,10 +333,12 @@ struct BcrElim {
 
     // W = Di^-1 [P' | Q | R] (Di^-1 in LDS), W -> global (the way back reads it), and the right neighbour:
     // D_c -= Q' W_Q, R_c -= Q' W_R
+    // (hasQ = false: the block has no right neighbour -- the last block of the single-workgroup top, bcr_top_body; Wg =
+    // nullptr: W is not wanted in memory)
     template <int WPE>
     __device__ __forceinline__ void phase1(int part, const double *Di, const double *P, bool hasP, const double *Q,
                                            const double *Ri, double *Dc, double *Rc, double *Wg, const double *zero,
-                                           int lane) {
+                                           int lane, bool hasQ = true) {
         constexpr int NS = (Dm::NT + WPE - 1) / WPE;
         static_assert(NS <= NTPW, "slots");
         double aop[Dm::MT][Dm::KS];
@@ -286,8 +361,10 @@ struct BcrElim {
                         stride[sl] = 1;
                     }
                 } else if (j < 2 * B) {
-                    base[sl] = Q + (j - B);
-                    stride[sl] = B;
+                    if (hasQ) {
+                        base[sl] = Q + (j - B);
+                        stride[sl] = B;
+                    }
                 } else if (j < Dm::NC) {
                     base[sl] = Ri + (j - 2 * B);
                     stride[sl] = NR;
@@ -309,17 +386,20 @@ struct BcrElim {
                 for (int mt = 0; mt < Dm::MT; mt++)
                     w[mt][sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mt][s], bop[sl], w[mt][sl], 0, 0, 0);
         }
+        if (Wg) {
 #pragma unroll
-        for (int sl = 0; sl < NS; sl++) {
-            const int j = 16 * (part + sl * WPE) + lj;
+            for (int sl = 0; sl < NS; sl++) {
+                const int j = 16 * (part + sl * WPE) + lj;
 #pragma unroll
-            for (int mt = 0; mt < Dm::MT; mt++)
+                for (int mt = 0; mt < Dm::MT; mt++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = 16 * mt + 4 * r + lk;
-                    if (row < B && j < Dm::NC) Wg[row * Dm::NC + j] = w[mt][sl][r];
-                }
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * mt + 4 * r + lk;
+                        if (row < B && j < Dm::NC) Wg[row * Dm::NC + j] = w[mt][sl][r];
+                    }
+            }
         }
+        if (!hasQ) return;
         bcr_load_a<B, true>(Q, lane, aop);
         v4d out[Dm::MT][NS];
 #pragma unroll
@@ -351,6 +431,35 @@ struct BcrElim {
                             Dc[row * B + c - B] -= out[mt][sl][r];
                         else if (c >= 2 * B && c < Dm::NC)
                             Rc[row * NR + c - 2 * B] -= out[mt][sl][r];
+                    }
+                }
+        }
+    }
+
+    // the single-workgroup top keeps W in LDS for its way back, in the places its elimination has freed: W_P over
+    // D_i^-1, W_Q over Q, W_R over R_i (after the barrier behind phase1: nobody reads those any more)
+    template <int WPE>
+    __device__ __forceinline__ void keep_w(int part, double *Di, double *Q, bool hasQ, double *Ri, int lane) const {
+        constexpr int NS = (Dm::NT + WPE - 1) / WPE;
+        const int lj = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int sl = 0; sl < NS; sl++) {
+            const int nt = part + sl * WPE;
+            if (nt >= Dm::NT) continue;
+            const int j = 16 * nt + lj;
+#pragma unroll
+            for (int mt = 0; mt < Dm::MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * mt + 4 * r + lk;
+                    if (row < B) {
+                        const double v = w[mt][sl][r];
+                        if (j < B)
+                            Di[row * B + j] = v;
+                        else if (j < 2 * B) {
+                            if (hasQ) Q[row * B + j - B] = v;
+                        } else if (j < Dm::NC)
+                            Ri[row * NR + j - 2 * B] = v;
                     }
                 }
         }
@@ -417,7 +526,7 @@ struct BcrElim {
 // of the band operator this solver factorises -- their weight is taken back out of the diagonal (the entry is
 // -w, the diagonal holds +w) and the closures re-enter by the Woodbury correction (bcr_solve). nfar > 0: the
 // right-hand-side columns 3 .. 3 + nfar of the row get the incidence vectors of the closures of this pass.
-template <int B, int NR>
+template <int B, int NR, int NBT = 12>
 __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int *__restrict__ sl_off,
                                                const int *__restrict__ col, const double *__restrict__ val,
                                                const double *__restrict__ diag, const double4 *__restrict__ rhs,
@@ -435,8 +544,9 @@ __device__ __forceinline__ void bcr_gather_row(int row, int lb, int r, const int
     const double dgv = diag[row];
     const double4 bb = rhs[row];
     // the row's entries in batches of NBT pairs: all loads of a batch are issued before the first value is
-    // scattered (a load per scatter was a memory round trip per pair)
-    constexpr int NBT = 12;
+    // scattered (a load per scatter was a memory round trip per pair). NBT = 24: the raw blocks of a mixed level 1 inside
+    // the single-launch upper reduction, where nine workgroups gather while sixty-four wait for them -- a row of the
+    // headline graph (42 entries) is then ONE batch, one memory round trip less
     for (int q0 = 0; q0 < w / 2; q0 += NBT) {
         v2i cc[NBT];
         v2d vv[NBT];
@@ -555,16 +665,64 @@ __device__ __forceinline__ void bcr_reduce_body(
     const bool placed = place && kreal < 8;                      // ... placed so that the last one is the separator
 
     // ---- load ----
-    for (int e = tid; e < 8 * BB; e += NT_) {
-        (&sD[0][0])[e] = 0.0;
-        (&sG[0][0])[e] = 0.0;
+    // A chunk of an upper level whose blocks all come from the level below and sit at their own positions (every chunk
+    // but a shard's partial ones and those of a mixed level 1 that hold raw level-0 blocks) is loaded by the FAST path
+    // below: every word of LDS is written exactly once -- value, identity or zero -- so LDS is not cleared first (18
+    // stores per thread and a barrier in front of the first load), the right-hand sides are requested together with the
+    // blocks (they were a second memory round trip) and the index arithmetic is that of a contiguous copy (round 5: the
+    // load phase of an upper level took 8 500 clocks, half of it address arithmetic of the general mapping).
+    const bool fastload = !L0 && !placed && !(chunk * 8 + 8 > nred && nred < nb);
+    if (!fastload) {
+        for (int e = tid; e < 8 * BB; e += NT_) {
+            (&sD[0][0])[e] = 0.0;
+            (&sG[0][0])[e] = 0.0;
+        }
+        for (int e = tid; e < 9 * B * NR; e += NT_) (&sR[0][0])[e] = 0.0;
+        if (tid < 2) sZ[tid] = 0.0;
     }
-    for (int e = tid; e < 9 * B * NR; e += NT_) (&sR[0][0])[e] = 0.0;
-    if (tid < 2) sZ[tid] = 0.0;
     bcr_stamp(stamps, 0);
-    __syncthreads();
+    if (!fastload) __syncthreads();
     bcr_stamp(stamps, 1);
-    if (L0) {
+    if (!L0 && fastload) {
+        // block gb = chunk 8 + i of this level = chunk gb of the level below; (gb BB + el) = chunk 8 BB + e: contiguous
+        constexpr int NIT = (8 * BB + NT_ - 1) / NT_, U = NIT <= 12 ? NIT : 8;
+        constexpr int NIR = (8 * B * NR + NT_ - 1) / NT_;
+        const size_t cb = (size_t)chunk * 8 * BB, cr = (size_t)chunk * 8 * B * NR;
+        double vr[NIR], vy[NIR];
+#pragma unroll
+        for (int u = 0; u < NIR; u++) {
+            const int e = tid + NT_ * u, i = e / (B * NR);
+            const bool ok = e < 8 * B * NR && i < kreal;
+            vr[u] = ok ? bcr_ld<COH>(inR + cr + e) : 0.0;
+            vy[u] = ok && chunk * 8 + i + 1 < nred ? bcr_ld<COH>(inXR + cr + B * NR + e) : 0.0;
+        }
+        for (int u0 = 0; u0 < NIT; u0 += U) {
+            double vd[U], vx[U], vg[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = tid + NT_ * (u0 + u), i = e / BB;
+                const bool ok = e < 8 * BB && i < kreal;
+                vd[u] = ok ? bcr_ld<COH>(inD + cb + e) : 0.0;
+                vx[u] = ok && chunk * 8 + i + 1 < nred ? bcr_ld<COH>(inXD + cb + BB + e) : 0.0;
+                vg[u] = ok && (chunk * 8 + i > 0 || ext0) ? bcr_ld<COH>(inXG + cb + e) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = tid + NT_ * (u0 + u), i = e / BB, el = e - i * BB;
+                if (e >= 8 * BB) continue;
+                // (a position without a block: the identity, its eliminations are skipped)
+                (&sD[0][0])[e] = i < kreal ? vd[u] + vx[u] : (el % (B + 1) == 0 ? 1.0 : 0.0);
+                (&sG[0][0])[e] = vg[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NIR; u++) {
+            const int e = tid + NT_ * u;
+            if (e < 8 * B * NR) (&sR[1][0])[e] = vr[u] + vy[u];
+        }
+        for (int e = tid; e < B * NR; e += NT_) sR[0][e] = 0.0;
+        if (tid < 2) sZ[tid] = 0.0;
+    } else if (L0) {
         const int row0 = chunk * 8 * B;
         for (int t = tid; t < kreal * B; t += NT_) {
             const int row = row0 + t, blk = t / B, r = t - blk * B;
@@ -604,7 +762,13 @@ __device__ __forceinline__ void bcr_reduce_body(
             return t;
         };
         constexpr int NIT = (8 * BB + NT_ - 1) / NT_, U = NIT <= 12 ? NIT : 8;
-        for (int u0 = 0; u0 < NIT; u0 += U) {
+        // (a chunk of a mixed level that holds raw level-0 blocks only has nothing to fetch from the level below: the
+        // positions without a block become the identity and the walk over the eight positions is skipped -- nine such
+        // workgroups are what the sixty-four others of level 1 wait for at 100k views)
+        const bool allraw = !placed && chunk * 8 >= nred;
+        if (allraw)
+            for (int e = tid; e < (8 - kreal) * B; e += NT_) sD[kreal + e / B][(e % B) * (B + 1)] = 1.0;
+        for (int u0 = 0; u0 < NIT && !allraw; u0 += U) {
             double vd[U], vx[U], vg[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -630,7 +794,7 @@ __device__ __forceinline__ void bcr_reduce_body(
                 }
             }
         }
-        {
+        if (!allraw) {
             constexpr int NIR = (8 * B * NR + NT_ - 1) / NT_;
             double vr[NIR], vy[NIR];
 #pragma unroll
@@ -650,8 +814,9 @@ __device__ __forceinline__ void bcr_reduce_body(
                 if (gb >= nred && gb < nb) {
                     const int lb = 8 * nred + (gb - nred), row = lb * B + r;
                     if (row < n)
-                        bcr_gather_row<B, NR>(row, lb, r, sl_off, col, val, diag, rhs, &sDG[0][0], i * BB, -1,
-                                              gb > 0 ? (8 + i) * BB : -1, sR[i + 1], nfar, far_i, far_j);
+                        bcr_gather_row<B, NR, (NW == 8 && B <= 24 ? 24 : 12)>(row, lb, r, sl_off, col, val, diag, rhs, &sDG[0][0],
+                                                                            i * BB, -1, gb > 0 ? (8 + i) * BB : -1, sR[i + 1],
+                                                                            nfar, far_i, far_j);
                     else
                         sD[i][r * B + r] = 1.0;
                 }
@@ -773,6 +938,200 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
                                                bghost, bval, ghost_extcol, place, stamps, Dinvg, topDinv, deadctr, reg);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The top of the hierarchy in ONE workgroup: up to sixteen blocks (round 5; until then a level of 9 ... 64 blocks was
+// reduced by chunks of eight to a top of <= 8 -- at 100k views the last two levels held 10 and 2 blocks and cost a load,
+// four rounds, a store and a level boundary more than the 10 blocks need). The blocks of the top level are loaded once;
+// every round eliminates up to four blocks no two of which are neighbours (four sweeps on four SIMDs, their products
+// dealt to the eight waves as in a chunk), by a schedule the host writes (bcr_top_schedule: the first four even positions
+// of the list of blocks still alive -- 10 blocks: 10 -> 6 -> 3 -> 1 in three rounds, 16: five); the block that is left
+// is solved. W stays in LDS, in the places an elimination frees (W_P over D_i^-1, W_Q over the coupling to the right
+// neighbour, W_R over R_i), so the way back of the top level follows at once: the workgroup writes the solutions of ALL
+// its blocks, and the ways back of the levels below start from them (k_bcr_back_top / k_bcr_back: one level less).
+// The coupling of block x to the next block alive lives in sG[x]; a fill-in A[a, c] takes the place of A[a, i].
+// Three right-hand sides, B <= 24 (LDS: (2 n - 1) blocks + 2 n right-hand-side slots = 158 KB for n = 16, B = 24), no
+// closures (their step programs know chunks only), not a shard.
+// ---------------------------------------------------------------------------------------------
+static BcrTopSched bcr_top_schedule(int n) {
+    BcrTopSched T;
+    memset(&T, 0, sizeof(T));
+    T.n = n;
+    std::vector<int> alive(n);
+    for (int k = 0; k < n; k++) alive[k] = k;
+    while (alive.size() > 1 && T.nr < kTopRounds) {
+        const int r = T.nr++;
+        std::vector<int> next;
+        int ne = 0;
+        for (size_t p = 0; p < alive.size(); p++) {
+            if (p % 2 == 0 && ne < 4) {
+                T.i[r][ne] = (signed char)alive[p];
+                T.a[r][ne] = (signed char)(p > 0 ? alive[p - 1] : -1);
+                T.c[r][ne] = (signed char)(p + 1 < alive.size() ? alive[p + 1] : -1);
+                ne++;
+            } else {
+                next.push_back(alive[p]);
+            }
+        }
+        T.ne[r] = (signed char)ne;
+        alive.swap(next);
+    }
+    T.last = alive[0];
+    return T;
+}
+static size_t bcr_top_lds(int B, int n) {
+    return ((size_t)(2 * n - 1) * B * B + (size_t)2 * n * B * 3 + 2) * sizeof(double) + sizeof(BcrTopSched);
+}
+
+template <int B, int NW, bool COH>
+__device__ __forceinline__ void bcr_top_body(double *smem, const BcrTopSched *__restrict__ Tg, const double *__restrict__ inD,
+                                             const double *__restrict__ inR, const double *__restrict__ inXD,
+                                             const double *__restrict__ inXR, const double *__restrict__ inXG,
+                                             double *__restrict__ xout, int dbg, long long *__restrict__ stamps) {
+    constexpr int NR = 3;
+    typedef BcrDim<B, NR> Dm;
+    constexpr int BB = B * B, XB = B * NR, NT_ = NW * 64;
+    static_assert(NW == 8, "eight waves");
+    const int n = Tg->n;
+    double(*sD)[BB] = reinterpret_cast<double(*)[BB]>(smem);
+    double(*sG)[BB] = sD + n;  // n - 1 slots
+    double(*sR)[XB] = reinterpret_cast<double(*)[XB]>(smem + (size_t)(2 * n - 1) * BB);
+    double(*sX)[XB] = sR + n;
+    double *sZ = &sX[n][0];
+    // (the schedule is read with indices that are not known at compile time, by every wave, in every round: LDS)
+    BcrTopSched &T = *reinterpret_cast<BcrTopSched *>(sZ + 2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    static_assert(sizeof(BcrTopSched) % 4 == 0, "copied by words");
+    if (tid < (int)(sizeof(BcrTopSched) / 4)) reinterpret_cast<int *>(&T)[tid] = reinterpret_cast<const int *>(Tg)[tid];
+    bcr_stamp(stamps, 0);
+    // ---- load: D_j = sepD[j] + extD[j + 1], R_j = sepR[j] + extR[j + 1], coupling j - 1 -> j = extG[j] ----
+    {
+        constexpr int U = 6;
+        const int nD = n * BB, nG = (n - 1) * BB, nR = n * XB;
+        for (int e0 = 0; e0 < nD; e0 += U * NT_) {
+            double vd[U], vx[U], vg[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = e0 + tid + NT_ * u;
+                vd[u] = e < nD ? bcr_ld<COH>(inD + e) : 0.0;
+                vx[u] = e < nG ? bcr_ld<COH>(inXD + BB + e) : 0.0;
+                vg[u] = e < nG ? bcr_ld<COH>(inXG + BB + e) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = e0 + tid + NT_ * u;
+                if (e < nD) (&sD[0][0])[e] = vd[u] + vx[u];
+                if (e < nG) (&sG[0][0])[e] = vg[u];
+            }
+        }
+        for (int e = tid; e < nR; e += NT_) {
+            const double vr = bcr_ld<COH>(inR + e);
+            const double vy = e < nR - XB ? bcr_ld<COH>(inXR + XB + e) : 0.0;
+            (&sR[0][0])[e] = vr + vy;
+        }
+        if (tid < 2) sZ[tid] = 0.0;
+    }
+    __syncthreads();
+    bcr_stamp(stamps, 1);
+    // ---- the rounds ----
+    for (int r = 0; r < T.nr; r++) {
+        const int ne = T.ne[r];
+        if (wave < ne && !(dbg & 1)) bcr_invert<B>(sD[T.i[r][wave]], lane);
+        __syncthreads();
+        bcr_stamp(stamps, 2 + 2 * r);
+        auto products = [&](auto wpe_tag) {
+            constexpr int WPE = decltype(wpe_tag)::value;
+            const int e = wave / WPE, part0 = wave - e * WPE;
+            const int part = WPE == 2 ? (part0 ^ ((e >> 1) & 1)) : part0;
+            const bool active = e < ne;
+            const int i = active ? T.i[r][e] : 0, a = active ? T.a[r][e] : -1, c = active ? T.c[r][e] : -1;
+            const bool hasP = a >= 0, hasQ = c >= 0;
+            BcrElim<B, NR, 2> E;
+            v4d out[Dm::MT][2];
+            if (active && !(dbg & 2))
+                E.template phase1<WPE>(part, sD[i], hasP ? sG[a] : sZ, hasP, hasQ ? sG[i] : sZ, sR[i], hasQ ? sD[c] : sD[i],
+                                       hasQ ? sR[c] : sR[i], (double *)nullptr, sZ, lane, hasQ);
+            __syncthreads();
+            if (active && hasP && !(dbg & 4)) E.template phase2_mul<WPE>(part, sG[a], out, lane);
+            if (active && !(dbg & 2)) E.template keep_w<WPE>(part, sD[i], hasQ ? sG[i] : sZ, hasQ, sR[i], lane);
+            __syncthreads();
+            if (active && hasP && !(dbg & 4)) E.template phase2_put<WPE>(part, out, sG[a], sD[a], false, sR[a], lane);
+            __syncthreads();
+        };
+        if (ne > 2) products(std::integral_constant<int, 2>());
+        else products(std::integral_constant<int, 4>());
+        bcr_stamp(stamps, 3 + 2 * r);
+    }
+    // ---- the block that is left ----
+    const int last = T.last;
+    if (wave == 0) {
+        bcr_invert<B>(sD[last], lane);
+        for (int o = lane; o < XB; o += 64) {
+            const int k = o / NR, q = o - NR * k;
+            double acc = 0.0;
+            for (int cidx = 0; cidx < B; cidx++) acc += sD[last][k * B + cidx] * sR[last][cidx * NR + q];
+            sX[last][o] = acc;
+        }
+    }
+    __syncthreads();
+    bcr_stamp(stamps, 14);
+    // ---- the way back: x_i = W_R - W_P x_a - W_Q x_c, rounds in reverse; a unit of work = four rows of a block ----
+    {
+        constexpr int UPB = B / 4, NCT = (2 * B + 15) / 16;
+        const int lk = lane >> 4, lp = lane & 15;
+        for (int r = T.nr - 1; r >= 0; r--) {
+            const int ne = T.ne[r];
+            for (int u = wave; u < ne * UPB; u += NW) {
+                const int e = u / UPB, it = u - e * UPB;
+                const int i = T.i[r][e], a = T.a[r][e], c = T.c[r][e];
+                const double *xa = sX[a >= 0 ? a : 0], *xc = sX[c >= 0 ? c : 0];
+                const int k = 4 * it + lk;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int t = 0; t < NCT; t++) {
+                    const int cidx = lp + 16 * t;
+                    if (cidx < B) {
+                        if (a >= 0) {
+                            const double wv = sD[i][k * B + cidx];
+                            s0 += wv * xa[cidx * 3 + 0];
+                            s1 += wv * xa[cidx * 3 + 1];
+                            s2 += wv * xa[cidx * 3 + 2];
+                        }
+                    } else if (cidx < 2 * B) {
+                        if (c >= 0) {
+                            const double wv = sG[i][k * B + cidx - B];
+                            s0 += wv * xc[(cidx - B) * 3 + 0];
+                            s1 += wv * xc[(cidx - B) * 3 + 1];
+                            s2 += wv * xc[(cidx - B) * 3 + 2];
+                        }
+                    }
+                }
+                s0 = bcr_row16_sum(s0);
+                s1 = bcr_row16_sum(s1);
+                s2 = bcr_row16_sum(s2);
+                if (lp == 0) {
+                    sX[i][k * 3 + 0] = sR[i][k * 3 + 0] - s0;
+                    sX[i][k * 3 + 1] = sR[i][k * 3 + 1] - s1;
+                    sX[i][k * 3 + 2] = sR[i][k * 3 + 2] - s2;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < n * XB; e += NT_) xout[e] = (&sX[0][0])[e];
+    bcr_stamp(stamps, 15);
+}
+
+// the top alone (a launch of its own: timing of single levels, a handle whose single-launch reduction was not admitted)
+template <int B>
+__global__ __launch_bounds__(512, 1) void k_bcr_top(const BcrTopSched *__restrict__ T, const double *__restrict__ inD, const double *__restrict__ inR,
+                                                    const double *__restrict__ inXD, const double *__restrict__ inXR,
+                                                    const double *__restrict__ inXG, double *__restrict__ xout, int dbg,
+                                                    long long *__restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) double top_smem[];
+    bcr_top_body<B, 8, false>(top_smem, T, inD, inR, inXD, inXR, inXG, xout, dbg, stamps);
+}
+
 // The reductions of ALL levels above level 0 in ONE launch (round 4). Those levels hold 1.6 % of the rows; each was a
 // launch of 73 / 10 / 2 / 1 workgroups that spends ~5 us of its 20 - 38 us starting, filling and draining. Here workgroup c
 // runs chunk c of every level that has one, level after level; between two levels the workgroups that go on wait for a
@@ -784,70 +1143,97 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && B <= 24 && NR == 3 ? 2 : 1)) v
 // XCDs). All workgroups of the launch fit the chip at once (one per CU), so nobody waits for a workgroup that cannot
 // start. A wait that does not end (~1 s) poisons the top separator: the solve then fails with IROTAVG_ERR_SOLVER at the
 // next score instead of hanging the device. W goes to memory as before: the ways back are later launches.
-constexpr int kUpLevels = 8;
-struct BcrUpLevel {
-    int nb, nred, nch;
-    const double *inD, *inR, *inXD, *inXR, *inXG;  // from the level below
-    double *W, *sepD, *sepR, *extD, *extR, *extG;
-};
-struct BcrUpArgs {
-    int nl;  // levels of the launch; lev[0] = level 1 of the solve
-    BcrUpLevel lev[kUpLevels];
-    // the level-0 operator, for the blocks of a mixed level 1 that no chunk reduced
-    int n;
-    const int *sl_off, *col;
-    const double *val, *diag;
-    const double4 *rhs;
-    double *xtop;
-    unsigned *cnt;
-    unsigned gen;
-    int dbg;
-};
-template <int B>
-__global__ __launch_bounds__(512, 1) void k_bcr_reduce_up(BcrUpArgs A) {
+// The bodies of the levels are separate FUNCTIONS (round 5): inlined into one kernel the three of them -- a chunk, a chunk
+// that is the top, the sixteen-block top -- shared one register allocation with the level loop around them, and the
+// kernel spilled (36 registers in round 4, 155 with the sixteen-block top) where each body alone needs 124 - 212 and
+// spills nothing. A call per level costs nothing against 30 us of work. Their arguments live in device memory (written
+// once per handle: only the generation, the debug word and the stamp array change from solve to solve and travel as
+// kernel arguments); LDS is the launch's dynamic allocation, named by the functions themselves.
+// (16-byte alignment: the sweeps read LDS by ds_read_b128; behind the kernel's one static word an 8-byte-aligned base made
+// every such read a split one and a sweep 3.5 x slower)
+extern __shared__ __attribute__((aligned(16))) double up_smem[];
+typedef IRH_GPTR(const BcrUpArgs) gp_args;
+template <int B, bool TOP>
+__device__ __noinline__ void bcr_up_chunk(gp_args A, int i, int dbg, long long *stl) {
     constexpr int NR = 3;
-    __shared__ double sDG[16][B * B];
-    __shared__ double sR[9][B * NR];
-    __shared__ double sZ[2];
+    IRH_GPTR(const BcrUpLevel) L = &A->lev[i];
+    double(*sDG)[B * B] = reinterpret_cast<double(*)[B * B]>(up_smem);
+    double(*sR)[B * NR] = reinterpret_cast<double(*)[B * NR]>(up_smem + 16 * B * B);
+    double *sZ = up_smem + 16 * B * B + 9 * B * NR;
+    bcr_reduce_body<B, NR, false, TOP, 8, true>(
+        blockIdx.x, sDG, sR, sZ, L->nb, L->nred, A->n, (const int *)A->sl_off, (const int *)A->col, (const double *)A->val,
+        (const double *)A->diag, (const double4 *)A->rhs, (const double *)L->inD, (const double *)L->inR, (const double *)L->inXD,
+        (const double *)L->inXR, (const double *)L->inXG, (double *)L->W, (double *)L->sepD, (double *)L->sepR, (double *)L->extD,
+        (double *)L->extR, (double *)L->extG, (double *)A->xtop, dbg, 0, (const int *)nullptr, (const int *)nullptr, 0, (const int *)nullptr, (const int *)nullptr,
+        (const double *)nullptr, (const int *)nullptr, 0, stl ? stl - (size_t)blockIdx.x * 16 : nullptr, (double *)nullptr,
+        (double *)nullptr, (int *)nullptr, 0);   // (bcr_stamp adds 16 x the workgroup's number)
+}
+template <int B>
+__device__ __noinline__ void bcr_up_top(gp_args A, int i, int dbg, long long *stl) {
+    IRH_GPTR(const BcrUpLevel) L = &A->lev[i];
+    bcr_top_body<B, 8, true>(up_smem, (const BcrTopSched *)&A->top, (const double *)L->inD, (const double *)L->inR,
+                             (const double *)L->inXD, (const double *)L->inXR, (const double *)L->inXG, (double *)A->xtop_all, dbg,
+                             stl ? stl - (size_t)blockIdx.x * 16 : nullptr);
+}
+template <int B>
+__global__ __launch_bounds__(512, 1) void k_bcr_reduce_up(const BcrUpArgs *__restrict__ Ap, unsigned gen, int dbg,
+                                                          long long *__restrict__ stamps) {
+    constexpr int NR = 3;
     __shared__ int s_ok;
+    const gp_args Ag = (gp_args)Ap;
+    const BcrUpArgs &A = *Ap;
     const int wg = blockIdx.x;
+    const int nl = A.nl;
     bool fine = true;
-    for (int i = 0; i < A.nl; i++) {
-        const BcrUpLevel &L = A.lev[i];
-        if (wg >= L.nch) break;  // (the chunk counts shrink level by level)
+    for (int i = 0; i < nl; i++) {
+        if (wg >= A.lev[i].nch) break;  // (the chunk counts shrink level by level)
+        long long *stl = stamps && wg == (dbg >> 8) ? stamps + 32 * i : nullptr;  // (the workgroup that stamps: dbg >> 8)
+        if (stl && threadIdx.x == 0) stl[16] = (long long)__builtin_readcyclecounter();
+        // (slots 20 ...: where the workgroup's waves sit -- HW_ID: wave [3:0], SIMD [5:4], CU [11:8], SE [15:13])
+        if (stl && (threadIdx.x & 63) == 0) stl[20 + (threadIdx.x >> 6)] = 0x10000 + (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
         if (i > 0) {
             if (threadIdx.x == 0) {
-                const unsigned target = A.gen * (unsigned)A.lev[i - 1].nch;
+                const unsigned target = gen * (unsigned)A.lev[i - 1].nch;
                 int good = 0;
                 for (int spin = 0; spin < (1 << 21); spin++) {
                     // (a difference: the counter may wrap)
-                    if ((int)(__hip_atomic_load(A.cnt + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) {
+                    if ((int)(__hip_atomic_load((const unsigned *)A.cnt + (i - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) {
                         good = 1;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(2);
                 }
+                if (!good) __hip_atomic_store((int *)A.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_ok = good;
             }
             __syncthreads();
             fine = fine && s_ok != 0;
         }
-#define IRH_UP_ARGS                                                                                                     \
-    wg, sDG, sR, sZ, L.nb, L.nred, A.n, A.sl_off, A.col, A.val, A.diag, A.rhs, L.inD, L.inR, L.inXD, L.inXR, L.inXG, L.W,     \
-        L.sepD, L.sepR, L.extD, L.extR, L.extG, A.xtop, A.dbg, 0, (const int *)nullptr, (const int *)nullptr, 0,             \
-        (const int *)nullptr, (const int *)nullptr, (const double *)nullptr, (const int *)nullptr, 0, (long long *)nullptr, \
-        (double *)nullptr, (double *)nullptr, (int *)nullptr, 0
-        if (i == A.nl - 1) {
-            bcr_reduce_body<B, NR, false, true, 8, true>(IRH_UP_ARGS);
-            if (!fine && threadIdx.x == 0) A.xtop[0] = __builtin_nan("");
+        if (stl && threadIdx.x == 0) stl[17] = (long long)__builtin_readcyclecounter();
+        if (i == nl - 1) {
+            // (the top workgroup has waited for every workgroup of the level below, and a workgroup sets the word before it
+            // counts itself)
+            const bool bad = !fine || __hip_atomic_load((const int *)A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            // bad: NaN into every entry -- it then reaches every solution row on the ways back, no view takes a step
+            // (step_apply leaves a rotation alone when its step is not finite) and the score is NaN
+            if (A.top16) {
+                if (!bad) bcr_up_top<B>(Ag, i, dbg, stl);
+                else
+                    for (int e = threadIdx.x; e < A.top.n * B * NR; e += 512) A.xtop_all[e] = __builtin_nan("");
+            } else {
+                if (!bad) bcr_up_chunk<B, true>(Ag, i, dbg, stl);
+                else
+                    for (int e = threadIdx.x; e < B * NR; e += 512) A.xtop[e] = __builtin_nan("");
+            }
         } else {
-            bcr_reduce_body<B, NR, false, false, 8, true>(IRH_UP_ARGS);
+            if (fine) bcr_up_chunk<B, false>(Ag, i, dbg, stl);
+            if (stl && threadIdx.x == 0) stl[18] = (long long)__builtin_readcyclecounter();
             // every thread's separator stores have been acknowledged before the workgroup is counted
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(A.cnt + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) __hip_atomic_fetch_add((unsigned *)A.cnt + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stl && threadIdx.x == 0) stl[19] = (long long)__builtin_readcyclecounter();
         }
-#undef IRH_UP_ARGS
     }
 }
 
@@ -859,6 +1245,11 @@ __global__ __launch_bounds__(512, 1) void k_bcr_reduce_up(BcrUpArgs A) {
 // all handles stays within the device; a handle keeps its share (its launches are ordered on its stream: the largest
 // counts, not the sum) until it is idle. A launch that is not admitted runs level by level, as before round 4.
 // IROTAVG_BCR_UP_CAP: the capacity in 1/1024ths (tests).
+template <int B>
+static size_t bcr_up_lds(int ntop) {
+    const size_t chunk = ((size_t)16 * B * B + 9 * B * 3 + 2) * sizeof(double);
+    return ntop > 0 ? std::max(chunk, bcr_top_lds(B, ntop)) : chunk;
+}
 namespace {
 std::atomic<int> g_up_used[16];
 template <int B>
@@ -868,7 +1259,8 @@ int bcr_up_capacity(int dev) {
     int c = cap[d].load(std::memory_order_relaxed);
     if (c == 0) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bcr_reduce_up<B>, 512, 0) != hipSuccess) per_cu = 0;
+        // (dynamic LDS: at least a chunk's; a sixteen-block top asks for more, still one workgroup per CU either way)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bcr_reduce_up<B>, 512, bcr_up_lds<B>(0)) != hipSuccess) per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         (void)hipGetLastError();
         c = per_cu > 0 && cus > 0 ? per_cu * cus : -1;
@@ -967,12 +1359,9 @@ __device__ __forceinline__ void bcr_back_rounds(const double *sW, double (*sX)[B
                         }
                     }
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s0 += __shfl_xor(s0, o, 64);
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
-                }
+                s0 = bcr_row16_sum(s0);
+                s1 = bcr_row16_sum(s1);
+                s2 = bcr_row16_sum(s2);
                 if (lp == 0) {
                     sX[i + 1][k * 3 + 0] = s0;
                     sX[i + 1][k * 3 + 1] = s1;
@@ -1144,7 +1533,10 @@ template <int B>
 __global__ __launch_bounds__(kBackTopThreads) void k_bcr_back_top(BcrBackPlan P, const double *__restrict__ xtop, double *__restrict__ xl,
                                                        double4 *__restrict__ X, int n, int nred,
                                                        double4 *__restrict__ Qap = nullptr, int fap = 0,
-                                                       double *__restrict__ part_ap = nullptr, int slot0 = 0) {
+                                                       double *__restrict__ part_ap = nullptr, int slot0 = 0,
+                                                       int top_all = 0) {
+    // top_all: xtop holds the solutions of ALL blocks of the level above P.top (the single-workgroup top, bcr_top_body,
+    // made its own way back): chunk q of level P.top takes blocks q and q - 1 of it
     constexpr int NR = 3;
     typedef BcrDim<B, NR> Dm;
     constexpr int WB = B * Dm::NC, XB = B * NR;
@@ -1210,8 +1602,8 @@ __global__ __launch_bounds__(kBackTopThreads) void k_bcr_back_top(BcrBackPlan P,
         deposit();
         for (int e = tid; e < 7 * XB; e += kBackTopThreads) (&sX[1][0])[e] = 0.0;
         for (int e = tid; e < XB; e += kBackTopThreads) {
-            sX[8][e] = L == P.top ? xtop[e] : winP[q - 8 * plo][e];
-            sX[0][e] = (L == P.top || q == 0) ? 0.0 : winP[q - 1 - 8 * plo][e];
+            sX[8][e] = L == P.top ? xtop[(top_all ? q * XB : 0) + e] : winP[q - 8 * plo][e];
+            sX[0][e] = q == 0 ? 0.0 : L == P.top ? (top_all ? xtop[(q - 1) * XB + e] : 0.0) : winP[q - 1 - 8 * plo][e];
         }
         // the next chunk: the same level's second chunk, else the first of the level below
         int Ln = L, qn = q + 1;
@@ -1800,6 +2192,10 @@ static void bcr_alloc(Graph &g) {
             nch0 = full;
         }
     }
+    // the last level: one chunk of <= 8 blocks, or (round 5) one workgroup of <= 16 blocks that also makes its way back
+    // -- three right-hand sides, blocks up to 24 rows (LDS), no closures (their step programs know chunks), not a shard
+    S.top16 = B <= 24 && S.nfar == 0 && !g.bcr_shard && !getenv("IROTAVG_BCR_NO_TOP16");
+    const int topmax = S.top16 ? kTopMax : 8;
     int nb = nb0, nch = nch0;
     for (int l = 0;; l++) {
         S.lev.emplace_back();
@@ -1807,9 +2203,23 @@ static void bcr_alloc(Graph &g) {
         L.nb = nb;
         L.nch = nch;
         L.nred = (l == 1 && nraw > 0) ? nb - nraw : nb;
+        const bool last = nb <= topmax && !g.bcr_shard && l > 0;
+        if (last && S.top16) {
+            // (a level 0 of <= 16 blocks keeps the chunk form: its blocks are gathered from the operator)
+            L.x.alloc((size_t)L.nch * 8 * B * NR);
+            S.tsched = bcr_top_schedule(nb);
+            S.tsched_dev.alloc(1);
+            IRH_CHECK(hipMemcpyAsync(S.tsched_dev.p, &S.tsched, sizeof(BcrTopSched), hipMemcpyHostToDevice, g.stream));
+            IRH_CHECK(hipStreamSynchronize(g.stream));
+            break;
+        }
+        if (l == 0 && nb <= 8) S.top16 = false;
         L.W.alloc((size_t)L.nch * 7 * B * NC);
         if (l > 0) L.x.alloc((size_t)L.nch * 8 * B * NR);
-        if (nb <= 8 && !g.bcr_shard) break;
+        if (nb <= 8 && !g.bcr_shard) {
+            S.top16 = false;
+            break;
+        }
         L.sepD.alloc((size_t)L.nch * B * B);
         L.extD.alloc((size_t)L.nch * B * B);
         L.extG.alloc((size_t)L.nch * B * B);
@@ -1856,37 +2266,76 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     bool fused_up = false;
     if constexpr (NR == 3 && B <= 24) {
         fused_up = nl >= 3 && nl - 1 <= kUpLevels && only < 0 && phase == 0 && !open_top && !g.bcr_shard && S.nfar == 0 &&
-                   S.lev[1].nch <= 256 && !(dbg & 64) && !getenv("IROTAVG_BCR_NARROW") && !getenv("IROTAVG_BCR_NO_FUSED_UP");
+                   S.lev[1].nch <= 256 && !(dbg & 64) && !getenv("IROTAVG_BCR_NARROW") && !getenv("IROTAVG_BCR_NO_FUSED_UP") &&
+                   !g.bcr_no_fused_up;
+        if ((dbg & 128) && !S.stamps.p) S.stamps.alloc((size_t)std::max(S.lev[0].nch * 16, 32 * kUpLevels));
         if (fused_up) fused_up = bcr_up_reserve<B>(g, S.lev[1].nch);
     }
+    if (only < 0 && phase != 2) S.up_used = false;
     for (int l = 0; l < nl && phase != 2; l++) {
         if (only >= 0 && only != l) continue;
         if constexpr (NR == 3 && B <= 24) {
+            if (S.top16 && l == nl - 1 && !fused_up) {
+                // the single-workgroup top in a launch of its own
+                const BcrLevel &F = S.lev[l - 1];
+                const size_t lds = bcr_top_lds(B, S.lev[l].nb);
+                static std::atomic<size_t> lds_set[16];
+                if (lds_set[g.device & 15].load() < lds) {
+                    IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_top<B>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    lds_set[g.device & 15].store(lds);
+                }
+                hipLaunchKernelGGL((k_bcr_top<B>), dim3(1), dim3(512), lds, st, S.tsched_dev.p, F.sepD.p, F.sepR.p, F.extD.p,
+                                   F.extR.p, F.extG.p, S.lev[l].x.p, dbg, stamps);
+                continue;
+            }
             if (fused_up && l >= 1) {
                 if (l > 1) continue;
-                if (S.up_cnt.n < (size_t)kUpLevels) {
-                    S.up_cnt.alloc(kUpLevels);
+                if (S.up_cnt.n < (size_t)kUpLevels + 1) {
+                    S.up_cnt.alloc(kUpLevels + 1);
                     S.up_cnt.zero(st);
                     S.up_gen = 0;
                 }
-                BcrUpArgs A;
-                A.nl = nl - 1;
-                for (int i = 0; i < A.nl; i++) {
-                    BcrLevel &Li = S.lev[1 + i], &Fi = S.lev[i];
-                    A.lev[i] = BcrUpLevel{Li.nb,   Li.nred,  Li.nch,   Fi.sepD.p, Fi.sepR.p, Fi.extD.p, Fi.extR.p, Fi.extG.p,
-                                          Li.W.p,  Li.sepD.p, Li.sepR.p, Li.extD.p, Li.extR.p, Li.extG.p};
+                if (!S.up_args.p) {
+                    // the launch's arguments: written once per handle
+                    BcrUpArgs A;
+                    memset(&A, 0, sizeof(A));
+                    A.nl = nl - 1;
+                    for (int i = 0; i < A.nl; i++) {
+                        BcrLevel &Li = S.lev[1 + i], &Fi = S.lev[i];
+                        A.lev[i] = BcrUpLevel{Li.nb,          Li.nred,        Li.nch,         (gp_cd)Fi.sepD.p, (gp_cd)Fi.sepR.p,
+                                              (gp_cd)Fi.extD.p, (gp_cd)Fi.extR.p, (gp_cd)Fi.extG.p, (gp_d)Li.W.p,   (gp_d)Li.sepD.p,
+                                              (gp_d)Li.sepR.p, (gp_d)Li.extD.p, (gp_d)Li.extR.p, (gp_d)Li.extG.p};
+                    }
+                    A.n = L0.n;
+                    A.sl_off = (gp_ci)L0.sl_off.p;
+                    A.col = (gp_ci)L0.col.p;
+                    A.val = (gp_cd)L0.val.p;
+                    A.diag = (gp_cd)L0.diag.p;
+                    A.rhs = (gp_cd4)L0.b.p;
+                    A.xtop = (gp_d)S.xtop.p;
+                    A.cnt = (gp_u)S.up_cnt.p;
+                    A.top16 = S.top16;
+                    A.top = S.tsched;
+                    A.xtop_all = (gp_d)S.lev[nl - 1].x.p;
+                    A.fail = (gp_i) reinterpret_cast<int *>(S.up_cnt.p + kUpLevels);
+                    S.up_args.alloc(1);
+                    IRH_CHECK(hipMemcpyAsync(S.up_args.p, &A, sizeof(A), hipMemcpyHostToDevice, st));
+                    IRH_CHECK(hipStreamSynchronize(st));  // (A is on this stack)
                 }
-                A.n = L0.n;
-                A.sl_off = L0.sl_off.p;
-                A.col = L0.col.p;
-                A.val = L0.val.p;
-                A.diag = L0.diag.p;
-                A.rhs = L0.b.p;
-                A.xtop = S.xtop.p;
-                A.cnt = S.up_cnt.p;
-                A.gen = ++S.up_gen;
-                A.dbg = dbg;
-                hipLaunchKernelGGL((k_bcr_reduce_up<B>), dim3(S.lev[1].nch), dim3(512), 0, st, A);
+                // (tests: the give-up path without a second process -- the word is set as if a wait had timed out)
+                if (getenv("IROTAVG_BCR_FAKE_UP_FAIL") && g.stats.direct_up_fallbacks == 0)
+                    IRH_CHECK(hipMemsetAsync(S.up_cnt.p + kUpLevels, 1, sizeof(int), st));
+                const size_t lds = bcr_up_lds<B>(S.top16 ? S.lev[nl - 1].nb : 0);
+                static std::atomic<size_t> lds_set[16];
+                if (lds_set[g.device & 15].load() < lds) {
+                    IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_reduce_up<B>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    lds_set[g.device & 15].store(lds);
+                }
+                hipLaunchKernelGGL((k_bcr_reduce_up<B>), dim3(S.lev[1].nch), dim3(512), lds, st, S.up_args.p, ++S.up_gen, dbg,
+                                   (dbg & 128) ? S.stamps.p : (long long *)nullptr);
+                S.up_used = true;
                 continue;
             }
         }
@@ -1926,12 +2375,15 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     // columns ride along or IROTAVG_BCR_NO_FUSED_BACK is set
     double4 *Xout = g.bcr_out ? g.bcr_out : g.X.p + g.ng;
     bool fused_back = false;
-    if constexpr (NR == 3) fused_back = nl >= 2 && !g.bcr_shard && !open_top && !getenv("IROTAVG_BCR_NO_FUSED_BACK");
+    // (a single-workgroup top has made its own way back: the levels below it are left)
+    const int ltop = S.top16 ? nl - 2 : nl - 1;
+    if constexpr (NR == 3) fused_back = ltop >= 1 && !g.bcr_shard && !open_top && !getenv("IROTAVG_BCR_NO_FUSED_BACK");
     // K6 inside the ways back (run_irls asked for it and bcr_apply_ok() said yes): every solution row of level 0 is written
     // by k_bcr_back (level 0's chunks: slots 0 .. nch0 - 1) or, on a mixed level 1, by k_bcr_back_top (slots nch0 ...)
-    const bool apply = NR == 3 && g.bcr_apply && only < 0 && phase == 0 && fused_back && !g.bcr_out && g.ng == 0;
+    const bool apply = NR == 3 && g.bcr_apply && only < 0 && phase == 0 && (fused_back || (S.top16 && nl == 2)) && !g.bcr_out &&
+                       g.ng == 0;
     g.bcr_applied = apply;
-    for (int l = nl - 1; l >= 0 && phase != 1; l--) {
+    for (int l = ltop; l >= 0 && phase != 1; l--) {
         if (only >= 0 && only != 100 + l) continue;
         BcrLevel &L = S.lev[l];
         if constexpr (NR == 3) {
@@ -1942,10 +2394,11 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
                     P.W[k] = S.lev[k].W.p;
                     P.nb[k] = S.lev[k].nb;
                 }
-                P.top = nl - 1;
+                P.top = ltop;
                 P.base = 1;
-                hipLaunchKernelGGL((k_bcr_back_top<B>), dim3(L.nch), dim3(kBackTopThreads), 0, st, P, S.xtop.p, L.x.p, Xout, L0.n,
-                                   L.nred, apply ? g.Q.p : (double4 *)nullptr, g.f, g.part_score.p, S.lev[0].nch);
+                hipLaunchKernelGGL((k_bcr_back_top<B>), dim3(L.nch), dim3(kBackTopThreads), 0, st, P,
+                                   S.top16 ? S.lev[nl - 1].x.p : S.xtop.p, L.x.p, Xout, L0.n, L.nred,
+                                   apply ? g.Q.p : (double4 *)nullptr, g.f, g.part_score.p, S.lev[0].nch, (int)S.top16);
                 continue;
             }
         }
@@ -2209,6 +2662,32 @@ int bcr_info(Graph &g, int64_t *out, int cap) {
     return k;
 }
 
+// development aid: a whole solve with stamps inside the single-launch upper reduction (IROTAVG_BCR_DBG & 128): out[32 i + k] =
+// shader clocks of workgroup 0 at level i of the launch relative to the launch's first stamp -- k < 16: the body's phases,
+// 16: level entered, 17: the wait for the level below is over, 18: body done, 19: counted; -1: not stamped
+int bcr_stamps_up(Graph &g, double *out) {
+    if (!g.bcr_B) return IROTAVG_ERR_BAD_ARG;
+    bcr_alloc(g);
+    BcrState &S = *g.bcr;
+    const char *old = getenv("IROTAVG_BCR_DBG");
+    const std::string keep = old ? old : "";
+    const char *wgs = getenv("IROTAVG_BCR_STAMP_CHUNK");
+    setenv("IROTAVG_BCR_DBG", std::to_string(128 + 256 * (wgs ? atoi(wgs) : 0)).c_str(), 1);
+    const size_t cnt = (size_t)std::max(S.lev[0].nch * 16, 32 * kUpLevels);
+    if (!S.stamps.p) S.stamps.alloc(cnt);
+    IRH_CHECK(hipMemsetAsync(S.stamps.p, 0, sizeof(long long) * cnt, g.stream));
+    const int rc = bcr_solve(g, -1);
+    if (old) setenv("IROTAVG_BCR_DBG", keep.c_str(), 1);
+    else unsetenv("IROTAVG_BCR_DBG");
+    if (rc != IROTAVG_OK) return rc;
+    long long h[32 * kUpLevels];
+    IRH_CHECK(hipMemcpyAsync(h, S.stamps.p, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+    IRH_CHECK(hipStreamSynchronize(g.stream));
+    bcr_up_release(g);
+    for (int k = 0; k < 32 * kUpLevels; k++) out[k] = !h[k] ? -1.0 : (k & 31) >= 20 ? (double)h[k] : (double)(h[k] - h[16]);
+    return S.up_used ? IROTAVG_OK : IROTAVG_ERR_BAD_ARG;
+}
+
 // development aid: the reduction of `level` once with stamps on; out[0..16) = shader clocks of chunk `chunk` relative to
 // its first stamp
 int bcr_stamps(Graph &g, int level, int chunk, double *out) {
@@ -2254,8 +2733,27 @@ int bcr_apply_slots(Graph &g) {
     bcr_alloc(g);
     const BcrState &S = *g.bcr;
     if (S.lev.size() < 2 || S.nfar != 0) return 0;
-    const int slots = S.lev[0].nch + S.lev[1].nch;
+    // (level 0's chunks and, when there is a level of chunks above them, level 1's: a mixed level 1 writes solution rows)
+    const int slots = S.lev[0].nch + (S.top16 && S.lev.size() == 2 ? 0 : S.lev[1].nch);
     return slots <= 4 * kMaxParts ? slots : 0;
+}
+
+const int *bcr_fail_word(Graph &g) {
+    if (!g.bcr || !g.bcr->up_used || g.bcr->up_cnt.n < (size_t)kUpLevels + 1) return nullptr;
+    return reinterpret_cast<const int *>(g.bcr->up_cnt.p + kUpLevels);
+}
+bool bcr_up_failed(Graph &g) {
+    const int *w = bcr_fail_word(g);
+    if (!w) return false;
+    int h = 0;
+    if (hipMemcpyAsync(&h, w, sizeof(int), hipMemcpyDeviceToHost, g.stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(g.stream) != hipSuccess) return false;
+    if (!h) return false;
+    (void)hipMemsetAsync(const_cast<int *>(w), 0, sizeof(int), g.stream);
+    g.bcr_no_fused_up = true;
+    g.stats.direct_up_fallbacks += 1;
+    bcr_up_release(g);
+    return true;
 }
 
 int bcr_levels(Graph &g) {

@@ -139,6 +139,7 @@ struct Graph {
     // in part_score, bcr_apply_slots() doubles; bcr_applied = the last solve did
     bool bcr_apply = false, bcr_applied = false;
     int bcr_up_held = 0;  // 1/1024ths of the device reserved for k_bcr_reduce_up's workgroups (bcr_up_reserve)
+    bool bcr_no_fused_up = false;  // a wait inside k_bcr_reduce_up gave up once (bcr_up_failed): level by level from then on
     std::unique_ptr<BcrState, BcrDeleter> bcr;
     std::vector<int> bcr_far_i, bcr_far_j, bcr_far_e;  // long-range edges (rows, edge id): Woodbury correction
     const double *bcr_wsrc = nullptr;                  // per-edge weights of the last assembly and whether the
@@ -292,6 +293,13 @@ int bcr_apply_slots(Graph &g);
 void bcr_gate(Graph &g);  // flags[FL_DONE] = 1 unless the last direct solve with closures saw a dead pivot (flags[3] = their number)
 void dense_invert_spd(Graph &g, double *A, int npad);  // in place, npad a multiple of 64 (dense.hip)
 int bcr_stamps(Graph &g, int level, int chunk, double *out);  // development aid
+int bcr_stamps_up(Graph &g, double *out);                      // development aid: 32 x 8 stamps of k_bcr_reduce_up
+// the last direct solve went through the single-launch upper reduction and a workgroup of it gave up waiting (its solution
+// is all NaN): clears the word, switches the handle to level-by-level launches and says so (one small synchronous read)
+bool bcr_up_failed(Graph &g);
+// the device word behind it while such a solve is the last one (kernels behind the solve skip their work when it is set),
+// or nullptr
+const int *bcr_fail_word(Graph &g);
 // the sharded form (dist.hip): every rank reduces its range to its last block; the `world` separators are one chunk
 struct BcrTop {
     int B = 0, world = 0;

@@ -396,6 +396,10 @@ __global__ __launch_bounds__(kRowBlock) void k_pd_dir(
             ad[h] = adx;
             tt[h] = d1 - d2;
             if (k + h >= m) continue;
+            // (a direction that is not a number -- the solve in front of this kernel failed -- passes every guard below
+            // and fmin drops it: the host would take the full step and back-track 32 times on NaN sums. No step bound is
+            // negative, so -1 says it)
+            if (!(adx == adx)) smin = -1.0;
             if (d1 < 0) smin = fmin(smin, -m1 / d1);
             if (d2 < 0) smin = fmin(smin, -m2 / d2);
             const double p = adx - d_u;
@@ -677,24 +681,40 @@ int l1decode_group(PdGroup &G, int pdmaxiter, int xplane, int *stuck) {
                 if (M.g->opt.mg_omega == 0.7) M.g->opt.mg_omega = 0.9;  // only the library's default is replaced
             }
         }
-        int rc = G.solve();  // dx in X component 0 of every member (owned views)
+        double s = 0.0;
+        for (int attempt = 0;; attempt++) {
+            int rc = G.solve();  // dx in X component 0 of every member (owned views)
+            if (rc != IROTAVG_OK) {
+                for (size_t q = 0; q < G.mem.size(); q++) {
+                    G.mem[q].g->opt.mg_kc = kc_keep[q];
+                    G.mem[q].g->opt.mg_omega = om_keep[q];
+                }
+                return rc == IROTAVG_ERR_NOT_CONVERGED ? rc : IROTAVG_ERR_SOLVER;
+            }
+            if (G.halo_x) G.halo_x();  // A dx needs dx of the ghost views
+            for (auto &M : G.mem) {
+                Graph &g = *M.g;
+                hipLaunchKernelGGL(k_pd_dir, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, g.f, g.ei.p,
+                                   g.ej.p, g.eflag.p, g.X.p, pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau,
+                                   pl(g, P_ADX), pl(g, P_T1), pd_part_slot(g, 0));
+                pd_publish(g, {{0, ge(g)}, {1, ge(g)}});
+            }
+            at_mul(P_T1, true, 2);  // Atdv (:383); its sum of squares is not used
+            sync_all();
+            s = std::fmin(1.0, ext_members(0, ge, false));  // :347-380
+            // a direct solve whose single-launch upper reduction gave up on a wait (another process on the device held
+            // its workgroups back) poisons its solution: once more, level by level -- nothing but derived planes was
+            // written since the solve
+            bool again = false;
+            if ((!(s == s) || s < 0.0) && attempt == 0)
+                for (auto &M : G.mem) again = bcr_up_failed(*M.g) || again;
+            if (!again) break;
+        }
         for (size_t q = 0; q < G.mem.size(); q++) {
             G.mem[q].g->opt.mg_kc = kc_keep[q];
             G.mem[q].g->opt.mg_omega = om_keep[q];
         }
-        if (rc != IROTAVG_OK) return rc == IROTAVG_ERR_NOT_CONVERGED ? rc : IROTAVG_ERR_SOLVER;
-        if (G.halo_x) G.halo_x();  // A dx needs dx of the ghost views
-        for (auto &M : G.mem) {
-            Graph &g = *M.g;
-            hipLaunchKernelGGL(k_pd_dir, dim3(ge(g)), dim3(kRowBlock), 0, g.stream, (long long)g.m, g.f, g.ei.p,
-                               g.ej.p, g.eflag.p, g.X.p, pl(g, P_F1), pl(g, P_F2), pl(g, P_L1), pl(g, P_L2), itau,
-                               pl(g, P_ADX), pl(g, P_T1), pd_part_slot(g, 0));
-            pd_publish(g, {{0, ge(g)}, {1, ge(g)}});
-        }
-        at_mul(P_T1, true, 2);  // Atdv (:383); its sum of squares is not used
-        sync_all();
-        double s = std::fmin(1.0, ext_members(0, ge, false));  // :347-380
-        if (!(s == s)) return IROTAVG_ERR_SOLVER;
+        if (!(s == s) || s < 0.0) return IROTAVG_ERR_SOLVER;  // (k_pd_dir: -1 = the direction is not a number)
         s *= 0.99;  // :381
         double rc4[4];
         sum_members(1, ge, rc4);  // |rcent|^2 at (fu, lamu, tau) of this iteration; combined with the first trial's sums

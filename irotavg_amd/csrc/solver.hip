@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void k_weights_then_residual(long long m, long
                                                                const double4 *__restrict__ Q,
                                                                const double *__restrict__ pub_src,
                                                                double *__restrict__ pub_dst, int pub_n,
-                                                               int *__restrict__ seqp, int seq, int with_residual) {
+                                                               int *__restrict__ seqp, int seq, int with_residual,
+                                                               const int *__restrict__ skip) {
     // the first workgroup hands the score's partial sums (left by the kernel in front of this one) to the host before it
     // turns to its edges -- what the one-workgroup k_publish did in a launch of its own (5 us per iteration)
     if (pub_n > 0 && blockIdx.x == 0) {
@@ -239,6 +240,9 @@ __global__ __launch_bounds__(256) void k_weights_then_residual(long long m, long
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(seqp, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // (skip: the solve in front of this kernel gave up -- bcr_up_failed, its solution is NaN: weights and residuals
+    // stay as they are, the host repeats the solve)
+    if (skip && *skip != 0) return;
     const long long k = 2ll * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
     if (k >= mpad) return;
     const int2 ii = *reinterpret_cast<const int2 *>(ei + k);
@@ -288,14 +292,15 @@ void launch_weights_then_residual(Graph &g, int cost, double sigma, const PubPar
     const double *ps = pub ? pub->src : nullptr;
     double *pd = pub ? pub->dst : nullptr;
     const int pn = pub ? pub->n : 0;
+    const int *skip = g.bcr_B ? bcr_fail_word(g) : nullptr;
     if (cost == IROTAVG_L2 || cost == IROTAVG_HUBER)
         hipLaunchKernelGGL((k_weights_then_residual<true>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
                            (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p, ps, pd,
-                           pn, g.h_seq(), g.pub_seq, with_residual ? 1 : 0);
+                           pn, g.h_seq(), g.pub_seq, with_residual ? 1 : 0, skip);
     else
         hipLaunchKernelGGL((k_weights_then_residual<false>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
                            (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p, ps, pd,
-                           pn, g.h_seq(), g.pub_seq, with_residual ? 1 : 0);
+                           pn, g.h_seq(), g.pub_seq, with_residual ? 1 : 0, skip);
 }
 
 // =============================================================================================
@@ -2350,6 +2355,7 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
         if (g.bcr_B) {
             // banded operator: assembly of level 0, direct solve, weight and rotation update -- ~14 launches and
             // ONE host round trip (the score) per iteration
+            const double score_before = score;
             g.bcr_apply = ap_slots > 0;
             g.bcr_applied = false;
             with_res = !(it + 1 >= max_iters || (it > 0 && score <= 50.0 * change_th)) || std::getenv("IROTAVG_NO_LAST_GUESS");
@@ -2395,6 +2401,14 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                 score = apply_step(g);
             }
             if (!std::isfinite(score)) {
+                // the single-launch upper reduction gave up on a wait (another process held its workgroups back: the
+                // reservation only knows this process): its solution is NaN, no view took a step, the kernel behind it left
+                // weights and residuals alone -- the iteration once more, level by level from now on
+                if (fuse_wr && bcr_up_failed(g)) {
+                    er_fresh = true;
+                    score = score_before;
+                    continue;
+                }
                 rc = IROTAVG_ERR_SOLVER;
                 break;
             }
@@ -2522,6 +2536,12 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
         double st[16];
         const int rc = cg2_phase_stamps(g, st, 16);
         *ms = st[which - 100];
+        return rc;
+    }
+    if (which >= 600 && which < 600 + 32 * 8) {  // development aid: stamps inside k_bcr_reduce_up (bcr_stamps_up)
+        double st[32 * 8];
+        const int rc = bcr_stamps_up(g, st);
+        *ms = st[which - 600];
         return rc;
     }
     if (which >= 200 && which < 200 + 16 * 16) {  // development aid: phase stamps (shader clocks) of k_bcr_reduce, level

@@ -420,6 +420,76 @@ def test_single_launch_upper_reduction_is_admitted_by_reservation(monkeypatch):
     np.testing.assert_array_equal(out[0], ref[0])
 
 
+# round 5: the last level is ONE workgroup of up to sixteen blocks that also makes its way back (bcr_top_body). Band 3 ->
+# blocks of 8 rows: n - 1 rows = 8 blocks per chunk x 8 rows; two levels (level 0 + a top of N = 2 ... 16 blocks, a launch
+# of its own) and three (level 0, a level of chunks, the top: the single-launch upper reduction runs both)
+@pytest.mark.parametrize("n", [65 + 64 * k for k in (1, 2, 3, 7, 8, 9, 12, 14, 15)] + [1025 + 512 * k for k in (0, 3, 8, 9, 13, 14)])
+def test_single_workgroup_top_of_up_to_sixteen_blocks_matches_oracle(n, monkeypatch):
+    S = synth.make_graph(n, 3 * n - 6, 0.0, seed=n, p_band_out=0.02)
+    Qm = mst_init(S, n)
+    rng = np.random.default_rng(n)
+    w = rng.uniform(0.1, 5.0, size=len(S["I"]))
+    w[rng.choice(len(w), len(w) // 30, replace=False)] *= 1e-4
+    ro = O.log_map(O.delta_rel(S["I"], S["QQ"], Qm))[:, :3]
+    rc, Xo = O.ls_solve(n, 1, S["I"], w, ro)
+    assert rc == 0
+    out = []
+    for no16 in (False, True):
+        if no16:
+            monkeypatch.setenv("IROTAVG_BCR_NO_TOP16", "1")
+        with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+            lev = G.direct_info()["levels"]
+            if not no16:   # the top holds what the level below left: its chunks (<= 16)
+                assert 2 <= lev[-1]["blocks"] <= 16 and lev[-1]["blocks"] == lev[-2]["chunks"], lev
+                assert lev[-2]["blocks"] > 8, lev
+            G.set_rotations(Qm)
+            G.edge_residual()
+            G.set_weights(w)
+            X = G.ls_solve()
+            assert np.abs(X - Xo).max() < 1e-9 * np.abs(Xo).max()
+            G.set_rotations(Qm)
+            a = G.l1ra(2, 1e-3)
+            b = G.irls(4, SIG, 30, 1e-4)
+            out.append((a["iters"], b["iters"], G.get_rotations(), G.get_weights()))
+            direct_stats(G.stats(), 8)
+    ra = O.l1ra(S["QQ"], S["I"], Qm, 1, 2, 1e-3)
+    rb = O.irls(S["QQ"], S["I"], ra["Q"], 1, 4, SIG, 30, 1e-4)
+    for ia, ib, Q, wts in out:
+        assert (ia, ib) == (ra["iters"], rb["iters"])
+        assert synth.angular_distance(Q, rb["Q"]).max() < 1e-9
+        np.testing.assert_allclose(wts, rb["weights"], rtol=1e-7)
+
+
+def test_a_wait_that_gives_up_is_repeated_level_by_level(monkeypatch):
+    """k_bcr_reduce_up's workgroups wait for each other; the reservation (bcr_up_reserve) only knows this process. A
+    workgroup whose wait does not end says so in a device word, the top workgroup then poisons the whole solution, no view
+    takes a step, the kernel behind the solve leaves weights and residuals alone, and the host repeats the iteration level
+    by level (stats.direct_up_fallbacks) -- in irls and inside l1decode_pd. IROTAVG_BCR_FAKE_UP_FAIL sets the word as a
+    timed-out wait would; the results are bit-identical to an undisturbed run (same arithmetic on both routes)."""
+    n, m = 20000, 400000
+    S = synth.make_graph(n, m, 0.0, seed=16, p_band_out=0.01)
+    Qm = mst_init(S, n)
+
+    def run(l1):
+        with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+            G.set_rotations(Qm)
+            if l1:
+                G.l1ra(2, 1e-3)
+            r = G.irls(4, SIG, 50, 1e-3)
+            return r["iters"], G.get_rotations(), G.get_weights(), G.stats()
+
+    for l1 in (False, True):
+        monkeypatch.delenv("IROTAVG_BCR_FAKE_UP_FAIL", raising=False)
+        ref = run(l1)
+        assert ref[3]["direct_up_fallbacks"] == 0
+        monkeypatch.setenv("IROTAVG_BCR_FAKE_UP_FAIL", "1")
+        out = run(l1)
+        assert out[3]["direct_up_fallbacks"] == 1, out[3]
+        assert out[0] == ref[0]
+        np.testing.assert_array_equal(out[1], ref[1])
+        np.testing.assert_array_equal(out[2], ref[2])
+
+
 def test_direct_path_is_bitwise_reproducible():
     S = synth.make_graph(5000, 100000, 0.0, seed=4, p_band_out=0.02)
     Qm = mst_init(S, 5000)

@@ -33,3 +33,16 @@ with capi.Graph(S["I"], S["QQ"], n, 1) as G:
             parts.append("%s %+d" % (NAMES[k], st[k] - prev))
             prev = st[k]
         print("level %d chunk 0: %d clocks in the kernel (launch %.1f us): %s" % (l, tot, 1e3 * red[l], "; ".join(parts)))
+
+    # the single-launch upper reduction (k_bcr_reduce_up): workgroup 0's stamps per level of the launch
+    UP = {16: "entered", 17: "waited", 18: "body done", 19: "counted"}
+    try:
+        for i in range(nl - 1):
+            st = [G.time_kernel(600 + 32 * i + k, 1) for k in range(28)]
+            print("   raw HW_ID:", ["%x" % (int(st[20 + w]) - 0x10000) if st[20 + w] >= 0 else None for w in range(8)])
+            print("   waves' (SIMD, slot) of workgroup 0:", [((int(st[20 + w]) >> 4) & 3, int(st[20 + w]) & 15) if st[20 + w] >= 0 else None for w in range(8)])
+            body = ["%d:%+d" % (k, st[k] - st[k - 1]) for k in range(1, 16) if st[k] >= 0 and st[k - 1] >= 0]
+            print("fused up, level %d of the launch: entered at %d, waited until %d, body done %s, counted %s; body stamps (slot:delta) %s"
+                  % (i + 1, st[16], st[17], st[18], st[19], " ".join(body)))
+    except Exception as e:  # not a handle that uses the single launch
+        print("no fused upper reduction:", e)
