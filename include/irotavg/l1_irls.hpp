@@ -201,19 +201,36 @@ inline bool soft(int rc, const char *where) {
     std::fprintf(stderr, "%s: warning: %s (result kept)\n", where, irotavg_error_string(rc));
     return true;
 }
-inline std::vector<int32_t> flat(const I_t &I) {
-    std::vector<int32_t> e(2 * I.size());
-    for (size_t k = 0; k < I.size(); k++) {
-        e[2 * k] = I[k].first;
-        e[2 * k + 1] = I[k].second;
+/* The edge list as the C ABI wants it: 2 m int32, (i, j) pairs. I_t = std::vector<std::pair<int, int>> already IS that in
+ * memory (a pair of two ints is two ints: checked below), so the caller's own array is handed over -- no copy, and the
+ * SAME pointer in l1ra and irls, which is what lets the library recognise the graph of the call before
+ * (irotavg_oneshot_cache in irotavg_hip.h: the reference's callers pass the same I, QQ to both, src/ViewGraph.cpp:1400-1417). */
+struct EdgeView {
+    const int32_t *p;
+    std::vector<int32_t> copy;  /* only when the layout assumption does not hold on this platform */
+    const int32_t *data() const { return copy.empty() ? p : &copy[0]; }
+};
+inline EdgeView flat(const I_t &I) {
+    EdgeView v;
+    typedef std::pair<int, int> P;
+    if (sizeof(P) == 2 * sizeof(int32_t) && sizeof(int) == sizeof(int32_t) && (I.empty() || (const void *)&I[0].second ==
+                                                                                (const void *)((const int32_t *)&I[0] + 1))) {
+        v.p = I.empty() ? (const int32_t *)0 : (const int32_t *)(const void *)&I[0];
+        return v;
     }
-    return e;
+    v.copy.resize(2 * I.size());
+    for (size_t k = 0; k < I.size(); k++) {
+        v.copy[2 * k] = I[k].first;
+        v.copy[2 * k + 1] = I[k].second;
+    }
+    v.p = v.copy.empty() ? (const int32_t *)0 : &v.copy[0];
+    return v;
 }
 }  // namespace detail
 
 /* ral/l1_irls.hpp:89 */
 inline void init_mst(Mat &Q, const Mat &QQ, const I_t &I, const int f) {
-    std::vector<int32_t> e = detail::flat(I);
+    detail::EdgeView e = detail::flat(I);
     int rc = irotavg_init_mst(Q.rows(), (int64_t)I.size(), Q.data(), shim_ld(Q), QQ.data(),
                               shim_ld(QQ), e.data(), f);
     if (rc != IROTAVG_OK) detail::fail(rc, "init_mst");
@@ -221,7 +238,7 @@ inline void init_mst(Mat &Q, const Mat &QQ, const I_t &I, const int f) {
 
 /* ral/l1_irls.hpp:91 */
 inline SpMat make_A(const int n, const int f, const I_t &I) {
-    std::vector<int32_t> e = detail::flat(I);
+    detail::EdgeView e = detail::flat(I);
     const long m = (long)I.size();
     std::vector<int64_t> colptr((size_t)(n - f + 1)), rowidx((size_t)(2 * m + 1));
     std::vector<double> vals((size_t)(2 * m + 1));
@@ -250,7 +267,7 @@ inline SpMat make_A(const int n, const int f, const I_t &I) {
 /* ral/l1_irls.hpp:100-102. `A` is accepted for signature parity; the core derives it from (n, f, I). */
 inline void l1ra(const Mat &QQ, const I_t &I, const SpMat & /*A*/, Mat &Q, const int f,
                  const int max_iters, double change_th, int &iter, double &runtime) {
-    std::vector<int32_t> e = detail::flat(I);
+    detail::EdgeView e = detail::flat(I);
     int rc = irotavg_l1ra((int64_t)I.size(), Q.rows(), f, e.data(), QQ.data(), shim_ld(QQ), Q.data(),
                           shim_ld(Q), max_iters, change_th, &iter, &runtime);
     if (rc != IROTAVG_OK && !detail::soft(rc, "l1ra")) detail::fail(rc, "l1ra");
@@ -260,7 +277,7 @@ inline void l1ra(const Mat &QQ, const I_t &I, const SpMat & /*A*/, Mat &Q, const
 inline void irls(const Mat &QQ, const I_t &I, const SpMat & /*A*/, Cost cost, double sigma, Mat &Q,
                  const int f, const int max_iters, double change_th, Vec &weights, int &iteration,
                  double &runtime) {
-    std::vector<int32_t> e = detail::flat(I);
+    detail::EdgeView e = detail::flat(I);
     if ((long)weights.size() != (long)I.size()) detail::fail(IROTAVG_ERR_BAD_ARG, "irls (weights size)");
     int rc = irotavg_irls((int64_t)I.size(), Q.rows(), f, e.data(), QQ.data(), shim_ld(QQ), (int)cost,
                           sigma, Q.data(), shim_ld(Q), max_iters, change_th, weights.data(),

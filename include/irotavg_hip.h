@@ -147,6 +147,18 @@ int irotavg_irls(int64_t m, int64_t n_total, int f, const int32_t *I, const doub
 /* replaces irotavg::quat_normalised (ral/l1_irls.hpp:112, ral/l1_irls.cpp:982-991) */
 int irotavg_quat_normalised(int64_t n, double *Q, int64_t ldq, int f);
 
+/* The reference's callers pass the SAME (I, QQ) to l1ra and then to irls (src/ViewGraph.cpp:1400-1417,
+ * ral/test.cpp:295-301). irotavg_l1ra / irotavg_irls therefore KEEP the handle of their last call (one slot per
+ * process): a following one-shot call with the same pointers, sizes and f whose content hashes equal (64 bits over every
+ * word of I and of the four columns of QQ, computed from the caller's arrays on all host cores at every call -- an array
+ * changed in place is a different graph) uploads Q only. A call in flight owns its handle (a concurrent call from another
+ * thread builds its own); the kept handle holds device memory until irotavg_oneshot_cache_clear(), a call with another
+ * graph, or process exit. irotavg_oneshot_cache(0) or IROTAVG_ONESHOT_CACHE=0 in the environment: every call builds and
+ * destroys its handle as before round 5. */
+void irotavg_oneshot_cache(int enable);
+void irotavg_oneshot_cache_clear(void);
+void irotavg_oneshot_cache_stats(int64_t *hits, int64_t *misses);
+
 /* ---------------------------------------------------------------------------------------------
  * Handle API: the graph (edges, relative rotations, adjacency, multigrid hierarchy, work
  * vectors) stays resident in HBM across calls. One HIP stream per handle; a handle is not

@@ -38,6 +38,7 @@ SYMBOLS = [
     "irotavg_graph_direct_info",
     "irotavg_graph_direct_residual",
     "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_trim_memory", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
+    "irotavg_oneshot_cache", "irotavg_oneshot_cache_clear", "irotavg_oneshot_cache_stats",
 ]
 
 
@@ -154,6 +155,12 @@ def lib():
                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     L.irotavg_trim_memory.argtypes = []
     L.irotavg_trim_memory.restype = C.c_int64
+    L.irotavg_oneshot_cache.argtypes = [C.c_int]
+    L.irotavg_oneshot_cache.restype = None
+    L.irotavg_oneshot_cache_clear.argtypes = []
+    L.irotavg_oneshot_cache_clear.restype = None
+    L.irotavg_oneshot_cache_stats.argtypes = [_i64p, _i64p]
+    L.irotavg_oneshot_cache_stats.restype = None
     L.irotavg_rmat2quat.argtypes = [_dp, _dp]
     L.irotavg_rmat2quat.restype = None
     L.irotavg_quat2rmat.argtypes = [_dp, _dp]
@@ -383,6 +390,22 @@ class Graph:
         ms = C.c_double(0)
         check(lib().irotavg_graph_time_kernel(self._h, which, reps, C.byref(ms)), "time_kernel")
         return ms.value
+
+
+def oneshot_cache(enable):
+    """irotavg_oneshot_cache: the one-shot calls keep the handle of their last call (on) or build one per call (off)."""
+    lib().irotavg_oneshot_cache(1 if enable else 0)
+
+
+def oneshot_cache_clear():
+    lib().irotavg_oneshot_cache_clear()
+
+
+def oneshot_cache_stats():
+    """(hits, misses) of the kept handle since the library was loaded."""
+    h, m = C.c_int64(0), C.c_int64(0)
+    lib().irotavg_oneshot_cache_stats(C.byref(h), C.byref(m))
+    return int(h.value), int(m.value)
 
 
 def trim_memory():
