@@ -106,6 +106,24 @@ struct irotavg_viewgraph {
     std::vector<char> touched;  // view has at least one connection
     long n_touched = 0, n_fixed = 0, n_conn = 0;
     void pose_changed(long idx) { res_pose_lo = std::min(res_pose_lo, idx); }
+    // A global re-solve on the resident graph leaves the QUATERNION of every free view here and marks the view: its
+    // rotation matrix (src/ViewGraph.cpp:1420-1434: q.normalized().toRotationMatrix()) is formed when somebody reads the
+    // pose -- get_pose, a window that holds the view, save_poses, the next delta for the device. Converting all 75k
+    // views at the end of the call was a third of it (round 4: 1.5 of 4.8 ms) for matrices that mostly nobody reads
+    // before the next global re-solve replaces them.
+    mutable std::vector<double> qlazy;  // 4 per view
+    mutable std::vector<char> lazy;
+    const double *pose_m(size_t x) const {
+        if (x < lazy.size() && lazy[x]) {
+            quat2rmat(&qlazy[4 * x], const_cast<double *>(pose[x].m));
+            lazy[x] = 0;
+        }
+        return pose[x].m;
+    }
+    double *pose_w(size_t x) {  // the pose is about to be overwritten
+        if (x < lazy.size()) lazy[x] = 0;
+        return pose[x].m;
+    }
     // a window extracted by rot_avg whose solve was deferred to a batched launch (irotavg_viewgraph_rot_avg_batch)
     struct Pending {
         bool on = false;
@@ -130,7 +148,7 @@ void rotavg_writeback(irotavg_viewgraph *vg, int f, long nv) {
     irh::parallel_for((int64_t)(nv - f), 4096, [&](int64_t a, int64_t b, int) {
         for (int64_t r = f + a; r < f + b; r++) {
             const double q[4] = {Q[(size_t)r], Q[(size_t)(nv + r)], Q[(size_t)(2 * nv + r)], Q[(size_t)(3 * nv + r)]};
-            quat2rmat(q, vg->pose[(size_t)i2v[(size_t)r]].m);
+            quat2rmat(q, vg->pose_w((size_t)i2v[(size_t)r]));
         }
     });
     // free views are relabelled in ascending id: the lowest one is row f
@@ -212,7 +230,7 @@ int irotavg_viewgraph_fix_pose(irotavg_viewgraph *vg, int idx, const double R[9]
     if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
     if (!vg->fixed[idx]) vg->n_fixed++;
     vg->fixed[idx] = 1;
-    std::copy(R, R + 9, vg->pose[idx].m);
+    std::copy(R, R + 9, vg->pose_w((size_t)idx));
     vg->pose_changed(idx);
     return IROTAVG_OK;
 }
@@ -228,12 +246,13 @@ int irotavg_viewgraph_count_fixed_poses(const irotavg_viewgraph *vg) {
 }
 int irotavg_viewgraph_get_pose(const irotavg_viewgraph *vg, int idx, double R[9]) {
     if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
-    std::copy(vg->pose[idx].m, vg->pose[idx].m + 9, R);
+    const double *P = vg->pose_m((size_t)idx);
+    std::copy(P, P + 9, R);
     return IROTAVG_OK;
 }
 int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]) {
     if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
-    std::copy(R, R + 9, vg->pose[idx].m);
+    std::copy(R, R + 9, vg->pose_w((size_t)idx));
     vg->pose_changed(idx);
     return IROTAVG_OK;
 }
@@ -288,7 +307,8 @@ bool rotavg_resident(irotavg_viewgraph *vg, irotavg_rotavg_info &loc, bool timin
         });
         irh::parallel_for((int64_t)(m - view_lo), 4096, [&](int64_t a, int64_t b, int) {
             for (int64_t x = view_lo + a; x < view_lo + b; x++) {
-                std::copy(vg->pose[(size_t)x].m, vg->pose[(size_t)x].m + 9, st.R + 9 * (size_t)(x - view_lo));
+                const double *P = vg->pose_m((size_t)x);
+                std::copy(P, P + 9, st.R + 9 * (size_t)(x - view_lo));
                 st.fixed[(size_t)(x - view_lo)] = (uint8_t)(vg->fixed[(size_t)x] ? 1 : 0);
             }
         });
@@ -317,10 +337,13 @@ bool rotavg_resident(irotavg_viewgraph *vg, irotavg_rotavg_info &loc, bool timin
         }
         if (dry) return true;
         const double t1 = irh::now_seconds();
-        irh::parallel_for((int64_t)m, 4096, [&](int64_t a, int64_t b, int) {
-            for (int64_t x = a; x < b; x++)
-                if (!vg->fixed[(size_t)x]) quat2rmat(st.Q + 4 * (size_t)x, vg->pose[(size_t)x].m);
-        });
+        // the quaternions are kept, the matrices are formed on demand (pose_m)
+        if ((long)vg->lazy.size() < m) {
+            vg->lazy.resize((size_t)m + (size_t)m / 2, 0);
+            vg->qlazy.resize(4 * vg->lazy.size());
+        }
+        std::memcpy(vg->qlazy.data(), st.Q, sizeof(double) * 4 * (size_t)m);
+        for (long x = 0; x < m; x++) vg->lazy[(size_t)x] = vg->fixed[(size_t)x] ? 0 : 1;
         if (timing) std::fprintf(stderr, "[rot_avg resident] %-24s %8.3f ms\n", "poses (host)", 1e3 * (irh::now_seconds() - t1));
         return true;
     } catch (...) {
@@ -462,7 +485,7 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
         for (int64_t p = a; p < b; p++) {
             const int x = vertices[(size_t)p];
             double q[4];
-            rmat2quat(vg->pose[x].m, q);
+            rmat2quat(vg->pose_m((size_t)x), q);
             const int r = v2i[x];
             for (int c = 0; c < 4; c++) Q[(size_t)c * nv + r] = q[c];
         }
@@ -664,7 +687,7 @@ int irotavg_viewgraph_save_poses(const irotavg_viewgraph *vg, const char *filena
     if (!fs) return IROTAVG_ERR_BAD_ARG;  // "Unable to save results."
     for (size_t v = 0; v < vg->pose.size(); v++) {
         double q[4];
-        rmat2quat(vg->pose[v].m, q);
+        rmat2quat(vg->pose_m(v), q);
         const double tx = t ? t[3 * v] : 0.0, ty = t ? t[3 * v + 1] : 0.0, tz = t ? t[3 * v + 2] : 0.0;
         std::fprintf(fs, "%zu\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\n", v, q[3], q[0], q[1],
                      q[2], tx, ty, tz);
