@@ -93,6 +93,31 @@ def test_l1ra_then_irls_matches_oracle_at_size(n, m, p_loop, f, band_direct):
         assert st["levels"] == 1      # a handle that solves directly builds no hierarchy
 
 
+@pytest.mark.parametrize("nclose", [100, 1000])
+def test_closures_on_the_direct_path_at_bench_size_match_the_oracle(nclose):
+    """The graphs `also_closures_100 / _1000` of the bench line are quoted on: 100k views / 2M edges (blocks of 24) plus
+    100 / 1000 loop closures, 3 / 30 of them wrong -- more than the 64 the Woodbury system takes in LDS, i.e. the blocked
+    sweep of dense.hip -- against the ORACLE (its conjugate gradients: the Cholesky cannot factor the closures). Until
+    round 5 the > 64-closure path had oracle legs on blocks of 8 / 12 / 16 / 32 only."""
+    n, m = 100000, 2000000
+    S, Q0 = problem(n, m, 0.0)
+    Sc = synth.add_closures(S, nclose, seed=7, wrong=max(1, nclose // 33))
+    Qc = np.zeros((n, 4)); Qc[:, 3] = 1; Qc[0] = Sc["Qgt"][0]
+    ral.init_mst(Qc, Sc["QQ"], Sc["I"], 1)
+    with capi.Graph(Sc["I"], Sc["QQ"], n, 1) as G:
+        assert G.direct_info()["block"] == 24 and G.direct_info()["closures"] == nclose
+        G.set_rotations(Qc)
+        r = G.irls(4, SIG, 100, 1e-3)
+        Q, w = G.get_rotations(), G.get_weights()
+        st = G.stats()
+    assert st["direct_solves"] > 0 and st["pcg_solves"] == 0 and st["direct_guarded"] == 0, st
+    O.solver_stats(reset=True)
+    ro = O.irls(Sc["QQ"], Sc["I"], Qc, 1, 4, SIG, 100, 1e-3)
+    sol = O.solver_stats(reset=True)
+    assert ro["rc"] == 0 and sol["pcg_solves"] > 0 and sol["pcg_worst_relres"] < 4e-13, sol
+    compare_irls(r, Q, w, ro)
+
+
 @pytest.mark.parametrize("p_loop", [0.0, 0.02])
 def test_eight_shards_100k_match_the_oracle(p_loop):
     """BASELINE config 4's workload in 8 vertex-range shards (loopback transport: all shards on the one
