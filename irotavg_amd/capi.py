@@ -48,7 +48,7 @@ class Options(C.Structure):
                 ("mg_dense_max", C.c_int), ("mg_omega", C.c_double), ("mg_kc", C.c_double),
                 ("device", C.c_int), ("mg_multiplicative_top", C.c_int), ("dense_always_refresh", C.c_int),
                 ("no_window_kernel", C.c_int), ("pcg_stall_accept", C.c_int), ("no_fused_pspmv", C.c_int), ("no_lowrank_repair", C.c_int), ("pcg_classic", C.c_int),
-                ("band_direct", C.c_int)]
+                ("band_direct", C.c_int), ("inexact_outer", C.c_int)]
 
 
 class Stats(C.Structure):
