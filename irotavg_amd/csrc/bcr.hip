@@ -2621,6 +2621,15 @@ __global__ __launch_bounds__(256) void k_bcr_residual(int n, const int *__restri
 // ||b - A x|| / ||b|| per coordinate of the handle's most recent direct solve -> relres[3] and stats.last_relres.
 int bcr_residual(Graph &g, double *relres) {
     if (!g.bcr_B || g.stats.direct_solves == 0 || g.levels.empty()) return IROTAVG_ERR_BAD_ARG;
+    // not for a shard (its rows sit behind the ghost views, and a rank's rows are no system of their own) ...
+    if (g.ng > 0 || g.bcr_shard) return IROTAVG_ERR_BAD_ARG;
+    // ... and after a GUARDED solve (run_irls: a dead pivot of the band part -> conjugate gradients on the full operator,
+    // preconditioned by the regularised direct solve) the right-hand side array holds that iteration's residual vector,
+    // not b: what it reached is in stats.last_relres already (its own convergence test); nothing to evaluate here
+    if (g.bcr_last_guarded) {
+        for (int c = 0; c < 3; c++) relres[c] = g.stats.last_relres[c];
+        return IROTAVG_OK;
+    }
     Level &L0 = g.levels[0];
     const int grid = (L0.n + 255) / 256;
     DevBuf<double> part;

@@ -67,11 +67,26 @@ struct DevPool {
     // headroom() > 1: requests of this thread are enlarged by that factor first (the handles of a GROWING view-graph,
     // resident.hip: every global re-solve is a few per cent larger than the last one; with half as much again the
     // blocks of one solve serve the following ones until the graph has grown by 50 %)
-    static std::atomic<int> &headroom_users() {  // process-wide: l1ra's solver clones allocate on their own threads
-        static std::atomic<int> n{0};
-        return n;
+    // Scoped to the THREADS that work for the handle that asked for it (round 5; until then a process-wide switch:
+    // while one session's re-solve ran, every other handle's allocations were enlarged as well): the thread that builds
+    // and drives the handle holds a HeadroomScope, and so does every worker thread while it runs a job for a Graph whose
+    // pool_headroom flag is set (l1ra's chains: the clones inherit the flag).
+    static int &headroom_depth() {
+        static thread_local int d = 0;
+        return d;
     }
-    static double headroom() { return headroom_users().load(std::memory_order_relaxed) > 0 ? 1.5 : 1.0; }
+    struct HeadroomScope {
+        bool on;
+        explicit HeadroomScope(bool enable = true) : on(enable) {
+            if (on) headroom_depth()++;
+        }
+        ~HeadroomScope() {
+            if (on) headroom_depth()--;
+        }
+        HeadroomScope(const HeadroomScope &) = delete;
+        HeadroomScope &operator=(const HeadroomScope &) = delete;
+    };
+    static double headroom() { return headroom_depth() > 0 ? 1.5 : 1.0; }
     static size_t round_up(size_t bytes) {
         if (headroom() > 1.0 && bytes >= (64u << 10)) bytes = (size_t)((double)bytes * headroom());
         if (bytes < (64u << 10)) return (bytes + 511) & ~(size_t)511;

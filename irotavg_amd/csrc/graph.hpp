@@ -139,6 +139,7 @@ struct Graph {
     // in part_score, bcr_apply_slots() doubles; bcr_applied = the last solve did
     bool bcr_apply = false, bcr_applied = false;
     int bcr_up_held = 0;  // 1/1024ths of the device reserved for k_bcr_reduce_up's workgroups (bcr_up_reserve)
+    bool pool_headroom = false;  // allocations made for this handle ask the device pool for half as much again (resident.hip)
     bool bcr_no_fused_up = false;  // a wait inside k_bcr_reduce_up gave up once (bcr_up_failed): level by level from then on
     std::unique_ptr<BcrState, BcrDeleter> bcr;
     std::vector<int> bcr_far_i, bcr_far_j, bcr_far_e;  // long-range edges (rows, edge id): Woodbury correction
@@ -148,6 +149,7 @@ struct Graph {
     // a CG solve of the full operator with the regularised direct solve (dead pivot -> the row's own diagonal entry) as
     // its preconditioner: bcr_guard switches bcr_solve to that mode, bcr_out redirects its result (nullptr: X)
     bool bcr_guard = false;
+    bool bcr_last_guarded = false;  // the most recent linear solve of this handle was such a guarded one (bcr_residual)
     double4 *bcr_out = nullptr;
     // a shard of a sharded sequence solved directly (dist.hip): bcr_ext0 = a rank lies before this one
     bool bcr_shard = false;

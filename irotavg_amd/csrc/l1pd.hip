@@ -979,6 +979,7 @@ int run_l1ra(Graph &g, int max_iters, double change_th, int *iters, double *runt
         const std::function<void(int)> chain = [&](int c) {
             try {
                 (void)hipSetDevice(g.device);
+                DevPool::HeadroomScope hs(g.pool_headroom);  // (a chain's thread allocates for its clone)
                 Graph &q = *g.l1_clones[c];
                 pd_prepare(q);
                 rcs[c] = l1decode_core(q, g.er.p + (size_t)c * g.mpad, l1_step, N_X0, nullptr);

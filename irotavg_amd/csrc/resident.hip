@@ -264,13 +264,11 @@ int resident_rot_avg(Resident &r, long n_views, long view_lo, long n_edges, long
         src.relabel = r.v2i.p;
         // (the handle of a growing graph and everything its solves allocate: blocks half as large again, so that the next
         // re-solves find them in the pool)
-        struct Headroom {
-            Headroom() { DevPool::headroom_users()++; }
-            ~Headroom() { DevPool::headroom_users()--; }
-        } headroom;
+        DevPool::HeadroomScope headroom;  // this thread; the handle's worker threads follow its flag (Graph::pool_headroom)
         int rc = graph_create_dev(&h, ne_solve, n_views, f, src, &opt);
         if (rc != IROTAVG_OK) return rc;
         Graph &g = graph_of(h);
+        g.pool_headroom = true;
         hipLaunchKernelGGL(k_res_gather, dim3(grid_of(n_views)), dim3(kT), 0, g.stream, (int)n_views, r.R.p, r.v2i.p, g.Q.p);
         if (timing) (void)hipStreamSynchronize(g.stream);
         lap("handle (device build)");

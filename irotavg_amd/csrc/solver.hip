@@ -2221,7 +2221,10 @@ int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ra
 int ls_solve(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
     if (tail_ran) *tail_ran = false;
     assemble(g, 0, g.dw.p, g.opt.dense_always_refresh == 1);
-    if (g.bcr_B) return bcr_solve(g);  // asynchronous; a non-finite result shows in the score of the step
+    if (g.bcr_B) {
+        g.bcr_last_guarded = false;
+        return bcr_solve(g);  // asynchronous; a non-finite result shows in the score of the step
+    }
     int rc = pcg_solve(g, tail, tail_ran);
     auto failed = [&]() { return rc == IROTAVG_ERR_NOT_CONVERGED || rc == IROTAVG_ERR_SOLVER; };
     // The reference's direct solvers always return an answer. Two more attempts before an error code:
@@ -2404,8 +2407,12 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                     g.stats.direct_guarded += 1;
                     g.stats.direct_dead_pivots = g.h_flags()[3];
                     g.bcr_guard = true;
+                    const int64_t ds_keep = g.stats.direct_solves;
                     rc = pcg_solve_classic(g);
                     g.bcr_guard = false;
+                    g.bcr_last_guarded = true;
+                    // (the preconditioner applications of that solve are not linear systems of the caller's)
+                    g.stats.direct_solves = ds_keep;
                     if (rc != IROTAVG_OK) break;
                     launch_update_weights(g, cost, sigma);
                     score = apply_step(g);
@@ -2624,10 +2631,24 @@ int time_kernel(Graph &g, int which, int reps, double *ms) {
                         g.opt.no_fused_pspmv != 1))
         return IROTAVG_ERR_BAD_ARG;  // this graph's PCG does not use the fused kernel
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
+    // kernel 11 (weights, then the next residuals) writes the handle's weights and residual planes: they are put back
+    // afterwards, so that a solve or a read-back behind the timing sees what it would have seen without it
+    DevBuf<double> keep_dw, keep_er;
+    if (which == 11) {
+        keep_dw.alloc((size_t)g.mpad);
+        keep_er.alloc((size_t)3 * g.mpad);
+        IRH_CHECK(hipMemcpyAsync(keep_dw.p, g.dw.p, sizeof(double) * (size_t)g.mpad, hipMemcpyDeviceToDevice, g.stream));
+        IRH_CHECK(hipMemcpyAsync(keep_er.p, g.er.p, sizeof(double) * 3 * (size_t)g.mpad, hipMemcpyDeviceToDevice, g.stream));
+    }
     once();  // warm-up
     IRH_CHECK(hipEventRecord(e0, g.stream));
     for (int r = 0; r < reps; r++) once();
     IRH_CHECK(hipEventRecord(e1, g.stream));
+    if (which == 11) {
+        IRH_CHECK(hipMemcpyAsync(g.dw.p, keep_dw.p, sizeof(double) * (size_t)g.mpad, hipMemcpyDeviceToDevice, g.stream));
+        IRH_CHECK(hipMemcpyAsync(g.er.p, keep_er.p, sizeof(double) * 3 * (size_t)g.mpad, hipMemcpyDeviceToDevice, g.stream));
+        IRH_CHECK(hipStreamSynchronize(g.stream));
+    }
     IRH_CHECK(hipEventSynchronize(e1));
     bcr_up_release(g);
     float t = 0.f;

@@ -333,6 +333,15 @@ bool rotavg_resident(irotavg_viewgraph *vg, irotavg_rotavg_info &loc, bool timin
             vg->res_pose_lo = 0;
             vg->res_edge_view = 0;
             irh::resident_invalidate(R);
+            // out of device memory (the resident copy and the enlarged blocks of its handles cost more than the general
+            // path's one-off handle) or a runtime error inside this path: the copy is dropped, the cached blocks go back
+            // to the driver and the call takes the general path, which may well succeed -- it reports on its own if not
+            if (*rc == IROTAVG_ERR_NOMEM || *rc == IROTAVG_ERR_HIP) {
+                (void)hipGetLastError();
+                (void)irotavg_trim_memory();
+                *rc = IROTAVG_OK;
+                return false;
+            }
             return true;
         }
         if (dry) return true;
@@ -350,8 +359,10 @@ bool rotavg_resident(irotavg_viewgraph *vg, irotavg_rotavg_info &loc, bool timin
         if (vg->res) irh::resident_invalidate(*vg->res);
         vg->res_pose_lo = 0;
         vg->res_edge_view = 0;
-        *rc = IROTAVG_ERR_HIP;
-        return true;
+        (void)hipGetLastError();
+        (void)irotavg_trim_memory();
+        *rc = IROTAVG_OK;
+        return false;  // (the general path: see above)
     }
 }
 }  // namespace
