@@ -144,6 +144,49 @@ def kernel_rooflines(G, S, st, sharded=False):
     return out
 
 
+def live_profile_l1ra(args):
+    """the same three rocprofv3 passes on `l1ra` alone (tools/prof_case.py --what l1ra): the kernels of the primal-dual
+    iteration in situ -- three solver chains at once -- with their HBM traffic. Returns (table, info) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out = os.path.join(ROOT, "gpurun_out", "bench_profile_l1ra")
+    try:
+        os.makedirs(out, exist_ok=True)
+    except OSError:
+        out = tempfile.mkdtemp(prefix="irotavg_bench_profile_l1ra_")
+    base = [sys.executable, os.path.join(ROOT, "tools", "prof_case.py"), "--views", str(args.views), "--edges", str(args.edges),
+            "--what", "l1ra", "--l1-iters", "5"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    info = None
+    for tag, flags, reps in (("trace", ["--kernel-trace", "--stats"], "4"), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"], "1"),
+                             ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"], "1")):
+        d = os.path.join(out, tag)
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = ["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "-o", tag[0], "--"] + base + ["--reps", reps]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        except Exception as e:
+            return None, "rocprofv3 %s pass: %s" % (tag, e)
+        if r.returncode != 0:
+            return None, "rocprofv3 %s pass exited with %d" % (tag, r.returncode)
+        if tag == "trace":
+            try:
+                info = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            except Exception:
+                info = None
+    try:
+        from tools.summarize_pmc import summarize
+        table = summarize(out)
+    except Exception as e:
+        return None, "summary failed: %s" % e
+    with open(os.path.join(out, "pmc_summary.json"), "w") as fh:
+        json.dump(dict(table, _meta=dict(workload="l1ra(5) alone, %d views / %d edges" % (args.views, args.edges), run=info)), fh, indent=1)
+    return table, dict(where=out, run=info, trace_reps=6)
+
+
 def live_profile(args, note):
     """rocprofv3 passes of THIS command (same workload, short run, no extras) launched from inside the bench run:
     kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in their own passes (they do not fit one pass), exactly as
@@ -733,6 +776,7 @@ def main():
                                         "frac": byb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "note": "k_edge_residual on 1M views / 20M edges: 1.3 GB per launch, beyond every cache"}
                     del Ib, QQb, Qb
+                    capi.trim_memory()   # (its blocks -- gigabytes -- would crowd the device pool of the legs below)
                 except Exception as e:   # (memory of a small test box)
                     re_["at_1M_20M"] = {"error": str(e)}
         ta = [traffic(k) for k in ("k_assemble0w", "k_coarse_level")]
@@ -978,6 +1022,48 @@ def main():
                         "iterations per outer iteration, each a Hessian solve by the handle's linear solver; mean of "
                         "5 runs of the pipeline"}
             G.restore_rotations()
+            # the primal-dual iteration against the HBM roofline (round 5): algorithmic bytes of its edge / view kernels per
+            # outer iteration (two primal-dual iterations of each of the three coordinate LPs) against the time an outer
+            # iteration takes, and every kernel in situ with its measured traffic
+            if not args.no_pmc:
+                tl1, il1 = live_profile_l1ra(args)
+                m_, nnz_, nu_ = S["m"], st["level_nnz"][0], S["n"] - 1
+                alg_l1 = {   # bytes per launch: planes of 8 B per edge read + written (l1pd.hip), SELL entries, view planes
+                    "k_pd_init": m_ * (8 + 5 * 8),
+                    "k_pd_sig": m_ * (4 * 8 + 3 * 8),
+                    "k_assemble0w": m_ * 16 + nnz_ * (4 + 8) + nu_ * (8 + 8 + 8 + 32),
+                    "k_pd_dir": m_ * (8 + 4 * 8 + 2 * 8) + nu_ * 32,
+                    "k_at_mul4": nnz_ * (4 + 8) + nu_ * 16,
+                    "k_pd_trial_edge": m_ * (6 * 8 + 6 * 8),
+                    "k_pd_commit_vert": nu_ * (32 + 8 + 8),
+                }
+                if tl1:
+                    per = {}
+                    tot_b = 0.0
+                    calls_l1ra = max(1, (il1.get("trace_reps") or 6) * 5)   # outer iterations in the traced process
+                    for kname, by in alg_l1.items():
+                        rows = prof_rows(tl1, kname, {0: "2"} if kname == "k_assemble0w" else None)
+                        if not rows:
+                            continue
+                        r0_ = rows[0]
+                        per[kname] = {"launches_per_outer_iteration": r0_["calls"] / calls_l1ra, "avg_us_in_situ": r0_["avg_us"],
+                                      "algorithmic_bytes": by, "traffic": r0_.get("traffic_bytes"),
+                                      "frac_in_situ": by / (r0_["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                        tot_b += by * r0_["calls"] / calls_l1ra
+                    ms_outer = 1e3 * ml / max(ra["iters"], 1)
+                    line["roofline_l1pd"] = {
+                        "kernel": "the edge / view kernels of l1decode_pd (ral/l1_irls.cpp:228-468) over one outer iteration of "
+                                  "l1ra: 3 coordinates x 2 primal-dual iterations, three solver chains at once",
+                        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_outer_iteration": tot_b, "ms_per_outer_iteration": ms_outer,
+                        "achieved": tot_b / (ms_outer * 1e-3) / 1e9, "frac": tot_b / (ms_outer * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "by_kernel": per,
+                        "note": "frac = the streaming kernels' bytes over the WHOLE outer iteration, six direct Hessian solves "
+                                "included (they move 6 x 158 MB more and are latency-bound, see roofline); frac_in_situ of a kernel "
+                                "= its bytes over its own duration while two other chains run next to it (they share the HBM)",
+                        "profile": il1.get("where")}
+                else:
+                    line["roofline_l1pd"] = {"error": il1}
             # what a caller of the drop-in irotavg_irls pays with HOST buffers: graph build (adjacency,
             # hierarchy, SELL) + upload + the same solve + download, per call (the resident
             # figure above is the amortised / incremental case)
