@@ -14,7 +14,7 @@ ap.add_argument("--cases", type=int, default=100)
 ap.add_argument("--debug-case", type=int, default=-1, help="one case, one IRLS iteration, where the rows differ")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
-bad = ran = refused = 0
+bad = ran = refused = conditioned = 0
 t0 = time.time()
 for case in range(a.cases):
     n = int(rng.integers(1200, 40000))
@@ -90,10 +90,32 @@ for case in range(a.cases):
     ran += 1
     ang = synth.angular_distance(Qa, Qb).max()
     werr = np.abs(wa - wb).max() / max(np.abs(wa).max(), 1e-300)
+    if ra["iters"] == rb["iters"] and not (ang < 1e-8) and ang < 1e-5 and werr < 1e-4:
+        # Two eliminations of the same operator in different orders: how far apart may they be? As far as either is from
+        # the exact answer. The referee is the ORACLE (its own Cholesky, a third order): the sharded run passes when it
+        # is no further from the oracle than 4 x the unsharded run is, or within the tool's 1e-8 of it. (Round 4 held the
+        # two GPU runs against each other at 1e-8 and flagged 3 of 116 cases -- Welsch on thin chains, whose floored
+        # weights spread the operator over eight decades: there the UNSHARDED run is as far from the oracle as the
+        # sharded one.)
+        from oracle import oracle as O
+        Qo = Q0.copy()
+        if l1:
+            Qo = O.l1ra(QQ, I, Qo, f, l1, 1e-3)["Q"]
+        ro = O.irls(QQ, I, Qo, f, cost, SIG, 3, 1e-3)
+        da, db = synth.angular_distance(Qa, ro["Q"]).max(), synth.angular_distance(Qb, ro["Q"]).max()
+        print("case %d: n %d band %d f %d world %d cost %d: sharded vs unsharded %.2e rad; vs the oracle: unsharded %.2e, "
+              "sharded %.2e -> %s" % (case, n, b, f, world, cost, ang, da, db,
+                                      "ok" if db <= max(1e-8, 4 * da) and ro["iters"] == rb["iters"] else "FAILED"), flush=True)
+        if not (db <= max(1e-8, 4 * da) and ro["iters"] == rb["iters"]):
+            bad += 1
+        else:
+            conditioned += 1
+        continue
     if ra["iters"] != rb["iters"] or not (ang < 1e-8) or not (werr < 1e-6):
         bad += 1
         print("case %d: n %d band %d f %d world %d cost %d l1 %d block %d: iters %d vs %d, angle %.2e, weights %.2e" % (
             case, n, b, f, world, cost, l1, direct, ra["iters"], rb["iters"], ang, werr), flush=True)
-print("seed %d: %d cases, %d on the sharded direct solver, %d not (too small for the world size), %d FAILED, %.0f s" % (
-    a.seed, a.cases, ran, refused, bad, time.time() - t0))
+print("seed %d: %d cases, %d on the sharded direct solver, %d not (too small for the world size), %d above 1e-8 rad between the two "
+      "GPU runs but as close to the oracle as the unsharded run, %d FAILED, %.0f s" % (
+          a.seed, a.cases, ran, refused, conditioned, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
