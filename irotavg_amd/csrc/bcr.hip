@@ -2494,10 +2494,35 @@ __global__ __launch_bounds__(256) void k_bcr_pack_top(BcrPtrs P, int ext0, const
     }
 }
 
+// rec (rank-major records of one rank's five slices, what ncclAllGather moves) <-> buf (array-major, what the separator
+// system is read from): mine >= 0: buf's slices of rank `mine` -> its record; mine < 0: every record -> buf
+__global__ __launch_bounds__(256) void k_bcr_top_records(int B, int world, int mine, double *__restrict__ buf, double *__restrict__ rec) {
+    const int BB = B * B, BR = B * 3, RS = 3 * BB + 2 * BR;
+    const int r0 = mine >= 0 ? mine : 0, r1 = mine >= 0 ? mine + 1 : world;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < (r1 - r0) * RS; idx += gridDim.x * 256) {
+        const int rank = r0 + idx / RS, e = idx % RS;
+        size_t b;   // position in buf
+        if (e < 3 * BB) b = (size_t)(e / BB) * world * BB + (size_t)rank * BB + e % BB;
+        else {
+            const int q = e - 3 * BB;
+            b = (size_t)3 * world * BB + (size_t)(q / BR) * world * BR + (size_t)rank * BR + q % BR;
+        }
+        if (mine >= 0) rec[(size_t)rank * RS + e] = buf[b];
+        else buf[b] = rec[(size_t)rank * RS + e];
+    }
+}
+void bcr_top_to_record(BcrTop &T, int rank, hipStream_t st) {
+    hipLaunchKernelGGL(k_bcr_top_records, dim3(8), dim3(256), 0, st, T.B, T.world, rank, T.buf.p, T.rec.p);
+}
+void bcr_top_from_records(BcrTop &T, hipStream_t st) {
+    hipLaunchKernelGGL(k_bcr_top_records, dim3(8 * T.world), dim3(256), 0, st, T.B, T.world, -1, T.buf.p, T.rec.p);
+}
+
 void bcr_top_alloc(BcrTop &T, int B, int world) {
     T.B = B;
     T.world = world;
     T.buf.alloc(T.n_doubles());
+    T.rec.alloc(T.n_doubles());
     T.W.alloc((size_t)7 * B * (2 * B + 3));
     T.x.alloc((size_t)8 * B * 3);
     T.xtop.alloc((size_t)B * 3);

@@ -661,7 +661,9 @@ static int pcg_dist_any(Dist &D) {
 // The direct solve of a sharded sequence: local reductions, one gather, the separator system, the ways back.
 static int bcr_dist(Dist &D) {
     BcrTop &T = D.top;
-    IRH_CHECK(hipMemsetAsync(T.buf.p, 0, sizeof(double) * T.n_doubles(), D.stream));
+    // (the hosted wire sums the ranks' buffers -- every rank writes its own slices into a zeroed one; RCCL gathers
+    // records and the loopback shards share the buffer: no clearing needed there)
+    if (D.hosted) IRH_CHECK(hipMemsetAsync(T.buf.p, 0, sizeof(double) * T.n_doubles(), D.stream));
     for (auto &sp : D.shards) bcr_shard_reduce(sp->g, T, sp->rank);
     if (D.hosted) {
         D.hbuf.assign(T.n_doubles(), 0.0);
@@ -671,8 +673,13 @@ static int bcr_dist(Dist &D) {
         IRH_CHECK(hipMemcpyAsync(T.buf.p, D.hbuf.data(), sizeof(double) * T.n_doubles(), hipMemcpyHostToDevice, D.stream));
         IRH_CHECK(hipStreamSynchronize(D.stream));  // hbuf is reused
     } else if (D.use_rccl) {
-        // every rank wrote its own slices into a zeroed buffer: the sum over the ranks is the gather
-        NCCL_CHECK(ncclAllReduce(T.buf.p, T.buf.p, T.n_doubles(), ncclDouble, ncclSum, D.comm, D.stream));
+        // an ALL-GATHER of one record per rank (its five slices, 15 KB at B = 24) -- until round 5 a sum-all-reduce of
+        // the whole zero-filled 120 KB buffer stood in for it: twice the bytes on every link and a memset per solve
+        const int rank = D.shards[0]->rank;
+        bcr_top_to_record(T, rank, D.stream);
+        NCCL_CHECK(ncclAllGather(T.rec.p + (size_t)rank * T.record_doubles(), T.rec.p, T.record_doubles(), ncclDouble, D.comm,
+                                 D.stream));
+        bcr_top_from_records(T, D.stream);
     }  // loopback: the shards of this process share the buffer
     bcr_top_solve(D.shards[0]->g, T);
     for (auto &sp : D.shards) bcr_shard_back(sp->g, T, sp->rank);

@@ -305,11 +305,15 @@ const int *bcr_fail_word(Graph &g);
 // the sharded form (dist.hip): every rank reduces its range to its last block; the `world` separators are one chunk
 struct BcrTop {
     int B = 0, world = 0;
-    DevBuf<double> buf;         // [sepD | extD | extG | sepR | extR], `world` blocks each: filled by the ranks, summed over them
+    DevBuf<double> buf;         // [sepD | extD | extG | sepR | extR], `world` blocks each: filled by the ranks
+    DevBuf<double> rec;         // the same data rank-major (a rank's five slices as one record): what an all-gather moves
+    size_t record_doubles() const { return 3 * (size_t)B * B + 2 * (size_t)B * 3; }
     DevBuf<double> W, x, xtop;  // factor and solution of the separator system (8 blocks)
     size_t n_doubles() const { return (size_t)world * (3 * (size_t)B * B + 2 * (size_t)B * 3); }
 };
 void bcr_top_alloc(BcrTop &T, int B, int world);
+void bcr_top_to_record(BcrTop &T, int rank, hipStream_t st);   // buf's slices of `rank` -> rec[rank]
+void bcr_top_from_records(BcrTop &T, hipStream_t st);          // every record -> buf
 void bcr_shard_reduce(Graph &g, BcrTop &T, int rank);  // local reduction; this rank's slices of T.buf
 void bcr_top_solve(Graph &g, BcrTop &T);               // after T.buf holds every rank's slices
 void bcr_shard_back(Graph &g, BcrTop &T, int rank);    // -> g.X (owned rows)

@@ -83,6 +83,27 @@ def test_rccl_transport_single_rank():
     assert synth.angular_distance(Qa, Qb).max() < 1e-8
 
 
+def test_rccl_transport_single_rank_direct_solver_gathers_records():
+    """The sharded DIRECT solver on the RCCL wire: the ranks' separator data travels as one record per rank through
+    ncclAllGather (round 5; a sum-all-reduce of the zero-filled buffer until then) -- a 1-rank communicator on the one
+    GPU of a test box runs that code: to-record, all-gather in place, from-records, the separator system."""
+    n, m = 20000, 300000
+    S, Q0 = problem(n, m, 0.0)
+    uid = capi.DistGraph.unique_id()
+    with capi.DistGraph(S["I"], S["QQ"], n, 1, 1, rank=0, unique_id=uid, band_direct=1) as D:
+        assert D.info()["direct_block"] > 0
+        D.set_rotations(Q0)
+        b = D.irls(4, SIG, 50, 1e-3)
+        Qb = D.get_rotations(into=Q0.copy())
+        assert D.stats()["direct_solves"] > 0
+    with capi.Graph(S["I"], S["QQ"], n, 1) as G:
+        G.set_rotations(Q0)
+        a = G.irls(4, SIG, 50, 1e-3)
+        Qa = G.get_rotations()
+    assert a["iters"] == b["iters"]
+    assert synth.angular_distance(Qa, Qb).max() < 1e-9
+
+
 def test_bad_world_size():
     S, Q0 = problem(200, 1200, 0.0)
     with pytest.raises(capi.IrotavgError):
