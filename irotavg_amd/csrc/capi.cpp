@@ -613,7 +613,17 @@ bool oneshot_cache_on() {
 }
 
 // 64-bit hash of n 8-byte words (chunks of 64K words hashed on all cores, combined in order)
-uint64_t hash_words(const uint64_t *p, int64_t n) {
+uint64_t hash_words(const void *base, int64_t n) {
+    // (the edge list is an int32 array: 4-byte aligned only -- words are fetched by memcpy, which compiles to one
+    // unaligned load)
+    struct Words {
+        const unsigned char *b;
+        uint64_t operator[](int64_t k) const {
+            uint64_t v;
+            std::memcpy(&v, b + 8 * k, 8);
+            return v;
+        }
+    } p{static_cast<const unsigned char *>(base)};
     const int64_t chunk = 1 << 16;
     const int64_t nch = (n + chunk - 1) / chunk;
     std::vector<uint64_t> part((size_t)std::max<int64_t>(nch, 1), 0);
@@ -651,10 +661,10 @@ OneShotKey oneshot_key(int64_t m, int64_t n_total, int f, const int32_t *I, cons
     k.ldqq = ldqq;
     k.f = f;
     (void)hipGetDevice(&k.dev);
-    k.hI = hash_words(reinterpret_cast<const uint64_t *>(I), m);  // an edge = two int32 = one word
+    k.hI = hash_words(I, m);  // an edge = two int32 = one word
     uint64_t h = 0;
     for (int c = 0; c < 4; c++)  // the four columns (ldqq may exceed m: the padding is not the graph)
-        h = h * 0x100000001B3ull ^ hash_words(reinterpret_cast<const uint64_t *>(QQ + (size_t)c * (size_t)ldqq), m);
+        h = h * 0x100000001B3ull ^ hash_words(QQ + (size_t)c * (size_t)ldqq, m);
     k.hQQ = h;
     return k;
 }
