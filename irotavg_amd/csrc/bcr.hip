@@ -126,6 +126,15 @@ struct BcrState {
     DevBuf<BcrTopSched> tsched_dev;
     DevBuf<int> ghost_extcol;  // per ghost view: its row in the previous rank's last block, or -1
     DevBuf<double> remD, remR; // what this shard's eliminations subtract from that separator (sum over its levels)
+    // closures on a shard: per local closure the slots that hold what is left on this rank's separator and on the one
+    // before it {own, remote} (255: nothing), its number in the global list, who adds its 1 / w; the rows whose diagonal
+    // loses the weight of a closure to a ghost view for the time of the reduction
+    DevBuf<int2> cl_fin;
+    DevBuf<int> cl_gid;
+    DevBuf<uint8_t> cl_own;
+    DevBuf<int> fix_row, fix_off, fix_e;
+    DevBuf<double> fix_saved;
+    int nfix = 0;
 };
 
 void BcrDeleter::operator()(BcrState *p) const { delete p; }
@@ -1684,18 +1693,28 @@ template <int B>
 __global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r, int nslots, const int *__restrict__ off,
                                                               const int4 *__restrict__ steps,
                                                               const int4 *__restrict__ init, double *__restrict__ recR,
-                                                              double *__restrict__ recW, double *__restrict__ T) {
+                                                              double *__restrict__ recW, double *__restrict__ T,
+                                                              const double *__restrict__ slot_init = nullptr,
+                                                              const int2 *__restrict__ fin = nullptr,
+                                                              const int *__restrict__ gid = nullptr,
+                                                              double *__restrict__ dep = nullptr, int world = 0,
+                                                              int rank = 0) {
     constexpr int NR = 3, NC = 2 * B + NR, BB = B * B, NCOL = NC + B;
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * (blockDim.x >> 6) + wave;
     if (q >= r) return;  // (no workgroup barrier below)
     double *slots = smem + (size_t)wave * nslots * B;
-    for (int e = lane; e < nslots * B; e += 64) slots[e] = 0.0;
-    const int4 in = init[q];
-    if (lane == 0) {
-        slots[in.x * B + in.y] += 1.0;
-        slots[in.z * B + in.w] -= 1.0;
+    if (slot_init) {
+        // the separator system of a sharded sequence: the column starts from what the ranks' eliminations left there
+        for (int e = lane; e < nslots * B; e += 64) slots[e] = slot_init[(size_t)q * nslots * B + e];
+    } else {
+        for (int e = lane; e < nslots * B; e += 64) slots[e] = 0.0;
+        const int4 in = init[q];
+        if (lane == 0) {  // (a slot of 255: that endpoint is a row of another rank)
+            if (in.x != 255) slots[in.x * B + in.y] += 1.0;
+            if (in.z != 255) slots[in.z * B + in.w] -= 1.0;
+        }
     }
     double tacc = 0.0;  // lanes 2B .. 2B + 2 of the first pass: a coordinate of T each
     for (int st = off[q]; st < off[q + 1]; st++) {
@@ -1763,6 +1782,16 @@ __global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r,
         for (int c = 0; c < 3; c++)
             if (((c0 + c) & 63) == lane) T[(size_t)q * 3 + c] = tacc;
     }
+    // a shard: what the column leaves on this rank's separator (block `rank` of the separator system) and on the one
+    // before it (block rank - 1) is ADDED to the ranks' common buffer (the loopback's shards run one after the other)
+    if (dep) {
+        const int2 fn = fin[q];
+        double *d = dep + (size_t)gid[q] * world * B;
+        if (lane < B) {
+            if (fn.x != 255) d[rank * B + lane] += slots[fn.x * B + lane];
+            if (fn.y != 255 && rank > 0) d[(rank - 1) * B + lane] += slots[fn.y * B + lane];
+        }
+    }
 }
 
 // S = C^-1 + V' A_b^-1 V: entry (p, q) = sum over the steps of p and q on the same block of R_p . (D^-1 R_q); the
@@ -1776,7 +1805,10 @@ __global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, int maxs
                                                         const double *__restrict__ recW, const int *__restrict__ far_e,
                                                         const double *__restrict__ wsrc, int wsquare,
                                                         double *__restrict__ S, double *__restrict__ T,
-                                                        int *__restrict__ alive) {
+                                                        int *__restrict__ alive, const int *__restrict__ gid = nullptr,
+                                                        const uint8_t *__restrict__ own = nullptr, int npadG = 0,
+                                                        double *__restrict__ Tx = nullptr,
+                                                        double *__restrict__ deadx = nullptr) {
     extern __shared__ int skey[];  // [32][maxsteps]: rows 0..15 the tile's p, 16..31 its q
     __shared__ double sx[2][16][B + 1], sy[2][16][B + 1];
     if (blockIdx.x < blockIdx.y) return;
@@ -1823,7 +1855,7 @@ __global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, int maxs
     }
     if (p >= npad || q >= npad || q < p) return;
     if (p >= r || q >= r) {  // padding of the inversion
-        S[(size_t)p * npad + q] = S[(size_t)q * npad + p] = p == q ? 1.0 : 0.0;
+        if (!gid) S[(size_t)p * npad + q] = S[(size_t)q * npad + p] = p == q ? 1.0 : 0.0;
         return;
     }
     double wp = wsrc[far_e[p]], wq = wsrc[far_e[q]];
@@ -1857,9 +1889,27 @@ __global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, int maxs
                 b++;
             }
         }
-        if (p == q) sum += 1.0 / wp;
+        if (p == q && (!gid || own[p])) sum += 1.0 / wp;
     } else {
         sum = p == q ? 1.0 : 0.0;
+    }
+    if (gid) {
+        // a shard: this rank's share of the system is ADDED at the closures' places in the global list (dist.hip sums
+        // the ranks' buffers); a closure of weight 0 is flagged by its owner and settled after the sum
+        const int gp = gid[p], gq = gid[q];
+        const bool live = wp > 0.0 && wq > 0.0;
+        if (live) {
+            S[(size_t)gp * npadG + gq] += sum;
+            if (p != q) S[(size_t)gq * npadG + gp] += sum;
+        }
+        if (p == q) {
+            if (live) {
+                for (int c = 0; c < 3; c++) Tx[3 * gp + c] += T[3 * p + c];
+            } else if (own[p]) {
+                deadx[gp] += 1.0;
+            }
+        }
+        return;
     }
     S[(size_t)p * npad + q] = sum;
     S[(size_t)q * npad + p] = sum;
@@ -1972,13 +2022,24 @@ __global__ __launch_bounds__(1024) void k_bcr_closure_correct(BcrClPlan P, const
 // e_i - e_j per closure. Blocks are tracked as (level, block of that level) -> slot; a chunk's eliminations run in the
 // kernel's order (0 2 4 6)(1 5)(3); what an elimination subtracts from the separator before its chunk is kept in the
 // slot of that separator's block of the NEXT level (the reduction adds sepR[j] + extR[j + 1] there as well).
+// Where the real block t of a chunk with kreal blocks sits (host mirror of bcr_pos / kBcrPlace)
+static const signed char kBcrPlaceHost[9][8] = {{-1, -1, -1, -1, -1, -1, -1, -1}, {7, -1, -1, -1, -1, -1, -1, -1},
+                                                {3, 7, -1, -1, -1, -1, -1, -1},   {3, 5, 7, -1, -1, -1, -1, -1},
+                                                {1, 3, 5, 7, -1, -1, -1, -1},     {1, 3, 5, 6, 7, -1, -1, -1},
+                                                {1, 3, 4, 5, 6, 7, -1, -1},       {1, 2, 3, 4, 5, 6, 7, -1},
+                                                {0, 1, 2, 3, 4, 5, 6, 7}};
+// A SHARD's plan (round 5): the partial chunks are placed (the last block sits at position 7 and survives as the
+// separator at every level), chunk 0 of every level subtracts from the separator of the rank before this one (one slot
+// per closure that lives through all levels), the last level is not solved -- what is left at its position 7 and in that
+// slot goes to the separator system (cl_fin), and an endpoint may be a row of another rank (row -1: no start value here).
 static void bcr_closure_plan(Graph &g) {
     BcrState &S = *g.bcr;
     const int B = S.B, nl = (int)S.lev.size(), r = S.nfar;
     const int nch0 = S.lev[0].nch;
-    const bool mixed = nl > 1 && S.lev[1].nred < S.lev[1].nb;
+    const bool shard = g.bcr_shard;
     std::vector<int> off(1, 0), owner;
     std::vector<int4> steps, init((size_t)r);
+    std::vector<int2> fin((size_t)r);
     std::vector<long long> koff((size_t)nl + 1, 0);  // sort keys: (level, chunk, rank in the schedule)
     for (int l = 0; l < nl; l++) koff[(size_t)l + 1] = koff[(size_t)l] + (long long)S.lev[l].nch * 8;
     static const int rank_of[7] = {0, 4, 1, 6, 2, 5, 3}, sched[7] = {0, 2, 4, 6, 1, 5, 3};
@@ -2003,8 +2064,11 @@ static void bcr_closure_plan(Graph &g) {
             return t;
         };
         int4 in;
+        in.x = in.z = 255;
+        in.y = in.w = 0;
         for (int e = 0; e < 2; e++) {
             const int row = e ? g.bcr_far_j[(size_t)q] : g.bcr_far_i[(size_t)q];
+            if (row < 0) continue;  // (a row of another rank)
             const int b = row / B;
             int l = 0, blk = b;
             if (nl > 1 && b >= 8 * nch0) {  // a block no chunk of level 0 reduces: a block of the mixed level 1
@@ -2021,26 +2085,32 @@ static void bcr_closure_plan(Graph &g) {
             }
         }
         init[(size_t)q] = in;
-        (void)mixed;
+        int remote = -1, own = -1;  // a shard: the slots of the two separators this rank's eliminations add to
         for (int l = 0; l < nl; l++) {
-            const bool top = l == nl - 1;
+            const bool top = l == nl - 1 && !shard;
             // chunks with non-zero blocks, ascending (std::map is ordered)
             while (!nz[(size_t)l].empty()) {
                 const int chunk = nz[(size_t)l].begin()->first / 8;
                 const int kreal = std::min(8, S.lev[l].nb - chunk * 8);
+                const bool placed = shard && kreal < 8;
+                auto pos_of = [&](int t) { return placed ? (int)kBcrPlaceHost[kreal][t] : t; };
+                bool real[8];
+                for (int i = 0; i < 8; i++) real[i] = false;
+                for (int t = 0; t < kreal; t++) real[pos_of(t)] = true;
                 int slot[9];  // positions 0..7, [8] = the separator before the chunk
                 for (int i = 0; i < 9; i++) slot[i] = -1;
-                for (int i = 0; i < 8; i++) {
-                    auto it = nz[(size_t)l].find(chunk * 8 + i);
+                for (int t = 0; t < kreal; t++) {
+                    auto it = nz[(size_t)l].find(chunk * 8 + t);
                     if (it != nz[(size_t)l].end()) {
-                        slot[i] = it->second;
+                        slot[pos_of(t)] = it->second;
                         nz[(size_t)l].erase(it);
                     }
                 }
-                const bool has_ext = chunk > 0;
+                const bool ext_remote = shard && chunk == 0 && S.ext0;
+                const bool has_ext = chunk > 0 || ext_remote;
                 for (int k = 0; k < 7; k++) {
                     const int i = sched[k];
-                    if (i >= kreal || slot[i] < 0) continue;
+                    if (!real[i] || slot[i] < 0) continue;
                     int a, c;
                     if (k < 4) {
                         a = i - 1;
@@ -2054,16 +2124,23 @@ static void bcr_closure_plan(Graph &g) {
                     }
                     int dA = 255, dC = 255;
                     if (a >= 0) {
+                        // (a placed chunk: every padding position has been skipped before it would be a neighbour)
+                        if (!real[a]) throw HipError{hipErrorUnknown};
                         if (slot[a] < 0) slot[a] = take();
                         dA = slot[a];
                     } else if (has_ext) {
                         if (slot[8] < 0) {
-                            // the separator before the chunk = block chunk - 1 of the next level (it may hold a value)
-                            slot[8] = slot_of(l + 1, chunk - 1);
+                            if (ext_remote) {
+                                if (remote < 0) remote = take();
+                                slot[8] = remote;
+                            } else {
+                                // the separator before the chunk = block chunk - 1 of the next level (it may hold a value)
+                                slot[8] = slot_of(l + 1, chunk - 1);
+                            }
                         }
                         dA = slot[8];
                     }
-                    if (c < kreal) {
+                    if (real[c]) {
                         if (slot[c] < 0) slot[c] = take();
                         dC = slot[c];
                     }
@@ -2076,8 +2153,8 @@ static void bcr_closure_plan(Graph &g) {
                     owner.push_back(q);
                     slot[i] = -1;  // (its slot is not reused: a new slot must start from zero)
                 }
-                // what is left: the separator (position 7 when the chunk is full)
-                if (kreal == 8 && slot[7] >= 0) {
+                // what is left: the separator (position 7 when the chunk is full or placed)
+                if (real[7] && slot[7] >= 0) {
                     if (top) {  // solved on the spot
                         int4 sp;
                         sp.x = -1;
@@ -2086,6 +2163,8 @@ static void bcr_closure_plan(Graph &g) {
                         sp.w = (int)(koff[(size_t)l] + (long long)chunk * 8 + 7);
                         steps.push_back(sp);
                         owner.push_back(q);
+                    } else if (l == nl - 1) {  // a shard's last level: this rank's block of the separator system
+                        own = slot[7];
                     } else {
                         auto it = nz[(size_t)l + 1].find(chunk);
                         if (it == nz[(size_t)l + 1].end()) {
@@ -2099,6 +2178,7 @@ static void bcr_closure_plan(Graph &g) {
                 }
             }
         }
+        fin[(size_t)q] = int2{own < 0 ? 255 : own, remote < 0 ? 255 : remote};
         nslots = std::max(nslots, next);
         S.cl_maxsteps = std::max(S.cl_maxsteps, (int)steps.size() - off.back());
         off.push_back((int)steps.size());
@@ -2147,7 +2227,18 @@ static void bcr_closure_plan(Graph &g) {
     S.cl_off.upload(off, g.stream);
     S.cl_step.upload(steps, g.stream);
     S.cl_init.upload(init, g.stream);
-    S.cl_owner.upload(owner, g.stream);
+    if (shard) {
+        // (the steps' owners as the correction reads them: numbers in the global list, where lambda lives)
+        std::vector<int> gowner(owner.size());
+        for (size_t k = 0; k < owner.size(); k++) gowner[k] = g.bcr_far_gid[(size_t)owner[k]];
+        if (gowner.empty()) gowner.push_back(0);
+        S.cl_owner.upload(gowner, g.stream);
+        S.cl_fin.upload(fin, g.stream);
+        S.cl_gid.upload(g.bcr_far_gid, g.stream);
+        S.cl_own.upload(g.bcr_far_own, g.stream);
+    } else {
+        S.cl_owner.upload(owner, g.stream);
+    }
     S.co_off.upload(eoff, g.stream);
     S.co_rec.upload(erec, g.stream);
     S.co_elim.upload(elim, g.stream);
@@ -2238,6 +2329,14 @@ static void bcr_alloc(Graph &g) {
     }
     S.xtop.alloc((size_t)B * NR);
     if (S.nfar > 0) bcr_closure_plan(g);
+    if (g.bcr_shard && !g.bcr_fix_row.empty()) {
+        S.nfix = (int)g.bcr_fix_row.size();
+        S.fix_row.upload(g.bcr_fix_row, g.stream);
+        S.fix_off.upload(g.bcr_fix_off, g.stream);
+        S.fix_e.upload(g.bcr_fix_e, g.stream);
+        S.fix_saved.alloc((size_t)S.nfix);
+        IRH_CHECK(hipStreamSynchronize(g.stream));
+    }
 }
 
 // open_top: the last level writes its separator data like every other level instead of solving it (a shard: the
@@ -2528,10 +2627,122 @@ void bcr_top_alloc(BcrTop &T, int B, int world) {
     T.xtop.alloc((size_t)B * 3);
 }
 
+// ---- loop closures on a sharded sequence (round 5) -------------------------------------------------------------
+// The Woodbury correction of "The closures' part of a solve" with the elimination tree cut at the ranks' separators:
+// a closure's incidence column is eliminated through the levels of the rank(s) that hold its endpoints
+// (k_bcr_closure_forward on the shard's own step programs), what it leaves on the rank's separator and on the one
+// before it is the column's right-hand side of the separator system, which every rank eliminates for ALL closures
+// after the ranks' buffers have been summed; S = C^-1 + V' A_b^-1 V and T = V' Y are sums over eliminated blocks --
+// a rank's blocks (its share, added to the same buffer) and the separator system's (added by everybody after the sum);
+// lambda is solved by every rank, the corrections of the stored right-hand sides are local again.
+
+// the rows with a closure to a GHOST view: their diagonal holds that closure's weight (a ghost edge is Dirichlet mass
+// on a shard) -- the band operator loses it for the time of the reduction as bcr_gather_row takes a local far entry out
+__global__ __launch_bounds__(256) void k_bcr_fix_diag(int nfix, const int *__restrict__ row, const int *__restrict__ off,
+                                                       const int *__restrict__ e, const double *__restrict__ wsrc, int wsquare,
+                                                       double *__restrict__ diag, double *__restrict__ saved, int restore) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nfix) return;
+    const int rw = row[k];
+    if (restore) {
+        diag[rw] = saved[k];
+        return;
+    }
+    const double d = diag[rw];
+    saved[k] = d;
+    double s = 0.0;
+    for (int t = off[k]; t < off[k + 1]; t++) {
+        const double w = wsrc[e[t]];
+        s += wsquare ? w * w : w;
+    }
+    diag[rw] = d - s;
+}
+
+__global__ void k_bcr_add_dead(const int *__restrict__ dead, double *__restrict__ sum) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *sum += (double)*dead;
+}
+
+// After the sum over the ranks: S += the separator system's share (sum over its eliminations of R_p . D^-1 R_q: every
+// closure has a record on every one of them -- a product of two r x (nst B) arrays), T += its share; a closure its owner
+// flagged as dead (weight 0) gets the identity's row and column and T = 0; the padding of the inversion.
+template <int B>
+__global__ __launch_bounds__(256) void k_bcr_top_closure_S(int r, int npad, int nst, const double *__restrict__ recR,
+                                                            const double *__restrict__ recW, const double *__restrict__ Ttop,
+                                                            double *__restrict__ S, double *__restrict__ T,
+                                                            const double *__restrict__ deadx) {
+    __shared__ double sx[16][65], sy[16][65];
+    if (blockIdx.x < blockIdx.y) return;
+    const int tp = threadIdx.x >> 4, tq = threadIdx.x & 15;
+    const int p = blockIdx.y * 16 + tp, q = blockIdx.x * 16 + tq;
+    const int K = nst * B;
+    double sum = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+            const int who = e >> 6, k = e & 63;
+            const int cl = who < 16 ? blockIdx.y * 16 + who : blockIdx.x * 16 + who - 16;
+            double v = 0.0;
+            if (cl < r && k0 + k < K) v = (who < 16 ? recR : recW)[(size_t)cl * K + k0 + k];
+            if (who < 16)
+                sx[who][k] = v;
+            else
+                sy[who - 16][k] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 64; k++) sum = fma(sx[tp][k], sy[tq][k], sum);
+        __syncthreads();
+    }
+    if (p >= npad || q >= npad || q < p) return;
+    if (p >= r || q >= r) {
+        S[(size_t)p * npad + q] = S[(size_t)q * npad + p] = p == q ? 1.0 : 0.0;
+        return;
+    }
+    const bool live = !(deadx[p] > 0.0) && !(deadx[q] > 0.0);
+    const double v = live ? S[(size_t)p * npad + q] + sum : (p == q ? 1.0 : 0.0);
+    S[(size_t)p * npad + q] = v;
+    S[(size_t)q * npad + p] = v;
+    if (p == q)
+        for (int c = 0; c < 3; c++) T[3 * p + c] = live ? T[3 * p + c] + Ttop[3 * p + c] : 0.0;
+}
+
+template <int B>
+static BcrClPlan bcr_local_clplan(BcrState &S) {
+    BcrClPlan P;
+    const int nl = (int)S.lev.size();
+    for (int l = 0; l < kMaxLevels; l++) {
+        P.W[l] = P.Wrw[l] = l < nl ? S.lev[l].W.p : nullptr;
+        P.Dinv[l] = l < nl && l < (int)S.Dinv.size() ? S.Dinv[(size_t)l].p : nullptr;
+    }
+    P.topDinv = S.topDinv.p;
+    P.xtop = S.xtop.p;
+    return P;
+}
+
+template <int B>
+static void bcr_launch_forward(hipStream_t st, const BcrClPlan &P, int r, int nslots, const int *off, const int4 *steps,
+                               const int4 *init, double *recR, double *recW, double *T, const double *slot_init,
+                               const int2 *fin, const int *gid, double *dep, int world, int rank) {
+    int wpb = 4;
+    while (wpb > 1 && (size_t)wpb * nslots * B * sizeof(double) > 60 * 1024) wpb >>= 1;
+    const size_t lds = (size_t)wpb * nslots * B * sizeof(double);
+    if (lds > 64 * 1024)
+        IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_forward<B>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_bcr_closure_forward<B>), dim3((r + wpb - 1) / wpb), dim3(64 * wpb), lds, st, P, r, nslots, off,
+                       steps, init, recR, recW, T, slot_init, fin, gid, dep, world, rank);
+}
+
 template <int B>
 static void bcr_shard_reduce_t(Graph &g, BcrTop &T, int rank) {
-    bcr_run<B, 3>(g, -1, 0, true, 1);
     BcrState &S = *g.bcr;
+    if (S.nfar > 0) IRH_CHECK(hipMemsetAsync(S.dead.p, 0, sizeof(int), g.stream));
+    if (S.nfix > 0)
+        hipLaunchKernelGGL(k_bcr_fix_diag, dim3((S.nfix + 255) / 256), dim3(256), 0, g.stream, S.nfix, S.fix_row.p, S.fix_off.p,
+                           S.fix_e.p, g.bcr_wsrc, g.bcr_wsquare, g.levels[0].diag.p, S.fix_saved.p, 0);
+    bcr_run<B, 3>(g, -1, 0, true, 1);
+    if (S.nfix > 0)
+        hipLaunchKernelGGL(k_bcr_fix_diag, dim3((S.nfix + 255) / 256), dim3(256), 0, g.stream, S.nfix, S.fix_row.p, S.fix_off.p,
+                           S.fix_e.p, g.bcr_wsrc, g.bcr_wsquare, g.levels[0].diag.p, S.fix_saved.p, 1);
     BcrPtrs P;
     P.n = (int)S.lev.size();
     for (int l = 0; l < P.n; l++) {
@@ -2543,7 +2754,7 @@ static void bcr_shard_reduce_t(Graph &g, BcrTop &T, int rank) {
                        T.buf.p, T.world, rank);
 }
 template <int B>
-static void bcr_top_solve_t(Graph &g, BcrTop &T) {
+static void bcr_top_reduce_launch(Graph &g, BcrTop &T, double *Dinv, double *topDinv, int *dead) {
     const int W = T.world;
     const size_t BB = (size_t)B * B, BR = (size_t)B * 3;
     double *buf = T.buf.p;
@@ -2553,14 +2764,150 @@ static void bcr_top_solve_t(Graph &g, BcrTop &T) {
                        buf + 3 * W * BB + W * BR, buf + 2 * W * BB, T.W.p, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr, (double *)nullptr, T.xtop.p, 0, 0, (const int *)nullptr,
                        (const int *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, nul, (const int *)nullptr, 0,
-                       (long long *)nullptr, (double *)nullptr, (double *)nullptr, (int *)nullptr, 0);
+                       (long long *)nullptr, Dinv, topDinv, dead, 0);
+}
+template <int B>
+static void bcr_top_back_launch(Graph &g, BcrTop &T) {
+    const int W = T.world;
+    const double *nul = nullptr;
     hipLaunchKernelGGL((k_bcr_back<B, 3, false>), dim3(1), dim3(256), 0, g.stream, W, W, 0, T.W.p, T.xtop.p, T.x.p,
                        (double4 *)nullptr, (double *)nullptr, 0, 0, 0, nul, 0);
+}
+template <int B>
+static void bcr_top_solve_t(Graph &g, BcrTop &T) {
+    bcr_top_reduce_launch<B>(g, T, nullptr, nullptr, nullptr);
+    bcr_top_back_launch<B>(g, T);
 }
 template <int B>
 static void bcr_shard_back_t(Graph &g, BcrTop &T, int rank) {
     const double *xs = T.x.p + (size_t)rank * B * 3;
     bcr_run<B, 3>(g, -1, 0, true, 2, xs, rank > 0 ? xs - (size_t)B * 3 : nullptr);
+}
+
+// this rank's closures: their forward eliminations through its levels, its share of S and T and its dead pivots -> T.xbuf
+template <int B>
+static void bcr_shard_closures_forward_t(Graph &g, BcrTop &T, int rank) {
+    BcrState &S = *g.bcr;
+    if (S.nfar == 0) return;
+    hipStream_t st = g.stream;
+    const BcrClPlan P = bcr_local_clplan<B>(S);
+    const int r = S.nfar;
+    bcr_launch_forward<B>(st, P, r, S.cl_nslots, S.cl_off.p, S.cl_step.p, S.cl_init.p, S.cl_R.p, S.cl_W.p, S.cl_T.p, nullptr,
+                          S.cl_fin.p, S.cl_gid.p, T.xbuf.p + T.x_dep(), T.world, rank);
+    const int nt = (S.cl_npad + 15) / 16;
+    hipLaunchKernelGGL((k_bcr_closure_S<B>), dim3(nt, nt), dim3(256), (size_t)32 * S.cl_maxsteps * sizeof(int), st, r,
+                       S.cl_npad, S.cl_maxsteps, S.cl_ndense, S.cl_dense.p, S.cl_off.p, S.cl_step.p, S.cl_R.p, S.cl_W.p,
+                       S.far_e.p, g.bcr_wsrc, g.bcr_wsquare, T.xbuf.p + T.x_S(), S.cl_T.p, S.cl_alive.p, S.cl_gid.p,
+                       S.cl_own.p, T.npad, T.xbuf.p + T.x_T(), T.xbuf.p + T.x_dead());
+    hipLaunchKernelGGL(k_bcr_add_dead, dim3(1), dim3(64), 0, st, S.dead.p, T.xbuf.p + T.x_pivots());
+}
+
+// the separator system with the closures' columns (every rank, after the sum of the ranks' buffers): factor, the columns'
+// forward eliminations, S and T completed, lambda, the corrected right-hand sides, the separators' solution
+template <int B>
+static void bcr_top_solve_closures_t(Graph &g, BcrTop &T) {
+    hipStream_t st = g.stream;
+    const int r = T.r, npad = T.npad, W = T.world;
+    IRH_CHECK(hipMemsetAsync(T.dead.p, 0, sizeof(int), st));
+    bcr_top_reduce_launch<B>(g, T, T.Dinv.p, T.topDinv.p, T.dead.p);
+    BcrClPlan P;
+    for (int l = 0; l < kMaxLevels; l++) {
+        P.W[l] = P.Wrw[l] = l == 0 ? T.W.p : nullptr;
+        P.Dinv[l] = l == 0 ? T.Dinv.p : nullptr;
+    }
+    P.topDinv = T.topDinv.p;
+    P.xtop = T.xtop.p;
+    double *xb = T.xbuf.p;
+    bcr_launch_forward<B>(st, P, r, W, T.cl_off.p, T.cl_step.p, nullptr, T.recR.p, T.recW.p, T.Ttop.p, xb + T.x_dep(), nullptr,
+                          nullptr, nullptr, 0, 0);
+    const int nt = (npad + 15) / 16;
+    hipLaunchKernelGGL((k_bcr_top_closure_S<B>), dim3(nt, nt), dim3(256), 0, st, r, npad, T.nst, T.recR.p, T.recW.p, T.Ttop.p,
+                       xb + T.x_S(), xb + T.x_T(), xb + T.x_dead());
+    if (r <= 64) {
+        hipLaunchKernelGGL(k_bcr_closure_solve64, dim3(1), dim3(256), 0, st, r, npad, xb + T.x_S(), xb + T.x_T(), T.lam.p);
+    } else {
+        dense_invert_spd(g, xb + T.x_S(), npad);
+        hipLaunchKernelGGL(k_bcr_closure_lambda, dim3((r + 3) / 4), dim3(256), 0, st, r, npad, xb + T.x_S(), xb + T.x_T(),
+                           T.lam.p);
+    }
+    hipLaunchKernelGGL((k_bcr_closure_correct<B>), dim3(T.nst), dim3(1024), 0, st, P, T.co_off.p, T.co_rec.p, T.co_elim.p,
+                       T.cl_owner.p, T.recW.p, T.lam.p);
+    bcr_top_back_launch<B>(g, T);
+}
+
+// the stored right-hand sides of this rank's blocks on the closures' paths -= sum_q (D^-1 R_q) lambda_q'
+template <int B>
+static void bcr_shard_closures_correct_t(Graph &g, BcrTop &T) {
+    BcrState &S = *g.bcr;
+    if (S.nfar == 0 || S.cl_nelim == 0) return;
+    const BcrClPlan P = bcr_local_clplan<B>(S);
+    hipLaunchKernelGGL((k_bcr_closure_correct<B>), dim3(S.cl_nelim), dim3(1024), 0, g.stream, P, S.co_off.p, S.co_rec.p,
+                       S.co_elim.p, S.cl_owner.p, S.cl_W.p, T.lam.p);
+}
+
+// the separator system's step program: one chunk of `world` blocks at their own positions, nothing before it; every
+// closure runs every elimination (slot t = block t, started from the summed deposits); the eighth block is solved
+void bcr_top_closures_alloc(Graph &g0, BcrTop &T, int r) {
+    T.r = r;
+    if (r <= 0) return;
+    const int B = T.B, W = T.world;
+    T.npad = r <= 64 ? r : (r + 63) / 64 * 64;
+    static const int sched[7] = {0, 2, 4, 6, 1, 5, 3};
+    std::vector<int4> prog;
+    std::vector<int2> elim;
+    for (int k = 0; k < 7; k++) {
+        const int i = sched[k];
+        if (i >= W) continue;
+        int a, c;
+        if (k < 4) {
+            a = i - 1;
+            c = i + 1;
+        } else if (k < 6) {
+            a = i == 1 ? -1 : 3;
+            c = i == 1 ? 3 : 7;
+        } else {
+            a = -1;
+            c = 7;
+        }
+        const int dA = a >= 0 ? a : 255, dC = c < W ? c : 255;
+        prog.push_back(int4{0, i, i | (dA << 8) | (dC << 16), 0});
+        elim.push_back(int2{0, i});
+    }
+    if (W == 8) {
+        prog.push_back(int4{-1, 0, 7 | (255 << 8) | (255 << 16), 0});
+        elim.push_back(int2{-1, 0});
+    }
+    const int nst = (int)prog.size();
+    T.nst = nst;
+    std::vector<int> off((size_t)r + 1), owner((size_t)r * nst), eoff((size_t)nst + 1), erec((size_t)r * nst);
+    std::vector<int4> steps((size_t)r * nst);
+    for (int q = 0; q <= r; q++) off[(size_t)q] = q * nst;
+    for (int q = 0; q < r; q++)
+        for (int d = 0; d < nst; d++) {
+            steps[(size_t)q * nst + d] = prog[(size_t)d];
+            owner[(size_t)q * nst + d] = q;
+        }
+    for (int d = 0; d <= nst; d++) eoff[(size_t)d] = d * r;
+    for (int d = 0; d < nst; d++)
+        for (int q = 0; q < r; q++) erec[(size_t)d * r + q] = q * nst + d;
+    hipStream_t st = g0.stream;
+    T.cl_off.upload(off, st);
+    T.cl_step.upload(steps, st);
+    T.cl_owner.upload(owner, st);
+    T.co_off.upload(eoff, st);
+    T.co_rec.upload(erec, st);
+    T.co_elim.upload(elim, st);
+    T.xbuf.alloc(T.x_doubles());
+    T.Dinv.alloc((size_t)7 * B * B);
+    T.topDinv.alloc((size_t)B * B);
+    T.recR.alloc((size_t)r * nst * B);
+    T.recW.alloc((size_t)r * nst * B);
+    T.Ttop.alloc((size_t)r * 3);
+    T.lam.alloc((size_t)T.npad * 3);
+    T.dead.alloc(1);
+    IRH_CHECK(hipMemsetAsync(T.topDinv.p, 0, sizeof(double) * (size_t)B * B, st));
+    IRH_CHECK(hipMemsetAsync(T.xbuf.p, 0, sizeof(double) * T.x_doubles(), st));
+    IRH_CHECK(hipStreamSynchronize(st));  // the host vectors go away
 }
 #define IRH_BCR_DISPATCH(fn, ...)              \
     switch (g.bcr_B) {                         \
@@ -2578,6 +2925,9 @@ void bcr_shard_back(Graph &g, BcrTop &T, int rank) {
     IRH_BCR_DISPATCH(bcr_shard_back_t, g, T, rank)
     g.stats.direct_solves += 1;
 }
+void bcr_shard_closures_forward(Graph &g, BcrTop &T, int rank) { IRH_BCR_DISPATCH(bcr_shard_closures_forward_t, g, T, rank) }
+void bcr_top_solve_closures(Graph &g, BcrTop &T) { IRH_BCR_DISPATCH(bcr_top_solve_closures_t, g, T) }
+void bcr_shard_closures_correct(Graph &g, BcrTop &T) { IRH_BCR_DISPATCH(bcr_shard_closures_correct_t, g, T) }
 
 // levels[0] values, diagonal and right-hand side (assemble_values) -> g.X. Asynchronous; only >= 0 launches one
 // kernel alone (bench: 0.. the reductions, 100.. the ways back).

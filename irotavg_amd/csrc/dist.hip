@@ -61,6 +61,11 @@ struct Dist {
     int bcr_B = 0;  // block size; 0: the sharded PCG
     int band0 = -1;
     BcrTop top;
+    // ... and (round 5) also with loop closures -- the sequence the reference's SLAM front end produces
+    // (src/IRotAvg.cpp:371-378): the long-range edges whose blocks are not neighbours, in edge order; every process
+    // derives the same list from the global graph. Woodbury correction across the ranks: bcr.hip, "loop closures on a
+    // sharded sequence".
+    std::vector<int64_t> cl_edge;
 };
 
 #define NCCL_CHECK(expr)                                                                      \
@@ -407,6 +412,34 @@ static int build_shard(Dist &D, Shard &S, const int32_t *I, const double *QQ, in
                 g.bcr_ghost_extcol[(size_t)q] = ec >= 0 ? (int)ec : -1;
             }
         }
+        // the closures with an endpoint in this range: local rows (-1: a row of another rank), the local edge, the number
+        // in the global list, whether this rank adds 1 / w (the owner of the first endpoint), and the rows whose diagonal
+        // holds the weight of a closure to a ghost view
+        std::map<int, std::vector<int>> fix;  // local row -> local edges
+        auto owner_of = [&](int64_t gfree) { return (int)std::min<int64_t>(gfree / D.chunk, D.world - 1); };
+        for (size_t c = 0; c < D.cl_edge.size(); c++) {
+            const int64_t k = D.cl_edge[c];
+            const int i = I[2 * k], j = I[2 * k + 1];
+            const bool oi = owned(i), oj = owned(j);
+            if (!oi && !oj) continue;
+            const auto it = std::lower_bound(P.ledge.begin(), P.ledge.end(), k);
+            if (it == P.ledge.end() || *it != k) return IROTAVG_ERR_BAD_ARG;
+            const int e = (int)(it - P.ledge.begin());
+            const int li = oi ? (int)(i - f - S.lo) : -1, lj = oj ? (int)(j - f - S.lo) : -1;
+            g.bcr_far_i.push_back(li);
+            g.bcr_far_j.push_back(lj);
+            g.bcr_far_e.push_back(e);
+            g.bcr_far_gid.push_back((int)c);
+            g.bcr_far_own.push_back(owner_of((int64_t)i - f) == S.rank ? 1 : 0);
+            if (oi && !oj) fix[li].push_back(e);
+            if (oj && !oi) fix[lj].push_back(e);
+        }
+        g.bcr_fix_off.assign(1, 0);
+        for (auto &kv : fix) {
+            g.bcr_fix_row.push_back(kv.first);
+            for (int e : kv.second) g.bcr_fix_e.push_back(e);
+            g.bcr_fix_off.push_back((int)g.bcr_fix_e.size());
+        }
     }
     rc = build_graph(g, Il.data(), QQl.data(), ml);
     if (rc != IROTAVG_OK) return rc;
@@ -658,19 +691,30 @@ static int pcg_dist_any(Dist &D) {
     return ok ? pcg_dist_cg(D) : pcg_dist(D);
 }
 
-// The direct solve of a sharded sequence: local reductions, one gather, the separator system, the ways back.
+// The direct solve of a sharded sequence: local reductions, one gather, the separator system, the ways back. With loop
+// closures (round 5) the ranks also sum ONE buffer -- what the closures' columns leave on the separators and every rank's
+// share of the Woodbury system -- and the separator system carries the columns along (bcr.hip).
 static int bcr_dist(Dist &D) {
     BcrTop &T = D.top;
+    const bool cl = T.r > 0;
     // (the hosted wire sums the ranks' buffers -- every rank writes its own slices into a zeroed one; RCCL gathers
     // records and the loopback shards share the buffer: no clearing needed there)
     if (D.hosted) IRH_CHECK(hipMemsetAsync(T.buf.p, 0, sizeof(double) * T.n_doubles(), D.stream));
-    for (auto &sp : D.shards) bcr_shard_reduce(sp->g, T, sp->rank);
+    if (cl) IRH_CHECK(hipMemsetAsync(T.xbuf.p, 0, sizeof(double) * T.x_doubles(), D.stream));
+    for (auto &sp : D.shards) {
+        bcr_shard_reduce(sp->g, T, sp->rank);
+        if (cl) bcr_shard_closures_forward(sp->g, T, sp->rank);
+    }
     if (D.hosted) {
-        D.hbuf.assign(T.n_doubles(), 0.0);
-        IRH_CHECK(hipMemcpyAsync(D.hbuf.data(), T.buf.p, sizeof(double) * T.n_doubles(), hipMemcpyDeviceToHost, D.stream));
+        const size_t n0 = T.n_doubles(), n1 = cl ? T.x_doubles() : 0;
+        if (n0 + n1 > 0x7fffffffULL) throw HipError{hipErrorUnknown};
+        D.hbuf.assign(n0 + n1, 0.0);
+        IRH_CHECK(hipMemcpyAsync(D.hbuf.data(), T.buf.p, sizeof(double) * n0, hipMemcpyDeviceToHost, D.stream));
+        if (cl) IRH_CHECK(hipMemcpyAsync(D.hbuf.data() + n0, T.xbuf.p, sizeof(double) * n1, hipMemcpyDeviceToHost, D.stream));
         IRH_CHECK(hipStreamSynchronize(D.stream));
-        if (D.tr.allreduce(D.tr.ctx, D.hbuf.data(), (int)T.n_doubles(), 0) != 0) throw HipError{hipErrorUnknown};
-        IRH_CHECK(hipMemcpyAsync(T.buf.p, D.hbuf.data(), sizeof(double) * T.n_doubles(), hipMemcpyHostToDevice, D.stream));
+        if (D.tr.allreduce(D.tr.ctx, D.hbuf.data(), (int)(n0 + n1), 0) != 0) throw HipError{hipErrorUnknown};
+        IRH_CHECK(hipMemcpyAsync(T.buf.p, D.hbuf.data(), sizeof(double) * n0, hipMemcpyHostToDevice, D.stream));
+        if (cl) IRH_CHECK(hipMemcpyAsync(T.xbuf.p, D.hbuf.data() + n0, sizeof(double) * n1, hipMemcpyHostToDevice, D.stream));
         IRH_CHECK(hipStreamSynchronize(D.stream));  // hbuf is reused
     } else if (D.use_rccl) {
         // an ALL-GATHER of one record per rank (its five slices, 15 KB at B = 24) -- until round 5 a sum-all-reduce of
@@ -680,10 +724,29 @@ static int bcr_dist(Dist &D) {
         NCCL_CHECK(ncclAllGather(T.rec.p + (size_t)rank * T.record_doubles(), T.rec.p, T.record_doubles(), ncclDouble, D.comm,
                                  D.stream));
         bcr_top_from_records(T, D.stream);
-    }  // loopback: the shards of this process share the buffer
-    bcr_top_solve(D.shards[0]->g, T);
+        if (cl) NCCL_CHECK(ncclAllReduce(T.xbuf.p, T.xbuf.p, T.x_doubles(), ncclDouble, ncclSum, D.comm, D.stream));
+    }  // loopback: the shards of this process share the buffers
+    if (cl) {
+        bcr_top_solve_closures(D.shards[0]->g, T);
+        for (auto &sp : D.shards) bcr_shard_closures_correct(sp->g, T);
+    } else {
+        bcr_top_solve(D.shards[0]->g, T);
+    }
     for (auto &sp : D.shards) bcr_shard_back(sp->g, T, sp->rank);
     D.stats.direct_solves += 1;
+    if (cl) {
+        // a dead pivot of the band part (a view that only a closure ties to the rest after robust weights went to zero):
+        // the Woodbury form does not hold. Every rank reads the same two counts (the ranks' own pivots were summed).
+        double piv = 0.0;
+        int topdead = 0;
+        IRH_CHECK(hipMemcpyAsync(&piv, T.xbuf.p + T.x_pivots(), sizeof(double), hipMemcpyDeviceToHost, D.stream));
+        IRH_CHECK(hipMemcpyAsync(&topdead, T.dead.p, sizeof(int), hipMemcpyDeviceToHost, D.stream));
+        IRH_CHECK(hipStreamSynchronize(D.stream));
+        if (piv > 0.0 || topdead > 0) {
+            D.stats.direct_dead_pivots += (int64_t)piv + topdead;
+            return IROTAVG_ERR_SOLVER;
+        }
+    }
     return IROTAVG_OK;
 }
 static int solve_dist(Dist &D) { return D.bcr_B ? bcr_dist(D) : pcg_dist_any(D); }
@@ -842,18 +905,50 @@ static int dist_create_impl(irotavg_dist **out, int world, int rank, const void 
         {   // the direct solver for a sharded view sequence? Decided from the GLOBAL graph: every process agrees.
             int mode = D.opt.band_direct;
             if (const char *e = std::getenv("IROTAVG_BAND_DIRECT")) mode = std::atoi(e);
-            int band = 0;
+            int band = 0, bandall = 0;
+            int64_t nfar = 0;
             bool ok = mode >= 0 && world <= 8;
             for (int64_t k = 0; k < m && ok; k++) {
                 const int i = I[2 * k], j = I[2 * k + 1];
                 if (i < 0 || j < 0 || i >= n_total || j >= n_total) ok = false;
-                else if (i >= f && j >= f) band = std::max(band, std::abs(i - j));
+                else if (i >= f && j >= f) {
+                    const int d = std::abs(i - j);
+                    bandall = std::max(bandall, d);
+                    if (d <= 32) band = std::max(band, d);
+                    else nfar++;
+                }
             }
-            D.band0 = ok ? band : -1;
-            if (ok && band <= 32 && (mode > 0 || D.nu > 2048)) {
+            D.band0 = ok ? bandall : -1;
+            // (the limits of the single-GPU plan, bcr_plan: at most 2048 long-range edges, 1024 on small graphs)
+            const bool closures_ok = !std::getenv("IROTAVG_BCR_NO_CLOSURES") && !std::getenv("IROTAVG_DIST_NO_CLOSURES");
+            if (ok && nfar > 0 && (!closures_ok || nfar > (D.nu < 8192 ? 1024 : 2048))) ok = false;
+            if (ok && (mode > 0 || D.nu > 2048)) {
                 const int B = band <= 8 ? 8 : band <= 16 ? 16 : band <= 24 ? 24 : 32;
                 const int64_t c192 = chunk_of(D.nu, world, 192);
                 if (c192 >= 2 * B && (int64_t)(world - 1) * c192 < D.nu) D.bcr_B = B;
+                if (D.bcr_B && nfar > 0) {
+                    // closures = long-range edges whose blocks are not neighbours (ranges are multiples of every block
+                    // size: a view's block number is the same on every rank). The band part alone must be positive
+                    // definite: every free view has a band edge to an earlier view or a kept edge to a fixed one
+                    // (bcr_plan's rule); otherwise the sharded PCG.
+                    std::vector<uint8_t> tied((size_t)D.nu, 0);
+                    for (int64_t k = 0; k < m; k++) {
+                        const int i = I[2 * k], j = I[2 * k + 1];
+                        if (i >= f && j >= f) {
+                            const int d = std::abs(i - j);
+                            if (d > 32 && std::abs((i - f) / B - (j - f) / B) >= 2) D.cl_edge.push_back(k);
+                            else if (i != j && d <= 32) tied[(size_t)(std::max(i, j) - f)] = 1;
+                        } else if (i < f && j >= f) {
+                            tied[(size_t)(j - f)] = 1;
+                        }
+                    }
+                    bool all = true;
+                    for (int64_t r = 0; r < D.nu && all; r++) all = tied[(size_t)r] != 0;
+                    if (!all) {
+                        D.cl_edge.clear();
+                        D.bcr_B = 0;
+                    }
+                }
             }
         }
         D.chunk = chunk_of(D.nu, world, D.bcr_B ? 192 : 64);
@@ -880,6 +975,7 @@ static int dist_create_impl(irotavg_dist **out, int world, int rank, const void 
                 return rc;
             }
         }
+        if (D.bcr_B && !D.cl_edge.empty()) bcr_top_closures_alloc(D.shards[0]->g, D.top, (int)D.cl_edge.size());
         *out = h;
         return IROTAVG_OK;
     } catch (const std::bad_alloc &) {

@@ -155,6 +155,14 @@ struct Graph {
     bool bcr_shard = false;
     int bcr_ext0 = 0;
     std::vector<int> bcr_ghost_extcol;                 // per ghost view: row in the previous rank's last block or -1
+    // ... whose sequence has loop closures (round 5): bcr_far_* list the closures with an endpoint on THIS rank (a row of
+    // -1: that endpoint lives on another rank), bcr_far_gid their numbers in the global list every rank agrees on,
+    // bcr_far_own whether this rank adds the closure's 1 / w to the Woodbury system (the owner of its first endpoint);
+    // bcr_fix_*: the local rows whose diagonal carries the weight of a closure to a GHOST view (a ghost edge is
+    // Dirichlet mass on the shard's diagonal; the band operator has to lose it as bcr_gather_row takes a local far entry out)
+    std::vector<int> bcr_far_gid;
+    std::vector<uint8_t> bcr_far_own;
+    std::vector<int> bcr_fix_row, bcr_fix_off, bcr_fix_e;
 
     double last_score_sum = 0.0;
     double irls_settle = -1.0;  // run_irls: > 0 while the last step was small enough for the weights to have settled (assemble())
@@ -310,6 +318,23 @@ struct BcrTop {
     size_t record_doubles() const { return 3 * (size_t)B * B + 2 * (size_t)B * 3; }
     DevBuf<double> W, x, xtop;  // factor and solution of the separator system (8 blocks)
     size_t n_doubles() const { return (size_t)world * (3 * (size_t)B * B + 2 * (size_t)B * 3); }
+    // loop closures on the sharded sequence (bcr_top_closures_*): r closures in the global list. xbuf is what the ranks
+    // SUM (loopback: one buffer every shard adds to; RCCL / hosted wire: an all-reduce):
+    //   [dep: r x world x B | S: npad x npad | T: npad x 3 | dead: npad | dead pivots: 1]
+    // dep = what the local forward eliminations of a closure's incidence column leave on the separators (the right-hand
+    // side of the separator system for that column), S / T = the ranks' shares of the Woodbury system, dead = closures of
+    // weight 0 (flagged by their owner).
+    int r = 0, npad = 0, nst = 0;
+    DevBuf<double> xbuf, Dinv, topDinv, recR, recW, Ttop, lam;
+    DevBuf<int> dead, cl_off, cl_owner, co_off, co_rec;
+    DevBuf<int4> cl_step;
+    DevBuf<int2> co_elim;
+    size_t x_dep() const { return 0; }
+    size_t x_S() const { return (size_t)r * world * B; }
+    size_t x_T() const { return x_S() + (size_t)npad * npad; }
+    size_t x_dead() const { return x_T() + (size_t)npad * 3; }
+    size_t x_pivots() const { return x_dead() + (size_t)npad; }
+    size_t x_doubles() const { return x_pivots() + 1; }
 };
 void bcr_top_alloc(BcrTop &T, int B, int world);
 void bcr_top_to_record(BcrTop &T, int rank, hipStream_t st);   // buf's slices of `rank` -> rec[rank]
@@ -317,6 +342,15 @@ void bcr_top_from_records(BcrTop &T, hipStream_t st);          // every record -
 void bcr_shard_reduce(Graph &g, BcrTop &T, int rank);  // local reduction; this rank's slices of T.buf
 void bcr_top_solve(Graph &g, BcrTop &T);               // after T.buf holds every rank's slices
 void bcr_shard_back(Graph &g, BcrTop &T, int rank);    // -> g.X (owned rows)
+// closures on a sharded sequence: r = their number in the global list (0: none). A solve runs
+//   every rank: bcr_shard_reduce, bcr_shard_closures_forward (adds its shares to T.xbuf)
+//   the wire:   the separators' gather, the SUM of T.xbuf
+//   every rank: bcr_top_solve_closures (separator system, Woodbury system, lambda; redundantly),
+//               bcr_shard_closures_correct, bcr_shard_back
+void bcr_top_closures_alloc(Graph &g0, BcrTop &T, int r);
+void bcr_shard_closures_forward(Graph &g, BcrTop &T, int rank);
+void bcr_top_solve_closures(Graph &g, BcrTop &T);
+void bcr_shard_closures_correct(Graph &g, BcrTop &T);
 // dense.hip
 void dense_refresh(Graph &g);
 void dense_select_slot(Graph &g, int slot);
