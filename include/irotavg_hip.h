@@ -385,8 +385,10 @@ int irotavg_dist_get_stats(irotavg_dist *d, irotavg_stats *out);
  * the RCCL communicator as RCCL reports them (ncclCommCount; 0 without one), info[2] = shards held by this
  * process, info[3] = world size the graph is partitioned for, info[4] = ghost views of this process's
  * shards (halo rows received per exchange), info[5] = peers of shard 0, info[6] = block size of the sharded direct
- * solver (a view sequence without loop closures: every rank reduces its range of the banded operator to its last
- * block, one gather, the `world` separators solved by every rank; 0: the sharded PCG), info[7] = 0. */
+ * solver (a view sequence, also with up to 2048 loop closures: every rank reduces its range of the banded operator to
+ * its last block, one gather, the `world` separators solved by every rank; 0: the sharded PCG), info[7] = the loop
+ * closures that solver carries (Woodbury correction across the ranks: besides the gather the ranks SUM one buffer of
+ * r x world x B + r^2 + 4 r doubles per linear solve). */
 int irotavg_dist_info(irotavg_dist *d, int64_t info[8]);
 int irotavg_dist_plan(irotavg_dist *d, int local_index, int64_t counts[6], int *peers, int *send_cnt,
                       int *recv_cnt, int cap);

@@ -1130,6 +1130,7 @@ int irotavg_dist_info(irotavg_dist *h, int64_t info[8]) {
     for (auto &sp : D.shards) info[4] += sp->g.ng;
     info[5] = D.shards.empty() ? 0 : (int64_t)D.shards[0]->peers.size();
     info[6] = D.bcr_B;  // block size of the sharded direct solver (0: the sharded PCG)
+    info[7] = D.bcr_B ? (int64_t)D.cl_edge.size() : 0;  // loop closures it carries (Woodbury correction across the ranks)
     return IROTAVG_OK;
     API_CATCH
 }

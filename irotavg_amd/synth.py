@@ -143,3 +143,20 @@ def add_closures(S, nclose, seed=7, wrong=0):
     QQ = np.concatenate([S["QQ"], QQc])
     order = np.lexsort((np.arange(len(I)), I[:, 1]))
     return dict(S, I=I[order], QQ=QQ[order], m=len(I))
+
+
+def closure_graph(n, m, nclose, seed, wrong=0, f=1):
+    """a view sequence (band) + nclose long-range edges, `wrong` of them with a random rotation -- the graph a SLAM
+    front end produces (sequence + loop closures, src/IRotAvg.cpp:371-378)"""
+    S = make_graph(n, m, 0.0, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    a = rng.integers(f, n - 200, nclose)
+    b = np.minimum(n - 1, a + rng.integers(100, n // 2, nclose))
+    QQc = qmul(qexp(rng.normal(scale=0.01, size=(nclose, 3))), qmul(S["Qgt"][b], qconj(S["Qgt"][a])))
+    if wrong:
+        R = rng.normal(size=(wrong, 4))
+        QQc[:wrong] = R / np.linalg.norm(R, axis=1, keepdims=True)
+    I = np.concatenate([S["I"], np.stack([a, b], 1)]).astype(np.int32)
+    QQ = np.concatenate([S["QQ"], QQc])
+    order = np.lexsort((np.arange(len(I)), I[:, 1]))      # stored under the later view, as the reference does
+    return dict(S, I=I[order], QQ=QQ[order], m=len(I))

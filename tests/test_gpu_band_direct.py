@@ -143,20 +143,7 @@ def test_mixed_level_one():
         np.testing.assert_allclose(w, rb["weights"], rtol=1e-7)
 
 
-def closure_graph(n, m, nclose, seed, wrong=0, f=1):
-    """a view sequence (band) + nclose long-range edges, `wrong` of them with a random rotation"""
-    S = synth.make_graph(n, m, 0.0, seed=seed)
-    rng = np.random.default_rng(seed + 100)
-    a = rng.integers(f, n - 200, nclose)
-    b = np.minimum(n - 1, a + rng.integers(100, n // 2, nclose))
-    QQc = synth.qmul(synth.qexp(rng.normal(scale=0.01, size=(nclose, 3))), synth.qmul(S["Qgt"][b], synth.qconj(S["Qgt"][a])))
-    if wrong:
-        R = rng.normal(size=(wrong, 4))
-        QQc[:wrong] = R / np.linalg.norm(R, axis=1, keepdims=True)
-    I = np.concatenate([S["I"], np.stack([a, b], 1)]).astype(np.int32)
-    QQ = np.concatenate([S["QQ"], QQc])
-    order = np.lexsort((np.arange(len(I)), I[:, 1]))      # stored under the later view, as the reference does
-    return dict(S, I=I[order], QQ=QQ[order], m=len(I))
+closure_graph = synth.closure_graph
 
 
 # 5 ... 64 closures: the Woodbury system is solved in LDS; 65, 300, 1000: by the blocked Gauss-Jordan sweep (round 4:

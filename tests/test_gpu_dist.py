@@ -213,3 +213,123 @@ def test_sharded_direct_solver_shapes_match_the_oracle(n, m, f, world):
     assert synth.angular_distance(Qb, rb["Q"]).max() < 1e-9
     np.testing.assert_allclose(wb, rb["weights"], rtol=1e-7)
     assert st["direct_solves"] > 0 and st["pcg_iters"] == 0
+
+
+# ---- loop closures on the sharded direct solver (round 5) ---------------------------------------------------------
+def closure_problem(n, m, nclose, wrong, seed=7):
+    S = synth.closure_graph(n, m, nclose, seed, wrong)
+    Q = np.zeros((n, 4)); Q[:, 3] = 1; Q[0] = S["Qgt"][0]
+    ral.init_mst(Q, S["QQ"], S["I"], 1)
+    return S, Q
+
+
+@pytest.mark.parametrize("n,m,nclose,wrong,world", [(3000, 12000, 5, 1, 2), (3000, 45000, 20, 3, 4), (4000, 80000, 40, 4, 3),
+                                                    (5000, 20000, 64, 6, 6), (5000, 20000, 65, 6, 5),
+                                                    (6000, 60000, 300, 20, 8), (2511, 74830, 100, 8, 2),
+                                                    (20000, 300000, 1000, 40, 8), (20000, 300000, 1000, 40, 1)])
+def test_loopback_sharded_sequence_with_closures_matches_the_oracle(n, m, nclose, wrong, world):
+    """A view sequence WITH loop closures (what src/IRotAvg.cpp:371-378 re-solves on every closure) in 1 ... 8 shards:
+    the sharded direct solver carries them by the Woodbury correction across the ranks -- a rank's step programs on its
+    own levels, one summed buffer, the separator system with the closures' columns (bcr.hip). Until round 5 one closure
+    sent the shards to the sharded PCG. 5 ... 64 closures: the Woodbury system in LDS; more: the blocked sweep; blocks
+    of 8 / 16 / 24 / 32; some closures wrong. l1ra then irls against the ORACLE."""
+    from oracle import oracle as O
+    S, Q0 = closure_problem(n, m, nclose, wrong)
+    with capi.DistGraph(S["I"], S["QQ"], n, 1, world, band_direct=1) as D:
+        info = D.info()
+        assert info["direct_block"] in (8, 16, 24, 32) and info["closures"] == nclose
+        D.set_rotations(Q0)
+        a = D.l1ra(2, 1e-3)
+        Qa = D.get_rotations(into=Q0.copy())
+        b = D.irls(4, SIG, 50, 1e-3)
+        Qb, wb = D.get_rotations(into=Q0.copy()), D.get_weights()
+        st = D.stats()
+    assert st["direct_solves"] > 0 and st["pcg_iters"] == 0, st
+    ra = O.l1ra(S["QQ"], S["I"], Q0, 1, 2, 1e-3)
+    rb = O.irls(S["QQ"], S["I"], ra["Q"], 1, 4, SIG, 50, 1e-3)
+    assert (a["iters"], b["iters"]) == (ra["iters"], rb["iters"])
+    np.testing.assert_allclose(a["scores"], ra["scores"], rtol=1e-7)
+    np.testing.assert_allclose(b["scores"], rb["scores"], rtol=1e-7, atol=1e-12)
+    assert synth.angular_distance(Qa, ra["Q"]).max() < 1e-9
+    assert synth.angular_distance(Qb, rb["Q"]).max() < 1e-9
+    np.testing.assert_allclose(wb, rb["weights"], rtol=1e-7, atol=1e-12)
+
+
+def test_sharded_closures_at_the_shard_boundaries_match_the_oracle():
+    """Closures placed where the ranks' bookkeeping has its corners (4 shards of 1536 views, blocks of 8): an endpoint
+    in a rank's LAST block (the separator: no local elimination at all), in block 0 behind a rank boundary, both
+    endpoints on one rank, neighbouring ranks, the first and the last rank, two closures sharing a view (one row's
+    diagonal loses two ghost weights), a closure from the block next to a boundary to the previous rank's last block
+    (a ghost that is ALSO a separator row), a wrong closure."""
+    from oracle import oracle as O
+    n, world = 6000, 4
+    S = synth.make_graph(n, 24000, 0.0, seed=3)
+    c = 1536                                                # chunk_of(5999, 4, 192)
+    pairs = [(c - 3, 3 * c + 40), (c + 2, 2 * c + 700), (100, 900), (c - 700, c + 650), (5, n - 2), (200, 3 * c + 40),
+             (c - 2, c + 35), (2 * c + 5, 2 * c + 1400), (3 * c - 1, n - 700), (50, 2 * c - 1)]
+    a = np.array([p[0] for p in pairs]) + 1
+    b = np.array([p[1] for p in pairs]) + 1                 # (+ 1: free view r is view r + f)
+    QQc = synth.qmul(S["Qgt"][b], synth.qconj(S["Qgt"][a]))
+    QQc[3] = QQc[6] = np.array([0.5, -0.5, 0.5, 0.5])      # two wrong ones: a long one (the chain bends) and a short one
+    I = np.concatenate([S["I"], np.stack([a, b], 1)]).astype(np.int32)
+    QQ = np.concatenate([S["QQ"], QQc])
+    order = np.lexsort((np.arange(len(I)), I[:, 1]))
+    I, QQ = I[order], QQ[order]
+    Q0 = np.zeros((n, 4)); Q0[:, 3] = 1; Q0[0] = S["Qgt"][0]
+    ral.init_mst(Q0, QQ, I, 1)
+    for cost in (4, 12):                                    # Geman-McClure; Talwar (weights of exactly 0: dead closures)
+        with capi.DistGraph(I, QQ, n, 1, world, band_direct=1) as D:
+            assert D.info()["direct_block"] == 8 and D.info()["closures"] == len(pairs)
+            D.set_rotations(Q0)
+            r = D.irls(cost, SIG, 50, 1e-3)
+            Q, w = D.get_rotations(into=Q0.copy()), D.get_weights()
+            st = D.stats()
+        assert st["direct_solves"] == r["iters"] and st["pcg_iters"] == 0
+        ro = O.irls(QQ, I, Q0, 1, cost, SIG, 50, 1e-3)
+        assert r["iters"] == ro["iters"]
+        np.testing.assert_allclose(r["scores"], ro["scores"], rtol=1e-7, atol=1e-12)
+        assert synth.angular_distance(Q, ro["Q"]).max() < 1e-9
+        np.testing.assert_allclose(w, ro["weights"], rtol=1e-7, atol=1e-12)
+        if cost == 12:                                      # ... which Talwar switches off: a dead row of the Woodbury system
+            k6 = np.flatnonzero((I[:, 0] == a[6]) & (I[:, 1] == b[6]))
+            assert len(k6) == 1 and w[k6[0]] == 0
+
+
+def test_sharded_closures_limits_and_switch(monkeypatch):
+    """2049 closures are one too many (the single-GPU plan's limit): the shards take the sharded PCG, as they do when
+    IROTAVG_DIST_NO_CLOSURES is set; same answers either way."""
+    S, Q0 = closure_problem(12000, 48000, 2049, 0, seed=11)
+    with capi.DistGraph(S["I"], S["QQ"], 12000, 1, 2, band_direct=1) as D:
+        assert D.info()["direct_block"] == 0 and D.info()["closures"] == 0
+    S, Q0 = closure_problem(6000, 60000, 30, 3)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("IROTAVG_DIST_NO_CLOSURES", "1")
+        with capi.DistGraph(S["I"], S["QQ"], 6000, 1, 3, band_direct=1) as D:
+            assert (D.info()["direct_block"] == 0) == off
+            D.set_rotations(Q0)
+            r = D.irls(4, SIG, 50, 1e-3)
+            res.append((r["iters"], D.get_rotations(into=Q0.copy()), D.stats()["pcg_iters"]))
+    assert res[0][0] == res[1][0] and res[0][2] == 0 and res[1][2] > 0
+    assert synth.angular_distance(res[0][1], res[1][1]).max() < 1e-8
+
+
+def test_rccl_transport_single_rank_closures_sum_one_buffer():
+    """The closures' exchange on the RCCL wire: ncclAllReduce (sum) of the one buffer behind the records' all-gather --
+    a 1-rank communicator on the one GPU of a test box runs that code."""
+    n, m = 8000, 120000
+    S, Q0 = closure_problem(n, m, 80, 6)
+    uid = capi.DistGraph.unique_id()
+    with capi.DistGraph(S["I"], S["QQ"], n, 1, 1, rank=0, unique_id=uid, band_direct=1) as D:
+        assert D.info()["direct_block"] > 0 and D.info()["closures"] == 80
+        D.set_rotations(Q0)
+        b = D.irls(4, SIG, 50, 1e-3)
+        Qb = D.get_rotations(into=Q0.copy())
+        assert D.stats()["direct_solves"] > 0 and D.stats()["pcg_iters"] == 0
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        G.set_rotations(Q0)
+        a = G.irls(4, SIG, 50, 1e-3)
+        Qa = G.get_rotations()
+    assert a["iters"] == b["iters"]
+    assert synth.angular_distance(Qa, Qb).max() < 1e-9

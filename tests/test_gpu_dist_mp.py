@@ -40,6 +40,16 @@ def test_processes_host_staged_wire_sharded_direct_solver(nproc):
     assert r.returncode == 0 and "DIST_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("nproc,closures", [(2, 12), (3, 150)])
+def test_processes_host_staged_wire_sharded_direct_solver_with_closures(nproc, closures):
+    """a view sequence WITH loop closures between processes (round 5): besides the separators' gather the ranks sum one
+    buffer (the closures' columns on the separators, every rank's share of the Woodbury system) through the hosted
+    wire's all-reduce; l1ra then irls against the single-GPU handle"""
+    r = run_worker("hosted", nproc=nproc, port=29629 + nproc, extra=["--p-loop", "0", "--views", "9000", "--edges", "90000",
+                                                                     "--closures", str(closures), "--expect-direct"])
+    assert r.returncode == 0 and "DIST_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_two_processes_rccl_on_one_device():
     try:
         r = run_worker("rccl", port=29613, timeout=300)

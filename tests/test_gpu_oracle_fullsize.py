@@ -139,6 +139,16 @@ def test_closures_on_the_direct_path_at_bench_size_match_the_oracle(nclose):
     sol = O.solver_stats(reset=True)
     assert ro["rc"] == 0 and sol["pcg_solves"] > 0 and sol["pcg_worst_relres"] < 4e-13, sol
     compare_irls(r, Q, w, ro)
+    # the same graph in 8 shards (loopback): closures on the SHARDED direct solver (round 5; the sharded PCG until then)
+    with capi.DistGraph(Sc["I"], Sc["QQ"], n, 1, 8) as D:
+        assert D.info()["direct_block"] == 24 and D.info()["closures"] == nclose
+        D.set_rotations(Qc)
+        rd = D.irls(4, SIG, 100, 1e-3)
+        Qd, wd = D.get_rotations(into=Qc.copy()), D.get_weights()
+        sd = D.stats()
+    assert sd["direct_solves"] > 0 and sd["pcg_iters"] == 0, sd
+    compare_irls(rd, Qd, wd, ro)
+    assert synth.angular_distance(Qd, Q).max() < 1e-9      # ... and the unsharded handle, far inside the oracle's bar
 
 
 @pytest.mark.parametrize("p_loop", [0.0, 0.02])

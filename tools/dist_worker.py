@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--views", type=int, default=6000)
     ap.add_argument("--edges", type=int, default=60000)
     ap.add_argument("--p-loop", type=float, default=0.01)
+    ap.add_argument("--closures", type=int, default=0, help="loop closures added to the sequence (a tenth of them wrong)")
     ap.add_argument("--expect-direct", action="store_true", help="fail unless the sharded direct solver ran")
     args = ap.parse_args()
     import torch
@@ -33,6 +34,8 @@ def main():
     SIG = 5 * np.pi / 180
     n, m, f = args.views, args.edges, 2
     S = synth.make_graph(n, m, args.p_loop, seed=2)
+    if args.closures:
+        S = synth.add_closures(S, args.closures, seed=7, wrong=args.closures // 10)
     Q0 = np.zeros((n, 4)); Q0[:, 3] = 1; Q0[:f] = S["Qgt"][:f]
     ral.init_mst(Q0, S["QQ"], S["I"], f)
     if args.wire == "hosted":
