@@ -248,3 +248,117 @@ def test_gloo_sharded_direct_solver_protocol_matches_unsharded(tmp_path, world):
         lo, hi = np.load(tmp_path / ("drange%d.npy" % rk))
         got[lo:hi] = np.load(tmp_path / ("dx%d.npy" % rk))
     assert np.abs(got - X).max() < 1e-9 * np.abs(X).max()
+
+
+def _closure_system(n, m, f, B, nclose, seed):
+    """a view sequence + closures (span > 32, blocks not neighbours), weights, right-hand side: what every rank holds"""
+    S = synth.add_closures(synth.make_graph(n, m, 0.0, seed=seed), nclose, seed=seed, wrong=0)
+    I = S["I"]
+    rng = np.random.default_rng(seed)
+    w = rng.uniform(0.3, 2.0, size=len(I))
+    r = rng.normal(scale=0.02, size=(len(I), 3))
+    i, j = I[:, 0].astype(np.int64), I[:, 1].astype(np.int64)
+    far = (i >= f) & (j >= f) & (np.abs(i - j) > 32) & (np.abs((i - f) // B - (j - f) // B) >= 2)
+    return S, I, w, r, far
+
+
+def _direct_closure_worker(rank, world, port, n, m, f, B, nclose, seed, out):
+    """One rank of the sharded direct solver's protocol WITH loop closures (dist.hip bcr_dist, bcr.hip "loop closures on
+    a sharded sequence"): the band part reduced to the range's last block as above; a closure's incidence column is
+    eliminated through the rank's own rows, what it leaves on the rank's separator and on the one before it, the rank's
+    share of S = C^-1 + V' A_b^-1 V and of T = V' Y go into ONE buffer [dep | S | T] that the ranks SUM next to the
+    separators' gather; the separator system carries the columns, lambda is solved by every rank, the corrections are
+    local. Dense NumPy algebra stands in for the kernels; the messages are the real ones."""
+    import torch
+    import torch.distributed as dist
+    import scipy.sparse as sp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, I, w, r, far = _closure_system(n, m, f, B, nclose, seed)
+    A = O.make_A(n, f, I).tocsr()
+    Ab = A[np.flatnonzero(~far)]
+    H = (Ab.T @ sp.diags((w * w)[~far]) @ Ab).toarray()           # the BAND operator
+    b = A.T @ ((w * w)[:, None] * r)                               # the right-hand side has every edge in it
+    V = A[np.flatnonzero(far)].T.toarray()                         # nu x r: +-1 at a closure's endpoints
+    wc = (w * w)[far]
+    nc = V.shape[1]
+    nu = n - f
+    chunk = ((nu + world - 1) // world + 191) // 192 * 192
+    lo, hi = rank * chunk, min(nu, (rank + 1) * chunk)
+    sep = np.arange(hi - B, hi)
+    inner = np.arange(lo, hi - B)
+    ext = np.arange(lo - B, lo) if rank > 0 else np.arange(0)
+    ne = len(ext)
+    Hii = H[np.ix_(inner, inner)]
+    Yi = np.linalg.solve(Hii, np.concatenate([H[np.ix_(inner, ext)], H[np.ix_(inner, sep)], b[inner], V[inner]], axis=1))
+    Ye, Ys, yb, Z = Yi[:, :ne], Yi[:, ne:ne + B], Yi[:, ne + B:ne + B + 3], Yi[:, ne + B + 3:]
+    sepD = H[np.ix_(sep, sep)] - H[np.ix_(sep, inner)] @ Ys
+    sepR = b[sep] - H[np.ix_(sep, inner)] @ yb
+    extD = -H[np.ix_(ext, inner)] @ Ye if ne else np.zeros((B, B))
+    extR = -H[np.ix_(ext, inner)] @ yb if ne else np.zeros((B, 3))
+    extG = (H[np.ix_(ext, sep)] - H[np.ix_(ext, inner)] @ Ys) if ne else np.zeros((B, B))
+    buf = np.zeros((world, 3 * B * B + 2 * B * 3))
+    buf[rank] = np.concatenate([sepD.ravel(), extD.ravel(), extG.ravel(), sepR.ravel(), extR.ravel()])
+    # the closures' buffer: dep[q][block of the separator system][B] | S | T  (BcrTop::xbuf)
+    dep = np.zeros((nc, world, B))
+    dep[:, rank, :] += (V[sep] - H[np.ix_(sep, inner)] @ Z).T      # what the columns leave on this rank's separator
+    if ne:
+        dep[:, rank - 1, :] += (-H[np.ix_(ext, inner)] @ Z).T      # ... and on the one before it
+    Sx = V[inner].T @ Z                                            # sum over this rank's eliminated rows
+    first = np.array([np.flatnonzero(V[:, q] > 0)[0] for q in range(nc)])   # I[:, 0]'s row: +1
+    owner = np.minimum(first // chunk, world - 1)
+    Sx[np.arange(nc), np.arange(nc)] += np.where(owner == rank, 1.0 / wc, 0.0)
+    Tx = V[inner].T @ yb
+    xbuf = np.concatenate([dep.ravel(), Sx.ravel(), Tx.ravel()])
+    t = torch.from_numpy(np.concatenate([buf.ravel(), xbuf]))
+    dist.all_reduce(t)                                             # (the hosted wire: one all-reduce of both buffers)
+    tot = t.numpy()
+    buf = tot[:buf.size].reshape(buf.shape)
+    xbuf = tot[buf.size:]
+    dep = xbuf[:dep.size].reshape(nc, world * B).T                 # world B x r: the columns' separator right-hand sides
+    Sx = xbuf[dep.size:dep.size + nc * nc].reshape(nc, nc)
+    Tx = xbuf[dep.size + nc * nc:].reshape(nc, 3)
+    sl = lambda k, a, z, shape: buf[k, a:z].reshape(shape)
+    oD, oXD, oXG, oR, oXR = 0, B * B, 2 * B * B, 3 * B * B, 3 * B * B + 3 * B
+    T = np.zeros((world * B, world * B)); R = np.zeros((world * B, 3))
+    for k in range(world):
+        Dk = sl(k, oD, oXD, (B, B)).copy(); Rk = sl(k, oR, oXR, (B, 3)).copy()
+        if k + 1 < world:
+            Dk += sl(k + 1, oXD, oXG, (B, B)); Rk += sl(k + 1, oXR, oXR + 3 * B, (B, 3))
+        T[k * B:(k + 1) * B, k * B:(k + 1) * B] = Dk
+        R[k * B:(k + 1) * B] = Rk
+        if k > 0:
+            G = sl(k, oXG, oR, (B, B))
+            T[(k - 1) * B:k * B, k * B:(k + 1) * B] = G
+            T[k * B:(k + 1) * B, (k - 1) * B:k * B] = G.T
+    sol = np.linalg.solve(T, np.concatenate([R, dep], axis=1))     # every rank, redundantly
+    xs0, Zt = sol[:, :3], sol[:, 3:]
+    lam = np.linalg.solve(Sx + dep.T @ Zt, Tx + dep.T @ xs0)
+    xs = xs0 - Zt @ lam
+    x_sep = xs[rank * B:(rank + 1) * B]
+    x_ext = xs[(rank - 1) * B:rank * B] if rank > 0 else np.zeros((0, 3))
+    x_in = (yb - Z @ lam) - Ys @ x_sep - (Ye @ x_ext if ne else 0.0)
+    np.save(os.path.join(out, "cx%d.npy" % rank), np.concatenate([x_in, x_sep]))
+    np.save(os.path.join(out, "crange%d.npy" % rank), np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sharded_direct_solver_protocol_with_closures_matches_unsharded(tmp_path, world):
+    """closures on the sharded direct solver: ONE more summed buffer per solve ([dep | S | T]), everything else local
+    or redundant -- against the oracle's solve of the FULL system (band + closures)"""
+    import torch.multiprocessing as mp
+    n, m, f, B, nclose, seed = 1300, 13000, 2, 16, 25, 9
+    port = _free_port()
+    mp.spawn(_direct_closure_worker, args=(world, port, n, m, f, B, nclose, seed, str(tmp_path)), nprocs=world, join=True)
+    S, I, w, r, far = _closure_system(n, m, f, B, nclose, seed)
+    assert far.sum() >= 20
+    rc, X = O.ls_solve(n, f, I, w, r)
+    assert rc == 0
+    got = np.zeros_like(X)
+    for rk in range(world):
+        lo, hi = np.load(tmp_path / ("crange%d.npy" % rk))
+        got[lo:hi] = np.load(tmp_path / ("cx%d.npy" % rk))
+    assert np.abs(got - X).max() < 1e-9 * np.abs(X).max()
