@@ -907,6 +907,31 @@ def main():
                                     value=Sc["m"] * rc_["iters"] * reps / dc, direct_solves_per_solve_call=sc.get("direct_solves", 0) / reps,
                                     direct_guarded=sc.get("direct_guarded", 0),
                                     pcg_iters_per_solve=sc["pcg_iters"] / max(sc["pcg_solves"], 1))
+                # the same graph in 8 shards, all on this GPU one after the other (loopback): closures on the SHARDED direct
+                # solver (round 5) against what the shards ran until then, the sharded PCG -- the only statement a one-GPU
+                # box can make about that path's cost (eight ranks' work in sequence; a node runs them side by side)
+                shard_leg = {}
+                for off, tag in ((False, "direct"), (True, "pcg")):
+                    if nclose == 1000 and off:
+                        continue
+                    if off:
+                        os.environ["IROTAVG_DIST_NO_CLOSURES"] = "1"
+                    try:
+                        with capi.DistGraph(Sc["I"], Sc["QQ"], Sc["n"], 1, 8, pcg_rtol=args.rtol) as Dc:
+                            Dc.set_rotations(Qc)
+                            Dc.snapshot_rotations()
+                            Dc.irls(4, SIG, 100, 1e-3)
+                            reps = 1 if off else 3
+                            t1 = time.perf_counter()
+                            for _ in range(reps):
+                                Dc.restore_rotations()
+                                rd_ = Dc.irls(4, SIG, 100, 1e-3)
+                            dd = time.perf_counter() - t1
+                            shard_leg[tag] = dict(ms_per_step=1e3 * dd / reps, iters_to_converge=rd_["iters"],
+                                                  closures_carried=Dc.info()["closures"], block=Dc.info()["direct_block"])
+                    finally:
+                        os.environ.pop("IROTAVG_DIST_NO_CLOSURES", None)
+                leg["direct"]["eight_shards_loopback"] = shard_leg
                 line["also_closures_%d" % nclose] = dict(
                     leg["direct"], unit="edge-updates/s", pcg_path=leg["pcg"],
                     note="the headline sequence + %d loop closures 100 ... n/2 views long, %d of them wrong (random rotation); "
