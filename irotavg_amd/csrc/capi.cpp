@@ -704,6 +704,20 @@ int oneshot_open(irotavg_graph **h, OneShotKey *key, bool *cached, int64_t m, in
     }
     return irotavg_graph_create(h, m, n_total, f, I, QQ, ldqq, nullptr);
 }
+// the handle of a failed one-shot call replaced by one that solves iteratively (band_direct = -1) -- when the failed one
+// was a direct-solver handle with loop closures; false: nothing to retry with
+bool oneshot_retry_iterative(irotavg_graph **h, int64_t m, int64_t n_total, int f, const int32_t *I, const double *QQ,
+                             int64_t ldqq) {
+    if (!*h || bcr_closures((*h)->g) == 0) return false;
+    irotavg_options opt;
+    irotavg_default_options(&opt);
+    opt.band_direct = -1;
+    irotavg_graph *it = nullptr;
+    if (irotavg_graph_create(&it, m, n_total, f, I, QQ, ldqq, &opt) != IROTAVG_OK) return false;
+    irotavg_graph_destroy(*h);
+    *h = it;
+    return true;
+}
 void oneshot_close(irotavg_graph *h, const OneShotKey &key, bool cached, int rc) {
     // (a handle whose call failed is not kept: whatever state it is in, the next call starts from a fresh one)
     if (cached && (rc == IROTAVG_OK || rc == IROTAVG_ERR_NOT_CONVERGED)) oneshot_keep(h, key);
@@ -752,6 +766,15 @@ int irotavg_irls(int64_t m, int64_t n_total, int f, const int32_t *I, const doub
     if (rc == IROTAVG_OK)
         rc = irotavg_graph_irls(h, cost, sigma, max_iters, change_th, iters, runtime, nullptr);
     lap("irls");
+    if (rc == IROTAVG_ERR_SOLVER && oneshot_retry_iterative(&h, m, n_total, f, I, QQ, ldqq)) {
+        // the direct solver gave the graph up (closures on a band part that is next to singular, run_irls): once more
+        // on the iterative solver, from the caller's rotations (nothing was written back) -- the reference has one
+        // solver for every graph (ral/l1_irls.cpp:536-556)
+        rc = irotavg_graph_set_rotations(h, Q, ldq);
+        if (rc == IROTAVG_OK)
+            rc = irotavg_graph_irls(h, cost, sigma, max_iters, change_th, iters, runtime, nullptr);
+        lap("irls, iterative solver");
+    }
     if (rc == IROTAVG_OK || rc == IROTAVG_ERR_NOT_CONVERGED) {
         (void)irotavg_graph_get_rotations(h, Q, ldq);
         lap("get_rotations");

@@ -299,6 +299,7 @@ int bcr_levels(Graph &g);
 int bcr_info(Graph &g, int64_t *out, int cap);
 int bcr_residual(Graph &g, double *relres);  // ||b - A x|| / ||b|| per coordinate of the last direct solve (one pass over level 0)
 int bcr_closures(Graph &g);  // loop closures the direct solver of this handle carries
+bool bcr_band_part_anchored(int64_t m, int f, int64_t nu, int B, const int32_t *I);  // the band part alone is positive definite (exact)
 int bcr_apply_slots(Graph &g);
 void bcr_gate(Graph &g);  // flags[FL_DONE] = 1 unless the last direct solve with closures saw a dead pivot (flags[3] = their number)
 void dense_invert_spd(Graph &g, double *A, int npad);  // in place, npad a multiple of 64 (dense.hip)

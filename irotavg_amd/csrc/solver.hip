@@ -2404,15 +2404,37 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                 launch_update_weights(g, cost, sigma, true);
                 score = apply_step(g, true);
                 if (g.h_flags()[FL_DONE] != 1) {
+                    // flags[FL_ITERS] = 1: no pivot died, but the residual of the full system is above the gate (the
+                    // Woodbury correction cancelled digits, bcr.hip k_bcr_gate) -- the same repair: CG on the true operator
+                    // with this very solve as the preconditioner, a few iterations; what it reaches is taken
+                    const bool inexact_only = g.h_flags()[FL_ITERS] == 1 && g.h_flags()[3] == 0;
                     g.stats.direct_guarded += 1;
                     g.stats.direct_dead_pivots = g.h_flags()[3];
                     g.bcr_guard = true;
                     const int64_t ds_keep = g.stats.direct_solves;
+                    const int maxit_keep = g.opt.pcg_max_iters;
+                    if (inexact_only) g.opt.pcg_max_iters = 12;
                     rc = pcg_solve_classic(g);
+                    g.opt.pcg_max_iters = maxit_keep;
                     g.bcr_guard = false;
                     g.bcr_last_guarded = true;
                     // (the preconditioner applications of that solve are not linear systems of the caller's)
                     g.stats.direct_solves = ds_keep;
+                    if (inexact_only && rc == IROTAVG_ERR_NOT_CONVERGED) {
+                        g.stats.pcg_stagnated += 1;
+                        rc = IROTAVG_OK;
+                    }
+                    // What those iterations reached must still be a solution. Where the band part is next to singular
+                    // (a thin chain whose robust weights are at their floor over whole stretches, held together by
+                    // hundreds of closures: fuzz seed 22 case 69) the Woodbury solve is no approximate inverse at all and
+                    // the repair stalls at 1e-3: an ERROR, rotations untouched -- such a graph belongs to the iterative
+                    // solver (band_direct = -1), which the one-shot calls and ViewGraph::rotAvg then take by themselves.
+                    if (rc == IROTAVG_OK && inexact_only) {
+                        const double worst = std::max(g.stats.last_relres[0], std::max(g.stats.last_relres[1], g.stats.last_relres[2]));
+                        if (!(worst <= 1e-6)) rc = IROTAVG_ERR_SOLVER;
+                    }
+                    // (tests: the give-up path on a graph the iterative solver can take)
+                    if (std::getenv("IROTAVG_BCR_FAKE_GIVE_UP")) rc = IROTAVG_ERR_SOLVER;
                     if (rc != IROTAVG_OK) break;
                     launch_update_weights(g, cost, sigma);
                     score = apply_step(g);

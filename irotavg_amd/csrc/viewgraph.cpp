@@ -336,7 +336,8 @@ bool rotavg_resident(irotavg_viewgraph *vg, irotavg_rotavg_info &loc, bool timin
             // out of device memory (the resident copy and the enlarged blocks of its handles cost more than the general
             // path's one-off handle) or a runtime error inside this path: the copy is dropped, the cached blocks go back
             // to the driver and the call takes the general path, which may well succeed -- it reports on its own if not
-            if (*rc == IROTAVG_ERR_NOMEM || *rc == IROTAVG_ERR_HIP) {
+            // (... or the direct solver gave the graph up: the general path repeats that and then solves iteratively)
+            if (*rc == IROTAVG_ERR_NOMEM || *rc == IROTAVG_ERR_HIP || *rc == IROTAVG_ERR_SOLVER) {
                 (void)hipGetLastError();
                 (void)irotavg_trim_memory();
                 *rc = IROTAVG_OK;
@@ -569,6 +570,22 @@ int irotavg_viewgraph_rot_avg(irotavg_viewgraph *vg, int win_size, irotavg_rotav
             rc = irotavg_graph_irls(g, IROTAVG_GEMAN_MCCLURE, 5 * M_PI / 180.0, 100, change_th,
                                     &loc.irls_iters, &loc.irls_runtime, nullptr);
         lap("irls");
+        if (rc == IROTAVG_ERR_SOLVER && vg->opt.band_direct >= 0) {
+            // the direct solver gave the graph up (loop closures on a band part that is next to singular, run_irls): the
+            // iterative solver takes every graph, like the reference's one code path (ral/l1_irls.cpp:536-556)
+            irotavg_graph_destroy(g);
+            g = nullptr;
+            irotavg_options it = vg->opt;
+            it.band_direct = -1;
+            rc = irotavg_graph_create(&g, ne, nv, f, I.data(), QQ.data(), ne, &it);
+            if (rc != IROTAVG_OK) return rc;
+            rc = irotavg_graph_set_rotations(g, Q.data(), nv);
+            if (rc == IROTAVG_OK) rc = irotavg_graph_l1ra(g, 100, change_th, &loc.l1_iters, &loc.l1_runtime, nullptr);
+            if (rc == IROTAVG_OK)
+                rc = irotavg_graph_irls(g, IROTAVG_GEMAN_MCCLURE, 5 * M_PI / 180.0, 100, change_th, &loc.irls_iters,
+                                        &loc.irls_runtime, nullptr);
+            lap("l1ra + irls, iterative solver");
+        }
         if (rc == IROTAVG_OK) rc = irotavg_graph_get_rotations(g, Q.data(), nv);
         lap("download");
         irotavg_graph_destroy(g);

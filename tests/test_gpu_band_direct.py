@@ -560,3 +560,28 @@ def test_time_kernel_reports_every_launch_of_a_direct_solve():
         np.testing.assert_array_equal(G.ls_solve(), X)
     with capi.Graph(S["I"], S["QQ"], 20000, 1, band_direct=-1) as G:
         assert capi.lib().irotavg_graph_time_kernel(G._h, 19, 1, C.byref(ms)) == capi.ERR_BAD_ARG
+
+
+def test_one_shot_call_and_rotavg_fall_back_to_the_iterative_solver_when_the_direct_one_gives_up(monkeypatch):
+    """A direct solve with closures whose residual does not pass the gate and that conjugate gradients cannot repair
+    ends irls with IROTAVG_ERR_SOLVER (run_irls; tests/test_gpu_dist.py holds a graph that does that by itself). The
+    one-shot calls -- what the drop-in header makes of irotavg::irls -- and ViewGraph::rotAvg then solve the graph
+    iteratively, like the reference's single code path (ral/l1_irls.cpp:536-556). Here the give-up is forced
+    (IROTAVG_BCR_FAKE_GIVE_UP) on a graph the iterative solver takes."""
+    n = 6000
+    S = closure_graph(n, 60000, 30, 7, 3)
+    Qm = mst_init(S, n)
+    ro = O.irls(S["QQ"], S["I"], Qm, 1, 4, SIG, 50, 1e-3)
+    monkeypatch.setenv("IROTAVG_BCR_FAKE_GIVE_UP", "1")
+    with capi.Graph(S["I"], S["QQ"], n, 1, band_direct=1) as G:
+        G.set_rotations(Qm)
+        with pytest.raises(capi.IrotavgError) as ei:
+            G.irls(4, SIG, 50, 1e-3)
+        assert ei.value.code == capi.ERR_SOLVER
+        np.testing.assert_array_equal(G.get_rotations(), Qm)       # the handle's rotations are untouched
+    from irotavg_amd import ral
+    Q, w = Qm.copy(), np.zeros(S["m"])
+    iters, _ = ral.irls(S["QQ"], S["I"], None, 4, SIG, Q, 1, 50, 1e-3, w)
+    assert iters == ro["iters"]
+    assert synth.angular_distance(Q, ro["Q"]).max() < 1e-7         # (the iterative solver's bar)
+    np.testing.assert_allclose(w, ro["weights"], rtol=1e-5, atol=1e-9)

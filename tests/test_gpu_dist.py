@@ -333,3 +333,64 @@ def test_rccl_transport_single_rank_closures_sum_one_buffer():
         Qa = G.get_rotations()
     assert a["iters"] == b["iters"]
     assert synth.angular_distance(Qa, Qb).max() < 1e-9
+
+
+def _fuzz_case(seed, case, closures_max):
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_sharded_direct", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                                      "fuzz_sharded_direct.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.case_of(seed, case, closures_max)
+
+
+def test_a_closure_solve_that_lost_digits_is_repaired_on_both_handles():
+    """fuzz campaign (seed 21, --closures-max 400), case 46: 38k views, band 24, 365 closures (18 of them wrong), Welsch.
+    In the third iteration whole stretches of the band sit at the weight floor (w^2 = 1e-8) and the closures hold them:
+    the Woodbury form cancels digits -- relative residual 4e-7, rotations 5e-5 rad (one GPU) / 3e-4 rad (5 shards) off
+    the oracle until round 5. Now the residual of the FULL system gates the step: the single-GPU handle repeats the
+    solve by conjugate gradients with the direct solve as the preconditioner, the shards refine it -- both within
+    5e-7 rad of the oracle (what the conditioning of this graph leaves: 1.4e-7 measured)."""
+    from oracle import oracle as O
+    c = _fuzz_case(21, 46, 400)
+    n, f, I, QQ, Q0 = c["n"], c["f"], c["I"], c["QQ"], c["Q0"]
+    assert (c["cost"], c["nclose"], c["world"]) == (13, 366, 5)
+    with capi.Graph(I, QQ, n, f, band_direct=1) as G:
+        G.set_rotations(Q0)
+        ra = G.irls(13, SIG, 3, 1e-3)
+        Qa, sa = G.get_rotations(), G.stats()
+    with capi.DistGraph(I, QQ, n, f, 5, band_direct=1) as D:
+        assert D.info()["closures"] == 365   # (one of the 366 ends at a fixed view)
+        D.set_rotations(Q0)
+        rb = D.irls(13, SIG, 3, 1e-3)
+        Qb, sb = D.get_rotations(into=Q0.copy()), D.stats()
+    ro = O.irls(QQ, I, Q0, f, 13, SIG, 3, 1e-3)
+    assert ra["iters"] == rb["iters"] == ro["iters"] == 3
+    assert sa["direct_guarded"] >= 1 and sa["direct_dead_pivots"] == 0     # the gate was the residual, not a dead pivot
+    assert synth.angular_distance(Qa, ro["Q"]).max() < 5e-7
+    assert synth.angular_distance(Qb, ro["Q"]).max() < 5e-7
+
+
+def test_a_band_part_next_to_singular_is_an_error_not_a_wrong_answer():
+    """fuzz campaign (seed 22, --closures-max 1000), case 69: a THIN chain (band 3, 30k views) with 928 closures, 46 of
+    them wrong, Welsch: from the third iteration on the band part alone is next to singular (the closures are the
+    structure) and the Woodbury solve is no approximate inverse -- until round 5 the direct path returned rotations
+    0.08 rad (one GPU) off the oracle without a word. Now both handles say IROTAVG_ERR_SOLVER and leave the rotations as
+    they were. (The multigrid-PCG does not converge on this chain either -- DESIGN.md section 2 lists the class; the
+    fall-back of the one-shot calls to the iterative solver is tested on a graph it takes, test_gpu_band_direct.py.)"""
+    from oracle import oracle as O
+    c = _fuzz_case(22, 69, 1000)
+    n, f, I, QQ, Q0 = c["n"], c["f"], c["I"], c["QQ"], c["Q0"]
+    assert (c["cost"], c["nclose"], c["world"]) == (13, 938, 8)
+    for make in (lambda: capi.Graph(I, QQ, n, f, band_direct=1), lambda: capi.DistGraph(I, QQ, n, f, 8, band_direct=1)):
+        with make() as H:
+            get = (lambda: H.get_rotations()) if isinstance(H, capi.Graph) else (lambda: H.get_rotations(into=Q0.copy()))
+            H.set_rotations(Q0)
+            H.irls(13, SIG, 2, 1e-3)                            # two iterations are fine ...
+            Q2 = get()
+            H.set_rotations(Q0)
+            with pytest.raises(capi.IrotavgError) as ei:        # ... the third one's system is not
+                H.irls(13, SIG, 3, 1e-3)
+            assert ei.value.code == capi.ERR_SOLVER
+            # the rotations are what the two good iterations left: the failed step was not taken
+            assert synth.angular_distance(Q2, get()).max() < 1e-9

@@ -411,3 +411,31 @@ def test_batched_rotavg_over_independent_graphs_equals_separate_calls():
     # the same graph twice in one batch is refused: its windows depend on each other
     with pytest.raises(capi.IrotavgError):
         rotAvgBatch([A[0], A[0]], 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3000, 6000])
+def test_global_rotavg_falls_back_to_the_iterative_solver_when_the_direct_one_gives_up(n, monkeypatch):
+    """ViewGraph::rotAvg has one code path for every graph (src/ViewGraph.cpp:1400-1417 over ral/l1_irls.cpp:536-556).
+    Here a global re-solve of a sequence with loop closures runs on the banded direct solver; when that solver gives a
+    system up (IROTAVG_ERR_SOLVER from irls: a band part next to singular under the closures -- forced here by
+    IROTAVG_BCR_FAKE_GIVE_UP), the call repeats on the iterative solver by itself: the general path (3000 views) and the
+    device-resident one (6000 views: above 20000 connections), same poses as the undisturbed call."""
+    Qgt, rel = build_sequence(n, seed=5, n_loops=12)
+    res = []
+    for fake in (False, True):
+        if fake:
+            monkeypatch.setenv("IROTAVG_BCR_FAKE_GIVE_UP", "1")
+        vg = ViewGraph()
+        rng = np.random.default_rng(1)
+        for v in range(n):
+            vg.addView(rot(synth.qmul(synth.qexp(rng.normal(scale=0.05, size=(1, 3)))[0], Qgt[v])))
+        for (i, j), R in rel.items():
+            vg.connect(i, j, R)
+        for idx in range(0, n, 500):
+            vg.fixPose(idx, rot(Qgt[idx]))
+        a = vg.rotAvg(5000000)
+        assert a["skipped"] == 0 and a["n_views"] == n
+        res.append((a, np.stack([vg.R(v) for v in range(n)])))
+    assert res[0][0]["irls_iters"] == res[1][0]["irls_iters"]
+    np.testing.assert_allclose(res[0][1], res[1][1], atol=1e-7)
