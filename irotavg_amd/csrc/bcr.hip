@@ -2758,7 +2758,7 @@ static void bcr_shard_reduce_t(Graph &g, BcrTop &T, int rank) {
                        T.buf.p, T.world, rank);
 }
 template <int B>
-static void bcr_top_reduce_launch(Graph &g, BcrTop &T, double *Dinv, double *topDinv, int *dead) {
+static void bcr_top_reduce_launch(Graph &g, BcrTop &T, double *Dinv, double *topDinv, int *dead, int reg = 0) {
     const int W = T.world;
     const size_t BB = (size_t)B * B, BR = (size_t)B * 3;
     double *buf = T.buf.p;
@@ -2768,7 +2768,7 @@ static void bcr_top_reduce_launch(Graph &g, BcrTop &T, double *Dinv, double *top
                        buf + 3 * W * BB + W * BR, buf + 2 * W * BB, T.W.p, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr, (double *)nullptr, T.xtop.p, 0, 0, (const int *)nullptr,
                        (const int *)nullptr, 0, (const int *)nullptr, (const int *)nullptr, nul, (const int *)nullptr, 0,
-                       (long long *)nullptr, Dinv, topDinv, dead, 0);
+                       (long long *)nullptr, Dinv, topDinv, dead, reg);
 }
 template <int B>
 static void bcr_top_back_launch(Graph &g, BcrTop &T) {
@@ -2813,7 +2813,7 @@ static void bcr_top_solve_closures_t(Graph &g, BcrTop &T) {
     hipStream_t st = g.stream;
     const int r = T.r, npad = T.npad, W = T.world;
     IRH_CHECK(hipMemsetAsync(T.dead.p, 0, sizeof(int), st));
-    bcr_top_reduce_launch<B>(g, T, T.Dinv.p, T.topDinv.p, T.dead.p);
+    bcr_top_reduce_launch<B>(g, T, T.Dinv.p, T.topDinv.p, T.dead.p, (int)g.bcr_guard);
     BcrClPlan P;
     for (int l = 0; l < kMaxLevels; l++) {
         P.W[l] = P.Wrw[l] = l == 0 ? T.W.p : nullptr;

@@ -744,8 +744,10 @@ static int bcr_dist(Dist &D) {
         IRH_CHECK(hipMemcpyAsync(&topdead, T.dead.p, sizeof(int), hipMemcpyDeviceToHost, D.stream));
         IRH_CHECK(hipStreamSynchronize(D.stream));
         if (piv > 0.0 || topdead > 0) {
-            D.stats.direct_dead_pivots += (int64_t)piv + topdead;
-            return IROTAVG_ERR_SOLVER;
+            D.stats.direct_dead_pivots = (int64_t)piv + topdead;
+            // (regularised, a dead pivot is the row's own diagonal entry and the result an approximate inverse that
+            // bcr_dist_checked refines; otherwise the Woodbury form does not hold)
+            if (!D.shards[0]->g.bcr_guard) return IROTAVG_ERR_SOLVER;
         }
     }
     return IROTAVG_OK;
@@ -771,53 +773,106 @@ __global__ __launch_bounds__(kRowBlock) void k_refine_resid(int n, const double4
     __syncthreads();
     block_sum3_store(c0, c1, c2, part_bb + 4 * blockIdx.x);
 }
-__global__ __launch_bounds__(256) void k_add4(int n, double4 *__restrict__ x, const double4 *__restrict__ y) {
+// per-column scalars of the repair below (three independent columns share the operator)
+struct Col3 {
+    double v[3];
+};
+// y += a o x;  p = z + b o p;  partial sums of u.v per column
+__global__ __launch_bounds__(256) void k_axpy3(int n, double4 *__restrict__ y, const double4 *__restrict__ x, Col3 a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
-        double4 a = x[i];
-        const double4 b = y[i];
-        a.x += b.x;
-        a.y += b.y;
-        a.z += b.z;
-        x[i] = a;
+        double4 yi = y[i];
+        const double4 xi = x[i];
+        yi.x += a.v[0] * xi.x;
+        yi.y += a.v[1] * xi.y;
+        yi.z += a.v[2] * xi.z;
+        y[i] = yi;
     }
 }
+__global__ __launch_bounds__(256) void k_xpby3(int n, double4 *__restrict__ p, const double4 *__restrict__ z, Col3 b) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const double4 pi = p[i], zi = z[i];
+        p[i] = make_double4(zi.x + b.v[0] * pi.x, zi.y + b.v[1] * pi.y, zi.z + b.v[2] * pi.z, 0.0);
+    }
+}
+__global__ __launch_bounds__(kRowBlock) void k_dot3(int n, const double4 *__restrict__ u, const double4 *__restrict__ v,
+                                                    double *__restrict__ part) {
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double4 ui = u[i], vi = v[i];
+        a0 += ui.x * vi.x;
+        a1 += ui.y * vi.y;
+        a2 += ui.z * vi.z;
+    }
+    block_sum3_store(a0, a1, a2, part + 4 * blockIdx.x);
+}
 
-// A direct solve with closures, checked: the Woodbury form loses digits where robust weights leave a stretch of the band
-// nearly free and the closures hold it (bcr.hip, k_bcr_gate -- the single-GPU handle repeats such a solve by conjugate
-// gradients). Here: the residual of the FULL sharded operator (one halo exchange of x, the sharded SpMV, one combined
-// sum), and while it is above the gate the solve is repeated on the residual and added (iterative refinement with the
-// direct solve as the approximate inverse: each round multiplies the error by the solve's own relative residual).
+// A direct solve with closures, checked. The Woodbury form loses digits where robust weights leave a stretch of the band
+// nearly free and the closures hold it (bcr.hip, k_bcr_gate), and it does not hold at all when the band part has a dead
+// pivot (a cost with exact-zero weights cut a view off all its band neighbours while a closure still holds it). The
+// single-GPU handle repeats such a solve by conjugate gradients on the full operator with the (regularised) direct solve
+// as the preconditioner (run_irls); the same here on the SHARDED operator: one residual of the full system per solve
+// (one halo exchange of x, the sharded SpMV, one combined sum); above the gate, or after a dead pivot, preconditioned CG
+// whose operator is the sharded SpMV (halo exchange of p) and whose preconditioner is bcr_dist itself -- regularised
+// when a pivot died: M = A + E with E positive semi-definite and of the rank of the dead pivots, so CG ends after about
+// as many iterations. Host-driven (a rare path): three sums per iteration, combined over the processes.
 static int bcr_dist_checked(Dist &D) {
     int rc = bcr_dist(D);
     static const bool no_res = std::getenv("IROTAVG_BCR_NO_RESIDUAL_GATE") != nullptr;
-    if (rc != IROTAVG_OK || D.top.r == 0 || no_res) return rc;
-    // the gate of the single-GPU handle (kBcrGateTol); once a solve is being repaired it is taken to the iterative
-    // solver's tolerance, as that handle's conjugate gradients do
-    double tol = 1e-8;
-    double last = HUGE_VAL;
-    for (int round = 0; round < 6; round++) {
-        halo_exchange(D, HALO_X);
+    static const bool dbg = std::getenv("IROTAVG_DIST_DEBUG") != nullptr;
+    if (D.top.r == 0 || no_res) return rc;
+    struct GuardOff {
+        Dist &D;
+        ~GuardOff() {
+            for (auto &sp : D.shards) sp->g.bcr_guard = false;
+        }
+    } guard_off{D};
+    const bool dead = rc == IROTAVG_ERR_SOLVER && D.stats.direct_dead_pivots > 0;
+    if (rc != IROTAVG_OK && !dead) return rc;
+    auto dots = [&](const double4 *(*U)(Shard &), const double4 *(*V)(Shard &), double out[3]) {
+        double sums[4] = {0, 0, 0, 0};
+        for (auto &sp : D.shards) {
+            Graph &g = sp->g;
+            const int n = g.levels[0].n, grid = grid_for_elems(n);
+            hipLaunchKernelGGL(k_dot3, dim3(grid), dim3(kRowBlock), 0, D.stream, n, U(*sp), V(*sp), g.part_rr.p);
+            reduce_pair(D, g.part_rr.p, grid, nullptr, 0);
+            double h[4];
+            IRH_CHECK(hipMemcpyAsync(h, g.part_rr.p, sizeof(double) * 4, hipMemcpyDeviceToHost, D.stream));
+            IRH_CHECK(hipStreamSynchronize(D.stream));
+            for (int c = 0; c < 3; c++) sums[c] += h[c];
+        }
+        combine_host(D, sums, 3, 0);
+        for (int c = 0; c < 3; c++) out[c] = sums[c];
+    };
+    // q = A p on every shard: p lives in g.P (ghost values by the halo exchange), q in g.AP
+    auto apply_A = [&]() {
+        halo_exchange(D, HALO_P);
+        for (auto &sp : D.shards) {
+            IRH_CHECK(hipMemsetAsync(sp->g.flags.p, 0, sizeof(int) * FL_COUNT, D.stream));
+            launch_spmv(sp->g);
+        }
+    };
+    const auto fB = +[](Shard &S) { return (const double4 *)S.g.levels[0].b.p; };
+    const auto fP = +[](Shard &S) { return (const double4 *)S.g.P.p; };
+    const auto fQ = +[](Shard &S) { return (const double4 *)S.g.AP.p; };
+    const auto fZ = +[](Shard &S) { return (const double4 *)(S.g.X.p + S.g.ng); };
+    const auto fRb = +[](Shard &S) { return (const double4 *)S.rf_b.p; };
+    double bb[3];
+    if (!dead) {
+        // the check of a solve that went through: r = b - A x
+        for (auto &sp : D.shards) {
+            const size_t bytes = sizeof(double4) * (size_t)sp->g.levels[0].n;
+            IRH_CHECK(hipMemcpyAsync(sp->g.P.p, sp->g.X.p + sp->g.ng, bytes, hipMemcpyDeviceToDevice, D.stream));
+        }
+        apply_A();
+        double rr[3] = {0, 0, 0};
         double sums[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (auto &sp : D.shards) {
             Graph &g = sp->g;
-            Level &L0 = g.levels[0];
-            const int n = L0.n;
-            IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, D.stream));
-            IRH_CHECK(hipMemcpyAsync(g.P.p, g.X.p + g.ng, sizeof(double4) * (size_t)n, hipMemcpyDeviceToDevice, D.stream));
-            if (g.ng > 0)
-                IRH_CHECK(hipMemcpyAsync(g.PG.p, g.X.p, sizeof(double4) * (size_t)g.ng, hipMemcpyDeviceToDevice, D.stream));
-            launch_spmv(g);  // AP = A x: the shard's rows of the full operator, ghost couplings and closures included
-            if (sp->rf_b.n < (size_t)n) {
-                sp->rf_b.alloc((size_t)n);
-                sp->rf_x.alloc((size_t)n);
-            }
-            // (round 0: L0.b is the system's own right-hand side; later rounds: it holds the residual that was solved for
-            // and the right-hand side sits in rf_b). The residual overwrites A x.
-            const int grid = grid_for_elems(n);
-            hipLaunchKernelGGL(k_refine_resid, dim3(grid), dim3(kRowBlock), 0, D.stream, n,
-                               round == 0 ? (const double4 *)L0.b.p : (const double4 *)sp->rf_b.p, g.AP.p, g.AP.p, g.part_rr.p,
-                               g.part_rz.p);
+            const int n = g.levels[0].n, grid = grid_for_elems(n);
+            hipLaunchKernelGGL(k_refine_resid, dim3(grid), dim3(kRowBlock), 0, D.stream, n, (const double4 *)g.levels[0].b.p,
+                               g.AP.p, g.AP.p, g.part_rr.p, g.part_rz.p);
             reduce_pair(D, g.part_rr.p, grid, g.part_rz.p, grid);
             double h[8];
             IRH_CHECK(hipMemcpyAsync(h, g.part_rr.p, sizeof(double) * 4, hipMemcpyDeviceToHost, D.stream));
@@ -828,40 +883,89 @@ static int bcr_dist_checked(Dist &D) {
         combine_host(D, sums, 8, 0);
         double worst = 0.0;
         for (int c = 0; c < 3; c++) {
-            const double rr = sums[4 + c] > 0.0 ? std::sqrt(sums[c] / sums[4 + c]) : (sums[c] > 0.0 ? HUGE_VAL : 0.0);
-            D.stats.last_relres[c] = rr;
-            worst = std::max(worst, rr);
+            rr[c] = sums[c];
+            bb[c] = sums[4 + c];
+            const double rel = bb[c] > 0.0 ? std::sqrt(rr[c] / bb[c]) : (rr[c] > 0.0 ? HUGE_VAL : 0.0);
+            D.stats.last_relres[c] = rel;
+            worst = std::max(worst, rel);
         }
-        const bool done = !(worst > tol) || round == 5 || !(worst < 0.5 * last);
-        if (done) {
-            // the right-hand side back where the callers left it (nobody reads it after a solve; kept for symmetry with
-            // the unsharded handle, whose residual can be asked for)
-            if (round > 0)
-                for (auto &sp : D.shards)
-                    IRH_CHECK(hipMemcpyAsync(sp->g.levels[0].b.p, sp->rf_b.p, sizeof(double4) * (size_t)sp->g.levels[0].n,
-                                             hipMemcpyDeviceToDevice, D.stream));
-            // (what the rounds reached must still be a solution -- see run_irls: a band part next to singular under
-            // hundreds of closures is no case for the Woodbury form; the caller creates the handle with band_direct = -1)
-            if (!std::isfinite(worst) || !(worst <= 1e-6)) return IROTAVG_ERR_SOLVER;
-            return IROTAVG_OK;
+        if (dbg) std::fprintf(stderr, "[bcr_dist_checked] relres of the direct solve %.3e\n", worst);
+        if (!(worst > 1e-8)) return IROTAVG_OK;  // (the gate of the single-GPU handle, kBcrGateTol)
+        if (!std::isfinite(worst)) return IROTAVG_ERR_SOLVER;
+    }
+    // ---- the repair: CG on A x = b, preconditioner = the sharded direct solve ----
+    D.stats.direct_guarded += 1;
+    if (dead)
+        for (auto &sp : D.shards) sp->g.bcr_guard = true;
+    for (auto &sp : D.shards) {
+        const int n = sp->g.levels[0].n;
+        if (sp->rf_b.n < (size_t)n) {
+            sp->rf_b.alloc((size_t)n);
+            sp->rf_x.alloc((size_t)n);
         }
-        last = worst;
-        tol = std::max(D.opt.pcg_rtol, 1e-12);
-        // solve for the correction: the right-hand side aside (once), L0.b = r, the solution so far aside, then x += dx
-        if (round == 0) D.stats.direct_guarded += 1;
-        for (auto &sp : D.shards) {
-            const size_t bytes = sizeof(double4) * (size_t)sp->g.levels[0].n;
-            if (round == 0) IRH_CHECK(hipMemcpyAsync(sp->rf_b.p, sp->g.levels[0].b.p, bytes, hipMemcpyDeviceToDevice, D.stream));
-            IRH_CHECK(hipMemcpyAsync(sp->g.levels[0].b.p, sp->g.AP.p, bytes, hipMemcpyDeviceToDevice, D.stream));
-            IRH_CHECK(hipMemcpyAsync(sp->rf_x.p, sp->g.X.p + sp->g.ng, bytes, hipMemcpyDeviceToDevice, D.stream));
-        }
-        rc = bcr_dist(D);
-        if (rc != IROTAVG_OK) return rc;
+        IRH_CHECK(hipMemcpyAsync(sp->rf_b.p, sp->g.levels[0].b.p, sizeof(double4) * (size_t)n, hipMemcpyDeviceToDevice, D.stream));
+        IRH_CHECK(hipMemsetAsync(sp->rf_x.p, 0, sizeof(double4) * (size_t)n, D.stream));
+    }
+    dots(fRb, fRb, bb);
+    const double rtol = std::max(D.opt.pcg_rtol, 1e-12);
+    const int maxit = dead ? 200 : 12;
+    double rz[3] = {0, 0, 0}, worst = HUGE_VAL;
+    int it = 0;
+    // r lives in L0.b (it IS the right-hand side of the preconditioner's solve), z = the solve's result (X), x in rf_x
+    for (;; it++) {
+        rc = bcr_dist(D);  // z = M^-1 r
+        if (rc != IROTAVG_OK && !(dead && rc == IROTAVG_ERR_SOLVER && D.shards[0]->g.bcr_guard)) break;
+        rc = IROTAVG_OK;
+        double rz_new[3];
+        dots(fB, fZ, rz_new);
+        Col3 beta;
+        for (int c = 0; c < 3; c++) beta.v[c] = it == 0 || rz[c] == 0.0 ? 0.0 : rz_new[c] / rz[c];
+        for (int c = 0; c < 3; c++) rz[c] = rz_new[c];
         for (auto &sp : D.shards) {
             const int n = sp->g.levels[0].n;
-            hipLaunchKernelGGL(k_add4, dim3((n + 255) / 256), dim3(256), 0, D.stream, n, sp->g.X.p + sp->g.ng, sp->rf_x.p);
+            if (it == 0)  // p = z (whatever the array held is not multiplied by a zero)
+                IRH_CHECK(hipMemcpyAsync(sp->g.P.p, sp->g.X.p + sp->g.ng, sizeof(double4) * (size_t)n, hipMemcpyDeviceToDevice,
+                                         D.stream));
+            else
+                hipLaunchKernelGGL(k_xpby3, dim3((n + 255) / 256), dim3(256), 0, D.stream, n, sp->g.P.p,
+                                   (const double4 *)(sp->g.X.p + sp->g.ng), beta);
         }
+        apply_A();
+        double pq[3];
+        dots(fP, fQ, pq);
+        Col3 al, nal;
+        for (int c = 0; c < 3; c++) {
+            al.v[c] = pq[c] > 0.0 ? rz[c] / pq[c] : 0.0;
+            nal.v[c] = -al.v[c];
+        }
+        for (auto &sp : D.shards) {
+            const int n = sp->g.levels[0].n;
+            hipLaunchKernelGGL(k_axpy3, dim3((n + 255) / 256), dim3(256), 0, D.stream, n, sp->rf_x.p, (const double4 *)sp->g.P.p, al);
+            hipLaunchKernelGGL(k_axpy3, dim3((n + 255) / 256), dim3(256), 0, D.stream, n, sp->g.levels[0].b.p,
+                               (const double4 *)sp->g.AP.p, nal);
+        }
+        double rr[3];
+        dots(fB, fB, rr);
+        worst = 0.0;
+        for (int c = 0; c < 3; c++) {
+            const double rel = bb[c] > 0.0 ? std::sqrt(rr[c] / bb[c]) : (rr[c] > 0.0 ? HUGE_VAL : 0.0);
+            D.stats.last_relres[c] = rel;
+            worst = std::max(worst, rel);
+        }
+        if (dbg) std::fprintf(stderr, "[bcr_dist_checked] cg %d relres %.3e (dead pivots %lld)\n", it + 1, worst,
+                              (long long)D.stats.direct_dead_pivots);
+        if (!(worst > rtol) || !std::isfinite(worst) || it + 1 >= maxit) break;
     }
+    // the solution where the callers read it, the right-hand side back
+    for (auto &sp : D.shards) {
+        const size_t bytes = sizeof(double4) * (size_t)sp->g.levels[0].n;
+        IRH_CHECK(hipMemcpyAsync(sp->g.X.p + sp->g.ng, sp->rf_x.p, bytes, hipMemcpyDeviceToDevice, D.stream));
+        IRH_CHECK(hipMemcpyAsync(sp->g.levels[0].b.p, sp->rf_b.p, bytes, hipMemcpyDeviceToDevice, D.stream));
+    }
+    if (rc != IROTAVG_OK) return rc;
+    // (what the iterations reached must still be a solution -- see run_irls: a band part next to singular under hundreds
+    // of closures is no case for the Woodbury form; the caller creates the handle with band_direct = -1)
+    if (!std::isfinite(worst) || !(worst <= 1e-6)) return IROTAVG_ERR_SOLVER;
     return IROTAVG_OK;
 }
 static int solve_dist(Dist &D) { return D.bcr_B ? bcr_dist_checked(D) : pcg_dist_any(D); }

@@ -239,6 +239,21 @@ def test_views_held_only_by_a_closure_match_oracle(stretch):
     # the stretch really hangs on the closure alone: all its band edges to the outside ended at weight 0
     out = (np.isin(I[:, 0], cut) ^ np.isin(I[:, 1], cut)) & (np.abs(I[:, 0] - I[:, 1]) <= 32)
     assert (w[out] == 0).all() and w[(I[:, 0] == 200) & (I[:, 1] == v0)][0] > 0
+    # the same on SHARDS (round 5: the closure crosses from rank 0 to rank 1 of two, and both endpoints lie on one rank of
+    # three): the dead pivot is noticed by every rank (the counts are summed with the closures' buffer), the solve is
+    # repeated with the regularised factor and refined on the sharded operator (M = A + E, E positive semi-definite:
+    # the rounds contract)
+    for world in (2, 3):
+        with capi.DistGraph(I, QQ, n, 1, world, band_direct=1) as D:
+            assert D.info()["direct_block"] == 8 and D.info()["closures"] == 7
+            D.set_rotations(Qm)
+            rd = D.irls(12, SIG, 30, 1e-3)
+            Qd, wd = D.get_rotations(into=Qm.copy()), D.get_weights()
+            sd = D.stats()
+        assert sd["direct_solves"] > 0 and sd["pcg_iters"] == 0
+        assert rd["iters"] == ro["iters"]
+        np.testing.assert_array_equal(wd == 0, ro["weights"] == 0)
+        assert synth.angular_distance(Qd, ro["Q"]).max() < 1e-8
 
 
 def test_blocks_of_32_with_a_mixed_level_match_the_iterative_solver():
