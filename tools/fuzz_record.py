@@ -1,0 +1,27 @@
+"""Rewrites the 'second session of round 5' section of profiles/r05_fuzz_parity.txt from the campaign logs in gpurun_out/
+(fzs_<seed>.log: tools/fuzz_sharded_direct.py --closures-max; fzb_<seed>.log: tools/fuzz_band_direct.py)."""
+import glob, os, re
+P = "profiles/r05_fuzz_parity.txt"
+MARK = "second session of round 5:"
+txt = open(P).read()
+if MARK in txt:
+    txt = txt[:txt.index(MARK)].rstrip("\n") + "\n"
+out = ["",
+       MARK + " loop closures on the SHARDED direct solver (tools/fuzz_sharded_direct.py --closures-max 400 / 1000: every case also gets",
+       "0 / 1-11 / 12-64 / 65-max loop closures 70 ... n/2 views long, 5 % of them with a random rotation; 2-8 loopback shards; three IRLS",
+       "iterations, after l1ra(1) in half of the cases; costs L1, Geman-McClure, Huber, Cauchy, Welsch), final library of the session",
+       "(residual gate 1e-9, CG repair on both handles, exact anchoring test). Lines: cases above 1e-8 rad between the two GPU runs, refereed",
+       "by the ORACLE, and the campaign summaries:"]
+for f in sorted(glob.glob("gpurun_out/fzs_*.log")):
+    out += [ln.rstrip() for ln in open(f) if ln.strip()]
+out += ["",
+        "what the first campaigns of this kind found (seeds 21 / 22 on the library BEFORE the gate; both handles, the single-GPU one as it was in",
+        "rounds 3-4): seed 21 case 46 (38k views, band 24, 365 closures, Welsch): unsharded 4.96e-05 rad, sharded 3.32e-04 rad off the oracle",
+        "(relative residual of the third iteration's solve 4e-7: the Woodbury form cancels digits where floored band weights leave a stretch to",
+        "the closures); seed 21 case 35 (20k views, band 3, 319 closures, Geman-McClure): 2.35e-06 / 1.31e-06 rad; seed 22 case 69 (30k views,",
+        "band 3, 938 closures, Welsch): 7.7e-02 / 1.36 rad -- the band part next to singular. Now: cases 46 and 35 within 1.5e-7 / 1e-10 rad on",
+        "both handles; case 69 is IROTAVG_ERR_SOLVER on both (rotations untouched) instead of an answer (tests/test_gpu_dist.py).",
+        "", "banded direct solver vs the oracle on the same library (0-30 closures, every cost):"]
+for f in sorted(glob.glob("gpurun_out/fzb_*.log")):
+    out += [ln.rstrip() for ln in open(f) if ln.startswith("seed")]
+open(P, "w").write(txt + "\n".join(out) + "\n")
