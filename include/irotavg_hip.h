@@ -193,7 +193,7 @@ int irotavg_graph_set_weights(irotavg_graph *g, const double *weights);         
 
 /* irls / l1ra / quat_normalised on the resident graph (same semantics as the one-shot calls).
  * A handle on the banded direct solver that carries loop closures checks every closure solve against the FULL system
- * (relative residual 1e-9; repaired by conjugate gradients with the direct solve as the preconditioner when it is
+ * (relative residual options.pcg_rtol, 1e-10 by default; repaired by conjugate gradients with the direct solve as the preconditioner when it is
  * above). IROTAVG_ERR_SOLVER from irls then means: the band part alone is next to singular under the closures (robust
  * weights at their floor over whole stretches of a thin chain) and the repair stalled above 1e-6 -- the rotations are
  * what the last good iteration left; such a graph belongs to the iterative solver (options.band_direct = -1). The

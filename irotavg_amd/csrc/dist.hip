@@ -892,7 +892,7 @@ static int bcr_dist_checked(Dist &D) {
             worst = std::max(worst, rel);
         }
         if (dbg) std::fprintf(stderr, "[bcr_dist_checked] relres of the direct solve %.3e\n", worst);
-        if (!(worst > 1e-9)) return IROTAVG_OK;  // (the gate of the single-GPU handle, kBcrGateTol)
+        if (!(worst > std::max(D.opt.pcg_rtol, 1e-12))) return IROTAVG_OK;  // (the gate of the single-GPU handle: pcg_rtol)
         if (!std::isfinite(worst)) return IROTAVG_ERR_SOLVER;
     }
     // ---- the repair: CG on A x = b, preconditioner = the sharded direct solve ----
