@@ -10,7 +10,7 @@ out = ["",
        MARK + " loop closures on the SHARDED direct solver (tools/fuzz_sharded_direct.py --closures-max 400 / 1000: every case also gets",
        "0 / 1-11 / 12-64 / 65-max loop closures 70 ... n/2 views long, 5 % of them with a random rotation; 2-8 loopback shards; three IRLS",
        "iterations, after l1ra(1) in half of the cases; costs L1, Geman-McClure, Huber, Cauchy, Welsch), final library of the session",
-       "(residual gate 1e-9, CG repair on both handles, exact anchoring test). Lines: cases above 1e-8 rad between the two GPU runs, refereed",
+       "(residual gate = options.pcg_rtol = 1e-10, CG repair on both handles, exact anchoring test). Lines: cases above 1e-8 rad between the two GPU runs, refereed",
        "by the ORACLE, and the campaign summaries:"]
 for f in sorted(glob.glob("gpurun_out/fzs_*.log")):
     out += [ln.rstrip() for ln in open(f) if ln.strip()]
