@@ -619,4 +619,6 @@ class DistGraph:
         return dict(pcg_solves=s.pcg_solves, pcg_iters=s.pcg_iters, pcg_iters_last=s.pcg_iters_last,
                     outer_iters=s.outer_iters, edge_updates=s.edge_updates, seconds_irls=s.seconds_irls,
                     levels=s.levels, level_rows=list(s.level_rows)[:s.levels],
-                    pcg_handed_over=s.pcg_handed_over, direct_solves=s.direct_solves)
+                    pcg_handed_over=s.pcg_handed_over, direct_solves=s.direct_solves,
+                    direct_guarded=s.direct_guarded, direct_dead_pivots=s.direct_dead_pivots,
+                    last_relres=list(s.last_relres))

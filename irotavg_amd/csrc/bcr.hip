@@ -2250,7 +2250,7 @@ static void bcr_closure_plan(Graph &g) {
     S.co_elim.upload(elim, g.stream);
     S.cl_R.alloc(steps.size() * (size_t)B);
     S.cl_W.alloc(steps.size() * (size_t)B);
-    S.cl_S.alloc((size_t)S.cl_npad * S.cl_npad);
+    if (!shard) S.cl_S.alloc((size_t)S.cl_npad * S.cl_npad);  // (a shard's share goes straight into the ranks' common buffer)
     S.cl_T.alloc((size_t)S.cl_npad * 3);
     S.lam.alloc((size_t)S.cl_npad * 3);
     S.cl_alive.alloc((size_t)S.cl_npad);

@@ -709,7 +709,7 @@ static int bcr_dist(Dist &D) {
     if (D.hosted) {
         const size_t n0 = T.n_doubles(), n1 = cl ? T.x_doubles() : 0;
         if (n0 + n1 > 0x7fffffffULL) throw HipError{hipErrorUnknown};
-        D.hbuf.assign(n0 + n1, 0.0);
+        D.hbuf.resize(n0 + n1);  // (both parts are overwritten whole)
         IRH_CHECK(hipMemcpyAsync(D.hbuf.data(), T.buf.p, sizeof(double) * n0, hipMemcpyDeviceToHost, D.stream));
         if (cl) IRH_CHECK(hipMemcpyAsync(D.hbuf.data() + n0, T.xbuf.p, sizeof(double) * n1, hipMemcpyDeviceToHost, D.stream));
         IRH_CHECK(hipStreamSynchronize(D.stream));

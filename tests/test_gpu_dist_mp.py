@@ -50,6 +50,16 @@ def test_processes_host_staged_wire_sharded_direct_solver_with_closures(nproc, c
     assert r.returncode == 0 and "DIST_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_two_processes_host_staged_wire_guarded_closure_solve():
+    """a dead pivot of the band part (Talwar cuts a view off all its band neighbours, one closure holds it) between two
+    processes: every rank reads the summed count, the solve is repeated by conjugate gradients whose operator is the
+    sharded SpMV (halo exchange of p through the wire), whose preconditioner is the regularised sharded direct solve and
+    whose three sums per iteration are combined over the processes (bcr_dist_checked)"""
+    r = run_worker("hosted", nproc=2, port=29641, extra=["--p-loop", "0", "--views", "9000", "--edges", "90000", "--closures", "6",
+                                                         "--cut-stretch", "--expect-direct"])
+    assert r.returncode == 0 and "DIST_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_two_processes_rccl_on_one_device():
     try:
         r = run_worker("rccl", port=29613, timeout=300)

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--edges", type=int, default=60000)
     ap.add_argument("--p-loop", type=float, default=0.01)
     ap.add_argument("--closures", type=int, default=0, help="loop closures added to the sequence (a tenth of them wrong)")
+    ap.add_argument("--cut-stretch", action="store_true",
+                    help="Talwar + a view whose band edges are all wrong and that one correct closure holds: a dead pivot of the "
+                         "band part, the shards' guarded re-solve (conjugate gradients across the processes)")
     ap.add_argument("--expect-direct", action="store_true", help="fail unless the sharded direct solver ran")
     args = ap.parse_args()
     import torch
@@ -36,6 +39,21 @@ def main():
     S = synth.make_graph(n, m, args.p_loop, seed=2)
     if args.closures:
         S = synth.add_closures(S, args.closures, seed=7, wrong=args.closures // 10)
+    cost = 4
+    if args.cut_stretch:
+        cost = 12                                                  # Talwar: weights of exactly 0
+        I, QQ = S["I"].copy(), S["QQ"].copy()
+        v0 = n // 2 + 37
+        rng = np.random.default_rng(9)
+        touching = ((I[:, 0] == v0) | (I[:, 1] == v0)) & (np.abs(I[:, 0] - I[:, 1]) <= 32)
+        R = rng.normal(size=(int(touching.sum()), 4))
+        QQ[touching] = R / np.linalg.norm(R, axis=1, keepdims=True)
+        far = np.array([[200, v0]], dtype=np.int32)
+        QQf = synth.qmul(S["Qgt"][v0:v0 + 1], synth.qconj(S["Qgt"][200:201]))
+        I = np.concatenate([I, far]).astype(np.int32)
+        QQ = np.concatenate([QQ, QQf])
+        order = np.lexsort((np.arange(len(I)), I[:, 1]))
+        S = dict(S, I=I[order], QQ=QQ[order])
     Q0 = np.zeros((n, 4)); Q0[:, 3] = 1; Q0[:f] = S["Qgt"][:f]
     ral.init_mst(Q0, S["QQ"], S["I"], f)
     if args.wire == "hosted":
@@ -46,7 +64,7 @@ def main():
         D = capi.DistGraph(S["I"], S["QQ"], n, f, world, rank=rank, unique_id=uid[0], device=0)
     D.set_rotations(Q0)
     b1 = D.l1ra(3, 1e-3)
-    b2 = D.irls(4, SIG, 20, 1e-3)
+    b2 = D.irls(cost, SIG, 20, 1e-3)
     st = D.stats()
     if args.expect_direct and (st["direct_solves"] == 0 or st["pcg_iters"] != 0 or D.info()["direct_block"] == 0):
         print("DIST_WORKER_FAIL rank %d: the sharded direct solver did not run: %r" % (rank, st), flush=True)
@@ -65,11 +83,14 @@ def main():
         with capi.Graph(S["I"], S["QQ"], n, f, device=0) as G:
             G.set_rotations(Q0)
             a1 = G.l1ra(3, 1e-3)
-            a2 = G.irls(4, SIG, 20, 1e-3)
+            a2 = G.irls(cost, SIG, 20, 1e-3)
+            ga = G.stats()
             Qa, wa = G.get_rotations(), G.get_weights()
         err = synth.angular_distance(Qa, Qd).max()
         werr = np.abs(wa - wt.numpy()).max() / np.abs(wa).max()
         ok = (a1["iters"], a2["iters"]) == (b1["iters"], b2["iters"]) and err < 1e-8 and werr < 1e-6
+        if args.cut_stretch:   # both handles must have met the dead pivot and repaired the solve
+            ok = ok and ga["direct_guarded"] >= 1 and st["direct_guarded"] >= 1
         print("DIST_WORKER_%s wire=%s world=%d l1ra_iters=%d irls_iters=%d max_angle=%.2e weights_rel=%.2e"
               % ("OK" if ok else "FAIL", args.wire, world, b1["iters"], b2["iters"], err, werr), flush=True)
     flag = torch.tensor([1 if ok else 0])
