@@ -24,4 +24,7 @@ out += ["",
         "", "banded direct solver vs the oracle on the same library (0-30 closures, every cost):"]
 for f in sorted(glob.glob("gpurun_out/fzb_*.log")):
     out += [ln.rstrip() for ln in open(f) if ln.startswith("seed")]
+out += ["", "handle path and window kernels vs the oracle (tools/fuzz_parity.py, bar 1e-6 rad), same library:"]
+for f in sorted(glob.glob("gpurun_out/fzp_*.log")):
+    out += [ln.rstrip() for ln in open(f) if ln.startswith("{")]
 open(P, "w").write(txt + "\n".join(out) + "\n")
