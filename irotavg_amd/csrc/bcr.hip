@@ -135,6 +135,7 @@ struct BcrState {
     // before it {own, remote} (255: nothing), its number in the global list, who adds its 1 / w; the rows whose diagonal
     // loses the weight of a closure to a ghost view for the time of the reduction
     DevBuf<double> res_part;   // k_bcr_residual's partial sums (bcr_gate)
+    DevBuf<int> res_zero;      // FL_COUNT zero words: the done flags the gate's SpMV runs behind
     DevBuf<int2> cl_fin;
     DevBuf<int> cl_gid;
     DevBuf<uint8_t> cl_own;
@@ -1692,11 +1693,141 @@ struct BcrClPlan {
     double *xtop;
 };
 
+// One WORKGROUP per closure: its step program. A step eliminates one block g of the path: R = slot[src];
+// slot[dstA] -= W_P' R, slot[dstC] -= W_Q' R (the block's W = D^-1 [P' | Q | R_main]), T += R' W_R(main),
+// and R and D^-1 R are recorded. The chain of steps is sequential in R (LDS) only: a step's block columns
+// ([W_P | W_Q | W_R | D^-1]: 14 KB at B = 24) do not depend on the step before. Round 4 ran a wave per closure that
+// fetched its block at every step -- ~40 memory round trips in sequence, 61 us whatever the number of closures; round
+// 5: the four waves of the workgroup stage the blocks of FOUR steps in LDS per round trip (each wave one step) and then
+// run the four steps from LDS together -- thread (column, part) sums a part of its column's rows, the parts meet in LDS
+// (one wave doing a step alone is two chains of B dependent multiply-adds: ~1 us, as long as the round trip it replaced).
+template <int B>
+__global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r, int nslots, const int *__restrict__ off,
+                                                              const int4 *__restrict__ steps,
+                                                              const int4 *__restrict__ init, double *__restrict__ recR,
+                                                              double *__restrict__ recW, double *__restrict__ T,
+                                                              const double *__restrict__ slot_init = nullptr,
+                                                              const int2 *__restrict__ fin = nullptr,
+                                                              const int *__restrict__ gid = nullptr,
+                                                              double *__restrict__ dep = nullptr, int world = 0,
+                                                              int rank = 0) {
+    constexpr int NR = 3, NC = 2 * B + NR, BB = B * B, NCOL = NC + B, NE = B * NCOL;
+    constexpr int NLD = (NE + 63) / 64;
+    constexpr int KP = B == 24 ? 3 : (NCOL * 4 <= 256 ? 4 : 2), KB = B / KP;  // parts of a column's rows, rows per part
+    static_assert(B % KP == 0 && NCOL * KP <= 256, "thread (col, part)");
+    extern __shared__ double smem[];  // [4][B][NCOL] staged blocks, KP x NCOL partial sums, then nslots x B slots
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x;
+    double *stage = smem + (size_t)wave * NE;
+    double *spart = smem + (size_t)4 * NE;
+    double *slots = spart + KP * NCOL;
+    if (wave == 0) {
+        if (slot_init) {
+            // the separator system of a sharded sequence: the column starts from what the ranks' eliminations left there
+            for (int e = lane; e < nslots * B; e += 64) slots[e] = slot_init[(size_t)q * nslots * B + e];
+        } else {
+            for (int e = lane; e < nslots * B; e += 64) slots[e] = 0.0;
+            const int4 in = init[q];
+            if (lane == 0) {  // (a slot of 255: that endpoint is a row of another rank)
+                if (in.x != 255) slots[in.x * B + in.y] += 1.0;
+                if (in.z != 255) slots[in.z * B + in.w] -= 1.0;
+            }
+        }
+    }
+    double tacc = 0.0;  // threads 2B .. 2B + 2: a coordinate of T each
+    const int s0 = off[q], s1 = off[q + 1];
+    __syncthreads();  // (the slots' start values)
+    for (int g0 = s0; g0 < s1; g0 += 4) {
+        // ---- every wave: the block of step g0 + wave into its stage, element (k, col) at k NCOL + col ----
+        const int st_w = g0 + wave;
+        if (st_w < s1) {
+            const int4 sp = steps[st_w];
+            const int lvl = __builtin_amdgcn_readfirstlane(sp.x), spy = __builtin_amdgcn_readfirstlane(sp.y);
+            const double *Wb = lvl >= 0 ? P.W[lvl] + (size_t)spy * B * NC : P.topDinv;
+            const double *Db = lvl >= 0 ? P.Dinv[lvl] + (size_t)spy * BB : P.topDinv;
+            double v[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; u++) {
+                const int e = lane + 64 * u;
+                const int k = e / NCOL, col = e - k * NCOL;
+                // (an address that is valid for every lane; what is not wanted is zeroed by a select below)
+                const double *src = Db;
+                if (e < NE) {
+                    if (col >= NC)
+                        src = Db + k * B + (col - NC);
+                    else if (lvl >= 0)
+                        src = Wb + k * NC + col;
+                    else if (col >= 2 * B)
+                        src = P.xtop + k * NR + (col - 2 * B);  // the top block: nothing beside it; its part of Y is xtop
+                }
+                v[u] = *src;
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; u++) {
+                const int e = lane + 64 * u;
+                const int k = e / NCOL, col = e - k * NCOL;
+                const bool zero = lvl < 0 && col < 2 * B;
+                if (e < NE) stage[e] = zero ? 0.0 : v[u];
+            }
+        }
+        __syncthreads();
+        // ---- all four waves: the (up to) four steps from LDS. Thread (col, part) sums its share of the rows of column
+        // col (a wave alone took ~1 us per step: two chains of B dependent multiply-adds), the parts meet in LDS ----
+        for (int w = 0; w < 4 && g0 + w < s1; w++) {
+            const int st = g0 + w;
+            const int spz = __builtin_amdgcn_readfirstlane(steps[st].z);
+            const int src = spz & 255, dA = (spz >> 8) & 255, dC = (spz >> 16) & 255;
+            const double *blk = smem + (size_t)w * NE;
+            const int tcol = threadIdx.x % NCOL, tpart = threadIdx.x / NCOL;
+            if (tpart < KP) {
+                const double *rs = slots + src * B + tpart * KB;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < KB; k++) acc = fma(blk[(tpart * KB + k) * NCOL + tcol], rs[k], acc);
+                spart[tpart * NCOL + tcol] = acc;
+            }
+            if (threadIdx.x < B) recR[(size_t)st * B + threadIdx.x] = slots[src * B + threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x < NCOL) {
+                const int col = threadIdx.x;
+                double acc = spart[col];
+#pragma unroll
+                for (int pp = 1; pp < KP; pp++) acc += spart[pp * NCOL + col];
+                if (col < B) {
+                    if (dA != 255) slots[dA * B + col] -= acc;
+                } else if (col < 2 * B) {
+                    if (dC != 255) slots[dC * B + col - B] -= acc;
+                } else if (col < NC) {
+                    tacc += acc;
+                } else {
+                    recW[(size_t)st * B + col - NC] = acc;
+                }
+            }
+            __syncthreads();  // (slots and spart before the next step; the stages before the next group)
+        }
+    }
+    // the T threads: column 2B + c is thread 2B + c in every step
+    if (threadIdx.x >= 2 * B && threadIdx.x < 2 * B + 3) T[(size_t)q * 3 + (threadIdx.x - 2 * B)] = tacc;
+    if (wave != 0) return;
+    // a shard: what the column leaves on this rank's separator (block `rank` of the separator system) and on the one
+    // before it (block rank - 1) is ADDED to the ranks' common buffer (the loopback's shards run one after the other)
+    if (dep) {
+        const int2 fn = fin[q];
+        double *d = dep + (size_t)gid[q] * world * B;
+        if (lane < B) {
+            if (fn.x != 255) d[rank * B + lane] += slots[fn.x * B + lane];
+            if (fn.y != 255 && rank > 0) d[(rank - 1) * B + lane] += slots[fn.y * B + lane];
+        }
+    }
+}
+
+// The same step programs, one WAVE per closure and the block fetched at every step (round 4's kernel): small in LDS, so
+// that a thousand closures run side by side -- the form for many closures, where the machine is filled by their number.
 // One wave per closure: its step program. A step eliminates one block g of the path: R = slot[src];
 // slot[dstA] -= W_P' R, slot[dstC] -= W_Q' R (the block's W = D^-1 [P' | Q | R_main]), T += R' W_R(main),
 // and R and D^-1 R are recorded. Every lane owns one column of [W_P | W_Q | W_R | D^-1] per pass.
 template <int B>
-__global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r, int nslots, const int *__restrict__ off,
+__global__ __launch_bounds__(256) void k_bcr_closure_forward_wave(BcrClPlan P, int r, int nslots, const int *__restrict__ off,
                                                               const int4 *__restrict__ steps,
                                                               const int4 *__restrict__ init, double *__restrict__ recR,
                                                               double *__restrict__ recW, double *__restrict__ T,
@@ -1816,7 +1947,8 @@ __global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, int maxs
                                                         double *__restrict__ Tx = nullptr,
                                                         double *__restrict__ deadx = nullptr) {
     extern __shared__ int skey[];  // [32][maxsteps]: rows 0..15 the tile's p, 16..31 its q
-    __shared__ double sx[2][16][B + 1], sy[2][16][B + 1];
+    constexpr int DB = 4;          // dense eliminations per batch
+    __shared__ double sx[DB][16][B + 1], sy[DB][16][B + 1];
     if (blockIdx.x < blockIdx.y) return;
     const int tp = threadIdx.x >> 4, tq = threadIdx.x & 15;
     const int p = blockIdx.y * 16 + tp, q = blockIdx.x * 16 + tq;
@@ -1827,36 +1959,52 @@ __global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, int maxs
         if (cl < r && k < off[cl + 1] - off[cl]) key = steps[off[cl] + k].w;
         skey[e] = key;
     }
+    __syncthreads();
     // the dense eliminations (the blocks of the top levels, on almost every closure's path): the records of the tile's
-    // sixteen p and sixteen q through LDS, double buffered -- each is used sixteen times
+    // sixteen p and sixteen q through LDS -- each is used sixteen times. DB eliminations per batch: their records are
+    // requested together (one elimination per round was one memory round trip per elimination: 36 of this kernel's
+    // 51 us at a hundred closures).
     double sum = 0.0;
     {
-        // thread -> (which of the 32 closures, a pair of entries): 32 x B / 2 pairs of doubles
-        auto fetch = [&](int d, int buf) {
-            for (int e = threadIdx.x; e < 32 * (B / 2); e += 256) {
-                const int who = e / (B / 2), k2 = e - who * (B / 2);
-                const int cl = who < 16 ? blockIdx.y * 16 + who : blockIdx.x * 16 + who - 16;
-                const int st = cl < r ? dense[(size_t)d * r + cl] : -1;
-                v2d v = v2d{0.0, 0.0};
-                if (st >= 0) v = *reinterpret_cast<const v2d *>((who < 16 ? recR : recW) + (size_t)st * B + 2 * k2);
-                double *dst = who < 16 ? &sx[buf][who][2 * k2] : &sy[buf][who - 16][2 * k2];
-                dst[0] = v.x;
-                dst[1] = v.y;
-            }
-        };
-        if (ndense > 0) fetch(0, 0);
-        __syncthreads();
-        for (int d = 0; d < ndense; d++) {
-            if (d + 1 < ndense) fetch(d + 1, (d + 1) & 1);
-            const double *x = sx[d & 1][tp], *y = sy[d & 1][tq];
-            double d0 = 0.0, d1 = 0.0;
+        constexpr int NE = 32 * (B / 2), NU = (DB * NE + 255) / 256;  // pairs of doubles per elimination; per thread and batch
+        for (int d0 = 0; d0 < ndense; d0 += DB) {
+            v2d v[NU];
 #pragma unroll
-            for (int k = 0; k < B; k += 2) {
-                d0 = fma(x[k], y[k], d0);
-                d1 = fma(x[k + 1], y[k + 1], d1);
+            for (int u = 0; u < NU; u++) {
+                const int e = threadIdx.x + 256 * u;
+                const int dd = e / NE, e1 = e - dd * NE;
+                const int who = e1 / (B / 2), k2 = e1 - who * (B / 2);
+                const int cl = who < 16 ? blockIdx.y * 16 + who : blockIdx.x * 16 + who - 16;
+                int st = -1;
+                if (dd < DB && d0 + dd < ndense && cl < r) st = dense[(size_t)(d0 + dd) * r + cl];
+                v[u] = v2d{0.0, 0.0};
+                if (st >= 0) v[u] = *reinterpret_cast<const v2d *>((who < 16 ? recR : recW) + (size_t)st * B + 2 * k2);
             }
-            sum += d0 + d1;
+            __syncthreads();  // (the previous batch has been read)
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int e = threadIdx.x + 256 * u;
+                const int dd = e / NE, e1 = e - dd * NE;
+                const int who = e1 / (B / 2), k2 = e1 - who * (B / 2);
+                if (dd < DB) {
+                    double *dst = who < 16 ? &sx[dd][who][2 * k2] : &sy[dd][who - 16][2 * k2];
+                    dst[0] = v[u].x;
+                    dst[1] = v[u].y;
+                }
+            }
             __syncthreads();
+#pragma unroll
+            for (int dd = 0; dd < DB; dd++) {
+                if (d0 + dd >= ndense) break;
+                const double *x = sx[dd][tp], *y = sy[dd][tq];
+                double d0s = 0.0, d1s = 0.0;
+#pragma unroll
+                for (int k = 0; k < B; k += 2) {
+                    d0s = fma(x[k], y[k], d0s);
+                    d1s = fma(x[k + 1], y[k + 1], d1s);
+                }
+                sum += d0s + d1s;
+            }
         }
     }
     if (p >= npad || q >= npad || q < p) return;
@@ -2208,7 +2356,7 @@ static void bcr_closure_plan(Graph &g) {
     // product, done tile-wise from LDS (k_bcr_closure_S); the key of a step carries the mark in its lowest bit
     std::vector<int> dense;
     for (size_t k = 0; k < steps.size(); k++) steps[k].w *= 2;
-    if (r > 64) {
+    if (r >= 8) {  // (round 5: also for the Woodbury systems that are solved in LDS -- the merge is a memory round trip per match)
         int d = 0;
         for (auto &kv : by_key)
             if ((long long)kv.second.size() * 4 >= r) {
@@ -2519,6 +2667,11 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
 }
 
 template <int B>
+static void bcr_launch_forward(hipStream_t st, const BcrClPlan &P, int r, int nslots, const int *off, const int4 *steps,
+                               const int4 *init, double *recR, double *recW, double *T, const double *slot_init,
+                               const int2 *fin, const int *gid, double *dep, int world, int rank);
+
+template <int B>
 static void bcr_run_all(Graph &g, int only) {
     BcrState &S = *g.bcr;
     if (S.nfar == 0 || only >= 0) {
@@ -2539,14 +2692,8 @@ static void bcr_run_all(Graph &g, int only) {
     }
     P.topDinv = S.topDinv.p;
     P.xtop = S.xtop.p;
-    int wpb = 4;
-    while (wpb > 1 && (size_t)wpb * S.cl_nslots * B * sizeof(double) > 60 * 1024) wpb >>= 1;
-    const size_t lds = (size_t)wpb * S.cl_nslots * B * sizeof(double);
-    if (lds > 64 * 1024)
-        IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_forward<B>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_bcr_closure_forward<B>), dim3((r + wpb - 1) / wpb), dim3(64 * wpb), lds, st, P, r, S.cl_nslots,
-                       S.cl_off.p, S.cl_step.p, S.cl_init.p, S.cl_R.p, S.cl_W.p, S.cl_T.p);
+    bcr_launch_forward<B>(st, P, r, S.cl_nslots, S.cl_off.p, S.cl_step.p, S.cl_init.p, S.cl_R.p, S.cl_W.p, S.cl_T.p, nullptr,
+                          nullptr, nullptr, nullptr, 0, 0);
     const int nt = (npad + 15) / 16;
     hipLaunchKernelGGL((k_bcr_closure_S<B>), dim3(nt, nt), dim3(256), (size_t)32 * S.cl_maxsteps * sizeof(int), st, r, npad,
                        S.cl_maxsteps, S.cl_ndense, S.cl_dense.p, S.cl_off.p, S.cl_step.p, S.cl_R.p,
@@ -2728,13 +2875,31 @@ template <int B>
 static void bcr_launch_forward(hipStream_t st, const BcrClPlan &P, int r, int nslots, const int *off, const int4 *steps,
                                const int4 *init, double *recR, double *recW, double *T, const double *slot_init,
                                const int2 *fin, const int *gid, double *dep, int world, int rank) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    // Few closures: one workgroup per closure, four staged blocks of B x (3B + 3) doubles (58 KB at B = 24, 100 KB at
+    // B = 32) + the slots -- the chain of a closure's steps is what takes the time, and two such workgroups fill a CU.
+    // Many closures (more than two per CU): a wave per closure, LDS for the slots only (measured at a thousand closures:
+    // 65 us against 100).
+    const size_t lds_wg = ((size_t)4 * B * (3 * B + 3) + (size_t)4 * (3 * B + 3) + (size_t)nslots * B) * sizeof(double);
+    if (r <= 400 && lds_wg <= 150 * 1024 && !getenv("IROTAVG_BCR_FORWARD_WAVE")) {
+        static std::atomic<size_t> lds_set[16];
+        if (lds_wg > 64 * 1024 && lds_set[dev & 15].load() < lds_wg) {
+            IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_forward<B>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wg));
+            lds_set[dev & 15].store(lds_wg);
+        }
+        hipLaunchKernelGGL((k_bcr_closure_forward<B>), dim3(r), dim3(256), lds_wg, st, P, r, nslots, off, steps, init, recR, recW,
+                           T, slot_init, fin, gid, dep, world, rank);
+        return;
+    }
     int wpb = 4;
     while (wpb > 1 && (size_t)wpb * nslots * B * sizeof(double) > 60 * 1024) wpb >>= 1;
     const size_t lds = (size_t)wpb * nslots * B * sizeof(double);
     if (lds > 64 * 1024)
-        IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_forward<B>),
+        IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_forward_wave<B>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_bcr_closure_forward<B>), dim3((r + wpb - 1) / wpb), dim3(64 * wpb), lds, st, P, r, nslots, off,
+    hipLaunchKernelGGL((k_bcr_closure_forward_wave<B>), dim3((r + wpb - 1) / wpb), dim3(64 * wpb), lds, st, P, r, nslots, off,
                        steps, init, recR, recW, T, slot_init, fin, gid, dep, world, rank);
 }
 
@@ -3127,7 +3292,7 @@ __global__ __launch_bounds__(256) void k_bcr_resid_norms(int n, const double4 *_
 // 1e-8 -- relative residual 4e-7 where the band-only solve reaches 1e-12). flags[1] = 1: the residual was the reason.
 __global__ __launch_bounds__(256) void k_bcr_gate(const int *__restrict__ dead, int *__restrict__ flags,
                                                   const double *__restrict__ part, int nparts, double tol2) {
-    __shared__ double sh[256][6];
+    __shared__ double sh[4][6];
     const int t = threadIdx.x;
     double a[6] = {0, 0, 0, 0, 0, 0};
     if (part)
@@ -3137,13 +3302,17 @@ __global__ __launch_bounds__(256) void k_bcr_gate(const int *__restrict__ dead, 
                 a[3 + c] += part[(size_t)b * 8 + 4 + c];
             }
         }
-    for (int c = 0; c < 6; c++) sh[t][c] = a[c];
+    // (the sums of the 256 threads: by wave shuffles, then over the four waves -- one thread adding 1536 LDS words took 8 us)
+    for (int c = 0; c < 6; c++) {
+        double v = a[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((t & 63) == 0) sh[t >> 6][c] = v;
+    }
     __syncthreads();
     if (t != 0) return;
     bool ok = true;
     if (part) {
-        for (int q = 1; q < 256; q++)
-            for (int c = 0; c < 6; c++) a[c] += sh[q][c];
+        for (int c = 0; c < 6; c++) a[c] = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c];
         for (int c = 0; c < 3; c++) ok = ok && (a[c] <= tol2 * a[3 + c]);  // (NaN: not ok)
     }
     const int d = dead ? dead[0] : 0;
@@ -3163,9 +3332,12 @@ void bcr_gate(Graph &g) {
         // took 45), then b - A x and the two norms in one small pass over the rows
         Level &L0 = g.levels[0];
         grid = (L0.n + 255) / 256;
-        if (S->res_part.n < (size_t)grid * 8) S->res_part.alloc((size_t)grid * 8);
-        IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));  // (the SpMV skips its work behind FL_DONE)
-        launch_spmv(g, g.X.p);
+        if (S->res_part.n < (size_t)grid * 8) {
+            S->res_part.alloc((size_t)grid * 8);
+            S->res_zero.alloc(FL_COUNT);
+            S->res_zero.zero(g.stream);  // (the SpMV skips its work behind a FL_DONE that is set: it gets words that never are)
+        }
+        launch_spmv(g, g.X.p, nullptr, S->res_zero.p);
         hipLaunchKernelGGL(k_bcr_resid_norms, dim3(grid), dim3(256), 0, g.stream, L0.n, L0.b.p, g.AP.p, S->res_part.p);
         part = S->res_part.p;
     }

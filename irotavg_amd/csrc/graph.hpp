@@ -232,7 +232,8 @@ void assemble(Graph &g, int mode, const double *wsrc, bool refresh_dense = true)
 void assemble_values(Graph &g, int mode, const double *wsrc);  // the value refresh alone (no dense-level decision)
 int pcg_solve(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr);
 int pcg_solve_classic(Graph &g, const std::function<void()> *tail = nullptr, bool *tail_ran = nullptr);  // the round-1 recurrences (separate launches), whatever Graph::cg2 says
-void launch_spmv(Graph &g, const double4 *p = nullptr, const double4 *pg = nullptr);  // AP = L p (p: g.P, ghost values: g.PG unless given)
+// AP = L p (p: g.P, ghost values: g.PG, the done word it skips its work behind: g.flags -- unless given)
+void launch_spmv(Graph &g, const double4 *p = nullptr, const double4 *pg = nullptr, const int *flags = nullptr);
 void launch_update(Graph &g, bool init, int par, int np_pq, const double4 *p = nullptr,
                    const double4 *rin = nullptr, double4 *rout = nullptr);
 void launch_pupdate(Graph &g, int par, int first, const PrecInfo &pi, bool check = false, int np_rr = 1,

@@ -2014,10 +2014,10 @@ PrecInfo precondition(Graph &g, int first, double rtol2, bool check) {
     return pi;
 }
 
-void launch_spmv(Graph &g, const double4 *p, const double4 *pg) {
+void launch_spmv(Graph &g, const double4 *p, const double4 *pg, const int *flags) {
     Level &L0 = g.levels[0];
     hipLaunchKernelGGL(k_spmv_dot, dim3(grid_for_rows(L0)), dim3(kRowBlock), 0, g.stream, view_of(L0),
-                       p ? p : (const double4 *)g.P.p, g.AP.p, g.part_pq.p, g.flags.p,
+                       p ? p : (const double4 *)g.P.p, g.AP.p, g.part_pq.p, flags ? flags : (const int *)g.flags.p,
                        g.ng > 0 ? (pg ? pg : (const double4 *)g.PG.p) : (const double4 *)nullptr, g.bptr.p,
                        g.bghost.p, g.bval.p);
 }
