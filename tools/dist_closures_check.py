@@ -45,11 +45,12 @@ def run(n, m, nclose, wrong, world, cost=4, with_oracle=True, l1=True):
 
 
 if __name__ == "__main__":
-    args = [int(x) for x in sys.argv[1:]]
+    no_oracle = "--no-oracle" in sys.argv
+    args = [int(x) for x in sys.argv[1:] if not x.startswith("--")]
     if not args:
         cases = [(3000, 12000, 5, 1, 2), (3000, 45000, 20, 3, 4), (4000, 80000, 40, 4, 3), (6000, 60000, 300, 20, 8),
                  (20000, 300000, 1000, 40, 8)]
     else:
         cases = [tuple(args[i:i + 5]) for i in range(0, len(args), 5)]
     for c in cases:
-        run(*c)
+        run(*c, with_oracle=not no_oracle)
