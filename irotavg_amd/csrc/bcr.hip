@@ -1682,7 +1682,7 @@ __global__ __launch_bounds__(kBackTopThreads) void k_bcr_back_top(BcrBackPlan P,
 // sides corrected by sum_q lambda_q D_g^-1 R_g(v_q) on the blocks of the paths. Which blocks a closure touches
 // depends on the positions of its endpoints only: the host writes a STEP PROGRAM per closure once (bcr_closure_plan),
 // a wave executes it per solve (k_bcr_closure_forward), pairs of closures are joined on the blocks they share
-// (k_bcr_closure_S), the Woodbury system is solved in LDS (<= 64 closures) or by the blocked Gauss-Jordan sweep of
+// (k_bcr_closure_S), the Woodbury system is solved in LDS (<= 96 closures) or by the blocked Gauss-Jordan sweep of
 // dense.hip, and one launch corrects the stored right-hand sides (k_bcr_closure_correct) before the ways back.
 // No second pass over the matrix, no n x r array: 2048 closures instead of 64.
 // ---------------------------------------------------------------------------------------------
@@ -2073,43 +2073,48 @@ __global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, int maxs
     }
 }
 
-// lambda = S^-1 T for at most 64 closures: one workgroup, S in LDS, Gauss-Jordan without pivoting on [S | T] (SPD)
-__global__ __launch_bounds__(256) void k_bcr_closure_solve64(int r, int npad, const double *__restrict__ Sg,
-                                                              const double *__restrict__ Tg, double *__restrict__ lam) {
-    __shared__ double S[64][65];
-    __shared__ double T[64][3];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < r * r; e += 256) {
-        const int p = e / r, q = e - p * r;
-        S[p][q] = Sg[(size_t)p * npad + q];
+// lambda = S^-1 T for at most 96 closures: one workgroup, [S | T] in LDS, Gauss-Jordan without pivoting (SPD). Thread
+// (row p, class c) updates the columns q = c, c + 4, ... BEHIND the pivot of its row: the row's factor is formed once,
+// nobody writes the pivot's row or column during its step, so ONE barrier per pivot. (Round 4's form -- an element per
+// thread found by an integer division, three barriers per pivot, every column -- took 225 us at sixty closures, a third
+// of such an IRLS iteration and more than the blocked sweep of dense.hip needs for a hundred: round 5, ~25 us; the time
+// grows with r^2 and meets the blocked sweep's 92 us at about a hundred closures.)
+constexpr int kSolveLdsMax = 96;  // (measured at 100k views: the blocked sweep of dense.hip takes over at ~ 100 closures: 92 us there)
+__global__ __launch_bounds__(512) void k_bcr_closure_solve_lds(int r, int npad, const double *__restrict__ Sg,
+                                                                const double *__restrict__ Tg, double *__restrict__ lam) {
+    extern __shared__ double A[];  // r x ld
+    const int nc = r + 3, ld = nc | 1;
+    const int tid = threadIdx.x, p = tid >> 2, c = tid & 3;
+    for (int e = tid; e < r * nc; e += blockDim.x) {
+        const int pp = e / nc, q = e - pp * nc;
+        A[pp * ld + q] = q < r ? Sg[(size_t)pp * npad + q] : Tg[3 * pp + (q - r)];
     }
-    for (int e = tid; e < r * 3; e += 256) T[e / 3][e % 3] = Tg[e];
     __syncthreads();
     for (int k = 0; k < r; k++) {
-        const double pinv = 1.0 / S[k][k];
-        __syncthreads();
-        for (int e = tid; e < r * (r + 3); e += 256) {
-            const int p = e / (r + 3), q = e - p * (r + 3);
-            if (p == k) continue;
-            const double f = S[p][k] * pinv;
-            if (q < r) {
-                if (q != k) S[p][q] -= f * S[k][q];
-            } else {
-                T[p][q - r] -= f * T[k][q - r];
-            }
+        if (p < r && p != k) {
+            const double f = A[p * ld + k] / A[k * ld + k];
+            const double *rk = A + k * ld;
+            double *rp = A + p * ld;
+            for (int q = k + 1 + ((c - (k + 1)) & 3); q < nc; q += 4) rp[q] = fma(-f, rk[q], rp[q]);
         }
         __syncthreads();
-        for (int p = tid; p < r; p += 256)
-            if (p != k) S[p][k] = 0.0;
-        __syncthreads();
     }
-    for (int e = tid; e < r * 3; e += 256) {
-        const int p = e / 3, q = e - 3 * p;
-        lam[e] = T[p][q] / S[p][p];
+    if (p < r && c < 3) lam[3 * p + c] = A[p * ld + r + c] / A[p * ld + p];
+}
+static void bcr_launch_solve_lds(hipStream_t st, int r, int npad, const double *S, const double *T, double *lam) {
+    const size_t lds = (size_t)r * ((r + 3) | 1) * sizeof(double);
+    static std::atomic<size_t> lds_set[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 64 * 1024 && lds_set[dev & 15].load() < lds) {
+        IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_solve_lds),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[dev & 15].store(lds);
     }
+    hipLaunchKernelGGL(k_bcr_closure_solve_lds, dim3(1), dim3(r <= 64 ? 256 : 512), lds, st, r, npad, S, T, lam);
 }
 
-// lambda = Sinv T (more than 64 closures: Sinv from the blocked Gauss-Jordan sweep); a wave per row
+// lambda = Sinv T (more than 96 closures: Sinv from the blocked Gauss-Jordan sweep); a wave per row
 __global__ __launch_bounds__(256) void k_bcr_closure_lambda(int r, int npad, const double *__restrict__ Sinv,
                                                              const double *__restrict__ T, double *__restrict__ lam) {
     const int lane = threadIdx.x & 63, p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -2374,7 +2379,7 @@ static void bcr_closure_plan(Graph &g) {
     S.cl_nslots = nslots;
     S.cl_nsteps = (int)steps.size();
     S.cl_nelim = (int)elim.size();
-    S.cl_npad = r <= 64 ? r : (r + 63) / 64 * 64;
+    S.cl_npad = r <= kSolveLdsMax ? r : (r + 63) / 64 * 64;
     S.far_i.upload(g.bcr_far_i, g.stream);
     S.far_j.upload(g.bcr_far_j, g.stream);
     S.far_e.upload(g.bcr_far_e, g.stream);
@@ -2698,8 +2703,8 @@ static void bcr_run_all(Graph &g, int only) {
     hipLaunchKernelGGL((k_bcr_closure_S<B>), dim3(nt, nt), dim3(256), (size_t)32 * S.cl_maxsteps * sizeof(int), st, r, npad,
                        S.cl_maxsteps, S.cl_ndense, S.cl_dense.p, S.cl_off.p, S.cl_step.p, S.cl_R.p,
                        S.cl_W.p, S.far_e.p, g.bcr_wsrc, g.bcr_wsquare, S.cl_S.p, S.cl_T.p, S.cl_alive.p);
-    if (r <= 64) {
-        hipLaunchKernelGGL(k_bcr_closure_solve64, dim3(1), dim3(256), 0, st, r, npad, S.cl_S.p, S.cl_T.p, S.lam.p);
+    if (r <= kSolveLdsMax) {
+        bcr_launch_solve_lds(st, r, npad, S.cl_S.p, S.cl_T.p, S.lam.p);
     } else {
         dense_invert_spd(g, S.cl_S.p, npad);
         hipLaunchKernelGGL(k_bcr_closure_lambda, dim3((r + 3) / 4), dim3(256), 0, st, r, npad, S.cl_S.p, S.cl_T.p,
@@ -2994,8 +2999,8 @@ static void bcr_top_solve_closures_t(Graph &g, BcrTop &T) {
     const int nt = (npad + 15) / 16;
     hipLaunchKernelGGL((k_bcr_top_closure_S<B>), dim3(nt, nt), dim3(256), 0, st, r, npad, T.nst, T.recR.p, T.recW.p, T.Ttop.p,
                        xb + T.x_S(), xb + T.x_T(), xb + T.x_dead());
-    if (r <= 64) {
-        hipLaunchKernelGGL(k_bcr_closure_solve64, dim3(1), dim3(256), 0, st, r, npad, xb + T.x_S(), xb + T.x_T(), T.lam.p);
+    if (r <= kSolveLdsMax) {
+        bcr_launch_solve_lds(st, r, npad, xb + T.x_S(), xb + T.x_T(), T.lam.p);
     } else {
         dense_invert_spd(g, xb + T.x_S(), npad);
         hipLaunchKernelGGL(k_bcr_closure_lambda, dim3((r + 3) / 4), dim3(256), 0, st, r, npad, xb + T.x_S(), xb + T.x_T(),
@@ -3022,7 +3027,7 @@ void bcr_top_closures_alloc(Graph &g0, BcrTop &T, int r) {
     T.r = r;
     if (r <= 0) return;
     const int B = T.B, W = T.world;
-    T.npad = r <= 64 ? r : (r + 63) / 64 * 64;
+    T.npad = r <= kSolveLdsMax ? r : (r + 63) / 64 * 64;
     static const int sched[7] = {0, 2, 4, 6, 1, 5, 3};
     std::vector<int4> prog;
     std::vector<int2> elim;
