@@ -883,7 +883,7 @@ def main():
             # solver carries up to 2048 of them (forward eliminations along the elimination tree + Woodbury system,
             # bcr.hip), beyond that -- and for comparison here -- the multigrid-PCG
             from irotavg_amd import ral, synth
-            for nclose in (100, 1000):
+            for nclose in (30, 100, 1000):
                 Sc = synth.add_closures(S, nclose, seed=7, wrong=max(1, nclose // 33))
                 Qc = np.zeros((Sc["n"], 4)); Qc[:, 3] = 1; Qc[0] = Sc["Qgt"][0]
                 ral.init_mst(Qc, Sc["QQ"], Sc["I"], 1)
@@ -912,7 +912,7 @@ def main():
                 # box can make about that path's cost (eight ranks' work in sequence; a node runs them side by side)
                 shard_leg = {}
                 for off, tag in ((False, "direct"), (True, "pcg")):
-                    if nclose == 1000 and off:
+                    if nclose != 100 and off:
                         continue
                     if off:
                         os.environ["IROTAVG_DIST_NO_CLOSURES"] = "1"
