@@ -78,8 +78,8 @@ typedef struct irotavg_options {
     int pcg_classic;           /* 1: the PCG iteration always runs as separate launches (default 0: on one
                                   GPU a graph without loop closures runs it as two launches, cgcg.hip) */
     int band_direct;           /* a graph whose edges between free views all span <= 32 views -- a view sequence --
-                                  except for at most 64 long-range edges (loop closures) has a banded operator plus
-                                  a low-rank part; on one GPU its linear systems are then solved DIRECTLY (block
+                                  except for at most 2048 long-range edges (loop closures) has a banded operator plus
+                                  a low-rank part; its linear systems are then solved DIRECTLY -- on one GPU and on shards -- (block
                                   cyclic reduction + Woodbury correction, bcr.hip) instead of the PCG:
                                   0 (default) = when it has more than 2048 free views (smaller graphs are one
                                   dense level already), 1 = whenever the band allows, -1 = never */

@@ -56,7 +56,8 @@ struct Dist {
     hipStream_t stream = nullptr;
     irotavg_options opt{};
     irotavg_stats stats{};
-    // A view sequence without loop closures is solved DIRECTLY also when it is sharded (bcr.hip): every rank
+    // A view sequence (round 5: also with up to 2048 loop closures, cl_edge below) is solved DIRECTLY also when it is
+    // sharded (bcr.hip): every rank
     // reduces its range of the banded operator to its last block, ONE gather of the `world` separators replaces
     // the ~22 halo exchanges + all-reduces of a PCG solve, every rank solves the separator system and walks back.
     int bcr_B = 0;  // block size; 0: the sharded PCG
