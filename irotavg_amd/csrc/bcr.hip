@@ -2887,7 +2887,9 @@ static void bcr_launch_forward(hipStream_t st, const BcrClPlan &P, int r, int ns
     // Many closures (more than two per CU): a wave per closure, LDS for the slots only (measured at a thousand closures:
     // 65 us against 100).
     const size_t lds_wg = ((size_t)4 * B * (3 * B + 3) + (size_t)4 * (3 * B + 3) + (size_t)nslots * B) * sizeof(double);
-    if (r <= 400 && lds_wg <= 150 * 1024 && !getenv("IROTAVG_BCR_FORWARD_WAVE")) {
+    // (blocks of 32: 100 KB, one workgroup per CU -- the chip takes 256 closures at a time then)
+    const int r_wg = lds_wg * 2 <= 150 * 1024 ? 400 : 256;
+    if (r <= r_wg && lds_wg <= 150 * 1024 && !getenv("IROTAVG_BCR_FORWARD_WAVE")) {
         static std::atomic<size_t> lds_set[16];
         if (lds_wg > 64 * 1024 && lds_set[dev & 15].load() < lds_wg) {
             IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_forward<B>),
