@@ -146,12 +146,13 @@ def test_mixed_level_one():
 closure_graph = synth.closure_graph
 
 
-# 5 ... 64 closures: the Woodbury system is solved in LDS; 65, 300, 1000: by the blocked Gauss-Jordan sweep (round 4:
+# 5 ... 96 closures: the Woodbury system is solved in LDS (round 5; 64 until then); 97, 300, 1000: by the blocked Gauss-Jordan sweep (round 4:
 # the closures' forward eliminations follow their paths up the elimination tree, bcr.hip; round 3 took at most 64,
 # sixteen per re-factorisation); blocks of 8, 12, 16, 24 and 32
 @pytest.mark.parametrize("n,m,nclose,wrong,block", [(3000, 12000, 5, 1, 8), (3000, 45000, 20, 3, 16),
                                                     (4000, 80000, 40, 4, 24), (5000, 20000, 64, 6, 8),
-                                                    (5000, 20000, 65, 6, 8), (6000, 60000, 300, 20, 12),
+                                                    (5000, 20000, 65, 6, 8), (5000, 20000, 96, 6, 8), (5000, 20000, 97, 6, 8),
+                                                    (6000, 60000, 300, 20, 12),
                                                     (2511, 74830, 100, 8, 32), (20000, 300000, 1000, 40, 16)])
 def test_loop_closures_on_the_direct_path_match_oracle(n, m, nclose, wrong, block):
     """A sequence with a few loop closures -- the SLAM case (src/IRotAvg.cpp:371-378 re-solves the whole graph on

@@ -224,7 +224,7 @@ def closure_problem(n, m, nclose, wrong, seed=7):
 
 
 @pytest.mark.parametrize("n,m,nclose,wrong,world", [(3000, 12000, 5, 1, 2), (3000, 45000, 20, 3, 4), (4000, 80000, 40, 4, 3),
-                                                    (5000, 20000, 64, 6, 6), (5000, 20000, 65, 6, 5),
+                                                    (5000, 20000, 64, 6, 6), (5000, 20000, 65, 6, 5), (5000, 20000, 96, 6, 4), (5000, 20000, 97, 6, 3),
                                                     (6000, 60000, 300, 20, 8), (2511, 74830, 100, 8, 2),
                                                     (20000, 300000, 1000, 40, 8), (20000, 300000, 1000, 40, 1)])
 def test_loopback_sharded_sequence_with_closures_matches_the_oracle(n, m, nclose, wrong, world):
