@@ -195,7 +195,7 @@ int irotavg_graph_set_weights(irotavg_graph *g, const double *weights);         
  * A handle on the banded direct solver that carries loop closures checks every closure solve against the FULL system
  * (relative residual options.pcg_rtol, 1e-10 by default; repaired by conjugate gradients with the direct solve as the preconditioner when it is
  * above). IROTAVG_ERR_SOLVER from irls then means: the band part alone is next to singular under the closures (robust
- * weights at their floor over whole stretches of a thin chain) and the repair stalled above 1e-6 -- the rotations are
+ * weights at their floor over whole stretches of a thin chain) and the repair stalled above 1e-8 -- the rotations are
  * what the last good iteration left; such a graph belongs to the iterative solver (options.band_direct = -1). The
  * one-shot irotavg_irls and irotavg_viewgraph_rot_avg repeat the call that way by themselves; the handle API and the
  * sharded handle (irotavg_dist_irls: the same check, by iterative refinement on the sharded operator) report it. */

@@ -968,7 +968,7 @@ static int bcr_dist_checked(Dist &D) {
     if (rc != IROTAVG_OK) return rc;
     // (what the iterations reached must still be a solution -- see run_irls: a band part next to singular under hundreds
     // of closures is no case for the Woodbury form; the caller creates the handle with band_direct = -1)
-    if (!std::isfinite(worst) || !(worst <= 1e-6)) return IROTAVG_ERR_SOLVER;
+    if (!std::isfinite(worst) || !(worst <= kClosureRepairAccept)) return IROTAVG_ERR_SOLVER;
     return IROTAVG_OK;
 }
 static int solve_dist(Dist &D) { return D.bcr_B ? bcr_dist_checked(D) : pcg_dist_any(D); }

@@ -300,6 +300,9 @@ int bcr_levels(Graph &g);
 int bcr_info(Graph &g, int64_t *out, int cap);
 int bcr_residual(Graph &g, double *relres);  // ||b - A x|| / ||b|| per coordinate of the last direct solve (one pass over level 0)
 int bcr_closures(Graph &g);  // loop closures the direct solver of this handle carries
+// a closure solve that had to be repaired (CG with the direct solve as the preconditioner) is taken at this relative residual
+// or better; above it the system counts as not solved (IROTAVG_ERR_SOLVER), on one GPU and on shards alike
+constexpr double kClosureRepairAccept = 1e-8;
 bool bcr_band_part_anchored(int64_t m, int f, int64_t nu, int B, const int32_t *I);  // the band part alone is positive definite (exact)
 int bcr_apply_slots(Graph &g);
 void bcr_gate(Graph &g);  // flags[FL_DONE] = 1 unless the last direct solve with closures saw a dead pivot (flags[3] = their number)

@@ -2424,14 +2424,15 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                         g.stats.pcg_stagnated += 1;
                         rc = IROTAVG_OK;
                     }
-                    // What those iterations reached must still be a solution. Where the band part is next to singular
+                    // What those iterations reached must still be a solution (relative residual 1e-8; a first bar of 1e-6 let a
+                    // run through that ended 1e-5 rad off the oracle: fuzz seed 36 case 93). Where the band part is next to singular
                     // (a thin chain whose robust weights are at their floor over whole stretches, held together by
                     // hundreds of closures: fuzz seed 22 case 69) the Woodbury solve is no approximate inverse at all and
                     // the repair stalls at 1e-3: an ERROR, rotations untouched -- such a graph belongs to the iterative
                     // solver (band_direct = -1), which the one-shot calls and ViewGraph::rotAvg then take by themselves.
                     if (rc == IROTAVG_OK && inexact_only) {
                         const double worst = std::max(g.stats.last_relres[0], std::max(g.stats.last_relres[1], g.stats.last_relres[2]));
-                        if (!(worst <= 1e-6)) rc = IROTAVG_ERR_SOLVER;
+                        if (!(worst <= kClosureRepairAccept)) rc = IROTAVG_ERR_SOLVER;
                     }
                     // (tests: the give-up path on a graph the iterative solver can take)
                     if (std::getenv("IROTAVG_BCR_FAKE_GIVE_UP")) rc = IROTAVG_ERR_SOLVER;
