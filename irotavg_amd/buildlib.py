@@ -36,14 +36,18 @@ def build(force=False, verbose=False):
         return LIB
     objs = []
     procs = []
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
     for src in SOURCES:
         obj = os.path.join(CSRC, src + ".o")
+        objs.append(obj)
+        # an object that is newer than its source and every header is kept (force=True recompiles everything)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            continue
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
-        objs.append(obj)
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)

@@ -2103,7 +2103,22 @@ int pcg_solve(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
 int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ran) {
     if (tail_ran) *tail_ran = false;
     Level &L0 = g.levels[0];
-    const double rtol2 = g.opt.pcg_rtol * g.opt.pcg_rtol;
+    // A graph that is ONE dense level (<= mg_dense_max views) has the explicit inverse of its whole operator as the
+    // preconditioner: an iteration is a step of iterative refinement. Stopping at pcg_rtol = 1e-10 leaves an error of up
+    // to cond * 1e-10 in the step -- on a barely connected graph (cond 1e6) whose IRLS iteration does not contract that
+    // is amplified from outer iteration to outer iteration until the strict `score > change_th` test
+    // (ral/l1_irls.cpp:590) ends the run after a different number of iterations than any exact factorisation would:
+    // fuzz seed 603 case 163, 15 iterations and 0.11 rad where four exact CPU solves agree on 13 (tools/referee.py,
+    // tests/test_gpu_referee.py). Such a level is therefore solved to the residual it can ATTAIN, as the reference's
+    // factorisations are (:536-556): the device tests against kRefineTol, and the host takes the iterate once the
+    // residual is within pcg_rtol and has stopped halving (or after kRefineExtra more iterations).
+    constexpr double kRefineTol = 1e-15;
+    constexpr int kRefineExtra = 6;
+    static const bool no_refine = std::getenv("IROTAVG_NO_DENSE_REFINE") != nullptr;
+    const bool refine = g.levels.size() == 1 && g.ndense > 0 && !g.bcr_B && g.ng == 0 && !no_refine &&
+                        g.opt.pcg_rtol > kRefineTol;
+    const double rtol_dev = refine ? kRefineTol : g.opt.pcg_rtol;
+    const double rtol2 = rtol_dev * rtol_dev;
     const int gr = grid_for_rows(L0);
     IRH_CHECK(hipMemsetAsync(g.flags.p, 0, sizeof(int) * FL_COUNT, g.stream));
     // with the level-1 down-sweep fused into the update (l1_fused) the residual ping-pongs between
@@ -2174,13 +2189,17 @@ int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ra
     int best_it = 0;
     bool stagnated = false;
     bool first_poll = true;
+    bool attained = false;      // refine: the residual is within pcg_rtol and no longer falls
+    int met_it = -1;            // refine: the iteration at which pcg_rtol was first seen met
+    double met_prev = HUGE_VAL;
     double *h_scal = g.h_scal();
+    if (refine) chunk = std::min(chunk, 2);
     while (true) {
         for (int c = 0; c < chunk; c++) {
             PrecInfo pi = precondition(g, it == 0, rtol2);
             iteration_tail(pi);
         }
-        chunk = g.bcr_guard ? 1 : std::max(2, check / 2);
+        chunk = (g.bcr_guard || refine) ? 1 : std::max(2, check / 2);
         // the convergence test of the last update runs in the next preconditioner prologue
         PrecInfo pi = precondition(g, it == 0, rtol2);
         const bool with_tail = tail != nullptr && first_poll;
@@ -2190,6 +2209,14 @@ int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ra
         first_poll = false;
         if (h_flags[FL_DONE] != 0) break;
         const double cur = std::max(h_scal[SC_RELRES], std::max(h_scal[SC_RELRES + 1], h_scal[SC_RELRES + 2]));
+        if (refine && cur <= g.opt.pcg_rtol) {
+            if (met_it < 0) met_it = it;
+            if (!(cur < 0.5 * met_prev) || it - met_it >= kRefineExtra) {
+                attained = true;
+                break;
+            }
+            met_prev = cur;
+        }
         if (cur < 0.5 * best) {
             best = cur;
             best_it = it;
@@ -2201,10 +2228,11 @@ int pcg_solve_classic(Graph &g, const std::function<void()> *tail, bool *tail_ra
         iteration_tail(pi);  // not converged: that preconditioner pass is the next iteration's
     }
     g.stats.pcg_solves += 1;
-    g.stats.pcg_iters += stagnated ? it : h_flags[FL_ITERS];
-    g.stats.pcg_iters_last = stagnated ? it : h_flags[FL_ITERS];
+    g.stats.pcg_iters += (stagnated || attained) ? it : h_flags[FL_ITERS];
+    g.stats.pcg_iters_last = (stagnated || attained) ? it : h_flags[FL_ITERS];
     for (int c = 0; c < 3; c++) g.stats.last_relres[c] = h_scal[SC_RELRES + c];
     if (h_flags[FL_DONE] == 2) return IROTAVG_ERR_SOLVER;
+    if (attained) return IROTAVG_OK;
     if (stagnated) {
         g.stats.pcg_stagnated += 1;
         return IROTAVG_OK;
