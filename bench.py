@@ -430,6 +430,34 @@ def pcg_iteration_roofline(S, st, kr, ia=None, iu=None):
             "own_bytes_both_kernels": kr["cg_apply"]["bytes"] + kr["cg_update"]["bytes"]}
 
 
+# DESIGN.md section 7's table "expected 1 -> 8 numbers, for the first hardware run to falsify", machine-readable:
+# ms per irls call by number of GPUs, from single-GPU kernel times, the loopback runs and 10-20 us per small RCCL
+# collective on xGMI. Nothing in it has run on more than one GPU.
+EXPECTED_MS_PER_IRLS = {
+    "100k/2M sequence, sharded direct solver": {1: 1.62, 2: 2.4, 4: 2.1, 8: 2.0},
+    "1M/20M sequence, sharded direct solver": {1: 16.7, 2: 10.5, 4: 6.3, 8: 4.4},
+    "100k/2M with 2% loop edges, sharded PCG": {1: 13.4, 2: 16.0, 4: 14.0, 8: 14.0},
+    "100k/2M + 100 loop closures, sharded direct solver": {1: 2.97, 2: 4.0, 4: 3.6, 8: 3.5},
+}
+
+
+def expected_scaling(args, world):
+    key = None
+    if args.views == 100000 and args.edges == 2000000:
+        key = "100k/2M sequence, sharded direct solver" if args.p_loop == 0.0 else (
+            "100k/2M with 2% loop edges, sharded PCG" if abs(args.p_loop - 0.02) < 1e-12 else None)
+    elif args.views == 1000000 and args.edges == 20000000 and args.p_loop == 0.0:
+        key = "1M/20M sequence, sharded direct solver"
+    if key is None:
+        return {"workload": None, "note": "no expectation recorded for this size (DESIGN.md section 7 has 100k/2M and 1M/20M)"}
+    t = EXPECTED_MS_PER_IRLS[key]
+    return {"workload": key, "ms_per_step_by_gpus": {str(k): v for k, v in t.items()},
+            "ms_per_step": t.get(world), "speedup_vs_1_gpu": (t[1] / t[world]) if world in t else None,
+            "falsified_if": "ms_per_step differs from the expectation by more than 1.5x either way",
+            "source": "DESIGN.md section 7: single-GPU kernel times + loopback runs + 10-20 us per small RCCL collective; "
+                      "never measured on more than one GPU"}
+
+
 def host_throttled_usec():
     """Microseconds this process's cgroup has spent throttled by its CPU quota so far (cgroup v2 cpu.stat), or None."""
     try:
@@ -464,6 +492,10 @@ def main():
                     help="A/B: the classic PCG recurrences (separate launches) instead of the two-launch iteration")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the sharded (RCCL) path even with one rank (exercises it on a 1-GPU box)")
+    ap.add_argument("--allow-hosted", action="store_true",
+                    help="N > 1 only: if the library's RCCL communicator cannot be formed, run the same sharded solver over "
+                         "the host-staged wire (torch.distributed/gloo) instead of FAILING. Without this flag a multi-GPU "
+                         "run either measures RCCL over xGMI or exits non-zero -- it can never silently measure gloo")
     ap.add_argument("--cpu-only", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_only:
@@ -536,11 +568,22 @@ def main():
         ok = torch.tensor([1 if D is not None else 0], dtype=torch.int32, device="cpu" if share else "cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
-            # every rank falls back together: the same sharded solver over the hosted transport
-            # (irotavg_dist_create_hosted: halo + all-reduce staged through host buffers and moved by
-            # torch.distributed/gloo) -- slower per exchange, same arithmetic
             if D is not None:
                 D.close()
+            if not args.allow_hosted:
+                # A scaling run must measure RCCL over xGMI or nothing: every rank leaves with an error (rank 0 prints one
+                # JSON line that says so, for whoever parses the output).
+                if rank == 0:
+                    print(json.dumps({"metric": "IRLS edge-updates/sec (+ iters-to-converge)", "value": None,
+                                      "n_gpus": world, "error": "RCCL communicator could not be formed on every rank; "
+                                      "refusing to measure the host-staged wire (pass --allow-hosted to do that on purpose)",
+                                      "dist": {"wire": "none", "ncclCommCount": 0}}), flush=True)
+                dist.barrier()
+                dist.destroy_process_group()
+                sys.exit(3)
+            # --allow-hosted: every rank falls back together: the same sharded solver over the hosted transport
+            # (irotavg_dist_create_hosted: halo + all-reduce staged through host buffers and moved by
+            # torch.distributed/gloo) -- slower per exchange, same arithmetic
             hosted = dist.new_group(backend="gloo")
             D = capi.DistGraph(S["I"], S["QQ"], S["n"], 1, world, rank=rank,
                                transport=capi.torch_transport(hosted), pcg_rtol=args.rtol, device=dev)
@@ -576,6 +619,16 @@ def main():
     dstats = D.stats() if D is not None else None
     if D is not None:
         dinfo = D.info()   # wire actually used + ranks of the RCCL communicator as RCCL counts them
+        # where an iteration goes, phase by phase (irotavg_dist_timing): a few UNTIMED solves with the phase clock on --
+        # the stream is drained at every phase boundary, so the phases are to be read against each other
+        D.timing(True)
+        for _ in range(3):
+            step()
+        dphases = D.timing(False)
+        tp = torch.tensor([dphases["us_per_iteration"][k] for k in capi.DistGraph.TIMING_PHASES], dtype=torch.float64,
+                          device="cpu" if share else "cuda")
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)   # the slowest rank's phases
+        dphases["us_per_iteration_max_over_ranks"] = {k: float(tp[i].item()) for i, k in enumerate(capi.DistGraph.TIMING_PHASES)}
         D.close()
         if rank == 0:   # kernel rooflines are measured on a single-GPU handle of the same graph
             G = capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=args.rtol, device=dev)
@@ -622,6 +675,21 @@ def main():
         line["build"] = build_record
         if dstats is not None:
             line["config"]["dist"] = dinfo
+            # the first multi-GPU run diagnoses itself: the wire that carried it, RCCL's own count of the communicator,
+            # per-phase microseconds of an IRLS iteration, and what DESIGN.md section 7 expects this run to show
+            line["dist"] = {
+                "wire": dinfo["wire"], "ncclCommCount": dinfo["rccl_comm_ranks"], "world": world,
+                "hosted_allowed": bool(args.allow_hosted),
+                "valid_scaling_measurement": bool(dinfo["wire"] == "rccl" and dinfo["rccl_comm_ranks"] == world and not share),
+                "sharded_solver": "direct" if dinfo.get("direct_block") else "pcg",
+                "closures": dinfo.get("closures", 0),
+                "phases_us_per_iteration": dphases["us_per_iteration_max_over_ranks"],
+                "phases_us_per_iteration_rank0": dphases["us_per_iteration"],
+                "phases_iterations": dphases["iterations"],
+                "phases_note": "3 untimed solves with irotavg_dist_timing on (stream drained at every phase boundary: read the "
+                               "phases against each other, their sum exceeds the undisturbed iteration); max over ranks",
+                "expected": expected_scaling(args, world),
+            }
         if args.no_kernels:
             G.close()
             print(json.dumps(line), flush=True)

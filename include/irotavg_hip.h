@@ -397,6 +397,14 @@ int irotavg_dist_get_stats(irotavg_dist *d, irotavg_stats *out);
  * closures that solver carries (Woodbury correction across the ranks: besides the gather the ranks SUM one buffer of
  * r x world x B + r^2 + 4 r doubles per linear solve). */
 int irotavg_dist_info(irotavg_dist *d, int64_t info[8]);
+/* Diagnostic of a first multi-GPU run -- where an IRLS iteration of the sharded handle spends its time. enable != 0:
+ * clear the counters and switch the phase clock ON for the following irotavg_dist_irls calls (the stream is drained at
+ * every phase boundary: such calls are slower than undisturbed ones, never time them); enable == 0: switch it off. Either
+ * way the means collected so far are returned first: us_per_iteration[0] local edge kernels + assembly, [1] local
+ * reductions (closures' forward eliminations; the whole solve on the sharded PCG), [2] gather of the separators, [3] sum
+ * of the closures' buffer, [4] separator system + corrections + ways back, [5] halo of the step, [6] weights + rotation
+ * update, [7] score all-reduce; *iterations = IRLS iterations they are means over. Either pointer may be NULL. */
+int irotavg_dist_timing(irotavg_dist *d, int enable, double us_per_iteration[8], int64_t *iterations);
 int irotavg_dist_plan(irotavg_dist *d, int local_index, int64_t counts[6], int *peers, int *send_cnt,
                       int *recv_cnt, int cap);
 /* host-only partition plan of one rank (no GPU): see irotavg_amd/csrc/dist.hip */

@@ -39,6 +39,7 @@ SYMBOLS = [
     "irotavg_graph_direct_residual",
     "irotavg_window_solve", "irotavg_window_solve_kernel", "irotavg_trim_memory", "irotavg_rmat2quat", "irotavg_quat2rmat", "irotavg_viewgraph_save_poses",
     "irotavg_oneshot_cache", "irotavg_oneshot_cache_clear", "irotavg_oneshot_cache_stats",
+    "irotavg_dist_timing",
 ]
 
 
@@ -183,6 +184,7 @@ def lib():
                                              C.c_int64, C.c_int, _ip, _dp, C.c_int64, C.POINTER(Options)]
     L.irotavg_dist_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.irotavg_dist_info.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.irotavg_dist_timing.argtypes = [vp, C.c_int, _dp, C.POINTER(C.c_int64)]
     L.irotavg_dist_plan.argtypes = [vp, C.c_int, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.c_int]
     L.irotavg_dist_plan_host.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _ip, _i64p,
@@ -612,6 +614,18 @@ class DistGraph:
         return dict(wire=["loopback", "rccl", "host-staged"][v[0]], rccl_comm_ranks=int(v[1]),
                     local_shards=int(v[2]), world=int(v[3]), ghost_views=int(v[4]), peers=int(v[5]),
                     direct_block=int(v[6]), closures=int(v[7]))
+
+    TIMING_PHASES = ["local_edge_kernels_and_assembly", "local_reductions", "gather_of_separators", "closure_sum",
+                     "separator_system_and_ways_back", "halo_of_the_step", "weights_and_rotation_update",
+                     "score_allreduce"]
+
+    def timing(self, enable):
+        """irotavg_dist_timing: the per-phase means (us per IRLS iteration) collected so far, then the phase clock is
+        switched on (cleared) or off. A diagnostic: calls made under it are slower and must not be timed."""
+        v = (C.c_double * 8)()
+        n = C.c_int64(0)
+        check(lib().irotavg_dist_timing(self._h, 1 if enable else 0, v, C.byref(n)), "dist_timing")
+        return dict(iterations=int(n.value), us_per_iteration={k: float(v[i]) for i, k in enumerate(self.TIMING_PHASES)})
 
     def stats(self):
         s = Stats()

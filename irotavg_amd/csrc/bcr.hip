@@ -120,6 +120,7 @@ struct BcrState {
     DevBuf<int> cl_dense;        // cl_ndense x nfar: the step of closure q on dense elimination d, or -1
     // a shard of a sharded sequence (dist.hip): the separator before the first chunk is the previous rank's
     int ext0 = 0;
+    int dbg_word = -1;         // development aid: the debug word of the NEXT solves of this handle (bcr_stamps*); -1: IROTAVG_BCR_DBG
     DevBuf<long long> stamps;  // development aid: bcr_stamp
     DevBuf<unsigned> up_cnt;   // k_bcr_reduce_up: arrivals per level boundary (they only grow: solve g waits for g x chunks);
                                // word kUpLevels: a wait gave up (bcr_up_failed)
@@ -2508,7 +2509,11 @@ static void bcr_run(Graph &g, int only, int pass, bool open_top = false, int pha
     Level &L0 = g.levels[0];
     hipStream_t st = g.stream;
     const int nl = (int)S.lev.size();
-    const int dbg = getenv("IROTAVG_BCR_DBG") ? atoi(getenv("IROTAVG_BCR_DBG")) : 0;
+    // (the stamp helpers steer ONE handle through BcrState::dbg_word instead of rewriting the process environment under
+    // other handles' and threads' solves -- advisor, round 5; the library itself never writes the environment)
+    const char *env_s = getenv("IROTAVG_BCR_DBG");
+    const int env_dbg = env_s ? atoi(env_s) : 0;
+    const int dbg = S.dbg_word >= 0 ? S.dbg_word : env_dbg;
     long long *stamps = nullptr;
     if (dbg & 64) {
         if (!S.stamps.p) S.stamps.alloc((size_t)S.lev[0].nch * 16);
@@ -3231,16 +3236,17 @@ int bcr_stamps_up(Graph &g, double *out) {
     if (!g.bcr_B) return IROTAVG_ERR_BAD_ARG;
     bcr_alloc(g);
     BcrState &S = *g.bcr;
-    const char *old = getenv("IROTAVG_BCR_DBG");
-    const std::string keep = old ? old : "";
     const char *wgs = getenv("IROTAVG_BCR_STAMP_CHUNK");
-    setenv("IROTAVG_BCR_DBG", std::to_string(128 + 256 * (wgs ? atoi(wgs) : 0)).c_str(), 1);
+    struct DbgScope {
+        BcrState &S;
+        ~DbgScope() { S.dbg_word = -1; }
+    } dbg_scope{S};
+    S.dbg_word = 128 + 256 * (wgs ? atoi(wgs) : 0);
     const size_t cnt = (size_t)std::max(S.lev[0].nch * 16, 32 * kUpLevels);
     if (!S.stamps.p) S.stamps.alloc(cnt);
     IRH_CHECK(hipMemsetAsync(S.stamps.p, 0, sizeof(long long) * cnt, g.stream));
     const int rc = bcr_solve(g, -1);
-    if (old) setenv("IROTAVG_BCR_DBG", keep.c_str(), 1);
-    else unsetenv("IROTAVG_BCR_DBG");
+    S.dbg_word = -1;
     if (rc != IROTAVG_OK) return rc;
     long long h[32 * kUpLevels];
     IRH_CHECK(hipMemcpyAsync(h, S.stamps.p, sizeof(h), hipMemcpyDeviceToHost, g.stream));
@@ -3257,14 +3263,15 @@ int bcr_stamps(Graph &g, int level, int chunk, double *out) {
     bcr_alloc(g);
     BcrState &S = *g.bcr;
     if (level < 0 || level >= (int)S.lev.size() || chunk < 0 || chunk >= S.lev[level].nch) return IROTAVG_ERR_BAD_ARG;
-    const char *old = getenv("IROTAVG_BCR_DBG");
-    const std::string keep = old ? old : "";
-    setenv("IROTAVG_BCR_DBG", "64", 1);
+    struct DbgScope {
+        BcrState &S;
+        ~DbgScope() { S.dbg_word = -1; }
+    } dbg_scope{S};
+    S.dbg_word = 64;
     if (!S.stamps.p) S.stamps.alloc((size_t)S.lev[0].nch * 16);
     IRH_CHECK(hipMemsetAsync(S.stamps.p, 0, sizeof(long long) * (size_t)S.lev[0].nch * 16, g.stream));
     const int rc = bcr_solve(g, level);
-    if (old) setenv("IROTAVG_BCR_DBG", keep.c_str(), 1);
-    else unsetenv("IROTAVG_BCR_DBG");
+    S.dbg_word = -1;
     if (rc != IROTAVG_OK) return rc;
     long long h[16];
     IRH_CHECK(hipMemcpyAsync(h, S.stamps.p + (size_t)chunk * 16, sizeof(h), hipMemcpyDeviceToHost, g.stream));

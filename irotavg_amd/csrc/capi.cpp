@@ -694,15 +694,30 @@ void oneshot_keep(irotavg_graph *h, const OneShotKey &k) {
 
 // handle for a one-shot call: the kept one or a new one; `cached` says whether it goes back to the slot afterwards
 int oneshot_open(irotavg_graph **h, OneShotKey *key, bool *cached, int64_t m, int64_t n_total, int f, const int32_t *I,
-                 const double *QQ, int64_t ldqq) {
+                 const double *QQ, int64_t ldqq, bool *hit = nullptr) {
     *cached = oneshot_cache_on() && I && QQ && m > 0 && ldqq >= m && irotavg_device_count() > 0;
     *h = nullptr;
+    if (hit) *hit = false;
     if (*cached) {
         *key = oneshot_key(m, n_total, f, I, QQ, ldqq);
         *h = oneshot_take(*key);
-        if (*h) return IROTAVG_OK;
+        if (*h) {
+            if (hit) *hit = true;
+            return IROTAVG_OK;
+        }
     }
     return irotavg_graph_create(h, m, n_total, f, I, QQ, ldqq, nullptr);
+}
+// A call that failed with a device or memory error on a KEPT handle (one that a device reset invalidated, or whose
+// pinned buffers are what the new work could not allocate next to) would have succeeded before handles were kept: the
+// kept one is destroyed, the pools are trimmed and the call gets ONE more attempt on a fresh handle (advisor, round 5).
+bool oneshot_retry_fresh(irotavg_graph **h, bool hit, int rc, int64_t m, int64_t n_total, int f, const int32_t *I,
+                         const double *QQ, int64_t ldqq) {
+    if (!hit || (rc != IROTAVG_ERR_HIP && rc != IROTAVG_ERR_NOMEM)) return false;
+    if (*h) irotavg_graph_destroy(*h);
+    *h = nullptr;
+    (void)irotavg_trim_memory();
+    return irotavg_graph_create(h, m, n_total, f, I, QQ, ldqq, nullptr) == IROTAVG_OK;
 }
 // the handle of a failed one-shot call replaced by one that solves iteratively (band_direct = -1) -- when the failed one
 // was a direct-solver handle with loop closures; false: nothing to retry with
@@ -757,15 +772,19 @@ int irotavg_irls(int64_t m, int64_t n_total, int f, const int32_t *I, const doub
     };
     irotavg_graph *h = nullptr;
     OneShotKey key;
-    bool cached = false;
-    int rc = oneshot_open(&h, &key, &cached, m, n_total, f, I, QQ, ldqq);
+    bool cached = false, hit = false;
+    int rc = oneshot_open(&h, &key, &cached, m, n_total, f, I, QQ, ldqq, &hit);
     if (rc != IROTAVG_OK) return rc;
     lap("handle (kept or created)");
-    rc = irotavg_graph_set_rotations(h, Q, ldq);
-    lap("set_rotations");
-    if (rc == IROTAVG_OK)
-        rc = irotavg_graph_irls(h, cost, sigma, max_iters, change_th, iters, runtime, nullptr);
-    lap("irls");
+    for (int attempt = 0; attempt < 2; attempt++) {
+        rc = irotavg_graph_set_rotations(h, Q, ldq);
+        lap("set_rotations");
+        if (rc == IROTAVG_OK)
+            rc = irotavg_graph_irls(h, cost, sigma, max_iters, change_th, iters, runtime, nullptr);
+        lap("irls");
+        if (attempt == 1 || !oneshot_retry_fresh(&h, hit, rc, m, n_total, f, I, QQ, ldqq)) break;
+    }
+    if (!h) return rc;
     if (rc == IROTAVG_ERR_SOLVER && oneshot_retry_iterative(&h, m, n_total, f, I, QQ, ldqq)) {
         // the direct solver gave the graph up (closures on a band part that is next to singular, run_irls): once more
         // on the iterative solver, from the caller's rotations (nothing was written back) -- the reference has one
@@ -792,11 +811,15 @@ int irotavg_l1ra(int64_t m, int64_t n_total, int f, const int32_t *I, const doub
     if (!Q || !iter || !runtime) return IROTAVG_ERR_BAD_ARG;
     irotavg_graph *h = nullptr;
     OneShotKey key;
-    bool cached = false;
-    int rc = oneshot_open(&h, &key, &cached, m, n_total, f, I, QQ, ldqq);
+    bool cached = false, hit = false;
+    int rc = oneshot_open(&h, &key, &cached, m, n_total, f, I, QQ, ldqq, &hit);
     if (rc != IROTAVG_OK) return rc;
-    rc = irotavg_graph_set_rotations(h, Q, ldq);
-    if (rc == IROTAVG_OK) rc = irotavg_graph_l1ra(h, max_iters, change_th, iter, runtime, nullptr);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        rc = irotavg_graph_set_rotations(h, Q, ldq);
+        if (rc == IROTAVG_OK) rc = irotavg_graph_l1ra(h, max_iters, change_th, iter, runtime, nullptr);
+        if (attempt == 1 || !oneshot_retry_fresh(&h, hit, rc, m, n_total, f, I, QQ, ldqq)) break;
+    }
+    if (!h) return rc;
     if (rc == IROTAVG_OK || rc == IROTAVG_ERR_NOT_CONVERGED) (void)irotavg_graph_get_rotations(h, Q, ldq);
     oneshot_close(h, key, cached, rc);
     return rc;

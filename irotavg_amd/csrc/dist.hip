@@ -68,7 +68,24 @@ struct Dist {
     // derives the same list from the global graph. Woodbury correction across the ranks: bcr.hip, "loop closures on a
     // sharded sequence".
     std::vector<int64_t> cl_edge;
+    // Diagnostic of a first multi-GPU run (irotavg_dist_timing; OFF in every timed region): wall time per phase of an
+    // IRLS iteration, the stream drained at every phase boundary -- which adds to the total, so the phases are to be
+    // read against each other, not against the undisturbed step. Phases: kDistPhases below.
+    bool timing = false;
+    double t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double t_mark = 0.0;
+    int64_t t_iters = 0;
 };
+// 0 local edge kernels + assembly | 1 local reductions (closures' forward eliminations; the whole solve on the sharded
+// PCG) | 2 gather of the separators | 3 closure sum | 4 separator system, corrections, ways back | 5 halo of the step |
+// 6 weights + rotation update | 7 score all-reduce
+static inline void tmark(Dist &D, int phase) {
+    if (!D.timing) return;
+    (void)hipStreamSynchronize(D.stream);
+    const double t = now_seconds();
+    if (phase >= 0 && phase < 8) D.t_acc[phase] += t - D.t_mark;
+    D.t_mark = t;
+}
 
 #define NCCL_CHECK(expr)                                                                      \
     do {                                                                                      \
@@ -707,6 +724,7 @@ static int bcr_dist(Dist &D) {
         bcr_shard_reduce(sp->g, T, sp->rank);
         if (cl) bcr_shard_closures_forward(sp->g, T, sp->rank);
     }
+    tmark(D, 1);
     if (D.hosted) {
         const size_t n0 = T.n_doubles(), n1 = cl ? T.x_doubles() : 0;
         if (n0 + n1 > 0x7fffffffULL) throw HipError{hipErrorUnknown};
@@ -726,8 +744,11 @@ static int bcr_dist(Dist &D) {
         NCCL_CHECK(ncclAllGather(T.rec.p + (size_t)rank * T.record_doubles(), T.rec.p, T.record_doubles(), ncclDouble, D.comm,
                                  D.stream));
         bcr_top_from_records(T, D.stream);
+        tmark(D, 2);
         if (cl) NCCL_CHECK(ncclAllReduce(T.xbuf.p, T.xbuf.p, T.x_doubles(), ncclDouble, ncclSum, D.comm, D.stream));
+        if (cl) tmark(D, 3);
     }  // loopback: the shards of this process share the buffers
+    tmark(D, 2);  // (the hosted wire moves separators and closure buffer in one sum: all of it under "gather")
     if (cl) {
         bcr_top_solve_closures(D.shards[0]->g, T);
         for (auto &sp : D.shards) bcr_shard_closures_correct(sp->g, T);
@@ -735,6 +756,7 @@ static int bcr_dist(Dist &D) {
         bcr_top_solve(D.shards[0]->g, T);
     }
     for (auto &sp : D.shards) bcr_shard_back(sp->g, T, sp->rank);
+    tmark(D, 4);
     D.stats.direct_solves += 1;
     if (cl) {
         // a dead pivot of the band part (a view that only a closure ties to the rest after robust weights went to zero):
@@ -823,12 +845,16 @@ static int bcr_dist_checked(Dist &D) {
     static const bool no_res = std::getenv("IROTAVG_BCR_NO_RESIDUAL_GATE") != nullptr;
     static const bool dbg = std::getenv("IROTAVG_DIST_DEBUG") != nullptr;
     if (D.top.r == 0 || no_res) return rc;
+    // (the preconditioner applications of the repair below are not linear systems of the caller's: direct_solves counts
+    // this call once, as run_irls does on one GPU -- advisor, round 5)
     struct GuardOff {
         Dist &D;
+        const int64_t ds_keep;
         ~GuardOff() {
             for (auto &sp : D.shards) sp->g.bcr_guard = false;
+            D.stats.direct_solves = ds_keep;
         }
-    } guard_off{D};
+    } guard_off{D, D.stats.direct_solves};
     const bool dead = rc == IROTAVG_ERR_SOLVER && D.stats.direct_dead_pivots > 0;
     if (rc != IROTAVG_OK && !dead) return rc;
     auto dots = [&](const double4 *(*U)(Shard &), const double4 *(*V)(Shard &), double out[3]) {
@@ -981,20 +1007,27 @@ static int irls_dist(Dist &D, int cost, double sigma, int max_iters, double chan
     int it = 0, rc = IROTAVG_OK;
     for (auto &sp : D.shards) fill(sp->g, sp->g.dw.p, (long long)sp->g.mpad, 1.0);
     while (score > change_th && it < max_iters) {
+        tmark(D, -1);
         for (auto &sp : D.shards) {
             launch_edge_residual(sp->g);
             assemble(sp->g, 0, sp->g.dw.p, D.opt.dense_always_refresh == 1);
         }
+        tmark(D, 0);
         rc = solve_dist(D);
         if (rc != IROTAVG_OK) break;
+        tmark(D, 1);  // (the sharded PCG: the whole solve; the direct solver has marked its own phases, this adds ~0)
         halo_exchange(D, HALO_X);  // ghost views receive their owners' steps
+        tmark(D, 5);
         double local = 0.0;
         for (auto &sp : D.shards) {
             launch_update_weights(sp->g, cost, sigma);
             (void)apply_step(sp->g);  // updates owned AND ghost rotations; scores owned views only
             local += sp->g.last_score_sum;
         }
+        tmark(D, 6);
         combine_host(D, &local, 1, 0);
+        tmark(D, 7);
+        if (D.timing) D.t_iters += 1;
         score = local / (double)D.nu;
         if (trace) trace[it] = score;
         it++;
@@ -1356,6 +1389,20 @@ int irotavg_dist_info(irotavg_dist *h, int64_t info[8]) {
     info[7] = D.bcr_B ? (int64_t)D.cl_edge.size() : 0;  // loop closures it carries (Woodbury correction across the ranks)
     return IROTAVG_OK;
     API_CATCH
+}
+
+int irotavg_dist_timing(irotavg_dist *h, int enable, double us_per_iteration[8], int64_t *iterations) {
+    if (!h) return IROTAVG_ERR_BAD_ARG;
+    Dist &D = h->D;
+    if (us_per_iteration)
+        for (int i = 0; i < 8; i++) us_per_iteration[i] = D.t_iters > 0 ? 1e6 * D.t_acc[i] / (double)D.t_iters : 0.0;
+    if (iterations) *iterations = D.t_iters;
+    if (enable) {
+        for (int i = 0; i < 8; i++) D.t_acc[i] = 0.0;
+        D.t_iters = 0;
+    }
+    D.timing = enable != 0;
+    return IROTAVG_OK;
 }
 
 int irotavg_dist_get_stats(irotavg_dist *h, irotavg_stats *out) {

@@ -167,10 +167,14 @@ __global__ __launch_bounds__(256) void k_update_weights(long long m, long long m
                                                         const double *__restrict__ er,
                                                         const double4 *__restrict__ X, int cost,
                                                         double sigma, double *__restrict__ dw,
-                                                        const int *__restrict__ gate) {
+                                                        const int *__restrict__ gate,
+                                                        const int *__restrict__ skip) {
     // gate: launched speculatively behind a PCG whose convergence the host has not read yet -- runs
     // only if that solve is done (run_irls reads the flag and the score in ONE round trip afterwards)
     if (gate != nullptr && gate[FL_DONE] != 1) return;
+    // skip: the direct solver's single-launch upper reduction gave up on a wait and poisoned the step (bcr.hip,
+    // bcr_fail_word) -- the weights stay what they are, the host repeats the solve (as k_weights_then_residual does)
+    if (skip != nullptr && *skip != 0) return;
     // EPT edges per thread in EPT / 2 pairs; a wave's pairs of one load lie next to each other (16 B per lane)
     const long long base = (long long)blockIdx.x * (256 * EPT) + 2 * threadIdx.x;
     int2 ii[EPT / 2], jj[EPT / 2];
@@ -207,13 +211,14 @@ __global__ __launch_bounds__(256) void k_update_weights(long long m, long long m
 void launch_update_weights(Graph &g, int cost, double sigma, bool gated) {
     // (four and eight edges per thread were measured: 17.6 -> 18.3 / 18.9 us at 2M edges; two it is)
     const int *gate = gated ? (const int *)g.flags.p : (const int *)nullptr;
+    const int *skip = g.bcr_B ? bcr_fail_word(g) : nullptr;
     const int grid = (int)((g.m + 511) / 512);
     if (cost == IROTAVG_L2 || cost == IROTAVG_HUBER)
         hipLaunchKernelGGL((k_update_weights<true, 2>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m, (long long)g.mpad, g.f,
-                           g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, gate);
+                           g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, gate, skip);
     else
         hipLaunchKernelGGL((k_update_weights<false, 2>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m, (long long)g.mpad, g.f,
-                           g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, gate);
+                           g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, gate, skip);
 }
 
 // K2 and the NEXT iteration's K1 in one pass over the edges (round 4; the direct solver's irls loop, run_irls): the
@@ -2438,16 +2443,25 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                     const bool inexact_only = g.h_flags()[FL_ITERS] == 1 && g.h_flags()[3] == 0;
                     g.stats.direct_guarded += 1;
                     g.stats.direct_dead_pivots = g.h_flags()[3];
-                    g.bcr_guard = true;
-                    const int64_t ds_keep = g.stats.direct_solves;
-                    const int maxit_keep = g.opt.pcg_max_iters;
-                    if (inexact_only) g.opt.pcg_max_iters = 12;
-                    rc = pcg_solve_classic(g);
-                    g.opt.pcg_max_iters = maxit_keep;
-                    g.bcr_guard = false;
+                    {
+                        // (restored on every way out, a HipError thrown inside the solve included: the handle must not
+                        // keep guard mode and a 12-iteration cap for its later calls -- advisor, round 5)
+                        struct GuardScope {
+                            Graph &g;
+                            const int64_t ds_keep;
+                            const int maxit_keep;
+                            ~GuardScope() {
+                                g.opt.pcg_max_iters = maxit_keep;
+                                g.bcr_guard = false;
+                                // (the preconditioner applications of that solve are not linear systems of the caller's)
+                                g.stats.direct_solves = ds_keep;
+                            }
+                        } guard_scope{g, g.stats.direct_solves, g.opt.pcg_max_iters};
+                        g.bcr_guard = true;
+                        if (inexact_only) g.opt.pcg_max_iters = 12;
+                        rc = pcg_solve_classic(g);
+                    }
                     g.bcr_last_guarded = true;
-                    // (the preconditioner applications of that solve are not linear systems of the caller's)
-                    g.stats.direct_solves = ds_keep;
                     if (inexact_only && rc == IROTAVG_ERR_NOT_CONVERGED) {
                         g.stats.pcg_stagnated += 1;
                         rc = IROTAVG_OK;
@@ -2489,8 +2503,10 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                 // the single-launch upper reduction gave up on a wait (another process held its workgroups back: the
                 // reservation only knows this process): its solution is NaN, no view took a step, the kernel behind it left
                 // weights and residuals alone -- the iteration once more, level by level from now on
-                if (fuse_wr && bcr_up_failed(g)) {
-                    er_fresh = true;
+                // (whichever kernel stood behind the solve: the plain weight update skips its work behind the same word
+                // as the fused weights-and-residual kernel does -- IROTAVG_NO_FUSED_WR, advisor round 5)
+                if (bcr_up_failed(g)) {
+                    er_fresh = true;  // (no view took a step: the residual planes still belong to Q)
                     score = score_before;
                     continue;
                 }

@@ -113,12 +113,20 @@ struct irotavg_viewgraph {
     // before the next global re-solve replaces them.
     mutable std::vector<double> qlazy;  // 4 per view
     mutable std::vector<char> lazy;
-    const double *pose_m(size_t x) const {
+    const double *pose_m(size_t x) const {  // (callers: the non-const paths of rot_avg; one thread per view)
         if (x < lazy.size() && lazy[x]) {
             quat2rmat(&qlazy[4 * x], const_cast<double *>(pose[x].m));
             lazy[x] = 0;
         }
         return pose[x].m;
+    }
+    // the same for the readers that hold a CONST handle (get_pose, save_poses): the matrix is formed into the caller's
+    // buffer and nothing of the handle is written, so concurrent readers of one view-graph do not race (advisor, round 5)
+    void pose_read(size_t x, double *out) const {
+        if (x < lazy.size() && lazy[x])
+            quat2rmat(&qlazy[4 * x], out);
+        else
+            std::copy(pose[x].m, pose[x].m + 9, out);
     }
     double *pose_w(size_t x) {  // the pose is about to be overwritten
         if (x < lazy.size()) lazy[x] = 0;
@@ -246,8 +254,7 @@ int irotavg_viewgraph_count_fixed_poses(const irotavg_viewgraph *vg) {
 }
 int irotavg_viewgraph_get_pose(const irotavg_viewgraph *vg, int idx, double R[9]) {
     if (!vg || !R || idx < 0 || idx >= (int)vg->pose.size()) return IROTAVG_ERR_BAD_ARG;
-    const double *P = vg->pose_m((size_t)idx);
-    std::copy(P, P + 9, R);
+    vg->pose_read((size_t)idx, R);
     return IROTAVG_OK;
 }
 int irotavg_viewgraph_set_pose(irotavg_viewgraph *vg, int idx, const double R[9]) {
@@ -714,8 +721,9 @@ int irotavg_viewgraph_save_poses(const irotavg_viewgraph *vg, const char *filena
     std::FILE *fs = std::fopen(filename, "w");
     if (!fs) return IROTAVG_ERR_BAD_ARG;  // "Unable to save results."
     for (size_t v = 0; v < vg->pose.size(); v++) {
-        double q[4];
-        rmat2quat(vg->pose_m(v), q);
+        double q[4], Rm[9];
+        vg->pose_read(v, Rm);
+        rmat2quat(Rm, q);
         const double tx = t ? t[3 * v] : 0.0, ty = t ? t[3 * v + 1] : 0.0, tz = t ? t[3 * v + 2] : 0.0;
         std::fprintf(fs, "%zu\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\t%.17e\n", v, q[3], q[0], q[1],
                      q[2], tx, ty, tz);

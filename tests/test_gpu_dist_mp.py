@@ -74,8 +74,9 @@ def test_two_processes_rccl_on_one_device():
 def test_bench_runs_with_two_ranks():
     """bench.py's own N > 1 branch (sharding, timing protocol, max over ranks, the JSON line), two ranks
     sharing the box's one GPU (IROTAVG_BENCH_SHARE_GPU=1). RCCL refuses two ranks on one device, so this
-    also exercises the fall-back every rank takes together when the library's communicator cannot be
-    formed: the same sharded solver over the host-staged transport."""
+    exercises both answers to "the library's communicator cannot be formed": the refusal (default) and, with
+    --allow-hosted, the fall-back every rank takes together -- the same sharded solver over the host-staged
+    transport -- with the `dist` record a first multi-GPU run diagnoses itself by."""
     import json
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -85,10 +86,30 @@ def test_bench_runs_with_two_ranks():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
            "--gpus", "2"] + common
+    # (1) without --allow-hosted a run whose RCCL communicator cannot be formed REFUSES: non-zero exit, one JSON line
+    # that says why and carries no value -- a first hardware run can never silently measure gloo
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    refused = json.loads(lines[0])
+    assert refused["value"] is None and "refusing" in refused["error"] and refused["dist"]["wire"] == "none"
+    # (2) with it: the same sharded solver over the host-staged wire, and the line says so in machine-readable form
+    cmd[cmd.index("29617")] = "29618"
+    r = subprocess.run(cmd + ["--allow-hosted"], capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     two = json.loads(lines[0])
+    d = two["dist"]
+    assert d["wire"] == "host-staged" and d["ncclCommCount"] == 0 and d["world"] == 2 and d["hosted_allowed"] is True
+    assert d["valid_scaling_measurement"] is False           # a hosted or GPU-sharing run is never a scaling figure
+    assert d["sharded_solver"] == "direct" and d["phases_iterations"] > 0
+    ph = d["phases_us_per_iteration"]
+    assert set(ph) == {"local_edge_kernels_and_assembly", "local_reductions", "gather_of_separators", "closure_sum",
+                       "separator_system_and_ways_back", "halo_of_the_step", "weights_and_rotation_update",
+                       "score_allreduce"}
+    assert ph["local_reductions"] > 0 and ph["gather_of_separators"] > 0 and ph["halo_of_the_step"] > 0
+    assert ph["closure_sum"] == 0.0                           # no closures in this graph
+    assert "ms_per_step_by_gpus" in d["expected"] or d["expected"]["workload"] is None
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
                          capture_output=True, text=True, timeout=420, cwd=ROOT)
     one = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])

@@ -1,6 +1,8 @@
 set -u
-# The round's judged numbers in one go (GPU box, from the repo root): the default bench line with its own rocprofv3 passes
-# (kernel trace + FETCH_SIZE + WRITE_SIZE, gpurun_out/bench_profile/), the other sizes, l1ra under the kernel trace, config 5.
+# The round's judged numbers in one go (GPU box, from the repo root; `gpurun -- bash tools/collect_profiles.sh`): the default
+# bench line with its own rocprofv3 passes (kernel trace + FETCH_SIZE + WRITE_SIZE, gpurun_out/bench_profile/), the other
+# sizes, l1ra under the kernel trace, config 5, the GPU test suite. Everything lands in gpurun_out/final;
+# tools/publish_profiles.sh NN copies the summaries to profiles/rNN_*.
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final
 mkdir -p $OUT
@@ -18,6 +20,6 @@ for rep in 1 2 3; do timeout 300 irotavg_amd/bin/stream_bench 50000 50000 10 0 1
 timeout 300 irotavg_amd/bin/stream_bench 50000 50000 10 0 1 0 > $OUT/stream_c4_no_prepare.json 2>> $OUT/stream.err
 for s in 1 8 64; do timeout 300 irotavg_amd/bin/stream_bench 5000 5000 0 0 $s 0 | cut -c1-700; done > $OUT/stream_sessions.jsonl 2>> $OUT/stream.err
 timeout 200 python tools/time_global_resolve.py > $OUT/global_resolve.log 2>&1
-timeout 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1
+timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log
 ls -la $OUT

@@ -1,6 +1,6 @@
 """Development aid: the banded direct solver (bcr.hip) against the oracle and against the PCG path, and its timing."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from irotavg_amd import capi, synth
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Development aid: band graphs with a few loop closures on the direct solver (Woodbury) against the oracle / the PCG."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from irotavg_amd import capi, synth, ral
 from oracle import oracle as O

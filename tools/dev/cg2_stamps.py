@@ -1,7 +1,7 @@
 """Development aid: per-phase wall-clock stamps of k_cg_apply (one mid-grid workgroup)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from irotavg_amd import capi, synth, ral
 n, m = 100000, 2000000
 S = synth.make_graph(n, m, 0.0, seed=0)

@@ -1,9 +1,9 @@
 """One workload under rocprofv3: `irls` on a view sequence with loop closures (the banded direct solver's closure path)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from irotavg_amd import capi, ral
-from tools.bcr_closures import graph
+from tools.dev.bcr_closures import graph
 n, m, nc = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 S = graph(n, m, nc, 7, max(1, nc // 33))
 Q0 = np.zeros((n, 4)); Q0[:, 3] = 1; Q0[0] = S["Qgt"][0]

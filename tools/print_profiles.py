@@ -1,4 +1,4 @@
-"""Prints the figures of a tools/final_profiles.sh run (gpurun_out/final or a directory given) that the docs quote."""
+"""Prints the figures of a tools/collect_profiles.sh run (gpurun_out/final or a directory given) that the docs quote."""
 import json, sys, glob
 D = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/final"
 def load(f):

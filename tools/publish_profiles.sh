@@ -1,5 +1,5 @@
-# copies the files of a tools/final_profiles.sh run (gpurun_out/final) to profiles/rNN_* (NN = $1, default 04)
-R=${1:-04}; F=gpurun_out/final; P=profiles/r${R}
+# copies the files of a tools/collect_profiles.sh run (gpurun_out/final) to profiles/rNN_* (NN = $1, default 06)
+R=${1:-06}; F=gpurun_out/final; P=profiles/r${R}
 if [ ! -f $F/bench_final.json ]; then echo "no run in $F"; exit 1; fi
 cp $F/bench_final.json ${P}_bench_final.json; cp $F/bench_1M20M.json ${P}_bench_1M20M.json
 cp $F/bench_10k150k.json ${P}_bench_10k150k.json; cp $F/bench_10k150k_loop02.json ${P}_bench_10k150k_loop02.json
