@@ -137,6 +137,8 @@ struct BcrState {
     // loses the weight of a closure to a ghost view for the time of the reduction
     DevBuf<double> res_part;   // k_bcr_residual's partial sums (bcr_gate)
     DevBuf<int> res_zero;      // FL_COUNT zero words: the done flags the gate's SpMV runs behind
+    DevBuf<int> gate_skip;     // k_bcr_gate's verdict as a skip word (1: do not touch weights / residuals)
+    bool dead_clean = false;   // the dead-pivot counter is known to be zero (k_bcr_gate read and cleared it)
     DevBuf<int2> cl_fin;
     DevBuf<int> cl_gid;
     DevBuf<uint8_t> cl_own;
@@ -1702,8 +1704,8 @@ struct BcrClPlan {
 // 5: the four waves of the workgroup stage the blocks of FOUR steps in LDS per round trip (each wave one step) and then
 // run the four steps from LDS together -- thread (column, part) sums a part of its column's rows, the parts meet in LDS
 // (one wave doing a step alone is two chains of B dependent multiply-adds: ~1 us, as long as the round trip it replaced).
-template <int B>
-__global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r, int nslots, const int *__restrict__ off,
+template <int B, int NWF = 4>
+__global__ __launch_bounds__(64 * NWF) void k_bcr_closure_forward(BcrClPlan P, int r, int nslots, const int *__restrict__ off,
                                                               const int4 *__restrict__ steps,
                                                               const int4 *__restrict__ init, double *__restrict__ recR,
                                                               double *__restrict__ recW, double *__restrict__ T,
@@ -1716,11 +1718,12 @@ __global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r,
     constexpr int NLD = (NE + 63) / 64;
     constexpr int KP = B == 24 ? 3 : (NCOL * 4 <= 256 ? 4 : 2), KB = B / KP;  // parts of a column's rows, rows per part
     static_assert(B % KP == 0 && NCOL * KP <= 256, "thread (col, part)");
-    extern __shared__ double smem[];  // [4][B][NCOL] staged blocks, KP x NCOL partial sums, then nslots x B slots
+    // NWF waves = NWF steps staged per memory round trip (four; eight measured slower, see bcr_launch_forward)
+    extern __shared__ double smem[];  // [NWF][B][NCOL] staged blocks, KP x NCOL partial sums, then nslots x B slots
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x;
     double *stage = smem + (size_t)wave * NE;
-    double *spart = smem + (size_t)4 * NE;
+    double *spart = smem + (size_t)NWF * NE;
     double *slots = spart + KP * NCOL;
     if (wave == 0) {
         if (slot_init) {
@@ -1738,7 +1741,7 @@ __global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r,
     double tacc = 0.0;  // threads 2B .. 2B + 2: a coordinate of T each
     const int s0 = off[q], s1 = off[q + 1];
     __syncthreads();  // (the slots' start values)
-    for (int g0 = s0; g0 < s1; g0 += 4) {
+    for (int g0 = s0; g0 < s1; g0 += NWF) {
         // ---- every wave: the block of step g0 + wave into its stage, element (k, col) at k NCOL + col ----
         const int st_w = g0 + wave;
         if (st_w < s1) {
@@ -1774,7 +1777,7 @@ __global__ __launch_bounds__(256) void k_bcr_closure_forward(BcrClPlan P, int r,
         __syncthreads();
         // ---- all four waves: the (up to) four steps from LDS. Thread (col, part) sums its share of the rows of column
         // col (a wave alone took ~1 us per step: two chains of B dependent multiply-adds), the parts meet in LDS ----
-        for (int w = 0; w < 4 && g0 + w < s1; w++) {
+        for (int w = 0; w < NWF && g0 + w < s1; w++) {
             const int st = g0 + w;
             const int spz = __builtin_amdgcn_readfirstlane(steps[st].z);
             const int src = spz & 255, dA = (spz >> 8) & 255, dC = (spz >> 16) & 255;
@@ -2066,6 +2069,89 @@ __global__ __launch_bounds__(256) void k_bcr_closure_S(int r, int npad, int maxs
         }
         return;
     }
+    S[(size_t)p * npad + q] = sum;
+    S[(size_t)q * npad + p] = sum;
+    if (p == q) {
+        alive[p] = wp > 0.0;
+        if (!(wp > 0.0)) T[3 * p] = T[3 * p + 1] = T[3 * p + 2] = 0.0;
+    }
+}
+
+// The same sums for FEW closures (round 6), a WAVE per pair (p, q), p <= q. With a tile of 16 x 16 pairs per workgroup
+// thirty closures are three workgroups -- three CUs of 256 -- and every thread walks its pair's merge alone, 24 doubles of
+// two records per shared block out of global memory: 34 us of an IRLS iteration that has thirty closures, most of it
+// latency. Here the wave looks every key of p's list up in q's list (a binary search in LDS, 64 keys at a time), lists
+// the matches, and eight groups of eight lanes take a match each per round -- lane e of a group the elements e, e + 8, ...
+// of the two records -- so that eight matches' loads are in flight together; one sum over the wave at the end. All
+// eliminations alike: the dense ones (the top levels' blocks, an odd key) need no table here. Same entries as
+// k_bcr_closure_S up to the order of the additions; single GPU only (a shard adds into the ranks' common buffer).
+constexpr int kClosurePairsMax = 192;  // closures up to which the pair kernel is used (above: the tiles' shared keys pay)
+template <int B>
+__global__ __launch_bounds__(256) void k_bcr_closure_S_pairs(int r, int npad, int maxsteps, const int *__restrict__ off,
+                                                              const int4 *__restrict__ steps, const double *__restrict__ recR,
+                                                              const double *__restrict__ recW, const int *__restrict__ far_e,
+                                                              const double *__restrict__ wsrc, int wsquare,
+                                                              double *__restrict__ S, double *__restrict__ T,
+                                                              int *__restrict__ alive) {
+    extern __shared__ int spairs[];  // per wave: maxsteps keys of q, then 64 matches (a | b << 16)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.y, q = blockIdx.x * 4 + wave;
+    if (q < p || q >= npad || p >= npad) return;   // (whole waves leave: no barrier below)
+    if (p >= r || q >= r) {  // padding of the inversion
+        if (lane == 0) S[(size_t)p * npad + q] = S[(size_t)q * npad + p] = p == q ? 1.0 : 0.0;
+        return;
+    }
+    double wp = wsrc[far_e[p]], wq = wsrc[far_e[q]];
+    if (wsquare) {
+        wp *= wp;
+        wq *= wq;
+    }
+    double sum = 0.0;
+    if (wp > 0.0 && wq > 0.0) {
+        int *kb = spairs + (size_t)wave * (maxsteps + 64);
+        int *ml = kb + maxsteps;
+        const int na = off[p + 1] - off[p], nb = off[q + 1] - off[q];
+        for (int k = lane; k < nb; k += 64) kb[k] = steps[off[q] + k].w;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const double *x0 = recR + (size_t)off[p] * B, *y0 = recW + (size_t)off[q] * B;
+        const int grp = lane >> 3, e = lane & 7;
+        double acc = 0.0;
+        for (int a0 = 0; a0 < na; a0 += 64) {
+            const int a = a0 + lane;
+            int found = -1;
+            if (a < na) {
+                const int ka = steps[off[p] + a].w;
+                int lo = 0, hi = nb;  // first index whose key is >= ka
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (kb[mid] < ka) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo < nb && kb[lo] == ka) found = lo;
+            }
+            const unsigned long long mask = __ballot(found >= 0);
+            const int nm = __popcll(mask);
+            if (found >= 0) ml[__popcll(mask & ((1ull << lane) - 1ull))] = a | (found << 16);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int i = grp; i < nm; i += 8) {
+                const int ab = ml[i];
+                const double *x = x0 + (size_t)(ab & 0xffff) * B, *y = y0 + (size_t)(ab >> 16) * B;
+#pragma unroll
+                for (int k = 0; k < (B + 7) / 8; k++)
+                    if (e + 8 * k < B) acc = fma(x[e + 8 * k], y[e + 8 * k], acc);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        sum = acc;
+        if (p == q) sum += 1.0 / wp;
+    } else {
+        sum = p == q ? 1.0 : 0.0;
+    }
+    if (lane != 0) return;
     S[(size_t)p * npad + q] = sum;
     S[(size_t)q * npad + p] = sum;
     if (p == q) {
@@ -2692,7 +2778,8 @@ static void bcr_run_all(Graph &g, int only) {
     // the Woodbury system, the corrected right-hand sides, the ways back
     hipStream_t st = g.stream;
     const int r = S.nfar, npad = S.cl_npad, nl = (int)S.lev.size();
-    IRH_CHECK(hipMemsetAsync(S.dead.p, 0, sizeof(int), st));
+    if (!S.dead_clean) IRH_CHECK(hipMemsetAsync(S.dead.p, 0, sizeof(int), st));
+    S.dead_clean = false;
     bcr_run<B, 3>(g, -1, 0, false, 1);
     BcrClPlan P;
     for (int l = 0; l < nl; l++) {
@@ -2705,6 +2792,13 @@ static void bcr_run_all(Graph &g, int only) {
     bcr_launch_forward<B>(st, P, r, S.cl_nslots, S.cl_off.p, S.cl_step.p, S.cl_init.p, S.cl_R.p, S.cl_W.p, S.cl_T.p, nullptr,
                           nullptr, nullptr, nullptr, 0, 0);
     const int nt = (npad + 15) / 16;
+    static const bool s_tiles = getenv("IROTAVG_BCR_S_TILES") != nullptr;  // A/B: the tile kernel for every closure count
+    const size_t lds_pairs = (size_t)4 * (S.cl_maxsteps + 64) * sizeof(int);
+    if (r <= kClosurePairsMax && S.cl_maxsteps < 32768 && lds_pairs <= 60 * 1024 && !s_tiles)
+        hipLaunchKernelGGL((k_bcr_closure_S_pairs<B>), dim3((npad + 3) / 4, npad), dim3(256), lds_pairs, st, r, npad,
+                           S.cl_maxsteps, S.cl_off.p, S.cl_step.p, S.cl_R.p, S.cl_W.p, S.far_e.p, g.bcr_wsrc, g.bcr_wsquare,
+                           S.cl_S.p, S.cl_T.p, S.cl_alive.p);
+    else
     hipLaunchKernelGGL((k_bcr_closure_S<B>), dim3(nt, nt), dim3(256), (size_t)32 * S.cl_maxsteps * sizeof(int), st, r, npad,
                        S.cl_maxsteps, S.cl_ndense, S.cl_dense.p, S.cl_off.p, S.cl_step.p, S.cl_R.p,
                        S.cl_W.p, S.far_e.p, g.bcr_wsrc, g.bcr_wsquare, S.cl_S.p, S.cl_T.p, S.cl_alive.p);
@@ -2894,6 +2988,22 @@ static void bcr_launch_forward(hipStream_t st, const BcrClPlan &P, int r, int ns
     const size_t lds_wg = ((size_t)4 * B * (3 * B + 3) + (size_t)4 * (3 * B + 3) + (size_t)nslots * B) * sizeof(double);
     // (blocks of 32: 100 KB, one workgroup per CU -- the chip takes 256 closures at a time then)
     const int r_wg = lds_wg * 2 <= 150 * 1024 ? 400 : 256;
+    // EIGHT steps per round trip (eight waves, twice the stages: IROTAVG_BCR_FORWARD8=1) was built and measured in round 6:
+    // 50 us against 35.5 at thirty closures -- the steps are bound by their two barriers each (sixteen waves' worth with
+    // 512 threads), not by the round trips. Kept behind the switch as the record of that measurement.
+    constexpr int kForward8Max = 128;
+    const size_t lds_wg8 = ((size_t)8 * B * (3 * B + 3) + (size_t)4 * (3 * B + 3) + (size_t)nslots * B) * sizeof(double);
+    if (r <= kForward8Max && lds_wg8 <= 150 * 1024 && !getenv("IROTAVG_BCR_FORWARD_WAVE") && getenv("IROTAVG_BCR_FORWARD8")) {
+        static std::atomic<size_t> lds_set8[16];
+        if (lds_wg8 > 64 * 1024 && lds_set8[dev & 15].load() < lds_wg8) {
+            IRH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bcr_closure_forward<B, 8>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wg8));
+            lds_set8[dev & 15].store(lds_wg8);
+        }
+        hipLaunchKernelGGL((k_bcr_closure_forward<B, 8>), dim3(r), dim3(512), lds_wg8, st, P, r, nslots, off, steps, init, recR,
+                           recW, T, slot_init, fin, gid, dep, world, rank);
+        return;
+    }
     if (r <= r_wg && lds_wg <= 150 * 1024 && !getenv("IROTAVG_BCR_FORWARD_WAVE")) {
         static std::atomic<size_t> lds_set[16];
         if (lds_wg > 64 * 1024 && lds_set[dev & 15].load() < lds_wg) {
@@ -3304,8 +3414,9 @@ __global__ __launch_bounds__(256) void k_bcr_resid_norms(int n, const double4 *_
 // arithmetic only: where robust weights leave a stretch of the band nearly free and the closures hold it, Y = A_b^-1 b is
 // huge along that stretch and the correction cancels it (fuzz seed 21 case 46: Welsch, 365 closures, weights^2 down to
 // 1e-8 -- relative residual 4e-7 where the band-only solve reaches 1e-12). flags[1] = 1: the residual was the reason.
-__global__ __launch_bounds__(256) void k_bcr_gate(const int *__restrict__ dead, int *__restrict__ flags,
-                                                  const double *__restrict__ part, int nparts, double tol2) {
+__global__ __launch_bounds__(256) void k_bcr_gate(int *__restrict__ dead, int *__restrict__ flags,
+                                                  const double *__restrict__ part, int nparts, double tol2,
+                                                  int *__restrict__ skip_out, int *__restrict__ flags_copy) {
     __shared__ double sh[4][6];
     const int t = threadIdx.x;
     double a[6] = {0, 0, 0, 0, 0, 0};
@@ -3333,10 +3444,30 @@ __global__ __launch_bounds__(256) void k_bcr_gate(const int *__restrict__ dead, 
     flags[FL_DONE] = d == 0 && ok ? 1 : 0;
     flags[FL_ITERS] = d == 0 && !ok ? 1 : 0;
     flags[3] = d;
+    // (round 6) the same verdict as a skip word for k_weights_then_residual, and the four flag words once more behind the
+    // score's partial sums, so that ONE publication -- that kernel's first workgroup -- carries score and verdict
+    if (dead) dead[0] = 0;  // (read: the next reduction counts from zero without a memset in front of it, BcrState::dead_clean)
+    if (skip_out) skip_out[0] = d == 0 && ok ? 0 : 1;
+    if (flags_copy) {
+        flags_copy[FL_DONE] = d == 0 && ok ? 1 : 0;
+        flags_copy[FL_ITERS] = d == 0 && !ok ? 1 : 0;
+        flags_copy[FL_STALE] = 0;
+        flags_copy[3] = d;
+    }
 }
-void bcr_gate(Graph &g) {
+const int *bcr_gate_skip_word(Graph &g) {
     BcrState *S = g.bcr.get();
-    const int *dead = S && S->nfar > 0 ? S->dead.p : nullptr;
+    if (!S) return nullptr;
+    if (!S->gate_skip.p) {
+        S->gate_skip.alloc(1);
+        S->gate_skip.zero(g.stream);
+    }
+    return S->gate_skip.p;
+}
+void bcr_gate(Graph &g, double *flags_copy) {
+    BcrState *S = g.bcr.get();
+    int *dead = S && S->nfar > 0 ? S->dead.p : nullptr;
+    if (dead) S->dead_clean = true;  // (the gate kernel leaves the counter at zero)
     const double *part = nullptr;
     int grid = 0;
     // (IROTAVG_BCR_NO_RESIDUAL_GATE: the dead-pivot gate alone, as until round 5)
@@ -3358,7 +3489,9 @@ void bcr_gate(Graph &g) {
     // (IROTAVG_BCR_FAKE_GIVE_UP, tests: no residual passes the gate)
     const double gate = std::max(g.opt.pcg_rtol, kBcrGateTolMin);
     const double tol = getenv("IROTAVG_BCR_FAKE_GIVE_UP") ? -1.0 : gate * gate;
-    hipLaunchKernelGGL(k_bcr_gate, dim3(1), dim3(256), 0, g.stream, dead, g.flags.p, part, grid, tol);
+    int *skip_out = (S && flags_copy) ? const_cast<int *>(bcr_gate_skip_word(g)) : nullptr;
+    hipLaunchKernelGGL(k_bcr_gate, dim3(1), dim3(256), 0, g.stream, dead, g.flags.p, part, grid, tol, skip_out,
+                       reinterpret_cast<int *>(flags_copy));
 }
 
 int bcr_closures(Graph &g) { return g.bcr_B ? (int)g.bcr_far_e.size() : 0; }

@@ -305,7 +305,8 @@ int bcr_closures(Graph &g);  // loop closures the direct solver of this handle c
 constexpr double kClosureRepairAccept = 1e-8;
 bool bcr_band_part_anchored(int64_t m, int f, int64_t nu, int B, const int32_t *I);  // the band part alone is positive definite (exact)
 int bcr_apply_slots(Graph &g);
-void bcr_gate(Graph &g);  // flags[FL_DONE] = 1 unless the last direct solve with closures saw a dead pivot (flags[3] = their number)
+void bcr_gate(Graph &g, double *flags_copy = nullptr);  // flags_copy: two doubles' room for a copy of the four flag words (+ the verdict as bcr_gate_skip_word)
+const int *bcr_gate_skip_word(Graph &g);  // flags[FL_DONE] = 1 unless the last direct solve with closures saw a dead pivot (flags[3] = their number)
 void dense_invert_spd(Graph &g, double *A, int npad);  // in place, npad a multiple of 64 (dense.hip)
 int bcr_stamps(Graph &g, int level, int chunk, double *out);  // development aid
 int bcr_stamps_up(Graph &g, double *out);                      // development aid: 32 x 8 stamps of k_bcr_reduce_up

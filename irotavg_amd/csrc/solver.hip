@@ -6,6 +6,7 @@
 //                         SuiteSparseQR (:550) and UMFPACK (:147-169)
 //   K6 apply_step         score, exp_map, Q update       (ral/l1_irls.cpp:729-737, 471-492)
 #include <sched.h>
+#include <cstring>
 
 #include "graph.hpp"
 #include "kernels.hpp"
@@ -291,13 +292,15 @@ __global__ __launch_bounds__(256) void k_weights_then_residual(long long m, long
 }
 
 // pub (n > 0): the kernel's first workgroup publishes that part first (publish_begin has been called)
-void launch_weights_then_residual(Graph &g, int cost, double sigma, const PubPart *pub, bool with_residual) {
+void launch_weights_then_residual(Graph &g, int cost, double sigma, const PubPart *pub, bool with_residual,
+                                  const int *skip_word = nullptr) {
     const long long threads = g.mpad / 2;
     const int grid = (int)((threads + 255) / 256);
     const double *ps = pub ? pub->src : nullptr;
     double *pd = pub ? pub->dst : nullptr;
     const int pn = pub ? pub->n : 0;
-    const int *skip = g.bcr_B ? bcr_fail_word(g) : nullptr;
+    // (skip_word: the closures' gate, bcr_gate_skip_word -- such solves never go through the single-launch upper reduction)
+    const int *skip = skip_word ? skip_word : (g.bcr_B ? bcr_fail_word(g) : nullptr);
     if (cost == IROTAVG_L2 || cost == IROTAVG_HUBER)
         hipLaunchKernelGGL((k_weights_then_residual<true>), dim3(grid), dim3(256), 0, g.stream, (long long)g.m,
                            (long long)g.mpad, g.f, g.ei.p, g.ej.p, g.er.p, g.X.p, cost, sigma, g.dw.p, g.qq.p, g.Q.p, ps, pd,
@@ -2433,9 +2436,27 @@ int run_irls(Graph &g, int cost, double sigma, int max_iters, double change_th, 
                 // back with the score. One or more: the system is solved again by conjugate gradients on the true operator
                 // (closures included), preconditioned by the regularised direct solve -- about one iteration per dead
                 // pivot -- and the tail runs ungated. (ral/l1_irls.cpp:536-556 always solves the full system.)
-                bcr_gate(g);
-                launch_update_weights(g, cost, sigma, true);
-                score = apply_step(g, true);
+                // (round 6) behind the gate: the step (K6, gated), then K2 and the NEXT iteration's K1 as one pass over
+                // the edges (k_weights_then_residual, skipping behind the gate's verdict) whose first workgroup hands
+                // score AND verdict to the host -- three launches and a copy kernel were four (K2, K6, k_publish, K1)
+                const int sgrid = grid_for_elems(g.nu);
+                const bool fuse_cl = fuse_wr && 4 * sgrid + 2 <= 4 * kMaxParts && !std::getenv("IROTAVG_NO_FUSED_CL");
+                if (fuse_cl) {
+                    bcr_gate(g, g.part_score.p + 4 * (size_t)sgrid);
+                    hipLaunchKernelGGL(k_apply_step, dim3(sgrid), dim3(kRowBlock), 0, g.stream, g.nu, g.f, g.ng, g.X.p, g.Q.p,
+                                       g.part_score.p, 1, (const int *)g.flags.p);
+                    const PubPart part = {g.part_score.p, g.h_part(), 4 * sgrid + 2};
+                    publish_begin(g);
+                    launch_weights_then_residual(g, cost, sigma, &part, with_res, bcr_gate_skip_word(g));
+                    wait_published(g);
+                    std::memcpy(g.h_flags(), g.h_part() + 4 * (size_t)sgrid, sizeof(int) * FL_COUNT);
+                    score = finish_apply_step(g);
+                    er_fresh = with_res && g.h_flags()[FL_DONE] == 1;
+                } else {
+                    bcr_gate(g);
+                    launch_update_weights(g, cost, sigma, true);
+                    score = apply_step(g, true);
+                }
                 if (g.h_flags()[FL_DONE] != 1) {
                     // flags[FL_ITERS] = 1: no pivot died, but the residual of the full system is above the gate (the
                     // Woodbury correction cancelled digits, bcr.hip k_bcr_gate) -- the same repair: CG on the true operator

@@ -23,6 +23,7 @@ from oracle import oracle as O  # noqa: E402
 STAG = [0, 0]  # cases with a stagnation-accepted solve: [compared, ill-conditioned]
 CAPPED = [0]   # runs at the IRLS iteration cap that agree within 1e-4 but not within --tol
 DIVERGING = [0]  # capped runs whose scores grow again (not compared beyond the turning point)
+AMPLIFYING = [0]  # runs below the cap on an input that amplifies inner rounding (cond > 1e5, non-contracting): held to 1e-4
 
 
 def random_case(rng, nmax):
@@ -102,6 +103,7 @@ def check(c, tol, sig):
     # exact zeros or by floor weights. The answer is then defined by the solver's rank decision /
     # rounding (SPQR basic solution, dead pivots, minimum norm), which SURVEY.md 8(c) lists as NOT
     # pinned: such cases must still run without an error, their rotations are not compared.
+    lam_min = 1.0
     if c.get("skip_eig"):
         ill = False
     else:
@@ -112,7 +114,8 @@ def check(c, tol, sig):
             ill = True
         else:
             Hs = H / np.sqrt(np.outer(d, d))
-            ill = np.linalg.eigvalsh(Hs)[0] < 1e-7
+            lam_min = float(np.linalg.eigvalsh(Hs)[0])
+            ill = lam_min < 1e-7
     if ill:
         try:
             with capi.Graph(I, QQ, n, f) as G:
@@ -138,6 +141,17 @@ def check(c, tol, sig):
         # scores stop falling) the 1e-10 of the inner solves is amplified from iteration to iteration and any
         # two solvers differ -- such runs are held to the north star's 1e-4 rad, counted
         capped = rb["iters"] >= 15
+        # ... and so is a run that is AMPLIFYING by a measurable criterion (round 6, tools/referee.py): the scaled normal
+        # matrix of the last iteration has lambda_min < 1e-5 (cond > 1e5) AND the oracle's own score trace rises somewhere
+        # after its third iteration (the outer fixed-point iteration is not contracting there). On such an input four EXACT
+        # CPU solves of every system -- sparse Cholesky, SuperLU, Householder QR of the LS form, long-double Cholesky --
+        # end 1.5e-5 rad apart from each other (seed 603 case 163; tests/test_referee.py), so no fp64 solver can be held
+        # to 1e-6 there; the iteration COUNT must still be the oracle's (checked above), the angle is held to 1e-4.
+        sc_all = np.asarray(rb["scores"])[:rb["iters"]]
+        amplifying = lam_min < 1e-5 and len(sc_all) >= 5 and float(np.max(sc_all[3:] / sc_all[2:-1])) > 1.0
+        if amplifying and not capped:
+            AMPLIFYING[0] += 1
+            capped = True
         # ... and a capped run whose scores GROW again (to more than twice the score at the first turning point: IRLS is
         # moving away from its fixed point, e.g. Geman-McClure on a tree-like graph, seed 301 case 386; Welsch with
         # scores going up and down by decades, seed 401 case 841) amplifies without bound: the
@@ -218,7 +232,8 @@ def main():
                       "oracle_gave_up_detail": gave_up, "cases_with_stagnation_accepted_solves": STAG,
                       "ill_conditioned_ran_ok_not_compared": ill,
                       "capped_runs_between_tol_and_1e-4": CAPPED[0],
-                      "capped_runs_with_growing_scores": DIVERGING[0], "seed": a.seed}))
+                      "capped_runs_with_growing_scores": DIVERGING[0],
+                      "amplifying_runs_held_to_1e-4": AMPLIFYING[0], "seed": a.seed}))
     max_capped = a.max_capped if a.max_capped >= 0 else 2 + a.cases // 500
     if CAPPED[0] > max_capped:
         print("FAILED: %d capped runs between tol and 1e-4 rad (allowed %d)" % (CAPPED[0], max_capped))
