@@ -678,7 +678,7 @@ def main():
             # the first multi-GPU run diagnoses itself: the wire that carried it, RCCL's own count of the communicator,
             # per-phase microseconds of an IRLS iteration, and what DESIGN.md section 7 expects this run to show
             line["dist"] = {
-                "wire": dinfo["wire"], "ncclCommCount": dinfo["rccl_comm_ranks"], "world": world,
+                "wire": dinfo["wire"], "halo": dinfo["halo"], "ncclCommCount": dinfo["rccl_comm_ranks"], "world": world,
                 "hosted_allowed": bool(args.allow_hosted),
                 "valid_scaling_measurement": bool(dinfo["wire"] == "rccl" and dinfo["rccl_comm_ranks"] == world and not share),
                 "sharded_solver": "direct" if dinfo.get("direct_block") else "pcg",

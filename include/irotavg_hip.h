@@ -388,7 +388,9 @@ int irotavg_dist_l1ra(irotavg_dist *d, int max_iters, double change_th, int *ite
                       double *score_trace);
 int irotavg_dist_get_stats(irotavg_dist *d, irotavg_stats *out);
 /* What the sharded handle actually runs on, so that a scaling run can be checked: info[0] = wire
- * (0 loopback: all shards in this process, 1 RCCL, 2 the caller's host-staged transport), info[1] = ranks of
+ * (0 loopback: all shards in this process, 1 RCCL, 2 the caller's host-staged transport) + 16 when the halo of a
+ * closure-free sharded sequence travels as ONE all-gather of a fixed boundary record per rank instead of point-to-point
+ * messages between neighbours (round 6; RCCL and loopback), info[1] = ranks of
  * the RCCL communicator as RCCL reports them (ncclCommCount; 0 without one), info[2] = shards held by this
  * process, info[3] = world size the graph is partitioned for, info[4] = ghost views of this process's
  * shards (halo rows received per exchange), info[5] = peers of shard 0, info[6] = block size of the sharded direct

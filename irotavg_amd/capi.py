@@ -611,7 +611,8 @@ class DistGraph:
         (0: the sharded PCG) (irotavg_dist_info)."""
         v = (C.c_int64 * 8)()
         check(lib().irotavg_dist_info(self._h, v), "dist_info")
-        return dict(wire=["loopback", "rccl", "host-staged"][v[0]], rccl_comm_ranks=int(v[1]),
+        return dict(wire=["loopback", "rccl", "host-staged"][v[0] & 15],
+                    halo="all-gather of boundary records" if v[0] & 16 else "point-to-point", rccl_comm_ranks=int(v[1]),
                     local_shards=int(v[2]), world=int(v[3]), ghost_views=int(v[4]), peers=int(v[5]),
                     direct_block=int(v[6]), closures=int(v[7]))
 

@@ -37,6 +37,7 @@ struct Shard {
     std::vector<int> send_off, send_cnt, recv_off, recv_cnt;
     DevBuf<int> send_idx;            // owned-local indices to pack, grouped by peer
     DevBuf<double4> sendbuf;
+    DevBuf<int> gather_dst;          // gathered halo (Dist::halo_gather): slot of every send entry inside this rank's record
     DevBuf<double> gsum;             // 16 doubles: staging of the all-reduced scalars
     DevBuf<uint8_t> eown;            // per local edge: 1 = this shard counts it in sums over edges (L1RA)
     DevBuf<double4> rf_x, rf_b;      // the refinement of a direct solve with closures: the solution so far, the right-hand side
@@ -68,6 +69,14 @@ struct Dist {
     // derives the same list from the global graph. Woodbury correction across the ranks: bcr.hip, "loop closures on a
     // sharded sequence".
     std::vector<int64_t> cl_edge;
+    // The halo of a sharded SEQUENCE without closures (round 6): a rank's ghosts are its two neighbours' boundary views, at
+    // most `band` <= bcr_B of them per side -- so the exchange is ONE all-gather of a fixed record per rank, [to the lower
+    // neighbour | to the upper neighbour], halo_w slots each (1.5 KB per rank at B = 24), instead of a group of two
+    // ncclSend + two ncclRecv of ~0.5 KB: the same shape as the separators' gather, one collective on the wire per halo.
+    // Loopback: the shards write their records into the one buffer. The hosted wire keeps its point-to-point round.
+    bool halo_gather = false;
+    int halo_w = 0;
+    DevBuf<double4> hall;  // world records of 2 halo_w views
     // Diagnostic of a first multi-GPU run (irotavg_dist_timing; OFF in every timed region): wall time per phase of an
     // IRLS iteration, the stream drained at every phase boundary -- which adds to the total, so the phases are to be
     // read against each other, not against the undisturbed step. Phases: kDistPhases below.
@@ -103,6 +112,19 @@ __global__ __launch_bounds__(256) void k_pack(int cnt, const int *__restrict__ i
                                               double4 *__restrict__ dst) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < cnt) dst[t] = src[idx[t]];
+}
+
+// the gathered halo: a send entry goes to its slot of the rank's record; the two neighbours' segments come out of theirs
+__global__ __launch_bounds__(256) void k_pack_to(int cnt, const int *__restrict__ idx, const int *__restrict__ dstslot,
+                                                 const double4 *__restrict__ src, double4 *__restrict__ rec) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < cnt) rec[dstslot[t]] = src[idx[t]];
+}
+__global__ __launch_bounds__(256) void k_unpack_from(const double4 *__restrict__ seg0, int cnt0, double4 *__restrict__ dst0,
+                                                     const double4 *__restrict__ seg1, int cnt1, double4 *__restrict__ dst1) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < cnt0) dst0[t] = seg0[t];
+    if (t < cnt1) dst1[t] = seg1[t];
 }
 
 // fixed-order reduction of up to two partial arrays IN PLACE: row 0 of each array receives the
@@ -210,6 +232,37 @@ static const double4 *halo_src(Shard &S, HaloWhat w) {
 static double4 *halo_dst(Shard &S, HaloWhat w) { return w == HALO_P ? S.g.PG.p : S.g.X.p; }
 
 static void halo_exchange(Dist &D, HaloWhat what) {
+    if (D.halo_gather) {
+        const int rec = 2 * D.halo_w;
+        for (auto &sp : D.shards) {
+            Shard &S = *sp;
+            if (S.send_total > 0)
+                hipLaunchKernelGGL(k_pack_to, dim3((S.send_total + 255) / 256), dim3(256), 0, D.stream, S.send_total,
+                                   S.send_idx.p, S.gather_dst.p, halo_src(S, what), D.hall.p + (size_t)S.rank * rec);
+        }
+        if (D.use_rccl) {
+            const int rank = D.shards[0]->rank;
+            NCCL_CHECK(ncclAllGather(D.hall.p + (size_t)rank * rec, D.hall.p, (size_t)rec * 4, ncclDouble, D.comm, D.stream));
+        }  // (loopback: the shards of this process share the buffer)
+        for (auto &sp : D.shards) {
+            Shard &S = *sp;
+            const double4 *seg[2] = {nullptr, nullptr};
+            double4 *dst[2] = {nullptr, nullptr};
+            int cnt[2] = {0, 0};
+            for (size_t q = 0; q < S.peers.size() && q < 2; q++) {
+                const int peer = S.peers[q];
+                // the lower neighbour's segment for me is its UPPER half, the upper neighbour's its LOWER half
+                seg[q] = D.hall.p + (size_t)peer * rec + (peer < S.rank ? D.halo_w : 0);
+                dst[q] = halo_dst(S, what) + S.recv_off[q];
+                cnt[q] = S.recv_cnt[q];
+            }
+            const int mx = std::max(cnt[0], cnt[1]);
+            if (mx > 0)
+                hipLaunchKernelGGL(k_unpack_from, dim3((mx + 255) / 256), dim3(256), 0, D.stream, seg[0], cnt[0], dst[0], seg[1],
+                                   cnt[1], dst[1]);
+        }
+        return;
+    }
     for (auto &sp : D.shards) {
         Shard &S = *sp;
         if (S.send_total > 0)
@@ -1232,6 +1285,28 @@ static int dist_create_impl(irotavg_dist **out, int world, int rank, const void 
             }
         }
         if (D.bcr_B && !D.cl_edge.empty()) bcr_top_closures_alloc(D.shards[0]->g, D.top, (int)D.cl_edge.size());
+        // the gathered halo of a closure-free sequence (Dist::halo_gather): decided from what EVERY process derives alike
+        // (the global plan above), then checked against this process's own shards -- a rank whose halo does not have the
+        // promised shape fails loudly here instead of disagreeing with the others about the wire
+        if (D.bcr_B && D.cl_edge.empty() && !D.hosted && world > 1 && !std::getenv("IROTAVG_DIST_HALO_P2P")) {
+            D.halo_gather = true;
+            D.halo_w = D.bcr_B;
+            D.hall.alloc((size_t)world * 2 * D.halo_w);
+            D.hall.zero(D.stream);
+            for (auto &sp : D.shards) {
+                Shard &S = *sp;
+                std::vector<int> dst((size_t)S.send_total + 1, 0);
+                if (S.peers.size() > 2) throw HipError{hipErrorUnknown};
+                for (size_t q = 0; q < S.peers.size(); q++) {
+                    const int peer = S.peers[q];
+                    if ((peer != S.rank - 1 && peer != S.rank + 1) || S.send_cnt[q] > D.halo_w || S.recv_cnt[q] > D.halo_w)
+                        throw HipError{hipErrorUnknown};
+                    for (int k = 0; k < S.send_cnt[q]; k++) dst[(size_t)S.send_off[q] + k] = (peer < S.rank ? 0 : D.halo_w) + k;
+                }
+                S.gather_dst.upload(dst, D.stream);
+                IRH_CHECK(hipStreamSynchronize(D.stream));  // (dst is on this stack)
+            }
+        }
         *out = h;
         return IROTAVG_OK;
     } catch (const std::bad_alloc &) {
@@ -1375,7 +1450,7 @@ int irotavg_dist_info(irotavg_dist *h, int64_t info[8]) {
     API_TRY
     Dist &D = h->D;
     for (int i = 0; i < 8; i++) info[i] = 0;
-    info[0] = D.hosted ? 2 : (D.use_rccl ? 1 : 0);
+    info[0] = (D.hosted ? 2 : (D.use_rccl ? 1 : 0)) + (D.halo_gather ? 16 : 0);
     if (D.use_rccl && D.comm) {
         int cnt = 0;
         NCCL_CHECK(ncclCommCount(D.comm, &cnt));

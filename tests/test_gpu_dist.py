@@ -394,3 +394,52 @@ def test_a_band_part_next_to_singular_is_an_error_not_a_wrong_answer():
             assert ei.value.code == capi.ERR_SOLVER
             # the rotations are what the two good iterations left: the failed step was not taken
             assert synth.angular_distance(Q2, get()).max() < 1e-9
+
+
+@pytest.mark.parametrize("world,n,m", [(2, 20000, 300000), (8, 100000, 2000000), (5, 30000, 120000)])
+def test_gathered_halo_equals_the_point_to_point_one_bit_for_bit(world, n, m):
+    """Round 6: the halo of a closure-free sharded sequence is ONE all-gather of a fixed boundary record per rank
+    ([to the lower neighbour | to the upper neighbour], block-size slots each) instead of point-to-point messages between
+    neighbours (IROTAVG_DIST_HALO_P2P=1 in a process of its own gives those back). Same values into the same ghost slots:
+    l1ra (halo of dx) then irls (halo of the step) bit for bit, in the loopback -- the RCCL form differs from it by the
+    ncclAllGather call alone, which the 1-rank communicator test below runs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import numpy as np\n"
+            "from tests.test_gpu_dist import problem, SIG\n"
+            "from irotavg_amd import capi\n"
+            "S, Q0 = problem(%d, %d, 0.0)\n"
+            "with capi.DistGraph(S['I'], S['QQ'], %d, 1, %d) as D:\n"
+            "    info = D.info(); D.set_rotations(Q0)\n"
+            "    a = D.l1ra(1, 1e-3); b = D.irls(4, SIG, 50, 1e-3)\n"
+            "    Q, w = D.get_rotations(into=Q0.copy()), D.get_weights()\n"
+            "print(info['halo'].split()[0], info['direct_block'], a['iters'], b['iters'],\n"
+            "      hashlib.sha256(np.ascontiguousarray(Q).tobytes() + np.ascontiguousarray(w).tobytes()).hexdigest())\n"
+            % (root, n, m, n, world))
+    outs = []
+    for p2p in (False, True):
+        env = dict(os.environ)
+        env.pop("IROTAVG_DIST_HALO_P2P", None)
+        if p2p:
+            env["IROTAVG_DIST_HALO_P2P"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(r.stdout.strip().splitlines()[-1].split())
+    assert outs[0][0] == "all-gather" and outs[1][0] == "point-to-point"
+    assert int(outs[0][1]) > 0                         # the sharded direct solver
+    assert outs[0][1:] == outs[1][1:]                  # block size, iteration counts, every bit of rotations and weights
+
+
+def test_rccl_single_rank_keeps_the_point_to_point_form_and_closures_do_too():
+    """world = 1 has no halo; a sharded sequence WITH closures has ghosts on distant ranks and keeps the point-to-point
+    exchange (the gathered record holds the two neighbours' boundaries only)."""
+    n, m = 20000, 300000
+    S, Q0 = problem(n, m, 0.0)
+    S2 = synth.add_closures(S, 12, 3, 1)
+    with capi.DistGraph(S2["I"], S2["QQ"], n, 1, 4, band_direct=1) as D:
+        info = D.info()
+        assert info["direct_block"] > 0 and info["closures"] > 0 and info["halo"] == "point-to-point"
+    with capi.DistGraph(S["I"], S["QQ"], n, 1, 4, band_direct=1) as D:
+        assert D.info()["halo"].startswith("all-gather")
