@@ -15,7 +15,11 @@ timeout 600 python bench.py --p-loop 0.02 --steps 20 > $OUT/bench_loop02.json 2>
 cp -r gpurun_out/bench_profile $OUT/bench_profile_loop02 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/l1band -o l -- python $GRAFT_REPO_ROOT/tools/prof_case.py --what l1ra --reps 7 > $GRAFT_REPO_ROOT/$OUT/l1band.log 2>&1
+for nc in 30 100; do timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/cl$nc -o c -- python $GRAFT_REPO_ROOT/tools/dev/prof_closures.py 100000 2000000 $nc > $GRAFT_REPO_ROOT/$OUT/cl$nc.log 2>&1; done
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/k1cold -o k -- python $GRAFT_REPO_ROOT/tools/dev/k1_cold_cache.py > $GRAFT_REPO_ROOT/$OUT/k1cold.log 2>&1
 cd $GRAFT_REPO_ROOT
+for c in neartree_seed603_case163 neartree_seed501_case196; do timeout 300 python tools/referee.py --npz tests/golden/$c.npz --gpu --json $OUT/referee_$c.json > $OUT/referee_$c.txt 2>&1; done
+timeout 600 python tools/dev/inexact_vs_oracle.py > $OUT/inexact_vs_oracle.jsonl 2>&1
 for rep in 1 2 3; do timeout 300 irotavg_amd/bin/stream_bench 50000 50000 10 0 1 1; done > $OUT/stream_c4.json 2> $OUT/stream.err
 timeout 300 irotavg_amd/bin/stream_bench 50000 50000 10 0 1 0 > $OUT/stream_c4_no_prepare.json 2>> $OUT/stream.err
 for s in 1 8 64; do timeout 300 irotavg_amd/bin/stream_bench 5000 5000 0 0 $s 0 | cut -c1-700; done > $OUT/stream_sessions.jsonl 2>> $OUT/stream.err
