@@ -601,3 +601,47 @@ def test_one_shot_call_and_rotavg_fall_back_to_the_iterative_solver_when_the_dir
     assert iters == ro["iters"]
     assert synth.angular_distance(Q, ro["Q"]).max() < 1e-7         # (the iterative solver's bar)
     np.testing.assert_allclose(w, ro["weights"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("nclose", [7, 30, 120])
+def test_round6_closure_kernels_equal_the_round5_ones(nclose):
+    """Round 6 changed HOW two things in a closure solve are computed, not what: the Woodbury system by a wave per pair of
+    closures (k_bcr_closure_S_pairs; IROTAVG_BCR_S_TILES=1: round 5's tile kernel) -- the same entries up to the order of
+    the additions -- and K6 / K2 / the next K1 behind the gate as two launches with one publication
+    (IROTAVG_NO_FUSED_CL=1: round 5's four) -- the same arithmetic, bit for bit. Each variant in a process of its own
+    (the switches are read once): iteration counts equal, the fused tail bit-identical, the pair kernel within 1e-12 rad."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import numpy as np\n"
+            "from irotavg_amd import capi, synth, ral\n"
+            "S = synth.add_closures(synth.make_graph(20000, 400000, 0.0, seed=5), %d, 11, max(1, %d // 30))\n"
+            "Q0 = np.zeros((20000, 4)); Q0[:, 3] = 1; Q0[0] = S['Qgt'][0]\n"
+            "ral.init_mst(Q0, S['QQ'], S['I'], 1)\n"
+            "with capi.Graph(S['I'], S['QQ'], 20000, 1, band_direct=1) as G:\n"
+            "    G.set_rotations(Q0); r = G.irls(4, 5 * np.pi / 180, 50, 1e-3)\n"
+            "    Q, w, st = G.get_rotations(), G.get_weights(), G.stats()\n"
+            "np.save(sys.argv[1], np.concatenate([Q.ravel(), w]))\n"
+            "print(r['iters'], st['direct_solves'], st['direct_guarded'], G.direct_info()['closures'] if False else 0)\n"
+            % (root, nclose, nclose))
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, env_add in (("new", {}), ("tiles", {"IROTAVG_BCR_S_TILES": "1"}), ("unfused", {"IROTAVG_NO_FUSED_CL": "1"})):
+            env = dict(os.environ)
+            for k in ("IROTAVG_BCR_S_TILES", "IROTAVG_NO_FUSED_CL"):
+                env.pop(k, None)
+            env.update(env_add)
+            f = os.path.join(td, name + ".npy")
+            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs[name] = (r.stdout.strip().splitlines()[-1].split(), np.load(f))
+    assert outs["new"][0] == outs["tiles"][0] == outs["unfused"][0]            # iteration and solve counts
+    assert int(outs["new"][0][1]) > 0
+    np.testing.assert_array_equal(outs["new"][1], outs["unfused"][1])           # the tail: bit for bit
+    n4 = 4 * 20000
+    Qa, Qb = outs["new"][1][:n4].reshape(-1, 4), outs["tiles"][1][:n4].reshape(-1, 4)
+    assert synth.angular_distance(Qa, Qb).max() < 1e-12
+    np.testing.assert_allclose(outs["new"][1][n4:], outs["tiles"][1][n4:], rtol=1e-9)
