@@ -430,7 +430,7 @@ def pcg_iteration_roofline(S, st, kr, ia=None, iu=None):
             "own_bytes_both_kernels": kr["cg_apply"]["bytes"] + kr["cg_update"]["bytes"]}
 
 
-# DESIGN.md section 7's table "expected 1 -> 8 numbers, for the first hardware run to falsify", machine-readable:
+# DESIGN.md section 8's table "expected 1 -> 8 numbers, for the first hardware run to falsify", machine-readable:
 # ms per irls call by number of GPUs, from single-GPU kernel times, the loopback runs and 10-20 us per small RCCL
 # collective on xGMI. Nothing in it has run on more than one GPU.
 EXPECTED_MS_PER_IRLS = {
@@ -454,7 +454,7 @@ def expected_scaling(args, world):
     return {"workload": key, "ms_per_step_by_gpus": {str(k): v for k, v in t.items()},
             "ms_per_step": t.get(world), "speedup_vs_1_gpu": (t[1] / t[world]) if world in t else None,
             "falsified_if": "ms_per_step differs from the expectation by more than 1.5x either way",
-            "source": "DESIGN.md section 7: single-GPU kernel times + loopback runs + 10-20 us per small RCCL collective; "
+            "source": "DESIGN.md section 8: single-GPU kernel times + loopback runs + 10-20 us per small RCCL collective; "
                       "never measured on more than one GPU"}
 
 
@@ -633,7 +633,7 @@ def main():
         if rank == 0:   # kernel rooflines are measured on a single-GPU handle of the same graph
             G = capi.Graph(S["I"], S["QQ"], S["n"], 1, pcg_rtol=args.rtol, device=dev)
             G.set_rotations(Q0)
-            G.irls(4, SIG, 100, 1e-3)
+            res_single = G.irls(4, SIG, 100, 1e-3)   # ... and the sharded run is held against it (dist.matches_single_gpu)
 
     if rank == 0:
         iters = res["iters"]
@@ -681,6 +681,14 @@ def main():
                 "wire": dinfo["wire"], "halo": dinfo["halo"], "ncclCommCount": dinfo["rccl_comm_ranks"], "world": world,
                 "hosted_allowed": bool(args.allow_hosted),
                 "valid_scaling_measurement": bool(dinfo["wire"] == "rccl" and dinfo["rccl_comm_ranks"] == world and not share),
+                # the sharded result against the same graph on ONE GPU of this node (rank 0's handle): a wrong exchange on
+                # a wire that no test could exercise shows here, not in a plausible-looking throughput
+                "matches_single_gpu": bool(res["iters"] == res_single["iters"] and
+                                           np.allclose(res["scores"], res_single["scores"], rtol=1e-6, atol=1e-12)),
+                "single_gpu_iters": int(res_single["iters"]),
+                "max_rel_score_diff": float(np.max(np.abs(np.asarray(res["scores"][:min(res["iters"], res_single["iters"])]) -
+                                                          np.asarray(res_single["scores"][:min(res["iters"], res_single["iters"])])) /
+                                                   np.maximum(np.abs(np.asarray(res_single["scores"][:min(res["iters"], res_single["iters"])])), 1e-300))),
                 "sharded_solver": "direct" if dinfo.get("direct_block") else "pcg",
                 "closures": dinfo.get("closures", 0),
                 "phases_us_per_iteration": dphases["us_per_iteration_max_over_ranks"],

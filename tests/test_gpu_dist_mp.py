@@ -103,6 +103,7 @@ def test_bench_runs_with_two_ranks():
     assert d["wire"] == "host-staged" and d["ncclCommCount"] == 0 and d["world"] == 2 and d["hosted_allowed"] is True
     assert d["valid_scaling_measurement"] is False           # a hosted or GPU-sharing run is never a scaling figure
     assert d["sharded_solver"] == "direct" and d["phases_iterations"] > 0
+    assert d["matches_single_gpu"] is True and d["single_gpu_iters"] == two["iters_to_converge"] and d["max_rel_score_diff"] < 1e-6
     ph = d["phases_us_per_iteration"]
     assert set(ph) == {"local_edge_kernels_and_assembly", "local_reductions", "gather_of_separators", "closure_sum",
                        "separator_system_and_ways_back", "halo_of_the_step", "weights_and_rotation_update",
