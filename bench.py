@@ -449,7 +449,7 @@ def expected_scaling(args, world):
     elif args.views == 1000000 and args.edges == 20000000 and args.p_loop == 0.0:
         key = "1M/20M sequence, sharded direct solver"
     if key is None:
-        return {"workload": None, "note": "no expectation recorded for this size (DESIGN.md section 7 has 100k/2M and 1M/20M)"}
+        return {"workload": None, "note": "no expectation recorded for this size (DESIGN.md section 8 has 100k/2M and 1M/20M)"}
     t = EXPECTED_MS_PER_IRLS[key]
     return {"workload": key, "ms_per_step_by_gpus": {str(k): v for k, v in t.items()},
             "ms_per_step": t.get(world), "speedup_vs_1_gpu": (t[1] / t[world]) if world in t else None,
@@ -676,7 +676,7 @@ def main():
         if dstats is not None:
             line["config"]["dist"] = dinfo
             # the first multi-GPU run diagnoses itself: the wire that carried it, RCCL's own count of the communicator,
-            # per-phase microseconds of an IRLS iteration, and what DESIGN.md section 7 expects this run to show
+            # per-phase microseconds of an IRLS iteration, and what DESIGN.md section 8 expects this run to show
             line["dist"] = {
                 "wire": dinfo["wire"], "halo": dinfo["halo"], "ncclCommCount": dinfo["rccl_comm_ranks"], "world": world,
                 "hosted_allowed": bool(args.allow_hosted),
