@@ -175,7 +175,9 @@ def check(c, tol, sig):
         # weights of the L1-type costs blow up (cap 1e4) on edges that are fitted exactly: there the
         # residual is rounding noise and so is the weight -- compare the others
         cmp = rb["weights"] < 1e2
-        if not np.allclose(w[cmp], rb["weights"][cmp], rtol=1e-4, atol=1e-9):
+        # (a run held to 1e-4 rad has edge residuals that differ by as much: its weights are held to 1e-2 relative --
+        # Welsch at three times its scale turns 5e-5 rad into 9e-4 of a weight, seed 708 case 1787)
+        if not np.allclose(w[cmp], rb["weights"][cmp], rtol=1e-2 if capped else 1e-4, atol=1e-9):
             bad.append("handle weights differ (max rel %.2e)" % np.max(np.abs(w - rb["weights"])[cmp] / (np.abs(rb["weights"][cmp]) + 1e-300)))
     except capi.IrotavgError as e:
         bad.append("handle error %d" % e.code)
